@@ -1,0 +1,101 @@
+/* r3d.h -- C ABI of libr3d_hip.so, the MI355X (gfx950) hot path of R3DFSSeg.
+ *
+ * The reference (Pixie8888/R3DFSSeg) is pure Python/PyTorch and has no FFI of its own;
+ * each entry point below names the reference code it replaces (file:line under
+ * /root/reference).  The binding a maintainer of the reference would add is a ctypes
+ * stub, shown in INTEGRATION.md (r3dfsseg_amd/_lib.py is that stub).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *     (PyTorch caching allocator in practice), borrowed for the duration of the call;
+ *   - kernels never allocate; scratch is passed in (sizes from the *_ws_words helpers);
+ *   - every function enqueues on `stream` (a hipStream_t passed as void*) and returns
+ *     immediately: 0 = OK, non-zero = error, message in r3d_last_error_string();
+ *   - no host synchronisation anywhere: data-dependent counts (points per class,
+ *     prototypes, graph nodes) stay in a device-side descriptor;
+ *   - activations are POINT-MAJOR fp32 matrices (one point per row, `ld*` = row stride in
+ *     floats); the reference's channel-major (B, C, N) tensors are converted at the
+ *     forward() boundary by r3d_cm_to_pm / r3d_pm_to_cm;
+ *   - indices are int32.
+ */
+#ifndef R3D_H
+#define R3D_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* r3d_last_error_string(void);
+int r3d_abi_version(void);
+
+/* ---- layout conversion at the forward() boundary (models/mpti.py:433-437) -------- */
+int r3d_cm_to_pm(const float* in /*(B,C,N)*/, int B, int C, int N, float* out /*(B*N,ld)*/, long ld, void* stream);
+int r3d_pm_to_cm(const float* in /*(B*N,ld)*/, long ld, int B, int C, int N, float* out /*(B,C,N)*/, void* stream);
+int r3d_copy_cols(const float* src, long ld_src, float* dst, long ld_dst, long M, int C, void* stream);
+
+/* ---- k nearest neighbours ----------------------------------------------------------
+ * mode 0: models/dgcnn.py:17-23 knn(x,k): score = -xx[j] + 2<xi,xj> - xx[i], k largest.
+ * mode 1: models/mpti.py:733-735 faiss.IndexFlatL2.search: score = -max(0,|xi|^2+|xj|^2-2<xi,xj>).
+ * Inner products are channel-ascending fp32 fma chains (bit-exact vs oracle/r3d_oracle.c);
+ * ties resolve to the lower index; columns are sorted best first.
+ * x (B*N, ldx); norm_ws (B*N) scratch; idx_out (B,N,k) int32; score_out optional (B,N,k);
+ * n_valid_dev optional device int: only rows < *n_valid_dev take part. 1 <= k <= min(N,256). */
+int r3d_sqnorm(const float* x, long ldx, long rows, int C, float* out, void* stream);
+int r3d_knn_topk(const float* x, long ldx, int B, int N, int C, int k, int mode, const int32_t* n_valid_dev,
+                 float* norm_ws, int32_t* idx_out, float* score_out, void* stream);
+
+/* ---- 1x1 convolution + folded BatchNorm/bias + activation ---------------------------
+ * models/dgcnn.py:64-80 conv1d, models/mpti.py:18-40 BaseLearner, models/attention.py:39-41.
+ * Out[m][j] = act(scale[j] * sum_k X[m][k] W[j][k] + shift[j]); act 0 none, 1 ReLU, 2 LeakyReLU(0.2).
+ * scale/shift may be NULL (1 / 0). */
+int r3d_pointwise_conv(const float* X, long ldx, const float* W /*(Co,K)*/, long M, int K, int Co,
+                       const float* scale, const float* shift, int act, float* Out, long ldo, void* stream);
+
+/* ---- fused EdgeConv: gather + 2-layer edge MLP + max over K --------------------------
+ * models/dgcnn.py:26-61,117-118.  PQ (B*N,128) = [s1*Wa x | s1*(Wb-Wa) x + t1] per point
+ * (from r3d_pointwise_conv), idx (B,N,K) local neighbour ids, W2 (64,64), s2/t2 (64) folded BN2.
+ * out (B*N, ldo) 64 columns; argmax_out optional (B*N,64) winning neighbour slot. */
+int r3d_edgeconv_fwd(const float* PQ, const int32_t* idx, const float* W2, const float* s2, const float* t2,
+                     float* out, long ldo, int B, int N, int K, int32_t* argmax_out, void* stream);
+
+/* ---- point self-attention, d = 64 (models/attention.py:43-46) ------------------------
+ * qkv (B*N, ld): q*(1/8) | k | v at columns 0 | 64 | 128.  out (B*N, ldo) 64 columns.
+ * lse_out optional (B*N). */
+int r3d_attention_fwd(const float* qkv, long ld, int B, int N, float* out, long ldo, float* lse_out, void* stream);
+
+/* ---- multi-prototype extraction (models/mpti.py:597-715) -----------------------------
+ * FPS (start index 0, ties lowest index) -> sorted unique seeds -> nearest-seed assignment ->
+ * cluster means, for background + each way, then query rows appended: fills node rows
+ * [0, n_proto) and [n_proto, n_proto + n_query_pts) of `nodes` and the label matrix Y.
+ * desc: device int32[r3d_head_desc_words()] = {seg_count[8], seg_m[8], seg_poff[8], n_proto, n_nodes,..}. */
+int r3d_head_desc_words(void);
+int r3d_head_max_k(void);
+long r3d_head_proto_ws_words(int n_way, int k_shot, int N);
+int r3d_head_proto_ws_offsets(int n_way, int k_shot, int N, long* out6 /* comp,mind,assign,cand,sel,seeds */);
+int r3d_head_prototypes(const int32_t* support_y /*(n_way*k_shot,N)*/, const int32_t* shot_keep /*opt (n_way*k_shot)*/,
+                        const float* feat /*(S*N,ldf)*/, long ldf, const float* featT /*(S,D,N)*/,
+                        const float* qfeat /*(n_q*N,ldq)*/, long ldq, int n_way, int k_shot, int N, int D,
+                        int n_query_pts, int k, float* nodes, long ldn, float* node_labels /*(n_cap,4)*/,
+                        int32_t* desc, int32_t* assign_out /*opt (2*S*N)*/, int32_t* cluster_count /*opt (n_cap)*/,
+                        int32_t* ws, void* stream);
+
+/* ---- affinity + label propagation (models/mpti.py:717-776) ---------------------------
+ * nbr (n_cap, kp1) from r3d_knn_topk mode 1 (column 0 is dropped as in mpti.py:736).
+ * Z = (I - alpha D^-1/2 A D^-1/2)^-1 Y by CG (all columns at once), A the symmetrised gaussian
+ * kNN affinity with zero diagonal.  Y, Z (n_cap, 4) fp32, 16-byte aligned.  stats_out optional
+ * device int32[2] = {converged, iterations}. */
+long r3d_lp_ws_words(int n_cap, int kp1);
+int r3d_label_propagate(const float* nodes, long ldn, int D, const int32_t* nbr, int kp1, const float* Y,
+                        const int32_t* n_dev, int n_cap, float sigma, float alpha, int max_iter, float tol,
+                        float* Z, int32_t* ws, int32_t* stats_out, void* stream);
+
+/* ---- query logits + cross entropy (models/mpti.py:558-559, 778-781) ------------------ */
+int r3d_query_logits_ce(const float* Z, const int32_t* n_proto_dev, int n_q, int N, int n_classes,
+                        const int64_t* labels /*opt (n_q,N)*/, float* logits /*(n_q,n_classes,N)*/,
+                        float* loss_out /*opt*/, int32_t* pred_out /*opt (n_q*N)*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

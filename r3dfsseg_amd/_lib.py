@@ -1,0 +1,76 @@
+"""ctypes binding of libr3d_hip.so (the C ABI declared in include/r3d.h).
+
+This is the stub a maintainer of the reference would add next to models/ to call the
+MI355X kernels.  There is NO fallback: if the shared library is missing or a symbol is
+absent, importing an op raises -- the product path never computes on the CPU.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libr3d_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "r3d.h")
+
+c_f = ctypes.c_void_p      # device pointers travel as void*
+c_i = ctypes.c_int
+c_l = ctypes.c_long
+c_fl = ctypes.c_float
+
+_SIGS = {
+    "r3d_last_error_string": (ctypes.c_char_p, []),
+    "r3d_abi_version": (c_i, []),
+    "r3d_cm_to_pm": (c_i, [c_f, c_i, c_i, c_i, c_f, c_l, c_f]),
+    "r3d_pm_to_cm": (c_i, [c_f, c_l, c_i, c_i, c_i, c_f, c_f]),
+    "r3d_copy_cols": (c_i, [c_f, c_l, c_f, c_l, c_l, c_i, c_f]),
+    "r3d_sqnorm": (c_i, [c_f, c_l, c_l, c_i, c_f, c_f]),
+    "r3d_knn_topk": (c_i, [c_f, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f]),
+    "r3d_pointwise_conv": (c_i, [c_f, c_l, c_f, c_l, c_i, c_i, c_f, c_f, c_i, c_f, c_l, c_f]),
+    "r3d_edgeconv_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f, c_f]),
+    "r3d_attention_fwd": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_f]),
+    "r3d_head_desc_words": (c_i, []),
+    "r3d_head_max_k": (c_i, []),
+    "r3d_head_proto_ws_words": (c_l, [c_i, c_i, c_i]),
+    "r3d_head_proto_ws_offsets": (c_i, [c_i, c_i, c_i, ctypes.POINTER(c_l)]),
+    "r3d_head_prototypes": (c_i, [c_f, c_f, c_f, c_l, c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_l,
+                                  c_f, c_f, c_f, c_f, c_f, c_f]),
+    "r3d_lp_ws_words": (c_l, [c_i, c_i]),
+    "r3d_label_propagate": (c_i, [c_f, c_l, c_i, c_f, c_i, c_f, c_f, c_i, c_fl, c_fl, c_i, c_fl, c_f, c_f,
+                                  c_f, c_f]),
+    "r3d_query_logits_ce": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f]),
+}
+
+_lib = None
+
+
+def header_symbols():
+    """Function names declared in include/r3d.h."""
+    txt = open(HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(r3d_[a-z0-9_]+)\s*\(", txt)))
+
+
+def load():
+    """Load the shared library and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "r3dfsseg_amd: %s not found -- build it with `python -m r3dfsseg_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise RuntimeError("r3dfsseg_amd: symbol %s missing from %s" % (name, LIB_PATH))
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("r3d: " + load().r3d_last_error_string().decode())

@@ -1,0 +1,59 @@
+"""Builds the gfx950 shared library r3dfsseg_amd/libr3d_hip.so with hipcc.
+
+    python -m r3dfsseg_amd.build
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off: the bit-exact index kernels
+spell out every fused multiply-add (``__builtin_fmaf``); nothing else may fuse.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libr3d_hip.so")
+SOURCES = ["error.hip", "knn.hip", "gemm.hip", "edgeconv.hip", "attention.hip", "head_proto.hip",
+           "head_graph.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall",
+         "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    hdr = [os.path.join(CSRC, "common.h")]
+    objs = []
+    procs = []
+    for s in [x for x in SOURCES if os.path.exists(os.path.join(CSRC, x))]:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdr):
+            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = False
+    for s, p in procs:
+        out = p.communicate()[0].decode()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write("hipcc failed on %s:\n%s\n" % (s, out))
+        elif out.strip() and verbose:
+            print(out)
+    if failed:
+        raise RuntimeError("r3dfsseg_amd: HIP build failed")
+    if force or procs or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

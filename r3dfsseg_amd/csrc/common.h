@@ -1,0 +1,59 @@
+// Shared helpers for the gfx950 kernels of the R3DFSSeg hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define R3D_OK 0
+#define R3D_ERR_ARG 1
+#define R3D_ERR_LAUNCH 2
+#define R3D_ERR_UNSUPPORTED 3
+
+void r3d_set_error(const char* fmt, ...);
+
+#define R3D_REQUIRE(cond, ...)          \
+  do {                                  \
+    if (!(cond)) {                      \
+      r3d_set_error(__VA_ARGS__);       \
+      return R3D_ERR_ARG;               \
+    }                                   \
+  } while (0)
+
+#define R3D_LAUNCH_CHECK(name)                                              \
+  do {                                                                      \
+    hipError_t e_ = hipGetLastError();                                      \
+    if (e_ != hipSuccess) {                                                 \
+      r3d_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));  \
+      return R3D_ERR_LAUNCH;                                                \
+    }                                                                       \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define R3D_WAVE 64
+
+static __device__ __forceinline__ int r3d_lane() { return threadIdx.x & 63; }
+
+// v_mfma_f32_32x32x2_f32 accumulator row of register r for this lane
+// (col = lane & 31): MI355X guide, "Fragment layout".
+static __device__ __forceinline__ int r3d_acc_row(int r, int lane) {
+  return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+}
+
+static __device__ __forceinline__ float r3d_readlane_f(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+static __device__ __forceinline__ float r3d_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+static __device__ __forceinline__ float r3d_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+static inline int r3d_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

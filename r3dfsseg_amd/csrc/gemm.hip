@@ -1,0 +1,158 @@
+// Point-wise (1x1) convolution as an fp32 matrix-core GEMM with fused per-channel
+// affine (+ folded BatchNorm / bias) and activation.
+//
+// Replaces the [Conv1d/Conv2d 1x1 -> BatchNorm -> (Leaky)ReLU] stacks of the reference:
+//   models/dgcnn.py:64-80,121-122  conv1d 192->512->256
+//   models/mpti.py:18-40           BaseLearner 256->128->64
+//   models/attention.py:39-41      q/k/v maps 256->64 (fused into one 256->192 GEMM)
+//   models/dgcnn.py:53-57          first EdgeConv conv, rewritten per point:
+//        W1 [x_j - x_i ; x_i] = Wa x_j + (Wb - Wa) x_i   (see edgeconv.hip)
+//
+//   Out[m][j] = act( scale[j] * sum_k X[m][k] * W[j][k] + shift[j] )
+// X (M, ldx) and Out (M, ldo) are point-major (one point per row); W is (Co, K)
+// row-major exactly as the reference stores conv weights.  v_mfma_f32_32x32x2_f32
+// keeps exact fp32 products (north_star tolerance 1e-4 rules out bf16 inputs).
+//
+// Tile: 64 x 64 per workgroup, 2 x 2 waves of one 32x32 accumulator, K in steps of 32
+// staged through LDS with an odd row stride (conflict-free ds_read_b32 operands).
+#include "common.h"
+
+#define G_BM 64
+#define G_BN 64
+#define G_BK 32
+#define G_LD (G_BK + 1)
+
+enum { R3D_ACT_NONE = 0, R3D_ACT_RELU = 1, R3D_ACT_LRELU02 = 2 };
+
+__global__ __launch_bounds__(256) void r3d_pointwise_gemm_kernel(
+    const float* __restrict__ X, long ldx, const float* __restrict__ W, int M, int K, int Co,
+    const float* __restrict__ scale, const float* __restrict__ shift, int act,
+    float* __restrict__ Out, long ldo) {
+  __shared__ float Xs[G_BM * G_LD];
+  __shared__ float Ws[G_BN * G_LD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const long m0 = (long)blockIdx.x * G_BM;
+  const int n0 = blockIdx.y * G_BN;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int srow = tid >> 5, scol = tid & 31;  // 8 rows x 32 cols per pass
+  for (int k0 = 0; k0 < K; k0 += G_BK) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < G_BM / 8; ++p) {
+      const int row = srow + 8 * p;
+      const long gm = m0 + row;
+      const int gk = k0 + scol;
+      Xs[row * G_LD + scol] = (gm < M && gk < K) ? X[gm * ldx + gk] : 0.f;
+      const int gj = n0 + row;
+      Ws[row * G_LD + scol] = (gj < Co && gk < K) ? W[(long)gj * K + gk] : 0.f;
+    }
+    __syncthreads();
+    const float* ap = Xs + (32 * wm + (lane & 31)) * G_LD + (lane >> 5);
+    const float* bp = Ws + (32 * wn + (lane & 31)) * G_LD + (lane >> 5);
+#pragma unroll
+    for (int kk = 0; kk < G_BK; kk += 2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk], acc, 0, 0, 0);
+  }
+  const int j = n0 + 32 * wn + (lane & 31);
+  if (j >= Co) return;
+  const float sc = scale ? scale[j] : 1.f;
+  const float sh = shift ? shift[j] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const long m = m0 + 32 * wm + r3d_acc_row(r, lane);
+    if (m >= M) continue;
+    float v = sc * acc[r] + sh;
+    if (act == R3D_ACT_RELU) v = fmaxf(v, 0.f);
+    else if (act == R3D_ACT_LRELU02) v = v > 0.f ? v : 0.2f * v;
+    Out[m * ldo + j] = v;
+  }
+}
+
+extern "C" int r3d_pointwise_conv(const float* X, long ldx, const float* W, long M, int K, int Co,
+                                  const float* scale, const float* shift, int act, float* Out,
+                                  long ldo, void* stream) {
+  R3D_REQUIRE(X && W && Out, "r3d_pointwise_conv: null pointer");
+  R3D_REQUIRE(M > 0 && K > 0 && Co > 0 && ldx >= K && ldo >= Co,
+              "r3d_pointwise_conv: bad shape M=%ld K=%d Co=%d ldx=%ld ldo=%ld", M, K, Co, ldx, ldo);
+  R3D_REQUIRE(act >= 0 && act <= 2, "r3d_pointwise_conv: unknown activation %d", act);
+  dim3 grid(r3d_cdiv(M, G_BM), r3d_cdiv(Co, G_BN));
+  hipLaunchKernelGGL(r3d_pointwise_gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, W,
+                     (int)M, K, Co, scale, shift, act, Out, ldo);
+  R3D_LAUNCH_CHECK("r3d_pointwise_conv");
+  return R3D_OK;
+}
+
+// ---- layout helpers -------------------------------------------------------
+// (B, C, N) channel-major (the reference's tensor layout at the forward() boundary,
+// models/mpti.py:433-436) -> (B*N, ld) point-major, via a 32x32 LDS tile transpose.
+__global__ void r3d_cm_to_pm_kernel(const float* __restrict__ in, int C, int N, float* __restrict__ out,
+                                    long ld) {
+  __shared__ float t[32][33];
+  const int b = blockIdx.z;
+  const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, n = n0 + tx;
+    t[i][tx] = (c < C && n < N) ? in[((long)b * C + c) * N + n] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int n = n0 + i, c = c0 + tx;
+    if (n < N && c < C) out[((long)b * N + n) * ld + c] = t[tx][i];
+  }
+}
+
+__global__ void r3d_pm_to_cm_kernel(const float* __restrict__ in, long ld, int C, int N,
+                                    float* __restrict__ out) {
+  __shared__ float t[32][33];
+  const int b = blockIdx.z;
+  const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int n = n0 + i, c = c0 + tx;
+    t[i][tx] = (c < C && n < N) ? in[((long)b * N + n) * ld + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, n = n0 + tx;
+    if (c < C && n < N) out[((long)b * C + c) * N + n] = t[tx][i];
+  }
+}
+
+extern "C" int r3d_cm_to_pm(const float* in, int B, int C, int N, float* out, long ld, void* stream) {
+  R3D_REQUIRE(in && out && B > 0 && C > 0 && N > 0 && ld >= C, "r3d_cm_to_pm: bad arguments");
+  dim3 grid(r3d_cdiv(N, 32), r3d_cdiv(C, 32), B);
+  hipLaunchKernelGGL(r3d_cm_to_pm_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, C, N, out, ld);
+  R3D_LAUNCH_CHECK("r3d_cm_to_pm");
+  return R3D_OK;
+}
+
+extern "C" int r3d_pm_to_cm(const float* in, long ld, int B, int C, int N, float* out, void* stream) {
+  R3D_REQUIRE(in && out && B > 0 && C > 0 && N > 0 && ld >= C, "r3d_pm_to_cm: bad arguments");
+  dim3 grid(r3d_cdiv(N, 32), r3d_cdiv(C, 32), B);
+  hipLaunchKernelGGL(r3d_pm_to_cm_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, ld, C, N, out);
+  R3D_LAUNCH_CHECK("r3d_pm_to_cm");
+  return R3D_OK;
+}
+
+// strided column-block copy: dst[m][0..C) = src[m][0..C)
+__global__ void r3d_copy_cols_kernel(const float* __restrict__ src, long lds_, float* __restrict__ dst,
+                                     long ldd, long M, int C) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * C) return;
+  long m = i / C;
+  int c = (int)(i - m * C);
+  dst[m * ldd + c] = src[m * lds_ + c];
+}
+
+extern "C" int r3d_copy_cols(const float* src, long ld_src, float* dst, long ld_dst, long M, int C,
+                             void* stream) {
+  R3D_REQUIRE(src && dst && M > 0 && C > 0, "r3d_copy_cols: bad arguments");
+  hipLaunchKernelGGL(r3d_copy_cols_kernel, dim3(r3d_cdiv(M * C, 256)), dim3(256), 0,
+                     (hipStream_t)stream, src, ld_src, dst, ld_dst, M, C);
+  R3D_LAUNCH_CHECK("r3d_copy_cols");
+  return R3D_OK;
+}

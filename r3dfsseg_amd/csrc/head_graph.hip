@@ -1,0 +1,485 @@
+// Transductive label propagation on the k-NN graph of [prototypes ; query points], gfx950.
+//
+// Replaces (reference): models/mpti.py:717-756 calculateLocalConstrainedAffinity and
+// :758-776 label_propagate.  The reference materialises a (n, 200, 192) neighbour tensor
+// (675 MB @ n=4396), a dense n x n affinity (77 MB) and inverts a dense n x n matrix
+// (170 GFLOP).  Here the graph stays sparse end to end:
+//   1. neighbour lists (r3d_knn_topk, mode L2, k+1 columns, column 0 dropped)
+//   2. symmetric pattern as an n x n BIT matrix (atomicOr; result order independent)
+//   3. CSR rows enumerated from the bitmap in ascending column order (deterministic),
+//      A_ij = [j in nbr(i)] w(i,j) + [i in nbr(j)] w(j,i),  w = exp(-0.5 (d/sigma)^2),
+//      d = || x_i - x_j + 1e-6 ||_2 (torch-1.8 pairwise_distance)
+//   4. S = D^-1/2 A D^-1/2, rounded as the reference's two diag matmuls
+//   5. Z = (I - alpha S)^-1 Y by conjugate gradients (I - alpha S is SPD with spectrum in
+//      [1-alpha, 1+alpha]); all n_way+1 right-hand sides share every SpMV.  The reference's
+//      "+ eps" on every matrix element (2.2e-16) is below fp32 resolution of the diagonal
+//      and perturbs Z by < 1e-9; it is dropped (tests/test_oracle_props.py shows the bound).
+// Node count n lives in device memory (descriptor word HD_N_NODES); grids are sized by
+// the capacity n_cap.
+#include "common.h"
+
+#define HG_NC 4                 // label columns carried (n_way + 1 <= 4), float4 per node
+#define HG_ROWS_PER_BLOCK 32    // CG: rows per 256-thread block (8 per wave)
+#define HG_MAX_PART 1024        // max CG blocks (n_cap <= 32768)
+
+// ---------------------------------------------------------------------------
+// 2. bitmaps: outb[i] = { j : j in nbr(i) } ; sym[i] = outb[i] | { j : i in nbr(j) }
+// ---------------------------------------------------------------------------
+__global__ void r3d_graph_bits_kernel(const int* __restrict__ nbr, int kp1, const int* __restrict__ n_dev,
+                                      int n_cap, int words, unsigned* __restrict__ outb,
+                                      unsigned* __restrict__ sym) {
+  const int n = min(*n_dev, n_cap);
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = kp1 - 1;
+  if (e >= (long)n * k) return;
+  const int i = (int)(e / k);
+  const int t = (int)(e - (long)i * k) + 1;  // column 0 is dropped (mpti.py:736)
+  const int j = nbr[(long)i * kp1 + t];
+  if (j < 0 || j >= n || j == i) return;      // diagonal is zeroed by the reference (mpti.py:755)
+  atomicOr(&outb[(long)i * words + (j >> 5)], 1u << (j & 31));
+  atomicOr(&sym[(long)i * words + (j >> 5)], 1u << (j & 31));
+  atomicOr(&sym[(long)j * words + (i >> 5)], 1u << (i & 31));
+}
+
+// ---------------------------------------------------------------------------
+// 3a. row lengths + exclusive scan (single workgroup; n_cap <= 32768)
+// ---------------------------------------------------------------------------
+__global__ void r3d_graph_rowlen_kernel(const unsigned* __restrict__ sym, int words,
+                                        const int* __restrict__ n_dev, int n_cap, int* __restrict__ row_len) {
+  const int n = min(*n_dev, n_cap);
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n_cap) return;
+  int c = 0;
+  if (row < n)
+    for (int wd = lane; wd < words; wd += 64) c += __popc(sym[(long)row * words + wd]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if (lane == 0) row_len[row] = c;
+}
+
+__global__ __launch_bounds__(1024) void r3d_scan_kernel(const int* __restrict__ in, int n, int* __restrict__ out) {
+  // exclusive scan of in[0..n) -> out[0..n], out[n] = total.  One workgroup.
+  __shared__ int wave_tot[16];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < n; t0 += 1024) {
+    const int i = t0 + tid;
+    const int v = i < n ? in[i] : 0;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wave_tot[w] = x;
+    __syncthreads();
+    int wbase = 0, tot = 0;
+    for (int q = 0; q < 16; ++q) {
+      const int tv = wave_tot[q];
+      if (q < w) wbase += tv;
+      tot += tv;
+    }
+    const int carry = carry_s;
+    if (i < n) out[i] = carry + wbase + x - v;
+    __syncthreads();
+    if (tid == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+  if (tid == 0) out[n] = carry_s;
+}
+
+// ---------------------------------------------------------------------------
+// 3b. CSR columns, ascending, one wave per row
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void r3d_graph_cols_kernel(const unsigned* __restrict__ sym, int words,
+                                                             const int* __restrict__ n_dev, int n_cap,
+                                                             const int* __restrict__ row_ptr, int* __restrict__ col) {
+  const int n = min(*n_dev, n_cap);
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= n) return;
+  // lane owns a contiguous run of bitmap words so that columns come out ascending
+  const int wpl = (words + 63) / 64;
+  const int w0 = lane * wpl;
+  int mycount = 0;
+  for (int t = 0; t < wpl; ++t) {
+    const int wd = w0 + t;
+    if (wd < words) mycount += __popc(sym[(long)i * words + wd]);
+  }
+  int incl = mycount;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(incl, o);
+    if (lane >= o) incl += y;
+  }
+  int wpos = row_ptr[i] + incl - mycount;
+  for (int t = 0; t < wpl; ++t) {
+    const int wd = w0 + t;
+    if (wd >= words) break;
+    unsigned bits = sym[(long)i * words + wd];
+    while (bits) {
+      const int b = __ffs((int)bits) - 1;
+      bits &= bits - 1;
+      col[wpos++] = wd * 32 + b;
+    }
+  }
+}
+
+// 3c. gaussian weights + row sums D; one wave per row, x_i in registers (D <= 256)
+__global__ __launch_bounds__(256) void r3d_graph_weights_kernel(
+    const float* __restrict__ nodes, long ldn, int D, const unsigned* __restrict__ outb, int words,
+    const int* __restrict__ n_dev, int n_cap, const int* __restrict__ row_ptr, const int* __restrict__ col,
+    float sigma, float* __restrict__ val, float* __restrict__ dinv) {
+  const int n = min(*n_dev, n_cap);
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const float* xi = nodes + (long)i * ldn;
+  const float x0 = lane < D ? xi[lane] : 0.f;
+  const float x1 = lane + 64 < D ? xi[lane + 64] : 0.f;
+  const float x2 = lane + 128 < D ? xi[lane + 128] : 0.f;
+  const float x3 = lane + 192 < D ? xi[lane + 192] : 0.f;
+  const int beg = row_ptr[i], end = row_ptr[i + 1];
+  float dsum = 0.f;
+  for (int e = beg; e < end; ++e) {
+    const int j = __builtin_amdgcn_readfirstlane(col[e]);
+    const float* xj = nodes + (long)j * ldn;
+    float a = 0.f, b = 0.f;  // a: ||x_i - x_j + eps||^2, b: ||x_j - x_i + eps||^2
+    if (lane < D)       { const float y = xj[lane];       const float d1 = (x0 - y) + 1e-6f, d2 = (y - x0) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b); }
+    if (lane + 64 < D)  { const float y = xj[lane + 64];  const float d1 = (x1 - y) + 1e-6f, d2 = (y - x1) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b); }
+    if (lane + 128 < D) { const float y = xj[lane + 128]; const float d1 = (x2 - y) + 1e-6f, d2 = (y - x2) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b); }
+    if (lane + 192 < D) { const float y = xj[lane + 192]; const float d1 = (x3 - y) + 1e-6f, d2 = (y - x3) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b); }
+    a = r3d_wave_sum(a);
+    b = r3d_wave_sum(b);
+    const bool out_ij = (outb[(long)i * words + (j >> 5)] >> (j & 31)) & 1u;
+    const bool out_ji = (outb[(long)j * words + (i >> 5)] >> (i & 31)) & 1u;
+    float wgt = 0.f;
+    if (out_ij) { const float d = sqrtf(a) / sigma; wgt += expf(-0.5f * (d * d)); }
+    if (out_ji) { const float d = sqrtf(b) / sigma; wgt += expf(-0.5f * (d * d)); }
+    if (lane == 0) val[e] = wgt;
+    dsum += wgt;
+  }
+  if (lane == 0) dinv[i] = sqrtf(1.0f / (dsum + 2.220446049250313e-16f));  // mpti.py:768-770
+}
+
+// 4. S_ij = (dinv_i * A_ij) * dinv_j   (mpti.py:771-772: two diagonal matmuls)
+__global__ void r3d_graph_normalize_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col,
+                                           const float* __restrict__ dinv, const int* __restrict__ n_dev,
+                                           int n_cap, float* __restrict__ val) {
+  const int n = min(*n_dev, n_cap);
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const float di = dinv[i];
+  for (int e = row_ptr[i] + lane; e < row_ptr[i + 1]; e += 64) val[e] = (di * val[e]) * dinv[col[e]];
+}
+
+// ---------------------------------------------------------------------------
+// 5. conjugate gradients on M = I - alpha S, HG_NC right-hand sides at once.
+//    Two launches per iteration; scalar reductions are done redundantly by every block
+//    from per-block partials written by the previous launch (no grid barrier, no host
+//    sync, deterministic summation order).
+// ---------------------------------------------------------------------------
+#define HG_MAX_ITER 1022
+struct CgState {            // device memory
+  float rr_hist[2][HG_NC];  // rr of the last two iterations
+  float bb[HG_NC];          // ||b||^2
+  int done;                 // statistics only: set once every column converged
+  int iters;                // statistics only: iterations actually performed
+  // stop[it] != 0: iteration `it` must not run.  A launch only READS stop[it] and only
+  // WRITES stop[it + 1], so no flag is read and written inside one launch.
+  int stop[HG_MAX_ITER + 2];
+};
+
+static __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// fixed-order block reduction of a float4, result broadcast to all threads
+static __device__ __forceinline__ float4 block_sum4(float4 v, float4* sm /*[4]*/) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o);
+    v.z += __shfl_xor(v.z, o); v.w += __shfl_xor(v.w, o);
+  }
+  __syncthreads();
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  float4 r = sm[0];
+  for (int q = 1; q < 4; ++q) { r.x += sm[q].x; r.y += sm[q].y; r.z += sm[q].z; r.w += sm[q].w; }
+  return r;
+}
+
+static __device__ __forceinline__ float4 reduce_partials(const float4* part, int nblk, float4* sm) {
+  float4 a = f4_zero();
+  for (int q = threadIdx.x; q < nblk; q += blockDim.x) {
+    const float4 p = part[q];
+    a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+  }
+  return block_sum4(a, sm);
+}
+
+__global__ __launch_bounds__(256) void r3d_cg_init_kernel(const float4* __restrict__ Y, const int* __restrict__ n_dev,
+                                                          int n_cap, float4* __restrict__ x, float4* __restrict__ r,
+                                                          float4* __restrict__ p, float4* __restrict__ part_rr,
+                                                          CgState* __restrict__ st) {
+  __shared__ float4 sm[4];
+  const int n = min(*n_dev, n_cap);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float4 b = f4_zero();
+  if (i < n) b = Y[i];
+  if (i < n_cap) { x[i] = f4_zero(); r[i] = b; p[i] = f4_zero(); }
+  float4 sq = make_float4(b.x * b.x, b.y * b.y, b.z * b.z, b.w * b.w);
+  sq = block_sum4(sq, sm);
+  if (threadIdx.x == 0) part_rr[blockIdx.x] = sq;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { st->done = 0; st->iters = 0; }
+  if (blockIdx.x == 0)
+    for (int q = threadIdx.x; q < HG_MAX_ITER + 2; q += 256) st->stop[q] = 0;
+}
+
+// A: p_new = r + beta p_old ; q = (I - alpha S) p_new ; partial <p_new, q>
+__global__ __launch_bounds__(256) void r3d_cg_spmv_kernel(
+    const int* __restrict__ row_ptr, const int* __restrict__ col, const float* __restrict__ val,
+    const int* __restrict__ n_dev, int n_cap, float alpha_lp, int it, int nblk_rr, float tol2,
+    const float4* __restrict__ r, const float4* __restrict__ p_old, float4* __restrict__ p_new,
+    float4* __restrict__ q, const float4* __restrict__ part_rr, float4* __restrict__ part_pq,
+    CgState* __restrict__ st) {
+  __shared__ float4 sm[4];
+  __shared__ float4 wsum[4];
+  if (st->stop[it]) return;
+  const int n = min(*n_dev, n_cap);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float4 rr = reduce_partials(part_rr, nblk_rr, sm);
+  float4 beta = f4_zero();
+  if (it == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->bb[0] = rr.x; st->bb[1] = rr.y; st->bb[2] = rr.z; st->bb[3] = rr.w; }
+  } else {
+    const float* ro = st->rr_hist[(it - 1) & 1];
+    beta.x = ro[0] > 0.f ? rr.x / ro[0] : 0.f;
+    beta.y = ro[1] > 0.f ? rr.y / ro[1] : 0.f;
+    beta.z = ro[2] > 0.f ? rr.z / ro[2] : 0.f;
+    beta.w = ro[3] > 0.f ? rr.w / ro[3] : 0.f;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float* rn = st->rr_hist[it & 1];
+    rn[0] = rr.x; rn[1] = rr.y; rn[2] = rr.z; rn[3] = rr.w;
+  }
+  float4 acc_pq = f4_zero();
+  const int row0 = blockIdx.x * HG_ROWS_PER_BLOCK + w * (HG_ROWS_PER_BLOCK / 4);
+  for (int rr_i = 0; rr_i < HG_ROWS_PER_BLOCK / 4; ++rr_i) {
+    const int i = row0 + rr_i;
+    if (i >= n) break;
+    float4 s = f4_zero();
+    for (int e = row_ptr[i] + lane; e < row_ptr[i + 1]; e += 64) {
+      const int j = col[e];
+      const float a = val[e];
+      const float4 rj = r[j], pj = p_old[j];
+      s.x += a * (rj.x + beta.x * pj.x);
+      s.y += a * (rj.y + beta.y * pj.y);
+      s.z += a * (rj.z + beta.z * pj.z);
+      s.w += a * (rj.w + beta.w * pj.w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s.x += __shfl_xor(s.x, o); s.y += __shfl_xor(s.y, o);
+      s.z += __shfl_xor(s.z, o); s.w += __shfl_xor(s.w, o);
+    }
+    if (lane == 0) {
+      const float4 ri = r[i], pi = p_old[i];
+      float4 pn = make_float4(ri.x + beta.x * pi.x, ri.y + beta.y * pi.y, ri.z + beta.z * pi.z, ri.w + beta.w * pi.w);
+      float4 qi = make_float4(pn.x - alpha_lp * s.x, pn.y - alpha_lp * s.y, pn.z - alpha_lp * s.z, pn.w - alpha_lp * s.w);
+      p_new[i] = pn;
+      q[i] = qi;
+      acc_pq.x += pn.x * qi.x; acc_pq.y += pn.y * qi.y; acc_pq.z += pn.z * qi.z; acc_pq.w += pn.w * qi.w;
+    }
+  }
+  // fixed-order combine of the four waves' lane-0 partials
+  __syncthreads();
+  if (lane == 0) wsum[w] = acc_pq;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float4 t = wsum[0];
+    for (int q2 = 1; q2 < 4; ++q2) { t.x += wsum[q2].x; t.y += wsum[q2].y; t.z += wsum[q2].z; t.w += wsum[q2].w; }
+    part_pq[blockIdx.x] = t;
+  }
+}
+
+// B: alpha = rr / <p,q> ; x += alpha p ; r -= alpha q ; partial rr ; convergence flag
+__global__ __launch_bounds__(256) void r3d_cg_update_kernel(
+    const int* __restrict__ n_dev, int n_cap, int it, int nblk_pq, float tol2, const float4* __restrict__ p,
+    const float4* __restrict__ q, float4* __restrict__ x, float4* __restrict__ r,
+    const float4* __restrict__ part_pq, float4* __restrict__ part_rr, CgState* __restrict__ st) {
+  __shared__ float4 sm[4];
+  if (st->stop[it]) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->stop[it + 1] = 1;
+    return;
+  }
+  const int n = min(*n_dev, n_cap);
+  const float4 pq = reduce_partials(part_pq, nblk_pq, sm);
+  const float* rn = st->rr_hist[it & 1];
+  const float* bb = st->bb;
+  // converged already before this step? (all columns)  -> freeze the solution
+  const bool conv = rn[0] <= tol2 * bb[0] && rn[1] <= tol2 * bb[1] && rn[2] <= tol2 * bb[2] && rn[3] <= tol2 * bb[3];
+  if (conv) {
+    // every block takes this branch together (same inputs, same arithmetic); the flag is
+    // only read by LATER launches
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->done = 1; st->stop[it + 1] = 1; }
+    return;
+  }
+  float4 al;
+  al.x = pq.x > 0.f ? rn[0] / pq.x : 0.f;
+  al.y = pq.y > 0.f ? rn[1] / pq.y : 0.f;
+  al.z = pq.z > 0.f ? rn[2] / pq.z : 0.f;
+  al.w = pq.w > 0.f ? rn[3] / pq.w : 0.f;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float4 sq = f4_zero();
+  if (i < n) {
+    const float4 pi = p[i], qi = q[i];
+    float4 xi = x[i], ri = r[i];
+    xi.x += al.x * pi.x; xi.y += al.y * pi.y; xi.z += al.z * pi.z; xi.w += al.w * pi.w;
+    ri.x -= al.x * qi.x; ri.y -= al.y * qi.y; ri.z -= al.z * qi.z; ri.w -= al.w * qi.w;
+    x[i] = xi; r[i] = ri;
+    sq = make_float4(ri.x * ri.x, ri.y * ri.y, ri.z * ri.z, ri.w * ri.w);
+  }
+  sq = block_sum4(sq, sm);
+  if (threadIdx.x == 0) part_rr[blockIdx.x] = sq;
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->iters = it + 1;
+}
+
+// ---------------------------------------------------------------------------
+// 6. query logits (mpti.py:558-559) + cross entropy (mpti.py:778-781)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void r3d_logits_ce_kernel(const float4* __restrict__ Z, const int* __restrict__ desc_nproto,
+                                                             int n_q, int N, int n_classes,
+                                                             const long long* __restrict__ labels,
+                                                             float* __restrict__ logits /* (n_q, n_classes, N) */,
+                                                             float* __restrict__ loss_out, int* __restrict__ pred_out) {
+  __shared__ float red[16];
+  const int n_proto = *desc_nproto;
+  float acc = 0.f;
+  for (int e = threadIdx.x; e < n_q * N; e += blockDim.x) {
+    const int qi = e / N, p = e - qi * N;
+    const float4 z = Z[n_proto + e];
+    const float zv[4] = {z.x, z.y, z.z, z.w};
+    float mx = zv[0];
+    int am = 0;
+    for (int c = 1; c < n_classes; ++c) if (zv[c] > mx) { mx = zv[c]; am = c; }
+    float se = 0.f;
+    for (int c = 0; c < n_classes; ++c) {
+      logits[((long)qi * n_classes + c) * N + p] = zv[c];
+      se += expf(zv[c] - mx);
+    }
+    if (labels) {
+      const int lab = (int)labels[e];
+      acc += (mx + logf(se)) - zv[lab];
+    }
+    if (pred_out) pred_out[e] = am;
+  }
+  acc = r3d_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    if (loss_out) *loss_out = t / (float)(n_q * N);
+  }
+}
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+// scratch words for r3d_label_propagate: bitmaps, CSR, CG vectors
+extern "C" long r3d_lp_ws_words(int n_cap, int kp1) {
+  const long words = (n_cap + 31) / 32;
+  const long nnz_cap = 2L * n_cap * (kp1 - 1);
+  long t = 0;
+  t += 2 * n_cap * words;          // outb, sym
+  t += n_cap + 8;                  // row_len
+  t += n_cap + 8;                  // row_ptr
+  t += nnz_cap * 2;                // col, val
+  t += n_cap;                      // dinv
+  t += 5L * n_cap * HG_NC;         // x(out is separate) r, p0, p1, q  (+1 spare)
+  t += 2L * HG_MAX_PART * HG_NC;   // partials
+  t += sizeof(CgState) / 4 + 8;    // CgState
+  return t + 64;
+}
+
+// nodes (n_cap, ldn), nbr (n_cap, kp1) from r3d_knn_topk (mode L2), Y (n_cap, 4) one-hot
+// rows for prototypes / zeros for queries.  Z (n_cap, 4) out.  n_dev: device int = n.
+// stats_out (optional, device, 2 ints): {converged flag, iterations}.
+extern "C" int r3d_label_propagate(const float* nodes, long ldn, int D, const int32_t* nbr, int kp1,
+                                   const float* Y, const int32_t* n_dev, int n_cap, float sigma,
+                                   float alpha, int max_iter, float tol, float* Z, int32_t* ws,
+                                   int32_t* stats_out, void* stream) {
+  R3D_REQUIRE(nodes && nbr && Y && n_dev && Z && ws, "r3d_label_propagate: null pointer");
+  R3D_REQUIRE(n_cap > 0 && n_cap <= 32768 && D > 0 && D <= 256 && kp1 >= 2,
+              "r3d_label_propagate: unsupported n_cap=%d D=%d kp1=%d", n_cap, D, kp1);
+  R3D_REQUIRE(max_iter > 0 && max_iter <= HG_MAX_ITER && sigma > 0.f, "r3d_label_propagate: bad solver parameters");
+  hipStream_t st = (hipStream_t)stream;
+  const long words = (n_cap + 31) / 32;
+  const long nnz_cap = 2L * n_cap * (kp1 - 1);
+  int32_t* wp = ws;
+  unsigned* outb = (unsigned*)wp; wp += n_cap * words;
+  unsigned* sym = (unsigned*)wp; wp += n_cap * words;
+  int* row_len = wp; wp += n_cap + 8;
+  int* row_ptr = wp; wp += n_cap + 8;
+  int* col = wp; wp += nnz_cap;
+  float* val = (float*)wp; wp += nnz_cap;
+  float* dinv = (float*)wp; wp += n_cap;
+  wp += (4 - ((wp - ws) & 3)) & 3;  // float4 alignment (ws itself must be 16-B aligned)
+  float4* r = (float4*)wp; wp += 4L * n_cap;
+  float4* p0 = (float4*)wp; wp += 4L * n_cap;
+  float4* p1 = (float4*)wp; wp += 4L * n_cap;
+  float4* q = (float4*)wp; wp += 4L * n_cap;
+  float4* part_rr = (float4*)wp; wp += 4L * HG_MAX_PART;
+  float4* part_pq = (float4*)wp; wp += 4L * HG_MAX_PART;
+  CgState* cg = (CgState*)wp;
+  R3D_REQUIRE(((uintptr_t)ws & 15) == 0 && ((uintptr_t)Y & 15) == 0 && ((uintptr_t)Z & 15) == 0,
+              "r3d_label_propagate: ws, Y and Z must be 16-byte aligned");
+
+  hipMemsetAsync(outb, 0, sizeof(unsigned) * 2 * n_cap * words, st);
+  const long edges = (long)n_cap * (kp1 - 1);
+  hipLaunchKernelGGL(r3d_graph_bits_kernel, dim3(r3d_cdiv(edges, 256)), dim3(256), 0, st, nbr, kp1, n_dev, n_cap,
+                     (int)words, outb, sym);
+  hipLaunchKernelGGL(r3d_graph_rowlen_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, sym, (int)words, n_dev,
+                     n_cap, row_len);
+  hipLaunchKernelGGL(r3d_scan_kernel, dim3(1), dim3(1024), 0, st, row_len, n_cap, row_ptr);
+  hipLaunchKernelGGL(r3d_graph_cols_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, sym, (int)words, n_dev,
+                     n_cap, row_ptr, col);
+  hipLaunchKernelGGL(r3d_graph_weights_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, nodes, ldn, D, outb,
+                     (int)words, n_dev, n_cap, row_ptr, col, sigma, val, dinv);
+  hipLaunchKernelGGL(r3d_graph_normalize_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, row_ptr, col, dinv,
+                     n_dev, n_cap, val);
+  const int nblk_v = r3d_cdiv(n_cap, 256);
+  const int nblk_s = r3d_cdiv(n_cap, HG_ROWS_PER_BLOCK);
+  R3D_REQUIRE(nblk_s <= HG_MAX_PART, "r3d_label_propagate: n_cap too large");
+  float4* x = (float4*)Z;
+  hipLaunchKernelGGL(r3d_cg_init_kernel, dim3(nblk_v), dim3(256), 0, st, (const float4*)Y, n_dev, n_cap, x, r, p0,
+                     part_rr, cg);
+  const float tol2 = tol * tol;
+  for (int it = 0; it < max_iter; ++it) {
+    float4* pold = (it & 1) ? p1 : p0;
+    float4* pnew = (it & 1) ? p0 : p1;
+    hipLaunchKernelGGL(r3d_cg_spmv_kernel, dim3(nblk_s), dim3(256), 0, st, row_ptr, col, val, n_dev, n_cap, alpha,
+                       it, nblk_v, tol2, r, pold, pnew, q, part_rr, part_pq, cg);
+    hipLaunchKernelGGL(r3d_cg_update_kernel, dim3(nblk_v), dim3(256), 0, st, n_dev, n_cap, it, nblk_s, tol2, pnew, q,
+                       x, r, part_pq, part_rr, cg);
+  }
+  if (stats_out) hipMemcpyAsync(stats_out, &cg->done, 2 * sizeof(int), hipMemcpyDeviceToDevice, st);
+  R3D_LAUNCH_CHECK("r3d_label_propagate");
+  return R3D_OK;
+}
+
+// logits (n_q, n_classes, N) fp32, loss (1) fp32, pred (n_q*N) int32 (argmax), labels int64
+extern "C" int r3d_query_logits_ce(const float* Z, const int32_t* n_proto_dev, int n_q, int N, int n_classes,
+                                   const int64_t* labels, float* logits, float* loss_out, int32_t* pred_out,
+                                   void* stream) {
+  R3D_REQUIRE(Z && n_proto_dev && logits, "r3d_query_logits_ce: null pointer");
+  R3D_REQUIRE(n_q > 0 && N > 0 && n_classes >= 2 && n_classes <= HG_NC, "r3d_query_logits_ce: bad shape");
+  hipLaunchKernelGGL(r3d_logits_ce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float4*)Z,
+                     n_proto_dev, n_q, N, n_classes, (const long long*)labels, logits, loss_out, pred_out);
+  R3D_LAUNCH_CHECK("r3d_query_logits_ce");
+  return R3D_OK;
+}

@@ -1,0 +1,478 @@
+// Multi-prototype extraction of the transductive head, gfx950.
+//
+// Replaces (reference): models/mpti.py:636-715 getForeground/BackgroundPrototypes and
+// :597-634 getMutiplePrototypes (torch_cluster.fps + nearest-seed argmin + python loop
+// of masked means).  Everything stays on the device: the data-dependent counts
+// (points per class, prototypes per class, graph nodes) live in a small descriptor in
+// device memory and kernels are launched on capacity-sized grids.
+//
+// Segments: 0 = background (all support clouds, mask == 0), 1 + w = foreground of way w
+// (mask == 1, optionally restricted to shots kept by clean-shot detection).  Compacted
+// point lists sit at fixed capacity offsets: seg 0 at 0 (capacity S*N), seg 1+w at
+// S*N + w*k_shot*N (capacity k_shot*N).  A "position" is an index inside a segment's
+// list; list order is the reference's torch.nonzero order, so ties resolve the same way.
+//
+// Bit-exactness contract with oracle/r3d_oracle.c: FPS and assignment distances are
+// channel-ascending fmaf chains evaluated by ONE thread per point.
+#include "common.h"
+
+#define HP_MAXSEG 8
+#define HP_BLOCK 256
+#define HP_MAXK 128
+
+// int32 words of the device-side descriptor
+enum {
+  HD_SEG_COUNT = 0,                     // [HP_MAXSEG] points per segment
+  HD_SEG_M = HP_MAXSEG,                 // [HP_MAXSEG] prototypes per segment
+  HD_SEG_POFF = 2 * HP_MAXSEG,          // [HP_MAXSEG] first node row of the segment's prototypes
+  HD_N_PROTO = 3 * HP_MAXSEG,
+  HD_N_NODES = 3 * HP_MAXSEG + 1,
+  HD_WORDS = 3 * HP_MAXSEG + 8
+};
+
+struct SegGeom {
+  int n_way, k_shot, N;
+  __host__ __device__ int nseg() const { return n_way + 1; }
+  __host__ __device__ long cap(int s) const { return s == 0 ? (long)n_way * k_shot * N : (long)k_shot * N; }
+  __host__ __device__ long off(int s) const {
+    return s == 0 ? 0 : (long)n_way * k_shot * N + (long)(s - 1) * k_shot * N;
+  }
+  __host__ __device__ long total_cap() const { return 2L * n_way * k_shot * N; }
+  __host__ __device__ int blocks(int s) const { return (int)((cap(s) + HP_BLOCK - 1) / HP_BLOCK); }
+  __host__ __device__ int block0(int s) const {
+    int b = 0;
+    for (int i = 0; i < s; ++i) b += blocks(i);
+    return b;
+  }
+  __host__ __device__ int total_blocks() const { return block0(nseg()); }
+  // segment of a block index
+  __device__ int seg_of_block(int blk, int* first) const {
+    int b = 0;
+    for (int s = 0; s < nseg(); ++s) {
+      int nb = blocks(s);
+      if (blk < b + nb) { *first = b; return s; }
+      b += nb;
+    }
+    *first = b;
+    return -1;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// 1. mask compaction (stable): one workgroup per segment
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void r3d_head_compact_kernel(const int* __restrict__ support_y,
+                                                                const int* __restrict__ shot_keep,
+                                                                SegGeom g, int* __restrict__ comp,
+                                                                int* __restrict__ desc) {
+  __shared__ int wave_tot[16];
+  __shared__ int base_s;
+  const int seg = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const long first = seg == 0 ? 0 : (long)(seg - 1) * g.k_shot * g.N;
+  const long count = g.cap(seg);
+  int* dst = comp + g.off(seg);
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (long t0 = 0; t0 < count; t0 += 1024) {
+    const long e = t0 + tid;
+    bool f = false;
+    long gp = 0;
+    if (e < count) {
+      gp = first + e;
+      const int y = support_y[gp];
+      if (seg == 0) f = (y == 0);
+      else {
+        f = (y == 1);
+        if (f && shot_keep) f = shot_keep[gp / g.N] != 0;
+      }
+    }
+    const unsigned long long m = __ballot(f);
+    const int pre = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[w] = __popcll(m);
+    __syncthreads();
+    int wbase = 0, tot = 0;
+    for (int i = 0; i < 16; ++i) {
+      const int v = wave_tot[i];
+      if (i < w) wbase += v;
+      tot += v;
+    }
+    const int base = base_s;
+    if (f) dst[base + wbase + pre] = (int)gp;
+    __syncthreads();
+    if (tid == 0) base_s = base + tot;
+    __syncthreads();
+  }
+  if (tid == 0) desc[HD_SEG_COUNT + seg] = base_s;
+}
+
+// ---------------------------------------------------------------------------
+// 2. farthest point sampling, one launch per round, all segments at once
+// ---------------------------------------------------------------------------
+struct Cand { float v; int pos; };
+
+static __device__ __forceinline__ void cand_better(float& v, int& p, float v2, int p2) {
+  if (v2 > v || (v2 == v && p2 < p)) { v = v2; p = p2; }
+}
+
+__global__ __launch_bounds__(HP_BLOCK) void r3d_fps_round_kernel(
+    const float* __restrict__ featT /* (S, D, N) channel-major */, int D, SegGeom g,
+    const int* __restrict__ comp, const int* __restrict__ desc, int k, int round,
+    float* __restrict__ mind, const Cand* __restrict__ cand_prev, Cand* __restrict__ cand_next,
+    int* __restrict__ sel /* [nseg][HP_MAXK] */) {
+  __shared__ float seedf[256];
+  __shared__ float red_v[4];
+  __shared__ int red_p[4];
+  __shared__ int seed_pos_s;
+  int blk0;
+  const int seg = g.seg_of_block(blockIdx.x, &blk0);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int count = desc[HD_SEG_COUNT + seg];
+  if (count <= k) return;  // identity case (mpti.py:631-634): no sampling
+  const int bis = blockIdx.x - blk0;  // block index inside the segment
+  if ((long)bis * HP_BLOCK >= count) return;
+  const int nblk = (count + HP_BLOCK - 1) / HP_BLOCK;
+  // --- seed of this round
+  if (round == 0) {
+    if (tid == 0) seed_pos_s = 0;
+  } else {
+    float v = -INFINITY;
+    int p = 0x7fffffff;
+    for (int i = tid; i < nblk; i += HP_BLOCK) {
+      const Cand c = cand_prev[blk0 + i];
+      cand_better(v, p, c.v, c.pos);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float v2 = __shfl_xor(v, o);
+      const int p2 = __shfl_xor(p, o);
+      cand_better(v, p, v2, p2);
+    }
+    if (lane == 0) { red_v[w] = v; red_p[w] = p; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int i = 1; i < 4; ++i) cand_better(v, p, red_v[i], red_p[i]);
+      seed_pos_s = p;
+    }
+  }
+  __syncthreads();
+  const int seed_pos = seed_pos_s;
+  if (bis == 0 && tid == 0) sel[seg * HP_MAXK + round] = seed_pos;
+  if (round == k - 1) return;
+  // --- stage the seed's feature vector
+  {
+    const int gp = comp[g.off(seg) + seed_pos];
+    const int cloud = gp / g.N, pp = gp - cloud * g.N;
+    for (int c = tid; c < D; c += HP_BLOCK) seedf[c] = featT[((long)cloud * D + c) * g.N + pp];
+  }
+  __syncthreads();
+  // --- distance update + block argmax
+  const int pos = bis * HP_BLOCK + tid;
+  float v = -INFINITY;
+  int p = 0x7fffffff;
+  if (pos < count) {
+    const int gp = comp[g.off(seg) + pos];
+    const int cloud = gp / g.N, pp = gp - cloud * g.N;
+    const float* fp = featT + (long)cloud * D * g.N + pp;
+    float acc = 0.f;
+    for (int c = 0; c < D; ++c) {
+      const float df = fp[(long)c * g.N] - seedf[c];
+      acc = __builtin_fmaf(df, df, acc);
+    }
+    float md = round == 0 ? INFINITY : mind[g.off(seg) + pos];
+    md = acc < md ? acc : md;
+    mind[g.off(seg) + pos] = md;
+    v = md;
+    p = pos;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float v2 = __shfl_xor(v, o);
+    const int p2 = __shfl_xor(p, o);
+    cand_better(v, p, v2, p2);
+  }
+  __syncthreads();  // red_* reuse
+  if (lane == 0) { red_v[w] = v; red_p[w] = p; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int i = 1; i < 4; ++i) cand_better(v, p, red_v[i], red_p[i]);
+    Cand c; c.v = v; c.pos = p;
+    cand_next[blockIdx.x] = c;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 3. finalize: sort + unique the sampled positions (torch .unique(), mpti.py:613),
+//    node-row offsets (background first, then ways: mpti.py:493)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(HP_MAXK) void r3d_fps_finalize_kernel(SegGeom g, int k, int n_query_pts,
+                                                                   const int* __restrict__ sel,
+                                                                   int* __restrict__ seeds /*[nseg][HP_MAXK]*/,
+                                                                   int* __restrict__ desc) {
+  __shared__ int a[HP_MAXK];
+  __shared__ int m_s[HP_MAXSEG];
+  const int tid = threadIdx.x;
+  for (int seg = 0; seg < g.nseg(); ++seg) {
+    const int count = desc[HD_SEG_COUNT + seg];
+    int m;
+    if (count <= k) {  // identity: every point is its own prototype
+      m = count;
+      if (tid < HP_MAXK) seeds[seg * HP_MAXK + tid] = tid < count ? tid : -1;
+    } else {
+      a[tid] = tid < k ? sel[seg * HP_MAXK + tid] : 0x7fffffff;
+      __syncthreads();
+      for (int sz = 2; sz <= HP_MAXK; sz <<= 1)
+        for (int st = sz >> 1; st > 0; st >>= 1) {
+          const int j = tid ^ st;
+          if (j > tid) {
+            const bool up = (tid & sz) == 0;
+            const int x = a[tid], y = a[j];
+            if ((x > y) == up) { a[tid] = y; a[j] = x; }
+          }
+          __syncthreads();
+        }
+      // unique on the sorted list
+      const bool keep = tid < k && (tid == 0 || a[tid] != a[tid - 1]);
+      __syncthreads();
+      // rank = number of kept entries before tid (k <= 128: serial count is fine)
+      __shared__ int keepf[HP_MAXK];
+      keepf[tid] = keep ? 1 : 0;
+      __syncthreads();
+      int rank = 0;
+      for (int i = 0; i < tid; ++i) rank += keepf[i];
+      int total = 0;
+      for (int i = 0; i < HP_MAXK; ++i) total += keepf[i];
+      m = total;
+      seeds[seg * HP_MAXK + tid] = -1;
+      __syncthreads();
+      if (keep) seeds[seg * HP_MAXK + rank] = a[tid];
+    }
+    if (tid == 0) m_s[seg] = m;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int off = 0;
+    for (int seg = 0; seg < g.nseg(); ++seg) {
+      desc[HD_SEG_M + seg] = m_s[seg];
+      desc[HD_SEG_POFF + seg] = off;
+      off += m_s[seg];
+    }
+    desc[HD_N_PROTO] = off;
+    desc[HD_N_NODES] = off + n_query_pts;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 4. nearest-seed assignment (mpti.py:618-622): dist = sqrt(chain(((x - s) + 1e-6)^2))
+// ---------------------------------------------------------------------------
+#define AS_TILE 16
+__global__ __launch_bounds__(HP_BLOCK) void r3d_assign_kernel(const float* __restrict__ featT, int D,
+                                                              SegGeom g, const int* __restrict__ comp,
+                                                              const int* __restrict__ desc,
+                                                              const int* __restrict__ seeds,
+                                                              int* __restrict__ assign) {
+  __shared__ float sf[256 * AS_TILE];  // [c][AS_TILE], D <= 256
+  int blk0;
+  const int seg = g.seg_of_block(blockIdx.x, &blk0);
+  const int tid = threadIdx.x;
+  const int count = desc[HD_SEG_COUNT + seg];
+  const int bis = blockIdx.x - blk0;
+  if ((long)bis * HP_BLOCK >= count) return;
+  const int m = desc[HD_SEG_M + seg];
+  const int pos = bis * HP_BLOCK + tid;
+  const bool ok = pos < count;
+  const float* fp = featT;
+  if (ok) {
+    const int gp = comp[g.off(seg) + pos];
+    const int cloud = gp / g.N, pp = gp - cloud * g.N;
+    fp = featT + (long)cloud * D * g.N + pp;
+  }
+  float best = INFINITY;
+  int besti = 0;
+  for (int s0 = 0; s0 < m; s0 += AS_TILE) {
+    __syncthreads();
+    for (int e = tid; e < D * AS_TILE; e += HP_BLOCK) {
+      const int c = e / AS_TILE, s = e - c * AS_TILE;
+      float v = 0.f;
+      if (s0 + s < m) {
+        const int gp = comp[g.off(seg) + seeds[seg * HP_MAXK + s0 + s]];
+        const int cloud = gp / g.N, pp = gp - cloud * g.N;
+        v = featT[((long)cloud * D + c) * g.N + pp];
+      }
+      sf[c * AS_TILE + s] = v;
+    }
+    __syncthreads();
+    if (ok) {
+      float acc[AS_TILE];
+#pragma unroll
+      for (int s = 0; s < AS_TILE; ++s) acc[s] = 0.f;
+      for (int c = 0; c < D; ++c) {
+        const float xv = fp[(long)c * g.N];
+#pragma unroll
+        for (int s = 0; s < AS_TILE; ++s) {
+          const float df = (xv - sf[c * AS_TILE + s]) + 1e-6f;
+          acc[s] = __builtin_fmaf(df, df, acc[s]);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < AS_TILE; ++s) {
+        if (s0 + s < m) {
+          const float d = sqrtf(acc[s]);
+          if (d < best) { best = d; besti = s0 + s; }
+        }
+      }
+    }
+  }
+  if (ok) assign[g.off(seg) + pos] = besti;
+}
+
+// ---------------------------------------------------------------------------
+// 5. cluster means -> prototype rows of the node matrix (mpti.py:625-629)
+//    one workgroup per (segment, prototype); deterministic summation order
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(HP_BLOCK) void r3d_cluster_mean_kernel(
+    const float* __restrict__ feat /* (S*N, ldf) point-major */, long ldf, int D, SegGeom g,
+    const int* __restrict__ comp, const int* __restrict__ desc, const int* __restrict__ assign,
+    float* __restrict__ nodes /* (n_cap, ldn) */, long ldn, float* __restrict__ node_labels /* (n_cap, 4) */,
+    int* __restrict__ cluster_count) {
+  __shared__ float part[4][256];
+  __shared__ int cnt_s[4];
+  const int seg = blockIdx.y, s = blockIdx.x;
+  const int m = desc[HD_SEG_M + seg];
+  if (s >= m) return;
+  const int count = desc[HD_SEG_COUNT + seg];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int cnt = 0;
+  const int* cp = comp + g.off(seg);
+  const int* ap = assign + g.off(seg);
+  for (int base = 64 * w; base < count; base += 256) {
+    const int pos = base + lane;
+    const bool f = pos < count && ap[pos] == s;
+    const int gp = f ? cp[pos] : 0;
+    unsigned long long mm = __ballot(f);
+    cnt += __popcll(mm);
+    while (mm) {
+      const int src = __ffsll((long long)mm) - 1;
+      mm &= mm - 1;
+      const long row = __builtin_amdgcn_readlane(gp, src);
+      const float* fr = feat + row * ldf;
+      if (lane < D) a0 += fr[lane];
+      if (lane + 64 < D) a1 += fr[lane + 64];
+      if (lane + 128 < D) a2 += fr[lane + 128];
+      if (lane + 192 < D) a3 += fr[lane + 192];
+    }
+  }
+  part[w][lane] = a0; part[w][lane + 64] = a1; part[w][lane + 128] = a2; part[w][lane + 192] = a3;
+  if (lane == 0) cnt_s[w] = cnt;
+  __syncthreads();
+  const int total = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
+  const int row = desc[HD_SEG_POFF + seg] + s;
+  if (tid < D) {
+    const float sum = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+    nodes[(long)row * ldn + tid] = sum / (float)total;  // 0/0 = NaN for an empty cluster, as torch
+  }
+  if (tid < 4) node_labels[(long)row * 4 + tid] = (tid == seg) ? 1.f : 0.f;
+  if (tid == 0 && cluster_count) cluster_count[row] = total;
+}
+
+// ---------------------------------------------------------------------------
+// 6. query rows of the node matrix (mpti.py:508: node_feat = cat(prototypes, query_feat))
+// ---------------------------------------------------------------------------
+__global__ void r3d_nodes_append_query_kernel(const float* __restrict__ qfeat, long ldq, int D, int nq_pts,
+                                              const int* __restrict__ desc, float* __restrict__ nodes,
+                                              long ldn, float* __restrict__ node_labels) {
+  const int n_proto = desc[HD_N_PROTO];
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)nq_pts * D) return;
+  const long r = i / D;
+  const int c = (int)(i - r * D);
+  nodes[(n_proto + r) * ldn + c] = qfeat[r * ldq + c];
+  if (c < 4) node_labels[(n_proto + r) * 4 + c] = 0.f;
+}
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+static int check_geom(const char* fn, int n_way, int k_shot, int N, int D) {
+  if (n_way < 1 || n_way + 1 > HP_MAXSEG || n_way > 3 || k_shot < 1 || N < 1 || D < 1 || D > 256) {
+    r3d_set_error("%s: unsupported geometry n_way=%d k_shot=%d N=%d D=%d (n_way<=3, D<=256)", fn, n_way,
+                  k_shot, N, D);
+    return R3D_ERR_ARG;
+  }
+  if ((long)n_way * k_shot * N > 65536L * 4) {
+    r3d_set_error("%s: too many support points", fn);
+    return R3D_ERR_ARG;
+  }
+  return 0;
+}
+
+extern "C" int r3d_head_desc_words(void) { return HD_WORDS; }
+extern "C" int r3d_head_max_k(void) { return HP_MAXK; }
+
+// Scratch sizes (in 4-byte words) the caller must provide for r3d_head_prototypes.
+extern "C" long r3d_head_proto_ws_words(int n_way, int k_shot, int N) {
+  SegGeom g{n_way, k_shot, N};
+  const long cap = g.total_cap();
+  // comp + mind + assign + cand(2 x blocks x 2 words) + sel + seeds
+  return cap * 3 + 4L * g.total_blocks() + 2L * HP_MAXSEG * HP_MAXK + 64;
+}
+
+// Builds prototypes into node rows [0, n_proto) and appends the query rows.
+//   support_y : (n_way*k_shot, N) int32 {0,1}
+//   shot_keep : optional (n_way*k_shot) int32, 0 drops a shot's foreground (clean-shot detection)
+//   feat      : (S*N, ldf) point-major support features;  featT: (S, D, N) channel-major copy
+//   qfeat     : (n_q*N, ldq) point-major query features
+//   nodes     : (n_cap, ldn) out, n_cap = (n_way+1)*k + n_q*N;  node_labels: (n_cap, 4) one-hot Y
+//   desc      : device descriptor (r3d_head_desc_words int32);  ws: scratch words
+extern "C" int r3d_head_prototypes(const int32_t* support_y, const int32_t* shot_keep, const float* feat,
+                                   long ldf, const float* featT, const float* qfeat, long ldq, int n_way,
+                                   int k_shot, int N, int D, int n_query_pts, int k, float* nodes, long ldn,
+                                   float* node_labels, int32_t* desc, int32_t* assign_out,
+                                   int32_t* cluster_count, int32_t* ws, void* stream) {
+  R3D_REQUIRE(support_y && feat && featT && qfeat && nodes && node_labels && desc && ws,
+              "r3d_head_prototypes: null pointer");
+  int rc = check_geom("r3d_head_prototypes", n_way, k_shot, N, D);
+  if (rc) return rc;
+  R3D_REQUIRE(k >= 1 && k <= HP_MAXK, "r3d_head_prototypes: k=%d unsupported (1..%d)", k, HP_MAXK);
+  hipStream_t st = (hipStream_t)stream;
+  SegGeom g{n_way, k_shot, N};
+  const long cap = g.total_cap();
+  int* comp = ws;
+  float* mind = (float*)(ws + cap);
+  int* assign = assign_out ? assign_out : ws + 2 * cap;
+  Cand* cand0 = (Cand*)(ws + 3 * cap);
+  Cand* cand1 = cand0 + g.total_blocks();
+  int* sel = ws + 3 * cap + 4L * g.total_blocks();
+  int* seeds = sel + HP_MAXSEG * HP_MAXK;
+  hipLaunchKernelGGL(r3d_head_compact_kernel, dim3(g.nseg()), dim3(1024), 0, st, support_y, shot_keep, g,
+                     comp, desc);
+  for (int t = 0; t < k; ++t) {
+    hipLaunchKernelGGL(r3d_fps_round_kernel, dim3(g.total_blocks()), dim3(HP_BLOCK), 0, st, featT, D, g, comp,
+                       desc, k, t, mind, (t & 1) ? cand0 : cand1, (t & 1) ? cand1 : cand0, sel);
+  }
+  hipLaunchKernelGGL(r3d_fps_finalize_kernel, dim3(1), dim3(HP_MAXK), 0, st, g, k, n_query_pts, sel, seeds,
+                     desc);
+  hipLaunchKernelGGL(r3d_assign_kernel, dim3(g.total_blocks()), dim3(HP_BLOCK), 0, st, featT, D, g, comp, desc,
+                     seeds, assign);
+  hipLaunchKernelGGL(r3d_cluster_mean_kernel, dim3(k, g.nseg()), dim3(HP_BLOCK), 0, st, feat, ldf, D, g, comp,
+                     desc, assign, nodes, ldn, node_labels, cluster_count);
+  hipLaunchKernelGGL(r3d_nodes_append_query_kernel, dim3(r3d_cdiv((long)n_query_pts * D, 256)), dim3(256), 0, st,
+                     qfeat, ldq, D, n_query_pts, desc, nodes, ldn, node_labels);
+  R3D_LAUNCH_CHECK("r3d_head_prototypes");
+  return R3D_OK;
+}
+
+// Word offsets of the scratch sub-arrays inside ws (for tests that inspect the
+// intermediate index results): comp, mind, assign, cand, sel, seeds.
+extern "C" int r3d_head_proto_ws_offsets(int n_way, int k_shot, int N, long* out6) {
+  SegGeom g{n_way, k_shot, N};
+  const long cap = g.total_cap();
+  out6[0] = 0;
+  out6[1] = cap;
+  out6[2] = 2 * cap;
+  out6[3] = 3 * cap;
+  out6[4] = 3 * cap + 4L * g.total_blocks();
+  out6[5] = out6[4] + HP_MAXSEG * HP_MAXK;
+  return R3D_OK;
+}

@@ -1,0 +1,107 @@
+"""Host-side mirror of the reference's models/mpti.py::MPTI_SelfAtten.
+
+Same constructor (an argparse-style ``args`` namespace, models/mpti.py:46-83), same
+forward() signature and return values (models/mpti.py:414-415, 573-577) and the same
+state-dict keys, so it drops into MPTILearner_V3 / mpti_train_noise.py / eval_noise.py.
+All tensor work runs in libr3d_hip.so; this file only orders the launches.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .dgcnn import DGCNN, BaseLearner, SelfAttention
+
+
+class MPTI_SelfAtten(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.n_way = args.n_way
+        self.k_shot = args.k_shot
+        self.in_channels = args.pc_in_dim
+        self.n_points = args.pc_npts
+        self.use_attention = args.use_attention
+        self.n_subprototypes = args.n_subprototypes
+        self.k_connect = args.k_connect
+        self.sigma = args.sigma
+        self.n_classes = self.n_way + 1
+        if self.n_classes > 4:
+            raise NotImplementedError("the label-propagation kernels carry at most 4 classes (n_way <= 3)")
+
+        self.encoder = DGCNN(args.edgeconv_widths, args.dgcnn_mlp_widths, args.pc_in_dim, k=args.dgcnn_k)
+        self.base_learner = BaseLearner(args.dgcnn_mlp_widths[-1], args.base_widths)
+        if self.use_attention:
+            self.att_learner = SelfAttention(args.dgcnn_mlp_widths[-1], args.output_dim)
+        else:
+            if args.output_dim != 64:
+                raise NotImplementedError("output_dim must be 64")
+            self.linear_mapper = nn.Conv1d(args.dgcnn_mlp_widths[-1], args.output_dim, 1, bias=False)
+        self.feat_dim = args.edgeconv_widths[0][-1] + args.output_dim + args.base_widths[-1]
+        self.shot_seed = getattr(args, "shot_seed", 1)
+        self.proj = nn.Linear(self.feat_dim, 128)
+        # solver knobs of the sparse label propagation (no reference counterpart: the reference
+        # inverts the dense matrix, mpti.py:775)
+        self.lp_max_iter = getattr(args, "lp_max_iter", 200)
+        self.lp_tol = getattr(args, "lp_tol", 1e-6)
+        self.shot_level_clean_ratio = 0
+        self._head = None
+
+    # ------------------------------------------------------------------ features (mpti.py:579-595)
+    def getFeatures_pm(self, x):
+        """x (B, C_in, N) -> point-major features (B*N, feat_dim): [level1 | att | base]."""
+        B, _, N = x.shape
+        cat, level2 = self.encoder.forward_pm(ops.cm_to_pm(x), B, N)
+        d1 = 64
+        feat = torch.empty(B * N, self.feat_dim, device=x.device, dtype=torch.float32)
+        ops.copy_cols(cat[:, :d1], feat[:, :d1])
+        if self.use_attention:
+            self.att_learner.forward_pm(level2, B, N, feat[:, d1:d1 + 64])
+        else:
+            W = self.linear_mapper.weight.reshape(64, -1).contiguous()
+            ops.pointwise_conv(level2, W, None, None, ops.ACT_NONE, out=feat[:, d1:d1 + 64])
+        self.base_learner.forward_pm(level2, feat[:, d1 + 64:])
+        return feat
+
+    def getFeatures(self, x):
+        """Reference signature: (B, C_in, L) -> (B, C_out, L)."""
+        B, _, N = x.shape
+        return ops.pm_to_cm(self.getFeatures_pm(x), B, N)
+
+    # ------------------------------------------------------------------ head buffers
+    def _head_buffers(self, n_q, device):
+        key = (n_q, str(device))
+        if self._head is None or self._head[0] != key:
+            hb = ops.HeadBuffers(self.n_way, self.k_shot, self.n_points, n_q * self.n_points,
+                                 self.n_subprototypes, self.k_connect, self.feat_dim, device)
+            self._head = (key, hb)
+        return self._head[1]
+
+    # ------------------------------------------------------------------ forward (mpti.py:414-577)
+    def forward(self, support_x, support_y, query_x, query_y, gt_support_y=None, gt_query_y=None, train=False,
+                logger=None, step=None, path=None, sampled_classes=None, bg_pcd_x=None, bg_pcd_y=None,
+                support_c=None, support_flag=None, pcd_1024=None, label_1024=None, pcd_cutout=None,
+                label_cutout=None, eval=False):
+        if train or self.training:
+            from . import train_ops
+            return train_ops.mpti_train_forward(self, support_x, support_y, query_x, query_y, gt_support_y,
+                                                gt_query_y, logger, support_flag)
+        S = self.n_way * self.k_shot
+        N = self.n_points
+        n_q = query_x.shape[0]
+        sx = support_x.reshape(S, self.in_channels, N)
+        # eval-mode BatchNorm uses running statistics, so support and query clouds share one pass
+        feat = self.getFeatures_pm(torch.cat((sx, query_x), 0))
+        sfeat, qfeat = feat[:S * N], feat[S * N:]
+        sfeatT = ops.pm_to_cm(sfeat, S, N)
+        shot_keep = None
+        if eval:  # clean-shot detection (mpti.py:440-442), eval only
+            from . import clean_detect
+            shot_keep = clean_detect.shot_keep_flags(self, sfeat, sfeatT, support_x, support_y)
+        hb = self._head_buffers(n_q, feat.device)
+        sy = support_y.reshape(S, N).to(torch.int32).contiguous()
+        ops.head_prototypes(hb, sy, shot_keep, sfeat, sfeatT, qfeat)
+        nbr = ops.knn(hb.nodes, 1, hb.n_cap, hb.kp1, mode=ops.SCORE_L2, n_valid=hb.desc[ops.HD_N_NODES:])
+        ops.label_propagate(hb, nbr, self.sigma, 0.99, self.lp_max_iter, self.lp_tol)
+        labels = query_y.to(torch.int64).contiguous() if query_y is not None else None
+        logits, loss, _ = ops.query_logits_ce(hb, n_q, self.n_classes, labels)
+        self.num_prototypes_dev = hb.desc[ops.HD_N_PROTO]
+        return logits, loss

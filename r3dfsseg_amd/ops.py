@@ -1,0 +1,165 @@
+"""Thin torch-tensor wrappers over the C ABI (include/r3d.h).
+
+PyTorch is plumbing here: device memory (caching allocator), the current HIP stream and
+tensor views.  All compute happens in libr3d_hip.so; there is no eager fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+SCORE_DGCNN, SCORE_L2 = 0, 1
+HD_SEG_COUNT, HD_SEG_M, HD_SEG_POFF, HD_N_PROTO, HD_N_NODES = 0, 8, 16, 24, 25
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _rows(t):
+    """(rows, ld) of a 2-D fp32 row-major view (unit column stride)."""
+    assert t.dim() == 2 and t.stride(1) == 1 and t.dtype == torch.float32 and t.is_cuda, \
+        "expected a 2-D fp32 CUDA tensor with unit column stride"
+    return t.shape[0], t.stride(0)
+
+
+def cm_to_pm(x, out=None):
+    """(B, C, N) channel-major -> (B*N, C) point-major."""
+    B, C, N = x.shape
+    x = x.contiguous().float()
+    if out is None:
+        out = torch.empty(B * N, C, device=x.device, dtype=torch.float32)
+    _, ld = _rows(out)
+    _lib.check(_lib.load().r3d_cm_to_pm(_p(x), B, C, N, _p(out), ld, _st()))
+    return out
+
+
+def pm_to_cm(x_pm, B, N):
+    """(B*N, C) point-major view -> (B, C, N) contiguous."""
+    M, ld = _rows(x_pm)
+    C = x_pm.shape[1]
+    assert M == B * N
+    out = torch.empty(B, C, N, device=x_pm.device, dtype=torch.float32)
+    _lib.check(_lib.load().r3d_pm_to_cm(_p(x_pm), ld, B, C, N, _p(out), _st()))
+    return out
+
+
+def copy_cols(src, dst):
+    M, lds = _rows(src)
+    M2, ldd = _rows(dst)
+    assert M == M2 and src.shape[1] == dst.shape[1]
+    _lib.check(_lib.load().r3d_copy_cols(_p(src), lds, _p(dst), ldd, M, src.shape[1], _st()))
+    return dst
+
+
+def knn(x_pm, B, N, k, mode=SCORE_DGCNN, n_valid=None, return_scores=False):
+    """x_pm (B*N, C) -> idx (B, N, k) int32, best first."""
+    M, ld = _rows(x_pm)
+    C = x_pm.shape[1]
+    assert M == B * N
+    dev = x_pm.device
+    norm = torch.empty(M, device=dev, dtype=torch.float32)
+    idx = torch.empty(B, N, k, device=dev, dtype=torch.int32)
+    sc = torch.empty(B, N, k, device=dev, dtype=torch.float32) if return_scores else None
+    _lib.check(_lib.load().r3d_knn_topk(_p(x_pm), ld, B, N, C, k, mode, _p(n_valid), _p(norm), _p(idx), _p(sc),
+                                        _st()))
+    return (idx, sc) if return_scores else idx
+
+
+def pointwise_conv(x_pm, W, scale=None, shift=None, act=ACT_NONE, out=None):
+    """act(scale * (x W^T) + shift); W (Co, K) contiguous."""
+    M, ldx = _rows(x_pm)
+    K = x_pm.shape[1]
+    Co = W.shape[0]
+    assert W.is_contiguous() and W.shape[1] == K and W.dtype == torch.float32
+    if out is None:
+        out = torch.empty(M, Co, device=x_pm.device, dtype=torch.float32)
+    M2, ldo = _rows(out)
+    assert M2 == M and out.shape[1] == Co
+    _lib.check(_lib.load().r3d_pointwise_conv(_p(x_pm), ldx, _p(W), M, K, Co, _p(scale), _p(shift), act,
+                                              _p(out), ldo, _st()))
+    return out
+
+
+def edgeconv(PQ, idx, W2, s2, t2, out, B, N, want_argmax=False):
+    K = idx.shape[-1]
+    assert PQ.is_contiguous() and PQ.shape == (B * N, 128) and idx.is_contiguous() and idx.dtype == torch.int32
+    assert W2.is_contiguous() and W2.shape == (64, 64)
+    M, ldo = _rows(out)
+    assert M == B * N and out.shape[1] == 64
+    am = torch.empty(B * N, 64, device=PQ.device, dtype=torch.int32) if want_argmax else None
+    _lib.check(_lib.load().r3d_edgeconv_fwd(_p(PQ), _p(idx), _p(W2), _p(s2), _p(t2), _p(out), ldo, B, N, K,
+                                            _p(am), _st()))
+    return am
+
+
+def attention(qkv, B, N, out, want_lse=False):
+    M, ld = _rows(qkv)
+    M2, ldo = _rows(out)
+    assert M == B * N and M2 == M and qkv.shape[1] == 192 and out.shape[1] == 64
+    lse = torch.empty(M, device=qkv.device, dtype=torch.float32) if want_lse else None
+    _lib.check(_lib.load().r3d_attention_fwd(_p(qkv), ld, B, N, _p(out), ldo, _p(lse), _st()))
+    return lse
+
+
+class HeadBuffers:
+    """Device buffers of one episode's transductive head (capacity sized, no host sync)."""
+
+    def __init__(self, n_way, k_shot, N, n_q_pts, k_sub, k_connect, D, device):
+        lib = _lib.load()
+        self.n_way, self.k_shot, self.N, self.n_q_pts, self.k_sub, self.kp1, self.D = \
+            n_way, k_shot, N, n_q_pts, k_sub, k_connect + 1, D
+        self.n_cap = (n_way + 1) * k_sub + n_q_pts
+        assert lib.r3d_head_desc_words() == 32
+        i32 = dict(device=device, dtype=torch.int32)
+        f32 = dict(device=device, dtype=torch.float32)
+        self.desc = torch.zeros(32, **i32)
+        self.nodes = torch.empty(self.n_cap, D, **f32)
+        self.Y = torch.empty(self.n_cap, 4, **f32)
+        self.Z = torch.empty(self.n_cap, 4, **f32)
+        self.proto_ws = torch.empty(lib.r3d_head_proto_ws_words(n_way, k_shot, N), **i32)
+        self.lp_ws = torch.empty(lib.r3d_lp_ws_words(self.n_cap, self.kp1), **i32)
+        self.assign = torch.empty(2 * n_way * k_shot * N, **i32)
+        self.cluster_count = torch.zeros(self.n_cap, **i32)
+        self.stats = torch.zeros(2, **i32)
+        off = (ctypes.c_long * 6)()
+        lib.r3d_head_proto_ws_offsets(n_way, k_shot, N, off)
+        self.ws_off = list(off)
+
+
+def head_prototypes(hb, support_y, shot_keep, sfeat_pm, sfeatT, qfeat_pm):
+    S = hb.n_way * hb.k_shot
+    M, ldf = _rows(sfeat_pm)
+    Mq, ldq = _rows(qfeat_pm)
+    assert M == S * hb.N and Mq == hb.n_q_pts and sfeatT.is_contiguous() and sfeatT.shape == (S, hb.D, hb.N)
+    assert support_y.dtype == torch.int32 and support_y.is_contiguous() and support_y.numel() == S * hb.N
+    _lib.check(_lib.load().r3d_head_prototypes(
+        _p(support_y), _p(shot_keep), _p(sfeat_pm), ldf, _p(sfeatT), _p(qfeat_pm), ldq, hb.n_way, hb.k_shot,
+        hb.N, hb.D, hb.n_q_pts, hb.k_sub, _p(hb.nodes), hb.nodes.stride(0), _p(hb.Y), _p(hb.desc),
+        _p(hb.assign), _p(hb.cluster_count), _p(hb.proto_ws), _st()))
+
+
+def label_propagate(hb, nbr, sigma, alpha=0.99, max_iter=200, tol=1e-6):
+    assert nbr.shape == (1, hb.n_cap, hb.kp1) or nbr.shape == (hb.n_cap, hb.kp1)
+    _lib.check(_lib.load().r3d_label_propagate(
+        _p(hb.nodes), hb.nodes.stride(0), hb.D, _p(nbr), hb.kp1, _p(hb.Y), _p(hb.desc[HD_N_NODES:]), hb.n_cap,
+        float(sigma), float(alpha), int(max_iter), float(tol), _p(hb.Z), _p(hb.lp_ws), _p(hb.stats), _st()))
+    return hb.Z
+
+
+def query_logits_ce(hb, n_q, n_classes, labels):
+    dev = hb.Z.device
+    logits = torch.empty(n_q, n_classes, hb.N, device=dev, dtype=torch.float32)
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    pred = torch.empty(n_q, hb.N, device=dev, dtype=torch.int32)
+    if labels is not None:
+        assert labels.dtype == torch.int64 and labels.is_contiguous()
+    _lib.check(_lib.load().r3d_query_logits_ce(_p(hb.Z), _p(hb.desc[HD_N_PROTO:]), n_q, hb.N, n_classes,
+                                               _p(labels), _p(logits), _p(loss), _p(pred), _st()))
+    return logits, loss, pred
