@@ -42,7 +42,6 @@ int orc_knn_topk(const float* x, int B, int C, int N, int k, int32_t* idx_out,
                  float* dist_out) {
   if (k > N) return 1;
   float* xx = (float*)malloc(sizeof(float) * N);
-  vi_t* row = (vi_t*)malloc(sizeof(vi_t) * N);
   for (int b = 0; b < B; ++b) {
     const float* xb = x + (size_t)b * C * N;
     for (int j = 0; j < N; ++j) {
@@ -50,23 +49,32 @@ int orc_knn_topk(const float* x, int B, int C, int N, int k, int32_t* idx_out,
       for (int c = 0; c < C; ++c) acc = fmaf(xb[(size_t)c * N + j], xb[(size_t)c * N + j], acc);
       xx[j] = acc;
     }
-    for (int i = 0; i < N; ++i) {
-      for (int j = 0; j < N; ++j) {
-        float dot = 0.f;
-        for (int c = 0; c < C; ++c) dot = fmaf(xb[(size_t)c * N + i], xb[(size_t)c * N + j], dot);
-        float inner = -2.f * dot;
-        float t = (-xx[j]) - inner;
-        row[j].v = t - xx[i];
-        row[j].i = j;
+    /* rows are independent: the OpenMP split changes nothing in any result */
+#pragma omp parallel
+    {
+      vi_t* row = (vi_t*)malloc(sizeof(vi_t) * N);
+      float* xi = (float*)malloc(sizeof(float) * C);
+#pragma omp for schedule(dynamic, 16)
+      for (int i = 0; i < N; ++i) {
+        for (int c = 0; c < C; ++c) xi[c] = xb[(size_t)c * N + i];
+        for (int j = 0; j < N; ++j) {
+          float dot = 0.f;
+          for (int c = 0; c < C; ++c) dot = fmaf(xi[c], xb[(size_t)c * N + j], dot);
+          float inner = -2.f * dot;
+          float t = (-xx[j]) - inner;
+          row[j].v = t - xx[i];
+          row[j].i = j;
+        }
+        qsort(row, N, sizeof(vi_t), cmp_desc);
+        for (int t = 0; t < k; ++t) {
+          idx_out[((size_t)b * N + i) * k + t] = row[t].i;
+          if (dist_out) dist_out[((size_t)b * N + i) * k + t] = row[t].v;
+        }
       }
-      qsort(row, N, sizeof(vi_t), cmp_desc);
-      for (int t = 0; t < k; ++t) {
-        idx_out[((size_t)b * N + i) * k + t] = row[t].i;
-        if (dist_out) dist_out[((size_t)b * N + i) * k + t] = row[t].v;
-      }
+      free(row); free(xi);
     }
   }
-  free(xx); free(row);
+  free(xx);
   return 0;
 }
 
@@ -107,30 +115,35 @@ int orc_knn_gap(const float* x, int B, int C, int N, int k, float* gap_out) {
 int orc_knn_l2(const float* X, int n, int d, int k, int32_t* idx_out, float* dist_out) {
   if (k > n) return 1;
   float* nrm = (float*)malloc(sizeof(float) * n);
-  vi_t* row = (vi_t*)malloc(sizeof(vi_t) * n);
   for (int i = 0; i < n; ++i) {
     float acc = 0.f;
     for (int c = 0; c < d; ++c) acc = fmaf(X[(size_t)i * d + c], X[(size_t)i * d + c], acc);
     nrm[i] = acc;
   }
-  for (int i = 0; i < n; ++i) {
-    const float* xi = X + (size_t)i * d;
-    for (int j = 0; j < n; ++j) {
-      const float* xj = X + (size_t)j * d;
-      float ip = 0.f;
-      for (int c = 0; c < d; ++c) ip = fmaf(xi[c], xj[c], ip);
-      float dis = (nrm[i] + nrm[j]) - 2.f * ip;
-      if (dis < 0.f) dis = 0.f;
-      row[j].v = dis;
-      row[j].i = j;
+#pragma omp parallel
+  {
+    vi_t* prow = (vi_t*)malloc(sizeof(vi_t) * n);
+#pragma omp for schedule(dynamic, 16)
+    for (int i = 0; i < n; ++i) {
+      const float* xi = X + (size_t)i * d;
+      for (int j = 0; j < n; ++j) {
+        const float* xj = X + (size_t)j * d;
+        float ip = 0.f;
+        for (int c = 0; c < d; ++c) ip = fmaf(xi[c], xj[c], ip);
+        float dis = (nrm[i] + nrm[j]) - 2.f * ip;
+        if (dis < 0.f) dis = 0.f;
+        prow[j].v = dis;
+        prow[j].i = j;
+      }
+      qsort(prow, n, sizeof(vi_t), cmp_asc);
+      for (int t = 0; t < k; ++t) {
+        idx_out[(size_t)i * k + t] = prow[t].i;
+        if (dist_out) dist_out[(size_t)i * k + t] = prow[t].v;
+      }
     }
-    qsort(row, n, sizeof(vi_t), cmp_asc);
-    for (int t = 0; t < k; ++t) {
-      idx_out[(size_t)i * k + t] = row[t].i;
-      if (dist_out) dist_out[(size_t)i * k + t] = row[t].v;
-    }
+    free(prow);
   }
-  free(nrm); free(row);
+  free(nrm);
   return 0;
 }
 
@@ -150,13 +163,15 @@ int orc_fps(const float* feat, int n, int d, int k, int32_t* out) {
   for (int t = 1; t < k; ++t) {
     const float* s = feat + (size_t)last * d;
     int best = 0; float bestv = -1.f;
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < n; ++i) {
       const float* xi = feat + (size_t)i * d;
       float acc = 0.f;
       for (int c = 0; c < d; ++c) { float df = xi[c] - s[c]; acc = fmaf(df, df, acc); }
       if (acc < mind[i]) mind[i] = acc;
-      if (mind[i] > bestv) { bestv = mind[i]; best = i; }
     }
+    for (int i = 0; i < n; ++i)
+      if (mind[i] > bestv) { bestv = mind[i]; best = i; }
     out[t] = best;
     last = best;
   }
@@ -172,6 +187,7 @@ int orc_fps(const float* feat, int n, int d, int k, int32_t* out) {
  * argmin over seeds (first minimum).
  * dist = sqrtf( fmaf chain of ((x_c - s_c) + 1e-6f)^2 ).                      */
 int orc_assign(const float* feat, int n, int d, const float* seeds, int m, int32_t* assign) {
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < n; ++i) {
     const float* xi = feat + (size_t)i * d;
     int best = 0; float bestv = INFINITY;
@@ -192,6 +208,7 @@ int orc_assign(const float* feat, int n, int d, const float* seeds, int m, int32
  * w = exp(-0.5 * (dist / sigma)^2).  Returns dist only (exp is taken in the
  * python restatement so its libm is the one torch would use).                 */
 int orc_pair_dist(const float* X, int n, int d, const int32_t* nbr, int k, float* dist_out) {
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < n; ++i) {
     const float* xi = X + (size_t)i * d;
     for (int t = 0; t < k; ++t) {

@@ -55,6 +55,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its bundled HIP runtime must be the one already mapped when our library's
+    # libamdhip64 dependency is resolved (two runtimes in one process see no device)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "r3dfsseg_amd: %s not found -- build it with `python -m r3dfsseg_amd.build` "

@@ -212,6 +212,152 @@ __global__ __launch_bounds__(256) void r3d_knn_topk_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// k <= 32, C <= 64 (the DGCNN encoder's kNN): register-resident selection.
+//
+// One wave owns 32 query rows and walks ALL candidates; 4 waves (128 queries) share the
+// candidate tiles staged in LDS.  Scores never leave the MFMA accumulator: register r of
+// lane half h holds, for query row r3d_acc_row(r), the 32 candidates of the tile (one per
+// lane of the half).  The sorted top-32 list of that query lives in register lv[r]/li[r]
+// across the SAME 32 lanes, so one instruction serves two queries (one per half) and an
+// insertion is ballot + popcount + DPP wave_shr:1.  No score tile in LDS, one barrier per
+// 64-candidate tile.
+// ---------------------------------------------------------------------------
+static __device__ __forceinline__ float dpp_wave_shr1_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+static __device__ __forceinline__ int dpp_wave_shr1_i(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false);
+}
+
+template <int CPAD>
+__global__ __launch_bounds__(256) void r3d_knn_small_kernel(
+    const float* __restrict__ x, long ldx, int N, int C, int k, int mode, const int* __restrict__ n_dev,
+    const float* __restrict__ nrm, int* __restrict__ idx_out, float* __restrict__ score_out) {
+  constexpr int KS = CPAD / 2;
+  constexpr int LD = CPAD + 1;
+  constexpr int TILE = 64;
+  constexpr int PER = TILE * CPAD / 256;
+  __shared__ float Bc[2][TILE * LD];
+  const int b = blockIdx.y;
+  const int n = n_dev ? min(*n_dev, N) : N;
+  if ((int)blockIdx.x * 128 >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, j = lane & 31;
+  const int qw0 = blockIdx.x * 128 + 32 * w;
+  const float* xb = x + (long)b * N * ldx;
+  const float* nb = nrm + (long)b * N;
+
+  float a[KS];
+  {
+    const int qrow = qw0 + j;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int c = 2 * s + h;
+      a[s] = (qrow < n && c < C) ? xb[(long)qrow * ldx + c] : 0.f;
+    }
+  }
+  float nq[16], lv[16], thr[16];
+  int li[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = qw0 + r3d_acc_row(r, lane);
+    nq[r] = row < n ? nb[row] : 0.f;
+    lv[r] = -INFINITY;
+    li[r] = -1;
+    thr[r] = -INFINITY;
+  }
+  float pre[PER];
+  auto gload = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = tid + 256 * i;
+      const int row = e / CPAD, c = e % CPAD;
+      const int grow = c0 + row;
+      pre[i] = (grow < n && c < C) ? xb[(long)grow * ldx + c] : 0.f;
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = tid + 256 * i;
+      Bc[buf][(e / CPAD) * LD + (e % CPAD)] = pre[i];
+    }
+  };
+  const int ntiles = (n + TILE - 1) / TILE;
+  const int klo = k - 1, khi = 32 + k - 1;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) gload(TILE * (t + 1));
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int cbase = TILE * t + 32 * sub;
+      if (cbase >= n) break;
+      const int cand = cbase + j;
+      const bool valid = cand < n;
+      const float nj = valid ? nb[cand] : 0.f;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* bp = &Bc[buf][(32 * sub + j) * LD + h];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bp[2 * s], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float sc;
+        if (mode == R3D_SCORE_DGCNN) {
+          const float inner = -2.f * acc[r];
+          const float tt = (-nj) - inner;
+          sc = tt - nq[r];
+        } else {
+          float dis = (nq[r] + nj) - 2.f * acc[r];
+          if (dis < 0.f) dis = 0.f;
+          sc = -dis;
+        }
+        if (!valid) sc = -INFINITY;
+        unsigned long long m = __ballot(sc > thr[r]);
+        while (m) {
+          unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+          const int slo = lo ? __ffs((int)lo) - 1 : 0;
+          const int shi = hi ? __ffs((int)hi) - 1 : 0;
+          const float cvlo = lo ? r3d_readlane_f(sc, slo) : -INFINITY;
+          const float cvhi = hi ? r3d_readlane_f(sc, 32 + shi) : -INFINITY;
+          lo &= lo - 1;
+          hi &= hi - 1;
+          m = ((unsigned long long)hi << 32) | lo;
+          const float cv = h ? cvhi : cvlo;
+          const int cidx = cbase + (h ? shi : slo);
+          const bool act = cv > thr[r];  // uniform within a half; false for the -inf filler
+          const unsigned long long ge = __ballot(lv[r] >= cv);
+          const int p = h ? __popc((unsigned)(ge >> 32)) : __popc((unsigned)ge);
+          const float upv = dpp_wave_shr1_f(lv[r]);
+          const int upi = dpp_wave_shr1_i(li[r]);
+          if (act) {
+            if (j == p) { lv[r] = cv; li[r] = cidx; }
+            else if (j > p) { lv[r] = upv; li[r] = upi; }
+          }
+          const float tlo = r3d_readlane_f(lv[r], klo);
+          const float thi = r3d_readlane_f(lv[r], khi);
+          thr[r] = h ? thi : tlo;
+        }
+      }
+    }
+    if (t + 1 < ntiles) sstore(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = qw0 + r3d_acc_row(r, lane);
+    if (row < n && j < k) {
+      idx_out[((long)b * N + row) * k + j] = li[r];
+      if (score_out) score_out[((long)b * N + row) * k + j] = lv[r];
+    }
+  }
+}
+
 static size_t knn_lds_bytes(int C) {
   const int Cp = (C + 1) & ~1;
   return sizeof(float) * ((size_t)KNN_Q * (Cp + 1) + (size_t)KNN_CH * (KNN_SLAB + 1) +
@@ -241,8 +387,19 @@ extern "C" int r3d_knn_topk(const float* x, long ldx, int B, int N, int C, int k
   R3D_REQUIRE(lds <= 160 * 1024, "r3d_knn_topk: C=%d needs %zu B of LDS (> 160 KiB)", C, lds);
   int rc = r3d_sqnorm(x, ldx, (long)B * N, C, norm_ws, stream);
   if (rc) return rc;
-  dim3 grid(r3d_cdiv(N, KNN_Q), B), block(256);
   hipStream_t st = (hipStream_t)stream;
+  if (k <= 32 && C <= 64) {
+    dim3 g2(r3d_cdiv(N, 128), B);
+    if (C <= 16)
+      hipLaunchKernelGGL(r3d_knn_small_kernel<16>, g2, dim3(256), 0, st, x, ldx, N, C, k, mode, n_valid_dev, norm_ws,
+                         idx_out, score_out);
+    else
+      hipLaunchKernelGGL(r3d_knn_small_kernel<64>, g2, dim3(256), 0, st, x, ldx, N, C, k, mode, n_valid_dev, norm_ws,
+                         idx_out, score_out);
+    R3D_LAUNCH_CHECK("r3d_knn_topk(small)");
+    return R3D_OK;
+  }
+  dim3 grid(r3d_cdiv(N, KNN_Q), B), block(256);
 #define KNN_LAUNCH(RR)                                                                           \
   do {                                                                                           \
     static bool attr_set = false;                                                                \

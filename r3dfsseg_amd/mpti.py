@@ -44,6 +44,12 @@ class MPTI_SelfAtten(nn.Module):
         self.lp_tol = getattr(args, "lp_tol", 1e-6)
         self.shot_level_clean_ratio = 0
         self._head = None
+        # CG launch budget: iterations are enqueued without knowing when the solver converges
+        # (no host sync in forward).  The budget follows the iteration count observed on earlier
+        # episodes (read back asynchronously); callers that synchronise anyway (learner.test)
+        # call lp_converged() and re-run with the full lp_max_iter in the rare miss.
+        self._lp_budget = min(32, self.lp_max_iter)
+        self._lp_probe = None
 
     # ------------------------------------------------------------------ features (mpti.py:579-595)
     def getFeatures_pm(self, x):
@@ -75,11 +81,35 @@ class MPTI_SelfAtten(nn.Module):
             self._head = (key, hb)
         return self._head[1]
 
+    def _lp_next_budget(self):
+        if self._lp_probe is not None:
+            host, ev = self._lp_probe
+            if ev.query():
+                conv, iters = int(host[0]), int(host[1])
+                if conv:
+                    self._lp_budget = min(self.lp_max_iter, max(12, iters + iters // 2 + 4))
+                else:
+                    self._lp_budget = min(self.lp_max_iter, self._lp_budget * 2)
+                self._lp_probe = None
+        return self._lp_budget
+
+    def _lp_post(self, hb):
+        if self._lp_probe is None:
+            host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            host.copy_(hb.stats, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._lp_probe = (host, ev)
+
+    def lp_converged(self):
+        """Host check (synchronises): did the last forward's label propagation converge?"""
+        return bool(self._head[1].stats[0].item())
+
     # ------------------------------------------------------------------ forward (mpti.py:414-577)
     def forward(self, support_x, support_y, query_x, query_y, gt_support_y=None, gt_query_y=None, train=False,
                 logger=None, step=None, path=None, sampled_classes=None, bg_pcd_x=None, bg_pcd_y=None,
                 support_c=None, support_flag=None, pcd_1024=None, label_1024=None, pcd_cutout=None,
-                label_cutout=None, eval=False):
+                label_cutout=None, eval=False, lp_iters=None):
         if train or self.training:
             from . import train_ops
             return train_ops.mpti_train_forward(self, support_x, support_y, query_x, query_y, gt_support_y,
@@ -100,7 +130,8 @@ class MPTI_SelfAtten(nn.Module):
         sy = support_y.reshape(S, N).to(torch.int32).contiguous()
         ops.head_prototypes(hb, sy, shot_keep, sfeat, sfeatT, qfeat)
         nbr = ops.knn(hb.nodes, 1, hb.n_cap, hb.kp1, mode=ops.SCORE_L2, n_valid=hb.desc[ops.HD_N_NODES:])
-        ops.label_propagate(hb, nbr, self.sigma, 0.99, self.lp_max_iter, self.lp_tol)
+        ops.label_propagate(hb, nbr, self.sigma, 0.99, lp_iters or self._lp_next_budget(), self.lp_tol)
+        self._lp_post(hb)
         labels = query_y.to(torch.int64).contiguous() if query_y is not None else None
         logits, loss, _ = ops.query_logits_ce(hb, n_q, self.n_classes, labels)
         self.num_prototypes_dev = hb.desc[ops.HD_N_PROTO]

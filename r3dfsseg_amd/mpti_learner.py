@@ -1,0 +1,82 @@
+"""Host-side mirror of the reference's models/mpti_learner.py::MPTILearner_V3.
+
+Identical constructor, attributes (.model/.optimizer/.lr_scheduler) and train()/test()
+signatures and return tuples (mpti_learner.py:50-102), so mpti_train_noise.py and
+eval_noise.py run against it unchanged.  A checkpoint path of the literal string
+"synthetic" initialises from r3dfsseg_amd.synthetic (no dataset/checkpoint files here).
+"""
+import torch
+from torch import optim
+
+from .checkpoint_util import load_model_checkpoint, load_pretrain_checkpoint
+from .mpti import MPTI_SelfAtten
+
+
+class MPTILearner_V3(object):
+    def __init__(self, args, mode='train'):
+        self.model = MPTI_SelfAtten(args)
+        if not torch.cuda.is_available():
+            raise RuntimeError("MPTILearner_V3 needs an MI355X: the forward pass has no CPU path")
+        self.model.cuda()
+        synthetic = 'synthetic' in (getattr(args, 'pretrain_checkpoint_path', None), getattr(args, 'model_checkpoint_path', None))
+        if synthetic:
+            from . import synthetic as S
+            self.model.load_state_dict(S.make_state_dict(vars(args) if not isinstance(args, dict) else args))
+        if mode == 'train':
+            if args.use_attention:
+                self.optimizer = torch.optim.Adam(
+                    [{'params': self.model.encoder.parameters(), 'lr': 0.0001},
+                     {'params': self.model.base_learner.parameters()},
+                     {'params': self.model.att_learner.parameters()},
+                     {'params': self.model.proj.parameters()}], lr=args.lr)
+            self.lr_scheduler = optim.lr_scheduler.StepLR(self.optimizer, step_size=args.step_size, gamma=args.gamma)
+            if not synthetic:
+                if args.model_checkpoint_path is None:
+                    self.model = load_pretrain_checkpoint(self.model, args.pretrain_checkpoint_path)
+                else:
+                    self.model, self.optimizer = load_model_checkpoint(self.model, args.model_checkpoint_path,
+                                                                       optimizer=self.optimizer, mode='train')
+        elif mode == 'test':
+            if not synthetic:
+                self.model = load_model_checkpoint(self.model, args.model_checkpoint_path, mode='test')
+        else:
+            raise ValueError('Wrong GraphLearner mode (%s)! Option:train/test' % mode)
+
+    def train(self, data, logger):
+        [support_x, support_y, query_x, query_y, support_c, query_c, gt_support_y, gt_query_y, bg_pcd_x, bg_pcd_y,
+         support_flag] = data
+        self.model.train()
+        (query_logits, lp_loss, contrastive_loss, query_acc_LP, query_acc_original, clean_ratio_LP_avg,
+         original_clean_ratio) = self.model(support_x, support_y, query_x, query_y, gt_support_y=gt_support_y,
+                                            gt_query_y=gt_query_y, train=True, logger=logger, bg_pcd_x=bg_pcd_x,
+                                            bg_pcd_y=bg_pcd_y, support_c=support_c, support_flag=support_flag)
+        loss = lp_loss + 0.1 * contrastive_loss
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        self.lr_scheduler.step()
+        query_pred = query_logits.argmax(dim=1)  # == softmax(dim=1).argmax(dim=1), mpti_learner.py:74
+        correct = torch.eq(query_pred, query_y).sum().item()
+        accuracy = correct / (query_y.shape[0] * query_y.shape[1])
+        return (loss, lp_loss, contrastive_loss, accuracy, query_acc_LP, query_acc_original, clean_ratio_LP_avg,
+                original_clean_ratio)
+
+    def test(self, data, sampled_classes, step=None, path=None, eval=False):
+        [support_x, support_y, query_x, query_y, _, _, gt_support_y] = data
+        self.model.eval()
+        with torch.no_grad():
+            logits, loss = self.model(support_x, support_y, query_x, query_y, gt_support_y=gt_support_y,
+                                      sampled_classes=sampled_classes, step=step, path=path, support_flag=None,
+                                      eval=eval)
+            pred = logits.argmax(dim=1)
+            correct = torch.eq(pred, query_y).sum().item()
+            if not self.model.lp_converged():  # CG launch budget too small for this episode: redo in full
+                logits, loss = self.model(support_x, support_y, query_x, query_y, gt_support_y=gt_support_y,
+                                          sampled_classes=sampled_classes, step=step, path=path,
+                                          support_flag=None, eval=eval, lp_iters=self.model.lp_max_iter)
+                pred = logits.argmax(dim=1)
+                correct = torch.eq(pred, query_y).sum().item()
+                if not self.model.lp_converged():
+                    raise RuntimeError("label propagation did not converge in %d CG iterations" % self.model.lp_max_iter)
+            accuracy = correct / (query_y.shape[0] * query_y.shape[1])
+        return pred, loss, accuracy

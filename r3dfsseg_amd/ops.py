@@ -18,6 +18,48 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+class KernelTimer:
+    """HIP-event timing of selected entry points on the stream they are launched on
+    (bench.py's roofline leg).  Disabled (None) by default: zero overhead."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.events = {n: [] for n in names}
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for n, ev in self.events.items():
+            ms = [a.elapsed_time(b) for a, b in ev]
+            out[n] = dict(launches=len(ms), total_ms=float(sum(ms)), avg_ms=float(sum(ms) / max(len(ms), 1)))
+        return out
+
+
+_TIMER = None
+
+
+def set_timer(timer):
+    global _TIMER
+    _TIMER = timer
+
+
+class _timed:
+    def __init__(self, name):
+        self.on = _TIMER is not None and name in _TIMER.names
+        self.name = name
+
+    def __enter__(self):
+        if self.on:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.b.record()
+            _TIMER.events[self.name].append((self.a, self.b))
+
+
 def _st():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -67,8 +109,9 @@ def knn(x_pm, B, N, k, mode=SCORE_DGCNN, n_valid=None, return_scores=False):
     norm = torch.empty(M, device=dev, dtype=torch.float32)
     idx = torch.empty(B, N, k, device=dev, dtype=torch.int32)
     sc = torch.empty(B, N, k, device=dev, dtype=torch.float32) if return_scores else None
-    _lib.check(_lib.load().r3d_knn_topk(_p(x_pm), ld, B, N, C, k, mode, _p(n_valid), _p(norm), _p(idx), _p(sc),
-                                        _st()))
+    with _timed("knn_topk_l2" if mode == SCORE_L2 else "knn_topk"):
+        _lib.check(_lib.load().r3d_knn_topk(_p(x_pm), ld, B, N, C, k, mode, _p(n_valid), _p(norm), _p(idx), _p(sc),
+                                            _st()))
     return (idx, sc) if return_scores else idx
 
 
@@ -82,8 +125,9 @@ def pointwise_conv(x_pm, W, scale=None, shift=None, act=ACT_NONE, out=None):
         out = torch.empty(M, Co, device=x_pm.device, dtype=torch.float32)
     M2, ldo = _rows(out)
     assert M2 == M and out.shape[1] == Co
-    _lib.check(_lib.load().r3d_pointwise_conv(_p(x_pm), ldx, _p(W), M, K, Co, _p(scale), _p(shift), act,
-                                              _p(out), ldo, _st()))
+    with _timed("pointwise_conv"):
+        _lib.check(_lib.load().r3d_pointwise_conv(_p(x_pm), ldx, _p(W), M, K, Co, _p(scale), _p(shift), act,
+                                                  _p(out), ldo, _st()))
     return out
 
 
@@ -94,8 +138,9 @@ def edgeconv(PQ, idx, W2, s2, t2, out, B, N, want_argmax=False):
     M, ldo = _rows(out)
     assert M == B * N and out.shape[1] == 64
     am = torch.empty(B * N, 64, device=PQ.device, dtype=torch.int32) if want_argmax else None
-    _lib.check(_lib.load().r3d_edgeconv_fwd(_p(PQ), _p(idx), _p(W2), _p(s2), _p(t2), _p(out), ldo, B, N, K,
-                                            _p(am), _st()))
+    with _timed("edgeconv"):
+        _lib.check(_lib.load().r3d_edgeconv_fwd(_p(PQ), _p(idx), _p(W2), _p(s2), _p(t2), _p(out), ldo, B, N, K,
+                                                _p(am), _st()))
     return am
 
 
@@ -104,7 +149,8 @@ def attention(qkv, B, N, out, want_lse=False):
     M2, ldo = _rows(out)
     assert M == B * N and M2 == M and qkv.shape[1] == 192 and out.shape[1] == 64
     lse = torch.empty(M, device=qkv.device, dtype=torch.float32) if want_lse else None
-    _lib.check(_lib.load().r3d_attention_fwd(_p(qkv), ld, B, N, _p(out), ldo, _p(lse), _st()))
+    with _timed("attention"):
+        _lib.check(_lib.load().r3d_attention_fwd(_p(qkv), ld, B, N, _p(out), ldo, _p(lse), _st()))
     return lse
 
 
@@ -139,17 +185,19 @@ def head_prototypes(hb, support_y, shot_keep, sfeat_pm, sfeatT, qfeat_pm):
     Mq, ldq = _rows(qfeat_pm)
     assert M == S * hb.N and Mq == hb.n_q_pts and sfeatT.is_contiguous() and sfeatT.shape == (S, hb.D, hb.N)
     assert support_y.dtype == torch.int32 and support_y.is_contiguous() and support_y.numel() == S * hb.N
-    _lib.check(_lib.load().r3d_head_prototypes(
-        _p(support_y), _p(shot_keep), _p(sfeat_pm), ldf, _p(sfeatT), _p(qfeat_pm), ldq, hb.n_way, hb.k_shot,
-        hb.N, hb.D, hb.n_q_pts, hb.k_sub, _p(hb.nodes), hb.nodes.stride(0), _p(hb.Y), _p(hb.desc),
-        _p(hb.assign), _p(hb.cluster_count), _p(hb.proto_ws), _st()))
+    with _timed("head_prototypes"):
+        _lib.check(_lib.load().r3d_head_prototypes(
+            _p(support_y), _p(shot_keep), _p(sfeat_pm), ldf, _p(sfeatT), _p(qfeat_pm), ldq, hb.n_way, hb.k_shot,
+            hb.N, hb.D, hb.n_q_pts, hb.k_sub, _p(hb.nodes), hb.nodes.stride(0), _p(hb.Y), _p(hb.desc),
+            _p(hb.assign), _p(hb.cluster_count), _p(hb.proto_ws), _st()))
 
 
 def label_propagate(hb, nbr, sigma, alpha=0.99, max_iter=200, tol=1e-6):
     assert nbr.shape == (1, hb.n_cap, hb.kp1) or nbr.shape == (hb.n_cap, hb.kp1)
-    _lib.check(_lib.load().r3d_label_propagate(
-        _p(hb.nodes), hb.nodes.stride(0), hb.D, _p(nbr), hb.kp1, _p(hb.Y), _p(hb.desc[HD_N_NODES:]), hb.n_cap,
-        float(sigma), float(alpha), int(max_iter), float(tol), _p(hb.Z), _p(hb.lp_ws), _p(hb.stats), _st()))
+    with _timed("label_propagate"):
+        _lib.check(_lib.load().r3d_label_propagate(
+            _p(hb.nodes), hb.nodes.stride(0), hb.D, _p(nbr), hb.kp1, _p(hb.Y), _p(hb.desc[HD_N_NODES:]), hb.n_cap,
+            float(sigma), float(alpha), int(max_iter), float(tol), _p(hb.Z), _p(hb.lp_ws), _p(hb.stats), _st()))
     return hb.Z
 
 
