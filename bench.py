@@ -110,7 +110,8 @@ def main():
         sx, sy, qx, qy = pool[i % n_pool]
         with torch.no_grad():
             logits, loss = model(sx, sy, qx, qy)
-        lp_flags.append(model._head[1].stats.clone())  # (converged, iterations) of this episode's CG
+        hb = model._head[1]
+        lp_flags.append(torch.cat((hb.stats, hb.knn_status)))  # (CG converged, CG iterations, kNN overflow)
         return logits, loss
 
     for i in range(args.warmup):
@@ -139,6 +140,8 @@ def main():
     ops.set_timer(None)
     ksum_all = timer.summary()
     lp = torch.stack(lp_flags[args.warmup:args.warmup + args.steps]).cpu()
+    if int(lp[:, 2].max()) != 0:
+        raise SystemExit("bench invalid: 201-NN survivor buffer overflowed")
     if int(lp[:, 0].min()) != 1:
         raise SystemExit("bench invalid: label propagation did not converge in %d timed episode(s)" % int((lp[:, 0] != 1).sum()))
 

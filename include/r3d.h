@@ -40,10 +40,17 @@ int r3d_copy_cols(const float* src, long ld_src, float* dst, long ld_dst, long M
  * Inner products are channel-ascending fp32 fma chains (bit-exact vs oracle/r3d_oracle.c);
  * ties resolve to the lower index; columns are sorted best first.
  * x (B*N, ldx); norm_ws (B*N) scratch; idx_out (B,N,k) int32; score_out optional (B,N,k);
- * n_valid_dev optional device int: only rows < *n_valid_dev take part. 1 <= k <= min(N,256). */
+ * n_valid_dev optional device int: only rows < *n_valid_dev take part. 1 <= k <= min(N,256).
+ * x_cm: optional (B,C,N) channel-major copy (the reference's own tensor layout); the streamed
+ * kernel (k <= 32, C <= 64) reads its operands from it and makes the copy into cm_ws (B*C*N
+ * floats) when x_cm is NULL.
+ * status: optional device int32.  For k > 32 a non-NULL status selects the two-pass
+ * append-and-rank kernel; bit 0 set afterwards means its survivor buffer overflowed and the
+ * call must be repeated with status == NULL (insertion kernel, always exact). */
 int r3d_sqnorm(const float* x, long ldx, long rows, int C, float* out, void* stream);
-int r3d_knn_topk(const float* x, long ldx, int B, int N, int C, int k, int mode, const int32_t* n_valid_dev,
-                 float* norm_ws, int32_t* idx_out, float* score_out, void* stream);
+int r3d_knn_topk(const float* x, long ldx, const float* x_cm, int B, int N, int C, int k, int mode,
+                 const int32_t* n_valid_dev, float* norm_ws, float* cm_ws, int32_t* idx_out, float* score_out,
+                 int32_t* status, void* stream);
 
 /* ---- 1x1 convolution + folded BatchNorm/bias + activation ---------------------------
  * models/dgcnn.py:64-80 conv1d, models/mpti.py:18-40 BaseLearner, models/attention.py:39-41.

@@ -24,7 +24,7 @@ _SIGS = {
     "r3d_pm_to_cm": (c_i, [c_f, c_l, c_i, c_i, c_i, c_f, c_f]),
     "r3d_copy_cols": (c_i, [c_f, c_l, c_f, c_l, c_l, c_i, c_f]),
     "r3d_sqnorm": (c_i, [c_f, c_l, c_l, c_i, c_f, c_f]),
-    "r3d_knn_topk": (c_i, [c_f, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f]),
+    "r3d_knn_topk": (c_i, [c_f, c_l, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "r3d_pointwise_conv": (c_i, [c_f, c_l, c_f, c_l, c_i, c_i, c_f, c_f, c_i, c_f, c_l, c_f]),
     "r3d_edgeconv_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f, c_f]),
     "r3d_attention_fwd": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_f]),

@@ -33,7 +33,10 @@ __global__ __launch_bounds__(256) void r3d_attention_fwd_kernel(
   // Q^T fragments: B[k = ch][j = query]
   float bq[32];
 #pragma unroll
-  for (int s = 0; s < 32; ++s) bq[s] = q_ok ? qkv[(base + q_row) * ld + 2 * s + (lane >> 5)] : 0.f;
+  for (int s = 0; s < 32; ++s) {
+    const float v = qkv[(base + min(q_row, N - 1)) * ld + 2 * s + (lane >> 5)];
+    bq[s] = r3d_keep(v, q_ok);
+  }
   f32x16 o0, o1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
@@ -44,16 +47,15 @@ __global__ __launch_bounds__(256) void r3d_attention_fwd_kernel(
   float4 kreg[2], vreg[2];
   auto load_tile = [&](int key0) {
     const int kr = key0 + st_row;
+    const bool ok = kr < N;
+    const int krc = min(kr, N - 1);  // unconditional loads, masked afterwards
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (kr < N) {
-        const float* p = qkv + (base + kr) * ld + 4 * (st_c4 + i);
-        kreg[i] = *reinterpret_cast<const float4*>(p + 64);
-        vreg[i] = *reinterpret_cast<const float4*>(p + 128);
-      } else {
-        kreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        vreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      const float* p = qkv + (base + krc) * ld + 4 * (st_c4 + i);
+      const float4 kk = *reinterpret_cast<const float4*>(p + 64);
+      const float4 vv = *reinterpret_cast<const float4*>(p + 128);
+      kreg[i] = make_float4(r3d_keep(kk.x, ok), r3d_keep(kk.y, ok), r3d_keep(kk.z, ok), r3d_keep(kk.w, ok));
+      vreg[i] = make_float4(r3d_keep(vv.x, ok), r3d_keep(vv.y, ok), r3d_keep(vv.z, ok), r3d_keep(vv.w, ok));
     }
   };
   auto store_tile = [&](int buf) {

@@ -56,4 +56,11 @@ static __device__ __forceinline__ float r3d_wave_max(float v) {
   return v;
 }
 
+// keep ? v : 0 WITHOUT a select on the loaded value: hipcc (CodeGenPrepare) turns
+// `cond ? load : 0` -- even with the load hoisted by hand -- into a branch around the load and
+// then waits vmcnt(0) after every such load, serialising a whole staging pass.
+static __device__ __forceinline__ float r3d_keep(float v, bool keep) {
+  return __uint_as_float(__float_as_uint(v) & (keep ? 0xffffffffu : 0u));
+}
+
 static inline int r3d_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

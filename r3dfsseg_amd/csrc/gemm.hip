@@ -39,15 +39,25 @@ __global__ __launch_bounds__(256) void r3d_pointwise_gemm_kernel(
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int srow = tid >> 5, scol = tid & 31;  // 8 rows x 32 cols per pass
   for (int k0 = 0; k0 < K; k0 += G_BK) {
-    __syncthreads();
+    // phase 1: all global loads (unconditional, clamped addresses; common.h: r3d_keep);
+    // phase 2: all LDS writes -- written as two loops so the loads stay in flight together
+    float xv[G_BM / 8], wv[G_BN / 8];
+    const int gk = k0 + scol;
+    const int gkc = min(gk, K - 1);
 #pragma unroll
     for (int p = 0; p < G_BM / 8; ++p) {
       const int row = srow + 8 * p;
       const long gm = m0 + row;
-      const int gk = k0 + scol;
-      Xs[row * G_LD + scol] = (gm < M && gk < K) ? X[gm * ldx + gk] : 0.f;
       const int gj = n0 + row;
-      Ws[row * G_LD + scol] = (gj < Co && gk < K) ? W[(long)gj * K + gk] : 0.f;
+      xv[p] = r3d_keep(X[min(gm, (long)M - 1) * ldx + gkc], gm < M && gk < K);
+      wv[p] = r3d_keep(W[(long)min(gj, Co - 1) * K + gkc], gj < Co && gk < K);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < G_BM / 8; ++p) {
+      const int row = srow + 8 * p;
+      Xs[row * G_LD + scol] = xv[p];
+      Ws[row * G_LD + scol] = wv[p];
     }
     __syncthreads();
     const float* ap = Xs + (32 * wm + (lane & 31)) * G_LD + (lane >> 5);

@@ -120,8 +120,10 @@ __global__ __launch_bounds__(256) void r3d_knn_topk_kernel(
   // stage the 32 query rows (zero beyond n and in the odd-C pad column)
   for (int r = w; r < KNN_Q; r += 4) {
     const int row = q0 + r;
-    for (int c = lane; c < Cp; c += 64)
-      Aq[r * As + c] = (row < n && c < C) ? xb[(long)row * ldx + c] : 0.f;
+    for (int c = lane; c < Cp; c += 64) {
+      const float v = xb[(long)min(row, n - 1) * ldx + min(c, C - 1)];
+      Aq[r * As + c] = r3d_keep(v, row < n && c < C);
+    }
   }
   if (tid < KNN_Q) nq[tid] = (q0 + tid < n) ? nb[q0 + tid] : 0.f;
 
@@ -142,8 +144,10 @@ __global__ __launch_bounds__(256) void r3d_knn_topk_kernel(
       __syncthreads();  // Bc (and, first time round, Dt of the previous chunk) free
       for (int r = w; r < KNN_CH; r += 4) {
         const int row = c0 + r;
-        for (int c = lane; c < sw; c += 64)
-          Bc[r * Bs + c] = (row < n && s0 + c < C) ? xb[(long)row * ldx + s0 + c] : 0.f;
+        for (int c = lane; c < sw; c += 64) {
+          const float v = xb[(long)min(row, n - 1) * ldx + min(s0 + c, C - 1)];
+          Bc[r * Bs + c] = r3d_keep(v, row < n && s0 + c < C);
+        }
       }
       __syncthreads();
       const float* ap = Aq + (lane & 31) * As + s0 + (lane >> 5);
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256) void r3d_knn_topk_kernel(
     {
       const int cj = c0 + 32 * w + (lane & 31);
       const bool valid = cj < n;
-      const float nj = valid ? nb[cj] : 0.f;
+      const float nj = r3d_keep(nb[min(cj, n - 1)], valid);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = r3d_acc_row(r, lane);
@@ -213,15 +217,27 @@ __global__ __launch_bounds__(256) void r3d_knn_topk_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// k <= 32, C <= 64 (the DGCNN encoder's kNN): register-resident selection.
+// k <= 32, C <= 64 (the DGCNN encoder's kNN): exact two-pass selection, streamed.
 //
-// One wave owns 32 query rows and walks ALL candidates; 4 waves (128 queries) share the
-// candidate tiles staged in LDS.  Scores never leave the MFMA accumulator: register r of
-// lane half h holds, for query row r3d_acc_row(r), the 32 candidates of the tile (one per
-// lane of the half).  The sorted top-32 list of that query lives in register lv[r]/li[r]
-// across the SAME 32 lanes, so one instruction serves two queries (one per half) and an
-// insertion is ballot + popcount + DPP wave_shr:1.  No score tile in LDS, one barrier per
-// 64-candidate tile.
+// Operands come from a CHANNEL-MAJOR copy xT (B, C, N): for a fixed channel the 32 lanes of
+// a half-wave read 32 consecutive points = one 128-B line, which is exactly the MFMA operand
+// layout (lane -> point, lane half -> channel of the k-pair).  So fragments go global -> VGPR
+// with no LDS staging and NO barrier in the main loops; every wave streams independently with
+// the next sub-tile's 32 loads in flight behind the current MFMA chain.
+//
+// One workgroup = 32 query rows; its 4 waves split the 32-candidate sub-tiles round-robin.
+// Scores never leave the MFMA accumulator: register r of lane half h holds, for query row
+// r3d_acc_row(r), the 32 candidates of the sub-tile, one per lane of the half.
+//   pass A  every (wave, lane) pair is a GROUP of candidates of a query; keep the group
+//           maximum (one v_max per score).  The k-th largest of the 128 group maxima is a
+//           lower bound tau of the k-th best score (128 distinct real candidates), and a
+//           tight one (expected rank ~ k + 2).
+//   pass B  recompute the scores (matrix-core time is cheap, insertion latency is not) and
+//           insert only candidates with score >= tau into the wave's sorted list, which
+//           lives in lv[r]/li[r] across the SAME 32 lanes: one instruction serves two
+//           queries (one per half), an insertion is ballot + popcount + DPP wave_shr:1.
+//   merge   the 4 partial lists of a query meet in LDS; rank by counting, emit rank < k.
+// Exactness never depends on tau (the lists keep the best 32 whatever passes).
 // ---------------------------------------------------------------------------
 static __device__ __forceinline__ float dpp_wave_shr1_f(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
@@ -229,133 +245,504 @@ static __device__ __forceinline__ float dpp_wave_shr1_f(float v) {
 static __device__ __forceinline__ int dpp_wave_shr1_i(int v) {
   return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false);
 }
+static __device__ __forceinline__ unsigned f2key(float v) {  // order-preserving float -> uint
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+static __device__ __forceinline__ float key2f(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+static __device__ __forceinline__ bool entry_better(float v1, int i1, float v2, int i2) {
+  return v1 > v2 || (v1 == v2 && i1 < i2);
+}
 
-template <int CPAD>
+// squared norms from the channel-major copy (same channel-ascending fmaf chain)
+__global__ void r3d_sqnorm_cm_kernel(const float* __restrict__ xT, int C, int N, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float* p = xT + (long)b * C * N + i;
+  float acc = 0.f;
+  for (int c = 0; c < C; ++c) acc = __builtin_fmaf(p[(long)c * N], p[(long)c * N], acc);
+  out[(long)b * N + i] = acc;
+}
+
+#ifdef KNN_STAMPS
+__device__ unsigned long long g_knn_dbg[16];
+#define KSTAMP(i) do { if (blockIdx.x == 7 && blockIdx.y == 3 && threadIdx.x == 0) g_knn_dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define KSTAMP(i)
+#endif
+
+template <int KS>
 __global__ __launch_bounds__(256) void r3d_knn_small_kernel(
-    const float* __restrict__ x, long ldx, int N, int C, int k, int mode, const int* __restrict__ n_dev,
+    const float* __restrict__ xT, int N, int C, int k, int mode, const int* __restrict__ n_dev,
     const float* __restrict__ nrm, int* __restrict__ idx_out, float* __restrict__ score_out) {
-  constexpr int KS = CPAD / 2;
-  constexpr int LD = CPAD + 1;
-  constexpr int TILE = 64;
-  constexpr int PER = TILE * CPAD / 256;
-  __shared__ float Bc[2][TILE * LD];
+  __shared__ float smem[32 * 129 > 2 * 32 * 128 ? 32 * 129 : 2 * 32 * 128];
+  __shared__ float tau_s[32];
   const int b = blockIdx.y;
   const int n = n_dev ? min(*n_dev, N) : N;
-  if ((int)blockIdx.x * 128 >= n) return;
+  const int q0 = blockIdx.x * 32;
+  if (q0 >= n) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, j = lane & 31;
-  const int qw0 = blockIdx.x * 128 + 32 * w;
-  const float* xb = x + (long)b * N * ldx;
+  const float* xb = xT + (long)b * C * N;
   const float* nb = nrm + (long)b * N;
 
   float a[KS];
   {
-    const int qrow = qw0 + j;
+    // loads are UNCONDITIONAL on clamped addresses and masked afterwards: a load inside a
+    // conditional arm makes hipcc branch around every one of them and wait vmcnt(0) each time
+    const int qrow = q0 + j;
+    const int qc = min(qrow, n - 1);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int c = 2 * s + h;
-      a[s] = (qrow < n && c < C) ? xb[(long)qrow * ldx + c] : 0.f;
+      const float v = xb[(long)min(c, C - 1) * N + qc];
+      a[s] = r3d_keep(v, qrow < n && c < C);
     }
   }
-  float nq[16], lv[16], thr[16];
+  float nq[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = q0 + r3d_acc_row(r, lane);
+    nq[r] = r3d_keep(nb[min(row, n - 1)], row < n);
+  }
+  const int nsub = (n + 31) / 32;
+
+  auto bload = [&](int st, float (&bf)[KS], float& nj) {
+    const int cand = 32 * st + j;
+    const bool ok = cand < n;
+    const int cc = min(cand, n - 1);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int c = 2 * s + h;
+      const float v = xb[(long)min(c, C - 1) * N + cc];
+      bf[s] = r3d_keep(v, ok && c < C);
+    }
+    nj = r3d_keep(nb[cc], ok);
+  };
+  auto scores = [&](int st, const float (&bf)[KS], float nj, f32x16& sc) {
+    const bool valid = 32 * st + j < n;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bf[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v;
+      if (mode == R3D_SCORE_DGCNN) {
+        const float inner = -2.f * acc[r];
+        const float tt = (-nj) - inner;
+        v = tt - nq[r];
+      } else {
+        float dis = (nq[r] + nj) - 2.f * acc[r];
+        if (dis < 0.f) dis = 0.f;
+        v = -dis;
+      }
+      sc[r] = valid ? v : -INFINITY;
+    }
+  };
+
+  float bfA[KS], bfB[KS], njA, njB;
+  KSTAMP(0);
+  // ------------------------------------------------------------------ pass A: group maxima
+  float gm[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) gm[r] = -INFINITY;
+  {
+    int st = w;
+    if (st < nsub) bload(st, bfA, njA);
+    while (st < nsub) {
+      const int st2 = st + 4;
+      if (st2 < nsub) bload(st2, bfB, njB);
+      {
+        f32x16 sc;
+        scores(st, bfA, njA, sc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gm[r] = fmaxf(gm[r], sc[r]);
+      }
+      st = st2;
+      if (st >= nsub) break;
+      const int st3 = st + 4;
+      if (st3 < nsub) bload(st3, bfA, njA);
+      {
+        f32x16 sc;
+        scores(st, bfB, njB, sc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gm[r] = fmaxf(gm[r], sc[r]);
+      }
+      st = st3;
+    }
+  }
+  KSTAMP(1);
+  // tau[q] = k-th largest of the 128 group maxima of query q
+  {
+    float* gmax = smem;  // [32][129]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gmax[r3d_acc_row(r, lane) * 129 + 32 * w + j] = gm[r];
+    __syncthreads();
+    for (int qq = 0; qq < 8; ++qq) {
+      const int q = 8 * w + qq;
+      const unsigned k0 = f2key(gmax[q * 129 + lane]);
+      const unsigned k1 = f2key(gmax[q * 129 + 64 + lane]);
+      unsigned res = 0;
+      for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = res | (1u << bit);
+        const int cnt = __popcll(__ballot(k0 >= cand)) + __popcll(__ballot(k1 >= cand));
+        if (cnt >= k) res = cand;
+      }
+      if (lane == 0) tau_s[q] = key2f(res);
+    }
+    __syncthreads();
+  }
+  float tauq[16], lv[16], thr[16];
   int li[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int row = qw0 + r3d_acc_row(r, lane);
-    nq[r] = row < n ? nb[row] : 0.f;
+    tauq[r] = tau_s[r3d_acc_row(r, lane)];
     lv[r] = -INFINITY;
     li[r] = -1;
     thr[r] = -INFINITY;
   }
-  float pre[PER];
-  auto gload = [&](int c0) {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int e = tid + 256 * i;
-      const int row = e / CPAD, c = e % CPAD;
-      const int grow = c0 + row;
-      pre[i] = (grow < n && c < C) ? xb[(long)grow * ldx + c] : 0.f;
-    }
-  };
-  auto sstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int e = tid + 256 * i;
-      Bc[buf][(e / CPAD) * LD + (e % CPAD)] = pre[i];
-    }
-  };
-  const int ntiles = (n + TILE - 1) / TILE;
   const int klo = k - 1, khi = 32 + k - 1;
-  gload(0);
-  sstore(0);
-  __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < ntiles) gload(TILE * (t + 1));
+  KSTAMP(2);
+
+  // ------------------------------------------------------------------ pass B: select
+  auto select = [&](int st, const f32x16& sc) {
+    const int cbase = 32 * st;
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      const int cbase = TILE * t + 32 * sub;
-      if (cbase >= n) break;
-      const int cand = cbase + j;
-      const bool valid = cand < n;
-      const float nj = valid ? nb[cand] : 0.f;
-      f32x16 acc;
+    for (int r = 0; r < 16; ++r) {
+      const float s_r = sc[r];
+      unsigned long long m = __ballot(s_r >= tauq[r] && s_r > thr[r]);
+      while (m) {
+        unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+        const int slo = lo ? __ffs((int)lo) - 1 : 0;
+        const int shi = hi ? __ffs((int)hi) - 1 : 0;
+        const float cvlo = lo ? r3d_readlane_f(s_r, slo) : -INFINITY;
+        const float cvhi = hi ? r3d_readlane_f(s_r, 32 + shi) : -INFINITY;
+        lo &= lo - 1;
+        hi &= hi - 1;
+        m = ((unsigned long long)hi << 32) | lo;
+        const float cv = h ? cvhi : cvlo;
+        const int cidx = cbase + (h ? shi : slo);
+        const bool act = cv > thr[r];  // uniform within a half; false for the -inf filler
+        const unsigned long long ge = __ballot(lv[r] >= cv);
+        const int p = h ? __popc((unsigned)(ge >> 32)) : __popc((unsigned)ge);
+        const float upv = dpp_wave_shr1_f(lv[r]);
+        const int upi = dpp_wave_shr1_i(li[r]);
+        if (act) {
+          if (j == p) { lv[r] = cv; li[r] = cidx; }
+          else if (j > p) { lv[r] = upv; li[r] = upi; }
+        }
+        const float tlo = r3d_readlane_f(lv[r], klo);
+        const float thi = r3d_readlane_f(lv[r], khi);
+        thr[r] = h ? thi : tlo;
+      }
+    }
+  };
+  {
+    int st = w;
+    if (st < nsub) bload(st, bfA, njA);
+    while (st < nsub) {
+      const int st2 = st + 4;
+      if (st2 < nsub) bload(st2, bfB, njB);
+      {
+        f32x16 sc;
+        scores(st, bfA, njA, sc);
+        select(st, sc);
+      }
+      st = st2;
+      if (st >= nsub) break;
+      const int st3 = st + 4;
+      if (st3 < nsub) bload(st3, bfA, njA);
+      {
+        f32x16 sc;
+        scores(st, bfB, njB, sc);
+        select(st, sc);
+      }
+      st = st3;
+    }
+  }
+  KSTAMP(3);
+
+  // ------------------------------------------------------------------ merge the 4 partial lists
+  __syncthreads();                         // gmax (aliased) fully consumed by every wave
+  float* mv = smem;                        // [32 queries][4 waves][32]
+  int* mi = (int*)(smem + 32 * 128);       // same shape
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int q = r3d_acc_row(r, lane);
+    mv[(q * 4 + w) * 32 + j] = lv[r];
+    mi[(q * 4 + w) * 32 + j] = li[r];
+  }
+  __syncthreads();
+  for (int qq = 0; qq < 8; ++qq) {
+    const int q = 8 * w + qq;
+    const int row = q0 + q;
+    if (row >= n) break;
+    // lane holds entries `lane` and `64 + lane` of the query's 4 x 32 slots (list = slot / 32)
+    const float v0 = mv[q * 128 + lane], v1 = mv[q * 128 + 64 + lane];
+    const int i0 = mi[q * 128 + lane], i1 = mi[q * 128 + 64 + lane];
+    int rank0 = 0, rank1 = 0;
+#pragma unroll
+    for (int l4 = 0; l4 < 4; ++l4) {
+      const float lvv = (l4 < 2) ? v0 : v1;
+      const int lii = (l4 < 2) ? i0 : i1;
+      const unsigned long long real = __ballot(lvv != -INFINITY);
+      const int cnt = __popc((unsigned)(real >> (32 * (l4 & 1))));  // sorted list: real entries first
+      for (int t = 0; t < cnt; ++t) {
+        const float ov = r3d_readlane_f(lvv, 32 * (l4 & 1) + t);
+        const int oi = __builtin_amdgcn_readlane(lii, 32 * (l4 & 1) + t);
+        rank0 += entry_better(ov, oi, v0, i0) ? 1 : 0;
+        rank1 += entry_better(ov, oi, v1, i1) ? 1 : 0;
+      }
+    }
+    if (v0 != -INFINITY && rank0 < k) {
+      idx_out[((long)b * N + row) * k + rank0] = i0;
+      if (score_out) score_out[((long)b * N + row) * k + rank0] = v0;
+    }
+    if (v1 != -INFINITY && rank1 < k) {
+      idx_out[((long)b * N + row) * k + rank1] = i1;
+      if (score_out) score_out[((long)b * N + row) * k + rank1] = v1;
+    }
+  }
+  KSTAMP(4);
+}
+
+// ---------------------------------------------------------------------------
+// 32 < k <= 256 (the head's 201-NN over graph nodes, C = 192): exact two-pass selection,
+// streamed like the small kernel, with the survivors of pass B APPENDED to a per-query LDS
+// buffer (one LDS atomic per survivor, no ordering work) and ranked once at the end.
+//
+// One workgroup = 32 query rows x 8 waves; wave w takes sub-tiles w, w+8, ...  A group of
+// candidates of a query is (wave, lane) = candidate index mod 256; pass A keeps the TOP-2
+// of every group (512 distinct real candidates per query): their k-th largest value is a
+// lower bound tau of the k-th best score, expected rank ~ 1.07 k.  Pass B appends every
+// candidate with score >= tau; the buffer (KB_CAP entries) is then ranked by counting
+// (score desc, index asc) and ranks < k are emitted, i.e. the output is sorted.  If more
+// than KB_CAP candidates reach tau (pathological index/score correlation, or > KB_CAP - k
+// exact ties at tau) the overflow bit of *status is set and the caller must fall back to the
+// insertion kernel above -- never silently wrong.
+// Channels run in chunks of 64 (32 MFMA k-pairs): fragments of the next chunk are in flight
+// behind the current chunk's MFMA chain; query fragments sit in LDS (conflict-free stride).
+// ---------------------------------------------------------------------------
+#define KB_WAVES 8
+#define KB_CAP 384
+#define KB_GROUPS (KB_WAVES * 32)
+
+__global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_big_kernel(
+    const float* __restrict__ xT, int N, int C, int k, int mode, const int* __restrict__ n_dev,
+    const float* __restrict__ nrm, int* __restrict__ idx_out, float* __restrict__ score_out,
+    int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int cnt_s[32];
+  __shared__ float tau_s[32];
+  const int b = blockIdx.y;
+  const int n = n_dev ? min(*n_dev, N) : N;
+  const int q0 = blockIdx.x * 32;
+  if (q0 >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, j = lane & 31;
+  const int nch = (C + 63) / 64;          // channel chunks of 64
+  const int Cs = nch * 64 + 1;            // LDS row stride of the query fragments (odd)
+  float* Aq = smem;                       // [32][Cs]
+  float* region = smem + 32 * Cs;         // pass A: gmax [32][2*KB_GROUPS + 1]; pass B: buffers
+  const float* xb = xT + (long)b * C * N;
+  const float* nb = nrm + (long)b * N;
+
+  for (int e = tid; e < 32 * nch * 64; e += 64 * KB_WAVES) {
+    const int c = e >> 5, jj = e & 31;
+    const float v = xb[(long)min(c, C - 1) * N + min(q0 + jj, n - 1)];
+    Aq[jj * Cs + c] = r3d_keep(v, c < C && q0 + jj < n);
+  }
+  if (tid < 32) cnt_s[tid] = 0;
+  float nq[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = q0 + r3d_acc_row(r, lane);
+    nq[r] = r3d_keep(nb[min(row, n - 1)], row < n);
+  }
+  __syncthreads();
+
+  const int nsub = (n + 31) / 32;
+  const int my_sub = (nsub - w + KB_WAVES - 1) / KB_WAVES;  // sub-tiles of this wave (w < nsub assumed below)
+  const int T = (w < nsub) ? my_sub * nch : 0;              // (sub-tile, chunk) units
+
+  auto bload = [&](int t, float (&bf)[32]) {
+    const int st = w + KB_WAVES * (t / nch), ch = t % nch;
+    const int cand = 32 * st + j;
+    const bool ok = cand < n;
+    const int cc = min(cand, n - 1);
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const int c = 64 * ch + 2 * s + h;
+      bf[s] = r3d_keep(xb[(long)min(c, C - 1) * N + cc], ok && c < C);
+    }
+  };
+  f32x16 acc;
+  auto mma = [&](int t, const float (&bf)[32]) {
+    const int ch = t % nch;
+    if (ch == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const float* bp = &Bc[buf][(32 * sub + j) * LD + h];
+    }
+    const float* ap = Aq + j * Cs + 64 * ch + h;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bp[2 * s], acc, 0, 0, 0);
+    for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bf[s], acc, 0, 0, 0);
+  };
+  auto scores = [&](int st, f32x16& sc) {
+    const int cand = 32 * st + j;
+    const bool valid = cand < n;
+    const float nj = r3d_keep(nb[min(cand, n - 1)], valid);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float sc;
-        if (mode == R3D_SCORE_DGCNN) {
-          const float inner = -2.f * acc[r];
-          const float tt = (-nj) - inner;
-          sc = tt - nq[r];
+    for (int r = 0; r < 16; ++r) {
+      float v;
+      if (mode == R3D_SCORE_DGCNN) {
+        const float inner = -2.f * acc[r];
+        const float tt = (-nj) - inner;
+        v = tt - nq[r];
+      } else {
+        float dis = (nq[r] + nj) - 2.f * acc[r];
+        if (dis < 0.f) dis = 0.f;
+        v = -dis;
+      }
+      sc[r] = valid ? v : -INFINITY;
+    }
+  };
+
+  float bfA[32], bfB[32];
+  // ------------------------------------------------------------------ pass A: top-2 per group
+  float g1[16], g2[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { g1[r] = -INFINITY; g2[r] = -INFINITY; }
+  auto finishA = [&](int t) {
+    if (t % nch != nch - 1) return;
+    f32x16 sc;
+    scores(w + KB_WAVES * (t / nch), sc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float x = sc[r];
+      const float lo = fminf(g1[r], x);
+      g1[r] = fmaxf(g1[r], x);
+      g2[r] = fmaxf(g2[r], lo);
+    }
+  };
+  if (T > 0) bload(0, bfA);
+  for (int t = 0; t < T; t += 2) {
+    if (t + 1 < T) bload(t + 1, bfB);
+    mma(t, bfA);
+    finishA(t);
+    if (t + 1 >= T) break;
+    if (t + 2 < T) bload(t + 2, bfA);
+    mma(t + 1, bfB);
+    finishA(t + 1);
+  }
+  {
+    constexpr int GS = 2 * KB_GROUPS + 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int q = r3d_acc_row(r, lane);
+      region[q * GS + 2 * (32 * w + j)] = g1[r];
+      region[q * GS + 2 * (32 * w + j) + 1] = g2[r];
+    }
+    __syncthreads();
+    for (int qq = 0; qq < 32 / KB_WAVES; ++qq) {
+      const int q = (32 / KB_WAVES) * w + qq;
+      unsigned key[2 * KB_GROUPS / 64];
+#pragma unroll
+      for (int i = 0; i < 2 * KB_GROUPS / 64; ++i) key[i] = f2key(region[q * GS + 64 * i + lane]) >> 16;
+      unsigned res = 0;  // largest 16-bit key prefix with at least k retained values at or above it
+      for (int bit = 15; bit >= 0; --bit) {
+        const unsigned cand = res | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < 2 * KB_GROUPS / 64; ++i) c += __popcll(__ballot(key[i] >= cand));
+        if (c >= k) res = cand;
+      }
+      if (lane == 0) tau_s[q] = key2f(res << 16);  // truncation rounds DOWN in key order: still a lower bound
+    }
+    __syncthreads();
+  }
+  float tauq[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tauq[r] = tau_s[r3d_acc_row(r, lane)];
+  __syncthreads();  // gmax region is reused as the survivor buffers from here on
+
+  // ------------------------------------------------------------------ pass B: append survivors
+  float* bufv = region;                      // [32][KB_CAP]
+  int* bufi = (int*)(region + 32 * KB_CAP);  // [32][KB_CAP]
+  bool overflow = false;
+  auto finishB = [&](int t) {
+    if (t % nch != nch - 1) return;
+    const int st = w + KB_WAVES * (t / nch);
+    f32x16 sc;
+    scores(st, sc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (sc[r] >= tauq[r]) {
+        const int q = r3d_acc_row(r, lane);
+        const int slot = atomicAdd(&cnt_s[q], 1);
+        if (slot < KB_CAP) {
+          bufv[q * KB_CAP + slot] = sc[r];
+          bufi[q * KB_CAP + slot] = 32 * st + j;
         } else {
-          float dis = (nq[r] + nj) - 2.f * acc[r];
-          if (dis < 0.f) dis = 0.f;
-          sc = -dis;
-        }
-        if (!valid) sc = -INFINITY;
-        unsigned long long m = __ballot(sc > thr[r]);
-        while (m) {
-          unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
-          const int slo = lo ? __ffs((int)lo) - 1 : 0;
-          const int shi = hi ? __ffs((int)hi) - 1 : 0;
-          const float cvlo = lo ? r3d_readlane_f(sc, slo) : -INFINITY;
-          const float cvhi = hi ? r3d_readlane_f(sc, 32 + shi) : -INFINITY;
-          lo &= lo - 1;
-          hi &= hi - 1;
-          m = ((unsigned long long)hi << 32) | lo;
-          const float cv = h ? cvhi : cvlo;
-          const int cidx = cbase + (h ? shi : slo);
-          const bool act = cv > thr[r];  // uniform within a half; false for the -inf filler
-          const unsigned long long ge = __ballot(lv[r] >= cv);
-          const int p = h ? __popc((unsigned)(ge >> 32)) : __popc((unsigned)ge);
-          const float upv = dpp_wave_shr1_f(lv[r]);
-          const int upi = dpp_wave_shr1_i(li[r]);
-          if (act) {
-            if (j == p) { lv[r] = cv; li[r] = cidx; }
-            else if (j > p) { lv[r] = upv; li[r] = upi; }
-          }
-          const float tlo = r3d_readlane_f(lv[r], klo);
-          const float thi = r3d_readlane_f(lv[r], khi);
-          thr[r] = h ? thi : tlo;
+          overflow = true;
         }
       }
     }
-    if (t + 1 < ntiles) sstore(buf ^ 1);
-    __syncthreads();
+  };
+  if (T > 0) bload(0, bfA);
+  for (int t = 0; t < T; t += 2) {
+    if (t + 1 < T) bload(t + 1, bfB);
+    mma(t, bfA);
+    finishB(t);
+    if (t + 1 >= T) break;
+    if (t + 2 < T) bload(t + 2, bfA);
+    mma(t + 1, bfB);
+    finishB(t + 1);
   }
+  if (__any(overflow) && lane == 0 && status) atomicOr(status, 1);
+  __syncthreads();
+
+  // ------------------------------------------------------------------ rank the survivors
+  for (int qq = 0; qq < 32 / KB_WAVES; ++qq) {
+    const int q = (32 / KB_WAVES) * w + qq;
+    const int row = q0 + q;
+    if (row >= n) break;
+    const int M = min(cnt_s[q], KB_CAP);
+    float mv[KB_CAP / 64];
+    int mi[KB_CAP / 64], rank[KB_CAP / 64];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = qw0 + r3d_acc_row(r, lane);
-    if (row < n && j < k) {
-      idx_out[((long)b * N + row) * k + j] = li[r];
-      if (score_out) score_out[((long)b * N + row) * k + j] = lv[r];
+    for (int i = 0; i < KB_CAP / 64; ++i) {
+      const int e = 64 * i + lane;
+      mv[i] = e < M ? bufv[q * KB_CAP + e] : -INFINITY;
+      mi[i] = e < M ? bufi[q * KB_CAP + e] : 0x7fffffff;
+      rank[i] = 0;
+    }
+    for (int t = 0; t < M; ++t) {
+      const float ov = bufv[q * KB_CAP + t];
+      const int oi = bufi[q * KB_CAP + t];
+#pragma unroll
+      for (int i = 0; i < KB_CAP / 64; ++i) rank[i] += entry_better(ov, oi, mv[i], mi[i]) ? 1 : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < KB_CAP / 64; ++i) {
+      if (64 * i + lane < M && rank[i] < k) {
+        idx_out[((long)b * N + row) * k + rank[i]] = mi[i];
+        if (score_out) score_out[((long)b * N + row) * k + rank[i]] = mv[i];
+      }
     }
   }
+}
+
+static size_t knn_big_lds_bytes(int C) {
+  const int nch = (C + 63) / 64;
+  const size_t a = 32 * (size_t)(nch * 64 + 1);
+  const size_t g = 32 * (size_t)(2 * KB_GROUPS + 1);
+  const size_t bsz = 2 * 32 * (size_t)KB_CAP;
+  return sizeof(float) * (a + (g > bsz ? g : bsz));
 }
 
 static size_t knn_lds_bytes(int C) {
@@ -372,33 +759,75 @@ extern "C" int r3d_sqnorm(const float* x, long ldx, long rows, int C, float* out
   return R3D_OK;
 }
 
+// Forward declarations of the layout kernel living in gemm.hip.
+extern "C" int r3d_pm_to_cm(const float* in, long ld, int B, int C, int N, float* out, void* stream);
+
 // x: (B*N, ldx) point-major fp32; norm_ws: (B*N) fp32 scratch; idx_out: (B, N, k) int32;
 // score_out: optional (B, N, k) fp32; n_valid_dev: optional device int, rows >= *n are
 // neither queried nor offered as candidates (used by the head where the node count
 // is data dependent and stays on the device).
-extern "C" int r3d_knn_topk(const float* x, long ldx, int B, int N, int C, int k, int mode,
-                            const int* n_valid_dev, float* norm_ws, int32_t* idx_out,
-                            float* score_out, void* stream) {
-  R3D_REQUIRE(x && norm_ws && idx_out, "r3d_knn_topk: null pointer");
-  R3D_REQUIRE(B > 0 && N > 0 && C > 0 && ldx >= C, "r3d_knn_topk: bad shape B=%d N=%d C=%d ldx=%ld", B, N, C, ldx);
+// x_cm: optional (B, C, N) channel-major copy of x (the reference's own layout); when NULL and
+// a streamed kernel applies the copy is made into cm_ws (B*C*N floats).
+// status: optional device int.  With k > 32 a non-NULL status selects the append-and-rank
+// kernel; bit 0 set afterwards = its survivor buffer overflowed and the result is unusable
+// (re-run with status == NULL for the insertion kernel).
+extern "C" int r3d_knn_topk(const float* x, long ldx, const float* x_cm, int B, int N, int C, int k, int mode,
+                            const int* n_valid_dev, float* norm_ws, float* cm_ws, int32_t* idx_out,
+                            float* score_out, int32_t* status, void* stream) {
+  R3D_REQUIRE((x || x_cm) && norm_ws && idx_out, "r3d_knn_topk: null pointer");
+  R3D_REQUIRE(B > 0 && N > 0 && C > 0 && (!x || ldx >= C), "r3d_knn_topk: bad shape B=%d N=%d C=%d ldx=%ld", B, N, C, ldx);
   R3D_REQUIRE(k > 0 && k <= N && k <= 256, "r3d_knn_topk: unsupported k=%d (need 1..min(N,256))", k);
   R3D_REQUIRE(mode == R3D_SCORE_DGCNN || mode == R3D_SCORE_L2, "r3d_knn_topk: unknown mode %d", mode);
-  const size_t lds = knn_lds_bytes(C);
-  R3D_REQUIRE(lds <= 160 * 1024, "r3d_knn_topk: C=%d needs %zu B of LDS (> 160 KiB)", C, lds);
-  int rc = r3d_sqnorm(x, ldx, (long)B * N, C, norm_ws, stream);
-  if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (k <= 32 && C <= 64) {
-    dim3 g2(r3d_cdiv(N, 128), B);
+    const float* xT = x_cm;
+    if (!xT) {
+      R3D_REQUIRE(cm_ws && x, "r3d_knn_topk: need x_cm or (x and cm_ws)");
+      int rc = r3d_pm_to_cm(x, ldx, B, C, N, cm_ws, stream);
+      if (rc) return rc;
+      xT = cm_ws;
+    }
+    hipLaunchKernelGGL(r3d_sqnorm_cm_kernel, dim3(r3d_cdiv(N, 256), B), dim3(256), 0, st, xT, C, N, norm_ws);
+    dim3 g2(r3d_cdiv(N, 32), B);
     if (C <= 16)
-      hipLaunchKernelGGL(r3d_knn_small_kernel<16>, g2, dim3(256), 0, st, x, ldx, N, C, k, mode, n_valid_dev, norm_ws,
+      hipLaunchKernelGGL(r3d_knn_small_kernel<8>, g2, dim3(256), 0, st, xT, N, C, k, mode, n_valid_dev, norm_ws,
                          idx_out, score_out);
     else
-      hipLaunchKernelGGL(r3d_knn_small_kernel<64>, g2, dim3(256), 0, st, x, ldx, N, C, k, mode, n_valid_dev, norm_ws,
+      hipLaunchKernelGGL(r3d_knn_small_kernel<32>, g2, dim3(256), 0, st, xT, N, C, k, mode, n_valid_dev, norm_ws,
                          idx_out, score_out);
     R3D_LAUNCH_CHECK("r3d_knn_topk(small)");
     return R3D_OK;
   }
+  if (status && k <= 256 && knn_big_lds_bytes(C) <= 160 * 1024) {
+    // fast path for large k; *status bit 0 reports survivor-buffer overflow (caller re-runs with
+    // status == NULL, which selects the insertion kernel below)
+    const float* xT = x_cm;
+    if (!xT) {
+      R3D_REQUIRE(cm_ws && x, "r3d_knn_topk: need x_cm or (x and cm_ws)");
+      int rc = r3d_pm_to_cm(x, ldx, B, C, N, cm_ws, stream);
+      if (rc) return rc;
+      xT = cm_ws;
+    }
+    hipLaunchKernelGGL(r3d_sqnorm_cm_kernel, dim3(r3d_cdiv(N, 256), B), dim3(256), 0, st, xT, C, N, norm_ws);
+    hipMemsetAsync(status, 0, sizeof(int), st);
+    static size_t big_attr = 0;  // static __shared__ arrays count against the 160 KiB too: ask for what is used
+    if (knn_big_lds_bytes(C) > big_attr) {
+      hipError_t e = hipFuncSetAttribute((const void*)r3d_knn_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)knn_big_lds_bytes(C));
+      R3D_REQUIRE(e == hipSuccess, "r3d_knn_topk(big): cannot reserve %zu B of LDS: %s", knn_big_lds_bytes(C),
+                  hipGetErrorString(e));
+      big_attr = knn_big_lds_bytes(C);
+    }
+    hipLaunchKernelGGL(r3d_knn_big_kernel, dim3(r3d_cdiv(N, 32), B), dim3(64 * KB_WAVES), knn_big_lds_bytes(C), st,
+                       xT, N, C, k, mode, n_valid_dev, norm_ws, idx_out, score_out, status);
+    R3D_LAUNCH_CHECK("r3d_knn_topk(big)");
+    return R3D_OK;
+  }
+  R3D_REQUIRE(x, "r3d_knn_topk: the insertion kernel needs the point-major matrix");
+  const size_t lds = knn_lds_bytes(C);
+  R3D_REQUIRE(lds <= 160 * 1024, "r3d_knn_topk: C=%d needs %zu B of LDS (> 160 KiB)", C, lds);
+  int rc = r3d_sqnorm(x, ldx, (long)B * N, C, norm_ws, stream);
+  if (rc) return rc;
   dim3 grid(r3d_cdiv(N, KNN_Q), B), block(256);
 #define KNN_LAUNCH(RR)                                                                           \
   do {                                                                                           \

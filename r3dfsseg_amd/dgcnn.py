@@ -101,8 +101,9 @@ class DGCNN(nn.Module):
         self._folded = (key, f)
         return f
 
-    def forward_pm(self, x_pm, B, N):
-        """x_pm (B*N, C_in) -> (edgeconv concat (B*N, 64*n_edgeconv), level2 (B*N, mlp[-1]))."""
+    def forward_pm(self, x_pm, B, N, x_cm=None):
+        """x_pm (B*N, C_in) -> (edgeconv concat (B*N, 64*n_edgeconv), level2 (B*N, mlp[-1])).
+        x_cm: the same input in the reference's (B, C_in, N) layout, if the caller has it."""
         if self.training:
             raise NotImplementedError("training-mode forward goes through r3dfsseg_amd.train_ops")
         f = self._fold()
@@ -111,7 +112,7 @@ class DGCNN(nn.Module):
         inp = x_pm
         for l in range(self.n_edgeconv):
             Wpq, sc, sh, W2, s2, t2 = f["ec"][l]
-            idx = ops.knn(inp, B, N, self.k)
+            idx = ops.knn(inp, B, N, self.k, x_cm=x_cm if l == 0 else None)
             PQ = ops.pointwise_conv(inp, Wpq, sc, sh, ops.ACT_NONE)
             out = cat[:, 64 * l:64 * (l + 1)]
             ops.edgeconv(PQ, idx, W2, s2, t2, out, B, N)
@@ -124,7 +125,8 @@ class DGCNN(nn.Module):
     def forward(self, x):
         """Reference signature: x (B, C, N) -> (edgeconv_0 (B,64,N), out (B,mlp[-1],N))."""
         B, _, N = x.shape
-        cat, h = self.forward_pm(ops.cm_to_pm(x), B, N)
+        x = x.contiguous().float()
+        cat, h = self.forward_pm(ops.cm_to_pm(x), B, N, x_cm=x)
         outs = [ops.pm_to_cm(cat[:, 64 * l:64 * (l + 1)], B, N) for l in range(self.n_edgeconv)]
         out = ops.pm_to_cm(h, B, N)
         if self.return_edgeconvs:

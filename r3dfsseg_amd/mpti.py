@@ -55,7 +55,8 @@ class MPTI_SelfAtten(nn.Module):
     def getFeatures_pm(self, x):
         """x (B, C_in, N) -> point-major features (B*N, feat_dim): [level1 | att | base]."""
         B, _, N = x.shape
-        cat, level2 = self.encoder.forward_pm(ops.cm_to_pm(x), B, N)
+        x = x.contiguous().float()
+        cat, level2 = self.encoder.forward_pm(ops.cm_to_pm(x), B, N, x_cm=x)
         d1 = 64
         feat = torch.empty(B * N, self.feat_dim, device=x.device, dtype=torch.float32)
         ops.copy_cols(cat[:, :d1], feat[:, :d1])
@@ -102,8 +103,11 @@ class MPTI_SelfAtten(nn.Module):
             self._lp_probe = (host, ev)
 
     def lp_converged(self):
-        """Host check (synchronises): did the last forward's label propagation converge?"""
-        return bool(self._head[1].stats[0].item())
+        """Host check (synchronises): did the last forward's label propagation converge AND did the
+        201-NN append kernel stay inside its survivor buffer?  False -> call forward again with
+        lp_iters=self.lp_max_iter (which also selects the always-exact insertion kNN kernel)."""
+        hb = self._head[1]
+        return bool(hb.stats[0].item()) and int(hb.knn_status.item()) == 0
 
     # ------------------------------------------------------------------ forward (mpti.py:414-577)
     def forward(self, support_x, support_y, query_x, query_y, gt_support_y=None, gt_query_y=None, train=False,
@@ -129,7 +133,10 @@ class MPTI_SelfAtten(nn.Module):
         hb = self._head_buffers(n_q, feat.device)
         sy = support_y.reshape(S, N).to(torch.int32).contiguous()
         ops.head_prototypes(hb, sy, shot_keep, sfeat, sfeatT, qfeat)
-        nbr = ops.knn(hb.nodes, 1, hb.n_cap, hb.kp1, mode=ops.SCORE_L2, n_valid=hb.desc[ops.HD_N_NODES:])
+        nbr = ops.knn(hb.nodes, 1, hb.n_cap, hb.kp1, mode=ops.SCORE_L2, n_valid=hb.desc[ops.HD_N_NODES:],
+                      status=None if lp_iters else hb.knn_status)
+        if lp_iters:
+            hb.knn_status.zero_()
         ops.label_propagate(hb, nbr, self.sigma, 0.99, lp_iters or self._lp_next_budget(), self.lp_tol)
         self._lp_post(hb)
         labels = query_y.to(torch.int64).contiguous() if query_y is not None else None

@@ -100,8 +100,9 @@ def copy_cols(src, dst):
     return dst
 
 
-def knn(x_pm, B, N, k, mode=SCORE_DGCNN, n_valid=None, return_scores=False):
-    """x_pm (B*N, C) -> idx (B, N, k) int32, best first."""
+def knn(x_pm, B, N, k, mode=SCORE_DGCNN, n_valid=None, return_scores=False, x_cm=None, status=None):
+    """x_pm (B*N, C) -> idx (B, N, k) int32, best first.  x_cm: optional (B, C, N) channel-major
+    copy of the same points (saves the internal transpose of the streamed k <= 32 kernel)."""
     M, ld = _rows(x_pm)
     C = x_pm.shape[1]
     assert M == B * N
@@ -109,9 +110,21 @@ def knn(x_pm, B, N, k, mode=SCORE_DGCNN, n_valid=None, return_scores=False):
     norm = torch.empty(M, device=dev, dtype=torch.float32)
     idx = torch.empty(B, N, k, device=dev, dtype=torch.int32)
     sc = torch.empty(B, N, k, device=dev, dtype=torch.float32) if return_scores else None
+    cm_ws = None
+    if k <= 32 and C <= 64:
+        if x_cm is None:
+            cm_ws = torch.empty(B * C * N, device=dev, dtype=torch.float32)
+        else:
+            assert x_cm.is_contiguous() and x_cm.shape == (B, C, N) and x_cm.dtype == torch.float32
+    elif status is not None:  # large-k streamed kernel (status bit 0 = overflow -> redo with status=None)
+        assert status.dtype == torch.int32
+        if x_cm is None:
+            cm_ws = torch.empty(B * C * N, device=dev, dtype=torch.float32)
+    else:
+        x_cm = None
     with _timed("knn_topk_l2" if mode == SCORE_L2 else "knn_topk"):
-        _lib.check(_lib.load().r3d_knn_topk(_p(x_pm), ld, B, N, C, k, mode, _p(n_valid), _p(norm), _p(idx), _p(sc),
-                                            _st()))
+        _lib.check(_lib.load().r3d_knn_topk(_p(x_pm), ld, _p(x_cm), B, N, C, k, mode, _p(n_valid), _p(norm),
+                                            _p(cm_ws), _p(idx), _p(sc), _p(status), _st()))
     return (idx, sc) if return_scores else idx
 
 
@@ -174,6 +187,7 @@ class HeadBuffers:
         self.assign = torch.empty(2 * n_way * k_shot * N, **i32)
         self.cluster_count = torch.zeros(self.n_cap, **i32)
         self.stats = torch.zeros(2, **i32)
+        self.knn_status = torch.zeros(1, **i32)
         off = (ctypes.c_long * 6)()
         lib.r3d_head_proto_ws_offsets(n_way, k_shot, N, off)
         self.ws_off = list(off)

@@ -108,7 +108,8 @@ def test_label_propagation_vs_closed_form(ops, n_proto, n_q_pts, cap_extra):
     hb.Y[:n] = Y.cuda()
     hb.desc[ops.HD_N_PROTO] = n_proto
     hb.desc[ops.HD_N_NODES] = n
-    nbr = ops.knn(hb.nodes, 1, hb.n_cap, 201, mode=ops.SCORE_L2, n_valid=hb.desc[ops.HD_N_NODES:])
+    nbr = ops.knn(hb.nodes, 1, hb.n_cap, 201, mode=ops.SCORE_L2, n_valid=hb.desc[ops.HD_N_NODES:], status=hb.knn_status)
+    assert int(hb.knn_status.item()) == 0
     want_nbr = O.knn_l2(x, 201)
     assert np.array_equal(nbr.cpu().numpy()[0, :n].astype(np.int64), want_nbr.numpy()), "201-NN indices differ"
     Z = ops.label_propagate(hb, nbr, 1.0, 0.99, 300, 1e-6)

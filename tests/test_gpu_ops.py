@@ -77,12 +77,20 @@ def test_knn_full_size_properties(ops):
 
 
 # ------------------------------------------------------------------ a11 search half (mpti.py:731-736)
-@pytest.mark.parametrize("n,n_valid,k", [(1400, 1400, 201), (1500, 1337, 201), (700, 700, 65)])
-def test_knn_l2_bitexact(ops, n, n_valid, k):
+@pytest.mark.parametrize("fast", [True, False])
+@pytest.mark.parametrize("n,n_valid,k", [(1400, 1400, 201), (1500, 1337, 201), (700, 700, 65), (4396, 4396, 201)])
+def test_knn_l2_bitexact(ops, n, n_valid, k, fast):
+    """fast=True: two-pass append-and-rank kernel; fast=False: insertion kernel (the fallback)."""
     X = _rand((n, 192), 31, 0.2)
+    if n > 2000:  # clustered like real features, plus exact duplicates (ties at distance 0)
+        X = X * 0.3 + _rand((8, 192), 32, 0.3)[torch.from_numpy(np.random.RandomState(33).randint(0, 8, n))]
+        X[100:140] = X[200:240]
     want, wd = O.knn_l2(X[:n_valid], k, return_dist=True)
     nv = torch.tensor([n_valid], dtype=torch.int32).cuda()
-    got, gs = ops.knn(_dev(X), 1, n, k, mode=ops.SCORE_L2, n_valid=nv, return_scores=True)
+    status = torch.zeros(1, dtype=torch.int32).cuda() if fast else None
+    got, gs = ops.knn(_dev(X), 1, n, k, mode=ops.SCORE_L2, n_valid=nv, return_scores=True, status=status)
+    if fast:
+        assert int(status.item()) == 0, "survivor buffer overflow"
     got, gs = got.cpu().numpy()[0, :n_valid], gs.cpu().numpy()[0, :n_valid]
     assert np.array_equal(-gs, wd.numpy()) or np.array_equal(np.abs(gs), wd.numpy()), "distances differ bitwise"
     assert np.array_equal(got.astype(np.int64), want.numpy())

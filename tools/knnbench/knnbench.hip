@@ -1,0 +1,37 @@
+// Micro-benchmark harness for knn.hip ablations (build-time -DABL_* switches).
+#include "../../r3dfsseg_amd/csrc/error.hip"
+#include "../../r3dfsseg_amd/csrc/knn.hip"
+#include "../../r3dfsseg_amd/csrc/gemm.hip"
+#include <vector>
+#include <cstdlib>
+int main(int argc, char** argv) {
+  int B = 12, N = 2048, C = argc > 1 ? atoi(argv[1]) : 64, k = argc > 2 ? atoi(argv[2]) : 20, mode = argc > 3 ? atoi(argv[3]) : 0;
+  if (argc > 4) { B = 1; N = atoi(argv[4]); }
+  std::vector<float> h((size_t)B * N * C);
+  srand(1);
+  for (auto& v : h) v = rand() / (float)RAND_MAX - 0.5f;
+  float *x, *nrm, *cm; int* idx; int* status; hipMalloc(&status, 4);
+  hipMalloc(&cm, h.size() * 4);
+  hipMalloc(&x, h.size() * 4); hipMalloc(&nrm, (size_t)B * N * 4); hipMalloc(&idx, (size_t)B * N * k * 4);
+  hipMemcpy(x, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int it = 0; it < 3; ++it) r3d_knn_topk(x, C, nullptr, B, N, C, k, mode, nullptr, nrm, cm, idx, nullptr, status, 0);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  const int reps = 10;
+  for (int it = 0; it < reps; ++it) r3d_knn_topk(x, C, nullptr, B, N, C, k, mode, nullptr, nrm, cm, idx, nullptr, status, 0);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  int hs = 0; hipMemcpy(&hs, status, 4, hipMemcpyDeviceToHost);
+  printf("B=%d N=%d C=%d k=%d mode=%d: %.1f us per call (%s) status=%d\n", B, N, C, k, mode, ms * 1000 / reps, r3d_last_error_string(), hs);
+#ifdef KNN_STAMPS
+  unsigned long long z[16] = {0}, d[16];
+  hipMemcpyToSymbol(HIP_SYMBOL(g_knn_dbg), z, sizeof(z));
+  r3d_knn_topk(x, C, nullptr, B, N, C, k, mode, nullptr, nrm, cm, idx, nullptr, status, 0);
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(d, HIP_SYMBOL(g_knn_dbg), sizeof(d));
+  printf("  stamps: passA %llu  tau %llu  passB %llu  merge %llu\n", d[1]-d[0], d[2]-d[1], d[3]-d[2], d[4]-d[3]);
+#endif
+  return 0;
+}
