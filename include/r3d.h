@@ -32,6 +32,8 @@ int r3d_abi_version(void);
 /* ---- layout conversion at the forward() boundary (models/mpti.py:433-437) -------- */
 int r3d_cm_to_pm(const float* in /*(B,C,N)*/, int B, int C, int N, float* out /*(B*N,ld)*/, long ld, void* stream);
 int r3d_pm_to_cm(const float* in /*(B*N,ld)*/, long ld, int B, int C, int N, float* out /*(B,C,N)*/, void* stream);
+int r3d_pm_to_cm_pitched(const float* in, long ld, int B, int C, int N, float* out /*(B,C,pitch)*/, long pitch, void* stream);
+long r3d_cm_pitch(int N); /* row pitch (floats) of internal channel-major copies: avoids power-of-two channel strides */
 int r3d_copy_cols(const float* src, long ld_src, float* dst, long ld_dst, long M, int C, void* stream);
 
 /* ---- k nearest neighbours ----------------------------------------------------------

@@ -22,6 +22,8 @@ _SIGS = {
     "r3d_abi_version": (c_i, []),
     "r3d_cm_to_pm": (c_i, [c_f, c_i, c_i, c_i, c_f, c_l, c_f]),
     "r3d_pm_to_cm": (c_i, [c_f, c_l, c_i, c_i, c_i, c_f, c_f]),
+    "r3d_pm_to_cm_pitched": (c_i, [c_f, c_l, c_i, c_i, c_i, c_f, c_l, c_f]),
+    "r3d_cm_pitch": (c_l, [c_i]),
     "r3d_copy_cols": (c_i, [c_f, c_l, c_f, c_l, c_l, c_i, c_f]),
     "r3d_sqnorm": (c_i, [c_f, c_l, c_l, c_i, c_f, c_f]),
     "r3d_knn_topk": (c_i, [c_f, c_l, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),

@@ -116,7 +116,7 @@ __global__ void r3d_cm_to_pm_kernel(const float* __restrict__ in, int C, int N, 
 }
 
 __global__ void r3d_pm_to_cm_kernel(const float* __restrict__ in, long ld, int C, int N,
-                                    float* __restrict__ out) {
+                                    float* __restrict__ out, long pitch) {
   __shared__ float t[32][33];
   const int b = blockIdx.z;
   const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -128,7 +128,7 @@ __global__ void r3d_pm_to_cm_kernel(const float* __restrict__ in, long ld, int C
   __syncthreads();
   for (int i = ty; i < 32; i += 8) {
     const int c = c0 + i, n = n0 + tx;
-    if (c < C && n < N) out[((long)b * C + c) * N + n] = t[tx][i];
+    if (c < C && n < N) out[((long)b * C + c) * pitch + n] = t[tx][i];
   }
 }
 
@@ -143,8 +143,18 @@ extern "C" int r3d_cm_to_pm(const float* in, int B, int C, int N, float* out, lo
 extern "C" int r3d_pm_to_cm(const float* in, long ld, int B, int C, int N, float* out, void* stream) {
   R3D_REQUIRE(in && out && B > 0 && C > 0 && N > 0 && ld >= C, "r3d_pm_to_cm: bad arguments");
   dim3 grid(r3d_cdiv(N, 32), r3d_cdiv(C, 32), B);
-  hipLaunchKernelGGL(r3d_pm_to_cm_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, ld, C, N, out);
+  hipLaunchKernelGGL(r3d_pm_to_cm_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, ld, C, N, out, (long)N);
   R3D_LAUNCH_CHECK("r3d_pm_to_cm");
+  return R3D_OK;
+}
+
+// same with a row pitch >= N between channels (out is (B, C, pitch))
+extern "C" int r3d_pm_to_cm_pitched(const float* in, long ld, int B, int C, int N, float* out, long pitch,
+                                    void* stream) {
+  R3D_REQUIRE(in && out && B > 0 && C > 0 && N > 0 && ld >= C && pitch >= N, "r3d_pm_to_cm_pitched: bad arguments");
+  dim3 grid(r3d_cdiv(N, 32), r3d_cdiv(C, 32), B);
+  hipLaunchKernelGGL(r3d_pm_to_cm_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, ld, C, N, out, pitch);
+  R3D_LAUNCH_CHECK("r3d_pm_to_cm_pitched");
   return R3D_OK;
 }
 

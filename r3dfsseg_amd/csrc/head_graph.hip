@@ -128,40 +128,58 @@ __global__ __launch_bounds__(256) void r3d_graph_cols_kernel(const unsigned* __r
   }
 }
 
-// 3c. gaussian weights + row sums D; one wave per row, x_i in registers (D <= 256)
+// 3c. gaussian weights + row sums D.  One wave per row i, ONE LANE PER ENTRY: each lane walks
+//     the 192 channels of its own neighbour row (float4 loads, L2 resident) against x_i held
+//     in LDS (broadcast reads), so there is no cross-lane reduction per entry and the
+//     squared distance is the channel-ascending chain of oracle/r3d_oracle.c:orc_pair_dist.
 __global__ __launch_bounds__(256) void r3d_graph_weights_kernel(
     const float* __restrict__ nodes, long ldn, int D, const unsigned* __restrict__ outb, int words,
     const int* __restrict__ n_dev, int n_cap, const int* __restrict__ row_ptr, const int* __restrict__ col,
     float sigma, float* __restrict__ val, float* __restrict__ dinv) {
+  __shared__ __attribute__((aligned(16))) float xs[4][256];
   const int n = min(*n_dev, n_cap);
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + w;
   const int lane = threadIdx.x & 63;
   if (i >= n) return;
   const float* xi = nodes + (long)i * ldn;
-  const float x0 = lane < D ? xi[lane] : 0.f;
-  const float x1 = lane + 64 < D ? xi[lane + 64] : 0.f;
-  const float x2 = lane + 128 < D ? xi[lane + 128] : 0.f;
-  const float x3 = lane + 192 < D ? xi[lane + 192] : 0.f;
+  for (int c = lane; c < 256; c += 64) xs[w][c] = c < D ? xi[c] : 0.f;
+  __builtin_amdgcn_wave_barrier();
   const int beg = row_ptr[i], end = row_ptr[i + 1];
+  const int D4 = D >> 2;
   float dsum = 0.f;
-  for (int e = beg; e < end; ++e) {
-    const int j = __builtin_amdgcn_readfirstlane(col[e]);
+  for (int e0 = beg; e0 < end; e0 += 64) {
+    const int e = e0 + lane;
+    const bool ok = e < end;
+    const int j = col[min(e, end - 1)];
     const float* xj = nodes + (long)j * ldn;
     float a = 0.f, b = 0.f;  // a: ||x_i - x_j + eps||^2, b: ||x_j - x_i + eps||^2
-    if (lane < D)       { const float y = xj[lane];       const float d1 = (x0 - y) + 1e-6f, d2 = (y - x0) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b); }
-    if (lane + 64 < D)  { const float y = xj[lane + 64];  const float d1 = (x1 - y) + 1e-6f, d2 = (y - x1) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b); }
-    if (lane + 128 < D) { const float y = xj[lane + 128]; const float d1 = (x2 - y) + 1e-6f, d2 = (y - x2) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b); }
-    if (lane + 192 < D) { const float y = xj[lane + 192]; const float d1 = (x3 - y) + 1e-6f, d2 = (y - x3) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b); }
-    a = r3d_wave_sum(a);
-    b = r3d_wave_sum(b);
+    for (int c4 = 0; c4 < D4; ++c4) {
+      const float4 y = *reinterpret_cast<const float4*>(xj + 4 * c4);
+      const float4 x = *reinterpret_cast<const float4*>(&xs[w][4 * c4]);
+      float d1, d2;
+      d1 = (x.x - y.x) + 1e-6f; d2 = (y.x - x.x) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b);
+      d1 = (x.y - y.y) + 1e-6f; d2 = (y.y - x.y) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b);
+      d1 = (x.z - y.z) + 1e-6f; d2 = (y.z - x.z) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b);
+      d1 = (x.w - y.w) + 1e-6f; d2 = (y.w - x.w) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b);
+    }
+    for (int c = 4 * D4; c < D; ++c) {
+      const float y = xj[c], x = xs[w][c];
+      const float d1 = (x - y) + 1e-6f, d2 = (y - x) + 1e-6f;
+      a = __builtin_fmaf(d1, d1, a);
+      b = __builtin_fmaf(d2, d2, b);
+    }
     const bool out_ij = (outb[(long)i * words + (j >> 5)] >> (j & 31)) & 1u;
     const bool out_ji = (outb[(long)j * words + (i >> 5)] >> (i & 31)) & 1u;
     float wgt = 0.f;
     if (out_ij) { const float d = sqrtf(a) / sigma; wgt += expf(-0.5f * (d * d)); }
     if (out_ji) { const float d = sqrtf(b) / sigma; wgt += expf(-0.5f * (d * d)); }
-    if (lane == 0) val[e] = wgt;
-    dsum += wgt;
+    if (ok) {
+      val[e] = wgt;
+      dsum += wgt;
+    }
   }
+  dsum = r3d_wave_sum(dsum);
   if (lane == 0) dinv[i] = sqrtf(1.0f / (dsum + 2.220446049250313e-16f));  // mpti.py:768-770
 }
 
@@ -272,14 +290,29 @@ __global__ __launch_bounds__(256) void r3d_cg_spmv_kernel(
     const int i = row0 + rr_i;
     if (i >= n) break;
     float4 s = f4_zero();
-    for (int e = row_ptr[i] + lane; e < row_ptr[i + 1]; e += 64) {
-      const int j = col[e];
-      const float a = val[e];
-      const float4 rj = r[j], pj = p_old[j];
-      s.x += a * (rj.x + beta.x * pj.x);
-      s.y += a * (rj.y + beta.y * pj.y);
-      s.z += a * (rj.z + beta.z * pj.z);
-      s.w += a * (rj.w + beta.w * pj.w);
+    {
+      const int rb = row_ptr[i], re = row_ptr[i + 1];
+      for (int e0 = rb + lane; e0 < re; e0 += 256) {  // 4 entries per lane in flight
+        int jv[4];
+        float av[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = e0 + 64 * u;
+          const int ec = min(e, re - 1);
+          jv[u] = col[ec];
+          av[u] = r3d_keep(val[ec], e < re);
+        }
+        float4 rj[4], pj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { rj[u] = r[jv[u]]; pj[u] = p_old[jv[u]]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          s.x += av[u] * (rj[u].x + beta.x * pj[u].x);
+          s.y += av[u] * (rj[u].y + beta.y * pj[u].y);
+          s.z += av[u] * (rj[u].z + beta.z * pj[u].z);
+          s.w += av[u] * (rj[u].w + beta.w * pj[u].w);
+        }
+      }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

@@ -107,6 +107,45 @@ __global__ __launch_bounds__(1024) void r3d_head_compact_kernel(const int* __res
 }
 
 // ---------------------------------------------------------------------------
+// 1b. compacted channel-major copy of the listed points: featC[c][off(seg) + pos].  FPS and the
+//     assignment then address their point by list position alone (no index indirection in the
+//     per-round dependency chain) and read perfectly coalesced.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(HP_BLOCK) void r3d_head_gather_kernel(const float* __restrict__ feat /* (S*N, ldf) */,
+                                                                   long ldf, int D, SegGeom g,
+                                                                   const int* __restrict__ comp,
+                                                                   const int* __restrict__ desc,
+                                                                   float* __restrict__ featC, long pitch) {
+  __shared__ float t[64][65];
+  int blk0;
+  const int seg = g.seg_of_block(blockIdx.x, &blk0);
+  const int count = desc[HD_SEG_COUNT + seg];
+  const int bis = blockIdx.x - blk0;
+  if ((long)bis * HP_BLOCK >= count) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // 256 list positions per block, 64 at a time: rows in (coalesced 64-float pieces), columns out
+  for (int p0 = 0; p0 < HP_BLOCK; p0 += 64) {
+    const int posb = bis * HP_BLOCK + p0;
+    if (posb >= count) break;
+    for (int c0 = 0; c0 < D; c0 += 64) {
+      __syncthreads();
+      for (int r = w; r < 64; r += 4) {
+        const int pos = posb + r;
+        const int gp = comp[g.off(seg) + min(pos, count - 1)];
+        const int c = c0 + lane;
+        t[r][lane] = feat[(long)gp * ldf + min(c, D - 1)];
+      }
+      __syncthreads();
+      for (int r = w; r < 64; r += 4) {
+        const int c = c0 + r;
+        const int pos = posb + lane;
+        if (c < D && pos < count) featC[(long)c * pitch + g.off(seg) + pos] = t[lane][r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // 2. farthest point sampling, one launch per round, all segments at once
 // ---------------------------------------------------------------------------
 struct Cand { float v; int pos; };
@@ -115,12 +154,13 @@ static __device__ __forceinline__ void cand_better(float& v, int& p, float v2, i
   if (v2 > v || (v2 == v && p2 < p)) { v = v2; p = p2; }
 }
 
+template <int DP>  // feature dimension rounded up to a multiple of 64 (registers hold the whole point)
 __global__ __launch_bounds__(HP_BLOCK) void r3d_fps_round_kernel(
-    const float* __restrict__ featT /* (S, D, N) channel-major */, int D, SegGeom g,
-    const int* __restrict__ comp, const int* __restrict__ desc, int k, int round,
+    const float* __restrict__ featC /* (D, pitch) compacted channel-major */, long pitch, int D, SegGeom g,
+    const int* __restrict__ desc, int k, int round,
     float* __restrict__ mind, const Cand* __restrict__ cand_prev, Cand* __restrict__ cand_next,
     int* __restrict__ sel /* [nseg][HP_MAXK] */) {
-  __shared__ float seedf[256];
+  __shared__ float seedf[DP];
   __shared__ float red_v[4];
   __shared__ int red_p[4];
   __shared__ int seed_pos_s;
@@ -132,6 +172,18 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_fps_round_kernel(
   const int bis = blockIdx.x - blk0;  // block index inside the segment
   if ((long)bis * HP_BLOCK >= count) return;
   const int nblk = (count + HP_BLOCK - 1) / HP_BLOCK;
+  // --- this thread's point: ALL its channel loads are issued first (they do not depend on the
+  //     seed), so their latency hides behind the seed election below
+  const int pos = bis * HP_BLOCK + tid;
+  const bool have = pos < count && round < k - 1;
+  float xv[DP];
+  float md_old = INFINITY;
+  {
+    const float* fp = featC + g.off(seg) + min(pos, count - 1);
+#pragma unroll
+    for (int c = 0; c < DP; ++c) xv[c] = fp[(long)min(c, D - 1) * pitch];
+    if (round > 0) md_old = mind[g.off(seg) + min(pos, count - 1)];
+  }
   // --- seed of this round
   if (round == 0) {
     if (tid == 0) seed_pos_s = 0;
@@ -160,30 +212,26 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_fps_round_kernel(
   if (bis == 0 && tid == 0) sel[seg * HP_MAXK + round] = seed_pos;
   if (round == k - 1) return;
   // --- stage the seed's feature vector
-  {
-    const int gp = comp[g.off(seg) + seed_pos];
-    const int cloud = gp / g.N, pp = gp - cloud * g.N;
-    for (int c = tid; c < D; c += HP_BLOCK) seedf[c] = featT[((long)cloud * D + c) * g.N + pp];
-  }
+  for (int c = tid; c < D; c += HP_BLOCK) seedf[c] = featC[(long)c * pitch + g.off(seg) + seed_pos];
   __syncthreads();
-  // --- distance update + block argmax
-  const int pos = bis * HP_BLOCK + tid;
+  // --- distance update (channel-ascending fmaf chain) + block argmax
   float v = -INFINITY;
   int p = 0x7fffffff;
-  if (pos < count) {
-    const int gp = comp[g.off(seg) + pos];
-    const int cloud = gp / g.N, pp = gp - cloud * g.N;
-    const float* fp = featT + (long)cloud * D * g.N + pp;
+  {
     float acc = 0.f;
-    for (int c = 0; c < D; ++c) {
-      const float df = fp[(long)c * g.N] - seedf[c];
-      acc = __builtin_fmaf(df, df, acc);
+#pragma unroll
+    for (int c = 0; c < DP; ++c) {
+      if (c < D) {
+        const float df = xv[c] - seedf[c];
+        acc = __builtin_fmaf(df, df, acc);
+      }
     }
-    float md = round == 0 ? INFINITY : mind[g.off(seg) + pos];
-    md = acc < md ? acc : md;
-    mind[g.off(seg) + pos] = md;
-    v = md;
-    p = pos;
+    const float md = acc < md_old ? acc : md_old;
+    if (have) {
+      mind[g.off(seg) + pos] = md;
+      v = md;
+      p = pos;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -266,9 +314,8 @@ __global__ __launch_bounds__(HP_MAXK) void r3d_fps_finalize_kernel(SegGeom g, in
 // 4. nearest-seed assignment (mpti.py:618-622): dist = sqrt(chain(((x - s) + 1e-6)^2))
 // ---------------------------------------------------------------------------
 #define AS_TILE 16
-__global__ __launch_bounds__(HP_BLOCK) void r3d_assign_kernel(const float* __restrict__ featT, int D,
-                                                              SegGeom g, const int* __restrict__ comp,
-                                                              const int* __restrict__ desc,
+__global__ __launch_bounds__(HP_BLOCK) void r3d_assign_kernel(const float* __restrict__ featC, long pitch, int D,
+                                                              SegGeom g, const int* __restrict__ desc,
                                                               const int* __restrict__ seeds,
                                                               int* __restrict__ assign) {
   __shared__ float sf[256 * AS_TILE];  // [c][AS_TILE], D <= 256
@@ -281,33 +328,37 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_assign_kernel(const float* __res
   const int m = desc[HD_SEG_M + seg];
   const int pos = bis * HP_BLOCK + tid;
   const bool ok = pos < count;
-  const float* fp = featT;
-  if (ok) {
-    const int gp = comp[g.off(seg) + pos];
-    const int cloud = gp / g.N, pp = gp - cloud * g.N;
-    fp = featT + (long)cloud * D * g.N + pp;
-  }
+  const float* fp = featC + g.off(seg) + min(pos, count - 1);
   float best = INFINITY;
   int besti = 0;
   for (int s0 = 0; s0 < m; s0 += AS_TILE) {
     __syncthreads();
     for (int e = tid; e < D * AS_TILE; e += HP_BLOCK) {
       const int c = e / AS_TILE, s = e - c * AS_TILE;
-      float v = 0.f;
-      if (s0 + s < m) {
-        const int gp = comp[g.off(seg) + seeds[seg * HP_MAXK + s0 + s]];
-        const int cloud = gp / g.N, pp = gp - cloud * g.N;
-        v = featT[((long)cloud * D + c) * g.N + pp];
-      }
-      sf[c * AS_TILE + s] = v;
+      const int sp = seeds[seg * HP_MAXK + min(s0 + s, m - 1)];
+      sf[c * AS_TILE + s] = r3d_keep(featC[(long)c * pitch + g.off(seg) + sp], s0 + s < m);
     }
     __syncthreads();
     if (ok) {
       float acc[AS_TILE];
 #pragma unroll
       for (int s = 0; s < AS_TILE; ++s) acc[s] = 0.f;
-      for (int c = 0; c < D; ++c) {
-        const float xv = fp[(long)c * g.N];
+      int c = 0;
+      for (; c + 8 <= D; c += 8) {  // 8 channel loads in flight; chains stay channel-ascending
+        float xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xv[u] = fp[(long)(c + u) * pitch];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+          for (int s = 0; s < AS_TILE; ++s) {
+            const float df = (xv[u] - sf[(c + u) * AS_TILE + s]) + 1e-6f;
+            acc[s] = __builtin_fmaf(df, df, acc[s]);
+          }
+        }
+      }
+      for (; c < D; ++c) {
+        const float xv = fp[(long)c * pitch];
 #pragma unroll
         for (int s = 0; s < AS_TILE; ++s) {
           const float df = (xv - sf[c * AS_TILE + s]) + 1e-6f;
@@ -328,28 +379,32 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_assign_kernel(const float* __res
 
 // ---------------------------------------------------------------------------
 // 5. cluster means -> prototype rows of the node matrix (mpti.py:625-629)
-//    one workgroup per (segment, prototype); deterministic summation order
+//    5a  partial sums per (segment, prototype, chunk of CM_CHUNK list positions)
+//    5b  chunks added in ascending order: a fixed summation order, whatever the cluster sizes
+//        (FPS clusters are very uneven: one workgroup per cluster would serialise on the
+//        largest one)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(HP_BLOCK) void r3d_cluster_mean_kernel(
+#define CM_CHUNK 2048
+__global__ __launch_bounds__(HP_BLOCK) void r3d_cluster_partial_kernel(
     const float* __restrict__ feat /* (S*N, ldf) point-major */, long ldf, int D, SegGeom g,
-    const int* __restrict__ comp, const int* __restrict__ desc, const int* __restrict__ assign,
-    float* __restrict__ nodes /* (n_cap, ldn) */, long ldn, float* __restrict__ node_labels /* (n_cap, 4) */,
-    int* __restrict__ cluster_count) {
-  __shared__ float part[4][256];
+    const int* __restrict__ comp, const int* __restrict__ desc, const int* __restrict__ assign, int max_chunks,
+    float* __restrict__ part /* [nseg][HP_MAXK][max_chunks][256] */, int* __restrict__ part_cnt) {
+  __shared__ float psum[4][256];
   __shared__ int cnt_s[4];
-  const int seg = blockIdx.y, s = blockIdx.x;
+  const int seg = blockIdx.z, s = blockIdx.x, chunk = blockIdx.y;
   const int m = desc[HD_SEG_M + seg];
-  if (s >= m) return;
   const int count = desc[HD_SEG_COUNT + seg];
+  if (s >= m || (long)chunk * CM_CHUNK >= count) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int cnt = 0;
   const int* cp = comp + g.off(seg);
   const int* ap = assign + g.off(seg);
-  for (int base = 64 * w; base < count; base += 256) {
+  const int end = min(count, (chunk + 1) * CM_CHUNK);
+  for (int base = chunk * CM_CHUNK + 64 * w; base < end; base += 256) {
     const int pos = base + lane;
-    const bool f = pos < count && ap[pos] == s;
-    const int gp = f ? cp[pos] : 0;
+    const bool f = pos < end && ap[min(pos, end - 1)] == s;
+    const int gp = cp[min(pos, end - 1)];
     unsigned long long mm = __ballot(f);
     cnt += __popcll(mm);
     while (mm) {
@@ -363,15 +418,33 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_cluster_mean_kernel(
       if (lane + 192 < D) a3 += fr[lane + 192];
     }
   }
-  part[w][lane] = a0; part[w][lane + 64] = a1; part[w][lane + 128] = a2; part[w][lane + 192] = a3;
+  psum[w][lane] = a0; psum[w][lane + 64] = a1; psum[w][lane + 128] = a2; psum[w][lane + 192] = a3;
   if (lane == 0) cnt_s[w] = cnt;
   __syncthreads();
-  const int total = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
-  const int row = desc[HD_SEG_POFF + seg] + s;
-  if (tid < D) {
-    const float sum = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
-    nodes[(long)row * ldn + tid] = sum / (float)total;  // 0/0 = NaN for an empty cluster, as torch
+  const long slot = ((long)(seg * HP_MAXK + s) * max_chunks + chunk);
+  part[slot * 256 + tid] = ((psum[0][tid] + psum[1][tid]) + psum[2][tid]) + psum[3][tid];
+  if (tid == 0) part_cnt[slot] = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
+}
+
+__global__ __launch_bounds__(HP_BLOCK) void r3d_cluster_reduce_kernel(
+    int D, const int* __restrict__ desc, int max_chunks, const float* __restrict__ part,
+    const int* __restrict__ part_cnt, float* __restrict__ nodes /* (n_cap, ldn) */, long ldn,
+    float* __restrict__ node_labels /* (n_cap, 4) */, int* __restrict__ cluster_count) {
+  const int seg = blockIdx.y, s = blockIdx.x;
+  const int m = desc[HD_SEG_M + seg];
+  if (s >= m) return;
+  const int count = desc[HD_SEG_COUNT + seg];
+  const int nchunks = (count + CM_CHUNK - 1) / CM_CHUNK;
+  const int tid = threadIdx.x;
+  float sum = 0.f;
+  int total = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const long slot = ((long)(seg * HP_MAXK + s) * max_chunks + c);
+    sum += part[slot * 256 + tid];
+    total += part_cnt[slot];
   }
+  const int row = desc[HD_SEG_POFF + seg] + s;
+  if (tid < D) nodes[(long)row * ldn + tid] = sum / (float)total;  // 0/0 = NaN for an empty cluster, as torch
   if (tid < 4) node_labels[(long)row * 4 + tid] = (tid == seg) ? 1.f : 0.f;
   if (tid == 0 && cluster_count) cluster_count[row] = total;
 }
@@ -414,8 +487,10 @@ extern "C" int r3d_head_max_k(void) { return HP_MAXK; }
 extern "C" long r3d_head_proto_ws_words(int n_way, int k_shot, int N) {
   SegGeom g{n_way, k_shot, N};
   const long cap = g.total_cap();
-  // comp + mind + assign + cand(2 x blocks x 2 words) + sel + seeds
-  return cap * 3 + 4L * g.total_blocks() + 2L * HP_MAXSEG * HP_MAXK + 64;
+  // comp + mind + assign + cand(2 x blocks x 2 words) + sel + seeds + cluster partial sums
+  const long max_chunks = (g.cap(0) + CM_CHUNK - 1) / CM_CHUNK;
+  return cap * 3 + 4L * g.total_blocks() + 2L * HP_MAXSEG * HP_MAXK + 64 +
+         (long)g.nseg() * HP_MAXK * max_chunks * 257 + 256L * (cap + 64);  // ... + featC (D <= 256 rows)
 }
 
 // Builds prototypes into node rows [0, n_proto) and appends the query rows.
@@ -445,18 +520,33 @@ extern "C" int r3d_head_prototypes(const int32_t* support_y, const int32_t* shot
   Cand* cand1 = cand0 + g.total_blocks();
   int* sel = ws + 3 * cap + 4L * g.total_blocks();
   int* seeds = sel + HP_MAXSEG * HP_MAXK;
+  const int max_chunks = (int)((g.cap(0) + CM_CHUNK - 1) / CM_CHUNK);
+  float* part = (float*)(seeds + HP_MAXSEG * HP_MAXK + 64);
+  int* part_cnt = (int*)(part + (long)g.nseg() * HP_MAXK * max_chunks * 256);
+  float* featC = (float*)(part_cnt + (long)g.nseg() * HP_MAXK * max_chunks);
+  const long pitch = cap + 32;
   hipLaunchKernelGGL(r3d_head_compact_kernel, dim3(g.nseg()), dim3(1024), 0, st, support_y, shot_keep, g,
                      comp, desc);
+  hipLaunchKernelGGL(r3d_head_gather_kernel, dim3(g.total_blocks()), dim3(HP_BLOCK), 0, st, feat, ldf, D, g, comp,
+                     desc, featC, pitch);
   for (int t = 0; t < k; ++t) {
-    hipLaunchKernelGGL(r3d_fps_round_kernel, dim3(g.total_blocks()), dim3(HP_BLOCK), 0, st, featT, D, g, comp,
-                       desc, k, t, mind, (t & 1) ? cand0 : cand1, (t & 1) ? cand1 : cand0, sel);
+#define FPS_LAUNCH(DPAD)                                                                                          \
+    hipLaunchKernelGGL(r3d_fps_round_kernel<DPAD>, dim3(g.total_blocks()), dim3(HP_BLOCK), 0, st, featC, pitch, D, g, \
+                       desc, k, t, mind, (t & 1) ? cand0 : cand1, (t & 1) ? cand1 : cand0, sel)
+    if (D <= 64) FPS_LAUNCH(64);
+    else if (D <= 128) FPS_LAUNCH(128);
+    else if (D <= 192) FPS_LAUNCH(192);
+    else FPS_LAUNCH(256);
+#undef FPS_LAUNCH
   }
   hipLaunchKernelGGL(r3d_fps_finalize_kernel, dim3(1), dim3(HP_MAXK), 0, st, g, k, n_query_pts, sel, seeds,
                      desc);
-  hipLaunchKernelGGL(r3d_assign_kernel, dim3(g.total_blocks()), dim3(HP_BLOCK), 0, st, featT, D, g, comp, desc,
+  hipLaunchKernelGGL(r3d_assign_kernel, dim3(g.total_blocks()), dim3(HP_BLOCK), 0, st, featC, pitch, D, g, desc,
                      seeds, assign);
-  hipLaunchKernelGGL(r3d_cluster_mean_kernel, dim3(k, g.nseg()), dim3(HP_BLOCK), 0, st, feat, ldf, D, g, comp,
-                     desc, assign, nodes, ldn, node_labels, cluster_count);
+  hipLaunchKernelGGL(r3d_cluster_partial_kernel, dim3(k, max_chunks, g.nseg()), dim3(HP_BLOCK), 0, st, feat, ldf, D,
+                     g, comp, desc, assign, max_chunks, part, part_cnt);
+  hipLaunchKernelGGL(r3d_cluster_reduce_kernel, dim3(k, g.nseg()), dim3(HP_BLOCK), 0, st, D, desc, max_chunks, part,
+                     part_cnt, nodes, ldn, node_labels, cluster_count);
   hipLaunchKernelGGL(r3d_nodes_append_query_kernel, dim3(r3d_cdiv((long)n_query_pts * D, 256)), dim3(256), 0, st,
                      qfeat, ldq, D, n_query_pts, desc, nodes, ldn, node_labels);
   R3D_LAUNCH_CHECK("r3d_head_prototypes");

@@ -257,13 +257,13 @@ static __device__ __forceinline__ bool entry_better(float v1, int i1, float v2, 
 }
 
 // squared norms from the channel-major copy (same channel-ascending fmaf chain)
-__global__ void r3d_sqnorm_cm_kernel(const float* __restrict__ xT, int C, int N, float* __restrict__ out) {
+__global__ void r3d_sqnorm_cm_kernel(const float* __restrict__ xT, long ldT, int C, int N, float* __restrict__ out) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  const float* p = xT + (long)b * C * N + i;
+  const float* p = xT + (long)b * C * ldT + i;
   float acc = 0.f;
-  for (int c = 0; c < C; ++c) acc = __builtin_fmaf(p[(long)c * N], p[(long)c * N], acc);
+  for (int c = 0; c < C; ++c) acc = __builtin_fmaf(p[(long)c * ldT], p[(long)c * ldT], acc);
   out[(long)b * N + i] = acc;
 }
 
@@ -276,7 +276,7 @@ __device__ unsigned long long g_knn_dbg[16];
 
 template <int KS>
 __global__ __launch_bounds__(256) void r3d_knn_small_kernel(
-    const float* __restrict__ xT, int N, int C, int k, int mode, const int* __restrict__ n_dev,
+    const float* __restrict__ xT, long ldT, int N, int C, int k, int mode, const int* __restrict__ n_dev,
     const float* __restrict__ nrm, int* __restrict__ idx_out, float* __restrict__ score_out) {
   __shared__ float smem[32 * 129 > 2 * 32 * 128 ? 32 * 129 : 2 * 32 * 128];
   __shared__ float tau_s[32];
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void r3d_knn_small_kernel(
   if (q0 >= n) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, j = lane & 31;
-  const float* xb = xT + (long)b * C * N;
+  const float* xb = xT + (long)b * C * ldT;
   const float* nb = nrm + (long)b * N;
 
   float a[KS];
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void r3d_knn_small_kernel(
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int c = 2 * s + h;
-      const float v = xb[(long)min(c, C - 1) * N + qc];
+      const float v = xb[(long)min(c, C - 1) * ldT + qc];
       a[s] = r3d_keep(v, qrow < n && c < C);
     }
   }
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void r3d_knn_small_kernel(
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int c = 2 * s + h;
-      const float v = xb[(long)min(c, C - 1) * N + cc];
+      const float v = xb[(long)min(c, C - 1) * ldT + cc];
       bf[s] = r3d_keep(v, ok && c < C);
     }
     nj = r3d_keep(nb[cc], ok);
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void r3d_knn_small_kernel(
 #define KB_GROUPS (KB_WAVES * 32)
 
 __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_big_kernel(
-    const float* __restrict__ xT, int N, int C, int k, int mode, const int* __restrict__ n_dev,
+    const float* __restrict__ xT, long ldT, int N, int C, int k, int mode, const int* __restrict__ n_dev,
     const float* __restrict__ nrm, int* __restrict__ idx_out, float* __restrict__ score_out,
     int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -549,12 +549,12 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_big_kernel(
   const int Cs = nch * 64 + 1;            // LDS row stride of the query fragments (odd)
   float* Aq = smem;                       // [32][Cs]
   float* region = smem + 32 * Cs;         // pass A: gmax [32][2*KB_GROUPS + 1]; pass B: buffers
-  const float* xb = xT + (long)b * C * N;
+  const float* xb = xT + (long)b * C * ldT;
   const float* nb = nrm + (long)b * N;
 
   for (int e = tid; e < 32 * nch * 64; e += 64 * KB_WAVES) {
     const int c = e >> 5, jj = e & 31;
-    const float v = xb[(long)min(c, C - 1) * N + min(q0 + jj, n - 1)];
+    const float v = xb[(long)min(c, C - 1) * ldT + min(q0 + jj, n - 1)];
     Aq[jj * Cs + c] = r3d_keep(v, c < C && q0 + jj < n);
   }
   if (tid < 32) cnt_s[tid] = 0;
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_big_kernel(
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
       const int c = 64 * ch + 2 * s + h;
-      bf[s] = r3d_keep(xb[(long)min(c, C - 1) * N + cc], ok && c < C);
+      bf[s] = r3d_keep(xb[(long)min(c, C - 1) * ldT + cc], ok && c < C);
     }
   };
   f32x16 acc;
@@ -760,14 +760,17 @@ extern "C" int r3d_sqnorm(const float* x, long ldx, long rows, int C, float* out
 }
 
 // Forward declarations of the layout kernel living in gemm.hip.
-extern "C" int r3d_pm_to_cm(const float* in, long ld, int B, int C, int N, float* out, void* stream);
+extern "C" int r3d_pm_to_cm_pitched(const float* in, long ld, int B, int C, int N, float* out, long pitch, void* stream);
+// row pitch of the internal channel-major copies: N + 32 floats, so that consecutive channels of
+// one point do not sit a power-of-two stride apart (same L2 channel for every load of a chain)
+extern "C" long r3d_cm_pitch(int N) { return (long)((N + 31) / 32) * 32 + 32; }
 
 // x: (B*N, ldx) point-major fp32; norm_ws: (B*N) fp32 scratch; idx_out: (B, N, k) int32;
 // score_out: optional (B, N, k) fp32; n_valid_dev: optional device int, rows >= *n are
 // neither queried nor offered as candidates (used by the head where the node count
 // is data dependent and stays on the device).
 // x_cm: optional (B, C, N) channel-major copy of x (the reference's own layout); when NULL and
-// a streamed kernel applies the copy is made into cm_ws (B*C*N floats).
+// a streamed kernel applies the copy is made into cm_ws (B*C*r3d_cm_pitch(N) floats).
 // status: optional device int.  With k > 32 a non-NULL status selects the append-and-rank
 // kernel; bit 0 set afterwards = its survivor buffer overflowed and the result is unusable
 // (re-run with status == NULL for the insertion kernel).
@@ -781,19 +784,21 @@ extern "C" int r3d_knn_topk(const float* x, long ldx, const float* x_cm, int B, 
   hipStream_t st = (hipStream_t)stream;
   if (k <= 32 && C <= 64) {
     const float* xT = x_cm;
+    long ldT = N;
     if (!xT) {
       R3D_REQUIRE(cm_ws && x, "r3d_knn_topk: need x_cm or (x and cm_ws)");
-      int rc = r3d_pm_to_cm(x, ldx, B, C, N, cm_ws, stream);
+      ldT = r3d_cm_pitch(N);
+      int rc = r3d_pm_to_cm_pitched(x, ldx, B, C, N, cm_ws, ldT, stream);
       if (rc) return rc;
       xT = cm_ws;
     }
-    hipLaunchKernelGGL(r3d_sqnorm_cm_kernel, dim3(r3d_cdiv(N, 256), B), dim3(256), 0, st, xT, C, N, norm_ws);
+    hipLaunchKernelGGL(r3d_sqnorm_cm_kernel, dim3(r3d_cdiv(N, 256), B), dim3(256), 0, st, xT, ldT, C, N, norm_ws);
     dim3 g2(r3d_cdiv(N, 32), B);
     if (C <= 16)
-      hipLaunchKernelGGL(r3d_knn_small_kernel<8>, g2, dim3(256), 0, st, xT, N, C, k, mode, n_valid_dev, norm_ws,
+      hipLaunchKernelGGL(r3d_knn_small_kernel<8>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, norm_ws,
                          idx_out, score_out);
     else
-      hipLaunchKernelGGL(r3d_knn_small_kernel<32>, g2, dim3(256), 0, st, xT, N, C, k, mode, n_valid_dev, norm_ws,
+      hipLaunchKernelGGL(r3d_knn_small_kernel<32>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, norm_ws,
                          idx_out, score_out);
     R3D_LAUNCH_CHECK("r3d_knn_topk(small)");
     return R3D_OK;
@@ -802,13 +807,15 @@ extern "C" int r3d_knn_topk(const float* x, long ldx, const float* x_cm, int B, 
     // fast path for large k; *status bit 0 reports survivor-buffer overflow (caller re-runs with
     // status == NULL, which selects the insertion kernel below)
     const float* xT = x_cm;
+    long ldT = N;
     if (!xT) {
       R3D_REQUIRE(cm_ws && x, "r3d_knn_topk: need x_cm or (x and cm_ws)");
-      int rc = r3d_pm_to_cm(x, ldx, B, C, N, cm_ws, stream);
+      ldT = r3d_cm_pitch(N);
+      int rc = r3d_pm_to_cm_pitched(x, ldx, B, C, N, cm_ws, ldT, stream);
       if (rc) return rc;
       xT = cm_ws;
     }
-    hipLaunchKernelGGL(r3d_sqnorm_cm_kernel, dim3(r3d_cdiv(N, 256), B), dim3(256), 0, st, xT, C, N, norm_ws);
+    hipLaunchKernelGGL(r3d_sqnorm_cm_kernel, dim3(r3d_cdiv(N, 256), B), dim3(256), 0, st, xT, ldT, C, N, norm_ws);
     hipMemsetAsync(status, 0, sizeof(int), st);
     static size_t big_attr = 0;  // static __shared__ arrays count against the 160 KiB too: ask for what is used
     if (knn_big_lds_bytes(C) > big_attr) {
@@ -819,7 +826,7 @@ extern "C" int r3d_knn_topk(const float* x, long ldx, const float* x_cm, int B, 
       big_attr = knn_big_lds_bytes(C);
     }
     hipLaunchKernelGGL(r3d_knn_big_kernel, dim3(r3d_cdiv(N, 32), B), dim3(64 * KB_WAVES), knn_big_lds_bytes(C), st,
-                       xT, N, C, k, mode, n_valid_dev, norm_ws, idx_out, score_out, status);
+                       xT, ldT, N, C, k, mode, n_valid_dev, norm_ws, idx_out, score_out, status);
     R3D_LAUNCH_CHECK("r3d_knn_topk(big)");
     return R3D_OK;
   }

@@ -113,13 +113,13 @@ def knn(x_pm, B, N, k, mode=SCORE_DGCNN, n_valid=None, return_scores=False, x_cm
     cm_ws = None
     if k <= 32 and C <= 64:
         if x_cm is None:
-            cm_ws = torch.empty(B * C * N, device=dev, dtype=torch.float32)
+            cm_ws = torch.empty(B * C * _lib.load().r3d_cm_pitch(N), device=dev, dtype=torch.float32)
         else:
             assert x_cm.is_contiguous() and x_cm.shape == (B, C, N) and x_cm.dtype == torch.float32
     elif status is not None:  # large-k streamed kernel (status bit 0 = overflow -> redo with status=None)
         assert status.dtype == torch.int32
         if x_cm is None:
-            cm_ws = torch.empty(B * C * N, device=dev, dtype=torch.float32)
+            cm_ws = torch.empty(B * C * _lib.load().r3d_cm_pitch(N), device=dev, dtype=torch.float32)
     else:
         x_cm = None
     with _timed("knn_topk_l2" if mode == SCORE_L2 else "knn_topk"):
