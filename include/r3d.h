@@ -104,6 +104,25 @@ int r3d_query_logits_ce(const float* Z, const int32_t* n_proto_dev, int n_q, int
                         const int64_t* labels /*opt (n_q,N)*/, float* logits /*(n_q,n_classes,N)*/,
                         float* loss_out /*opt*/, int32_t* pred_out /*opt (n_q*N)*/, void* stream);
 
+/* ---- clean-shot detection, eval only (models/mpti.py:87-223, 316-371) -----------------
+ * Per shot: box means of foreground features at scales (1,1,1) and (2,2,1) -> cosine map ->
+ * majority vote -> shot_keep (n_way*k_shot) int32 (0 = drop the shot's foreground). */
+long r3d_clean_ws_words(int n_way, int k_shot);
+int r3d_clean_shot_detect(const float* feat /*(S*N,ldf)*/, long ldf, int D, const float* support_x /*(S,Cin,N)*/,
+                          int Cin, const int32_t* support_y, int n_way, int k_shot, int N, int32_t* shot_keep,
+                          float* dbg_cos_sum /*opt (n_way,2,4*k_shot)*/, int32_t* ws, void* stream);
+
+/* ---- ProtoNet head (models/protonet.py:295-349): masked average pooling + similarity ----
+ * method 0 cosine * scaler, 1 -euclidean^2; anything else returns non-zero like the reference's
+ * NotImplementedError.  Z (n_query_pts, 4) similarity rows; ws S*2*256 floats. */
+int r3d_protonet_head(const float* sfeat, long ldf, const float* qfeat, long ldq, int D, const int32_t* support_y,
+                      int n_way, int k_shot, int N, int n_query_pts, int method, float scaler, float* Z, float* ws,
+                      void* stream);
+
+/* ---- mIoU accumulator (eval_noise.py:23-72): hist (3, n_classes) uint64 = GT | predicted | TP */
+int r3d_miou_accumulate(const int32_t* pred, const int64_t* gt, long n, const int32_t* lut, int n_lut, int n_classes,
+                        uint64_t* hist, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,10 @@ _SIGS = {
     "r3d_lp_ws_words": (c_l, [c_i, c_i]),
     "r3d_label_propagate": (c_i, [c_f, c_l, c_i, c_f, c_i, c_f, c_f, c_i, c_fl, c_fl, c_i, c_fl, c_f, c_f,
                                   c_f, c_f]),
+    "r3d_clean_ws_words": (c_l, [c_i, c_i]),
+    "r3d_clean_shot_detect": (c_i, [c_f, c_l, c_i, c_f, c_i, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),
+    "r3d_protonet_head": (c_i, [c_f, c_l, c_f, c_l, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_f, c_f, c_f]),
+    "r3d_miou_accumulate": (c_i, [c_f, c_f, c_l, c_f, c_i, c_i, c_f, c_f]),
     "r3d_query_logits_ce": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f]),
 }
 

@@ -225,3 +225,56 @@ def query_logits_ce(hb, n_q, n_classes, labels):
     _lib.check(_lib.load().r3d_query_logits_ce(_p(hb.Z), _p(hb.desc[HD_N_PROTO:]), n_q, hb.N, n_classes,
                                                _p(labels), _p(logits), _p(loss), _p(pred), _st()))
     return logits, loss, pred
+
+
+def clean_shot_detect(sfeat_pm, support_x, support_y, n_way, k_shot, N, want_debug=False):
+    """shot_keep (n_way*k_shot) int32 of the eval-only clean-shot detection (mpti.py:178-223)."""
+    M, ldf = _rows(sfeat_pm)
+    S = n_way * k_shot
+    assert M == S * N
+    sx = support_x.reshape(S, -1, N).contiguous().float()
+    sy = support_y.reshape(S, N).to(torch.int32).contiguous()
+    dev = sfeat_pm.device
+    keep = torch.empty(S, device=dev, dtype=torch.int32)
+    dbg = torch.zeros(n_way, 2, 4 * k_shot, device=dev, dtype=torch.float32) if want_debug else None
+    ws = torch.empty(_lib.load().r3d_clean_ws_words(n_way, k_shot), device=dev, dtype=torch.int32)
+    _lib.check(_lib.load().r3d_clean_shot_detect(_p(sfeat_pm), ldf, sfeat_pm.shape[1], _p(sx), sx.shape[1], _p(sy),
+                                                 n_way, k_shot, N, _p(keep), _p(dbg), _p(ws), _st()))
+    return (keep, dbg) if want_debug else keep
+
+
+def protonet_head(sfeat_pm, qfeat_pm, support_y, n_way, k_shot, N, method, scaler=10.0):
+    """Similarity rows (n_q*N, 4) of the ProtoNet head; method 'cosine' | 'euclidean'."""
+    M, ldf = _rows(sfeat_pm)
+    Mq, ldq = _rows(qfeat_pm)
+    codes = {"cosine": 0, "euclidean": 1}
+    if method not in codes:
+        raise NotImplementedError('Error! Distance computation method (%s) is unknown!' % method)
+    sy = support_y.reshape(n_way * k_shot, N).to(torch.int32).contiguous()
+    dev = sfeat_pm.device
+    Z = torch.empty(Mq, 4, device=dev, dtype=torch.float32)
+    ws = torch.empty(n_way * k_shot * 2 * 256, device=dev, dtype=torch.float32)
+    _lib.check(_lib.load().r3d_protonet_head(_p(sfeat_pm), ldf, _p(qfeat_pm), ldq, sfeat_pm.shape[1], _p(sy), n_way,
+                                             k_shot, N, Mq, codes[method], float(scaler), _p(Z), _p(ws), _st()))
+    return Z
+
+
+def logits_ce_from_rows(Z, n_q, N, n_classes, labels):
+    """Z (n_q*N, 4) -> logits (n_q, n_classes, N), CE loss, argmax."""
+    dev = Z.device
+    zero = torch.zeros(1, device=dev, dtype=torch.int32)
+    logits = torch.empty(n_q, n_classes, N, device=dev, dtype=torch.float32)
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    pred = torch.empty(n_q, N, device=dev, dtype=torch.int32)
+    _lib.check(_lib.load().r3d_query_logits_ce(_p(Z), _p(zero), n_q, N, n_classes, _p(labels), _p(logits), _p(loss),
+                                               _p(pred), _st()))
+    return logits, loss, pred
+
+
+def miou_accumulate(pred, gt, lut, hist):
+    """hist (3, n_classes) int64 += counts of this episode (eval_noise.py:39-62)."""
+    pred = pred.to(torch.int32).contiguous()
+    gt = gt.to(torch.int64).contiguous()
+    _lib.check(_lib.load().r3d_miou_accumulate(_p(pred), _p(gt), pred.numel(), _p(lut), lut.numel(), hist.shape[1],
+                                               _p(hist), _st()))
+    return hist
