@@ -104,6 +104,52 @@ int r3d_query_logits_ce(const float* Z, const int32_t* n_proto_dev, int n_q, int
                         const int64_t* labels /*opt (n_q,N)*/, float* logits /*(n_q,n_classes,N)*/,
                         float* loss_out /*opt*/, int32_t* pred_out /*opt (n_q*N)*/, void* stream);
 
+/* ==== training mode (BatchNorm with batch statistics, backward) =======================
+ * A conv+BN+act layer: z = r3d_pointwise_conv (no affine) -> r3d_colstats mode 0 -> r3d_bn_fold ->
+ * r3d_affine_act.  Backward: r3d_colstats mode 1 (sum du, sum du*zhat = dbeta, dgamma) ->
+ * r3d_bn_bwd_apply (dz) -> r3d_pointwise_conv(_acc)(dz, W^T) for dX, r3d_gemm_tn(dz, X) for dW.
+ * Reference: nn.BatchNorm{1,2}d in train mode inside models/dgcnn.py:45-80, models/mpti.py:31-39. */
+int r3d_pointwise_conv_acc(const float* X, long ldx, const float* W, long M, int K, int Co, const float* scale,
+                           const float* shift, int act, float* Out, long ldo, void* stream);
+long r3d_colstats_ws_words(long M, int C);
+int r3d_colstats(const float* X, long ldx, const float* DY, long lddy, long M, int C, int mode, const float* scale,
+                 const float* shift, const float* mean, const float* invstd, int act, float* sums_out /*[2][C]*/,
+                 float* ws, void* stream);
+int r3d_bn_fold(const float* sums, double count, int C, const float* gamma, const float* beta, float eps,
+                float momentum, float* running_mean /*opt*/, float* running_var /*opt*/, float* mean, float* invstd,
+                float* scale, float* shift, void* stream);
+int r3d_affine_act(const float* Z, long ldz, long M, int C, const float* scale, const float* shift, int act, float* Y,
+                   long ldy, void* stream);
+int r3d_bn_bwd_apply(const float* Z, long ldz, const float* DY, long lddy, long M, int C, const float* scale,
+                     const float* shift, const float* mean, const float* invstd, int act, const float* sums,
+                     double count, float* DZ, long lddz, void* stream);
+long r3d_gemm_tn_ws_words(long M, int Ca, int Cb);
+int r3d_gemm_tn(const float* A, long lda, const float* B, long ldb, long M, int Ca, int Cb, float alpha, float* out,
+                int accumulate, float* ws, void* stream);
+int r3d_add_cols(const float* src, long ld_src, float* dst, long ld_dst, long M, int C, void* stream);
+
+/* EdgeConv with batch statistics over all B*N*K edges (models/dgcnn.py:53-57 in train mode) and its
+ * backward; PQ is the RAW point-wise GEMM [Wa x | (Wb-Wa) x]. */
+long r3d_edgeconv_train_ws_words(void);
+int r3d_edge_stats1(const float* PQ, const int32_t* idx, int B, int N, int K, float* sums_out /*[2][64]*/, float* ws,
+                    void* stream);
+int r3d_edgeconv_train_fwd(const float* PQ, const int32_t* idx, const float* s1, const float* t1, const float* W2,
+                           const float* s2, const float* t2, int mode /*1: stats of z2, 0: output*/, float* out, long ldo,
+                           int B, int N, int K, int32_t* argmax_out, float* zmax_out, float* sums_out, float* ws,
+                           void* stream);
+int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float* s1, const float* t1, const float* mean1,
+                     const float* invstd1, const float* W2, const float* s2, const float* t2, const float* mean2,
+                     const float* invstd2, const float* bn2_sums, const float* dout, long lddo, const int32_t* argmax,
+                     int B, int N, int K, float* DY1 /*(B*N*K,64) scratch*/, float* dW2, float* bn1_sums, float* dPQ,
+                     float* ws, void* stream);
+
+/* attention with dropout on the weights (attention.py:45) and flash-style backward */
+int r3d_attention_fwd_train(const float* qkv, long ld, int B, int N, float* out, long ldo, float* lse_out, float p_drop,
+                            unsigned seed, void* stream);
+int r3d_attention_bwd(const float* qkv, long ld, int B, int N, const float* O, long ldo, const float* dO, long lddo,
+                      const float* lse, float p_drop, unsigned seed, float q_scale, float* dqkv, long ldd, float* ws,
+                      void* stream);
+
 /* ---- clean-shot detection, eval only (models/mpti.py:87-223, 316-371) -----------------
  * Per shot: box means of foreground features at scales (1,1,1) and (2,2,1) -> cosine map ->
  * majority vote -> shot_keep (n_way*k_shot) int32 (0 = drop the shot's foreground). */

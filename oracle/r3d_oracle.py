@@ -188,8 +188,8 @@ def self_attention(sd, x, prefix="att_learner", drop_mask=None):
 # --------------------------------------------------------------------------
 # a8  getFeatures (models/mpti.py:579-595)
 # --------------------------------------------------------------------------
-def get_features(sd, x, cfg, train=False, new_stats=None, drop_mask=None):
-    l1, l2 = dgcnn_forward(sd, x, k=cfg["dgcnn_k"], train=train, new_stats=new_stats)
+def get_features(sd, x, cfg, train=False, new_stats=None, drop_mask=None, idx_override=None):
+    l1, l2 = dgcnn_forward(sd, x, k=cfg["dgcnn_k"], train=train, new_stats=new_stats, idx_override=idx_override)
     l3 = base_learner(sd, l2, train=train, new_stats=new_stats)
     if cfg.get("use_attention", True):
         att = self_attention(sd, l2, drop_mask=drop_mask)

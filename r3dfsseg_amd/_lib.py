@@ -16,6 +16,8 @@ c_f = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
 c_l = ctypes.c_long
 c_fl = ctypes.c_float
+c_d = ctypes.c_double
+c_u = ctypes.c_uint
 
 _SIGS = {
     "r3d_last_error_string": (ctypes.c_char_p, []),
@@ -39,6 +41,21 @@ _SIGS = {
     "r3d_lp_ws_words": (c_l, [c_i, c_i]),
     "r3d_label_propagate": (c_i, [c_f, c_l, c_i, c_f, c_i, c_f, c_f, c_i, c_fl, c_fl, c_i, c_fl, c_f, c_f,
                                   c_f, c_f]),
+    "r3d_pointwise_conv_acc": (c_i, [c_f, c_l, c_f, c_l, c_i, c_i, c_f, c_f, c_i, c_f, c_l, c_f]),
+    "r3d_colstats_ws_words": (c_l, [c_l, c_i]),
+    "r3d_colstats": (c_i, [c_f, c_l, c_f, c_l, c_l, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_f]),
+    "r3d_bn_fold": (c_i, [c_f, c_d, c_i, c_f, c_f, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "r3d_affine_act": (c_i, [c_f, c_l, c_l, c_i, c_f, c_f, c_i, c_f, c_l, c_f]),
+    "r3d_bn_bwd_apply": (c_i, [c_f, c_l, c_f, c_l, c_l, c_i, c_f, c_f, c_f, c_f, c_i, c_f, c_d, c_f, c_l, c_f]),
+    "r3d_gemm_tn_ws_words": (c_l, [c_l, c_i, c_i]),
+    "r3d_gemm_tn": (c_i, [c_f, c_l, c_f, c_l, c_l, c_i, c_i, c_fl, c_f, c_i, c_f, c_f]),
+    "r3d_add_cols": (c_i, [c_f, c_l, c_f, c_l, c_l, c_i, c_f]),
+    "r3d_edgeconv_train_ws_words": (c_l, []),
+    "r3d_edge_stats1": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f]),
+    "r3d_edgeconv_train_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_l, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f]),
+    "r3d_edgeconv_bwd": (c_i, [c_f] * 13 + [c_l, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "r3d_attention_fwd_train": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_fl, c_u, c_f]),
+    "r3d_attention_bwd": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_l, c_f, c_fl, c_u, c_fl, c_f, c_l, c_f, c_f]),
     "r3d_clean_ws_words": (c_l, [c_i, c_i]),
     "r3d_clean_shot_detect": (c_i, [c_f, c_l, c_i, c_f, c_i, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),
     "r3d_protonet_head": (c_i, [c_f, c_l, c_f, c_l, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_f, c_f, c_f]),

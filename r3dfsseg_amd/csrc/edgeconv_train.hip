@@ -1,0 +1,431 @@
+// EdgeConv in TRAINING mode (batch-statistics BatchNorm over all B*N*K edges) and its backward, gfx950.
+//
+// Reference: models/dgcnn.py:26-61,117-118 with nn.BatchNorm2d in train mode.  With W1 = [Wa | Wb]:
+//   e1(i,t) = P[j_it] + Q[i],  P = Wa x, Q = (Wb - Wa) x          (PQ: one point-wise GEMM, raw)
+//   h1 = lrelu(s1 e1 + t1)        s1 = g1 / sqrt(var1 + eps), t1 = b1 - mu1 s1   (stats over edges)
+//   z2 = W2 h1 ;  a2 = lrelu(s2 z2 + t2) ;  out[i] = max_t a2(i,t)
+// Forward:  r3d_edge_stats1 (sum e1, sum e1^2) -> fold -> r3d_edgeconv_train_fwd mode 1 (sum z2,
+// sum z2^2) -> fold -> mode 0 (output, argmax, z2 at the argmax).
+// Backward: the max routes dout to one edge per (point, channel), but BatchNorm's mean terms make
+// dz2 DENSE over edges, so the backward re-runs the edge GEMM:
+//   B1 (matrix core): recompute h1, z2; dz2 = s2 (dy2 - m1 - zhat2 m2); dW2 += dz2^T h1;
+//       dh1 = dz2 W2; dy1 = dh1 lrelu'(u1) -> stored per edge; partial sums of dy1, dy1 ehat1
+//   B2 (gather/scatter): de1 = s1 (dy1 - n1 - ehat1 n2); dQ[i] = sum_t de1; dP[j] += de1 (float atomics
+//       on whole 256-B rows, the shape the memory-side atomic units run at full rate).
+#include "common.h"
+
+#define ET_PTS 8
+#define ET_LD 65
+#define ET_MAXBLK 1024
+
+static __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : 0.2f * v; }
+
+// ---- BN1 statistics over edges: partial[block][2][64] ------------------------------------------
+__global__ __launch_bounds__(256) void r3d_edge_stats1_kernel(const float* __restrict__ PQ, const int* __restrict__ idx,
+                                                              int N, int K, long total_points,
+                                                              float* __restrict__ part) {
+  __shared__ float sa[4][64], sb[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float a = 0.f, b = 0.f;
+  for (long pt = (long)blockIdx.x * 4 + w; pt < total_points; pt += (long)gridDim.x * 4) {
+    const long cloud0 = (pt / N) * N;
+    const float q = PQ[pt * 128 + 64 + lane];
+    const int my_idx = idx[pt * K + min(lane, K - 1)];
+    for (int t = 0; t < K; ++t) {
+      const int j = __builtin_amdgcn_readlane(my_idx, t);
+      const float e = PQ[(cloud0 + j) * 128 + lane] + q;
+      a += e;
+      b += e * e;
+    }
+  }
+  sa[w][lane] = a;
+  sb[w][lane] = b;
+  __syncthreads();
+  if (w == 0) {
+    part[((long)blockIdx.x * 2 + 0) * 64 + lane] = ((sa[0][lane] + sa[1][lane]) + sa[2][lane]) + sa[3][lane];
+    part[((long)blockIdx.x * 2 + 1) * 64 + lane] = ((sb[0][lane] + sb[1][lane]) + sb[2][lane]) + sb[3][lane];
+  }
+}
+
+__global__ void r3d_part_reduce64_kernel(const float* __restrict__ part, int nblk, int nvec, float* __restrict__ out) {
+  // out[v][c] = sum over blocks of part[blk][v][c], c < 64, in fp64, ascending block order
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nvec * 64) return;
+  double s = 0.0;
+  for (int k = 0; k < nblk; ++k) s += (double)part[(long)k * nvec * 64 + i];
+  out[i] = (float)s;
+}
+
+// ---- forward: mode 0 = output (+argmax, z at argmax); mode 1 = statistics of z2 -------------------
+template <int MODE>
+__global__ __launch_bounds__(512) void r3d_edgeconv_train_fwd_kernel(
+    const float* __restrict__ PQ, const int* __restrict__ idx, const float* __restrict__ s1, const float* __restrict__ t1,
+    const float* __restrict__ W2, const float* __restrict__ s2, const float* __restrict__ t2, float* __restrict__ out,
+    long ldo, int N, int K, long total_points, int* __restrict__ argmax_out, float* __restrict__ zmax_out,
+    float* __restrict__ part /* mode 1: [grid][2][64] */) {
+  extern __shared__ __attribute__((aligned(16))) float H[];  // [8K][ET_LD]
+  __shared__ float ps[16][2][64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nwaves = blockDim.x >> 6;
+  float b0[32], b1[32];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {
+    b0[s] = W2[(lane & 31) * 64 + 2 * s + (lane >> 5)];
+    b1[s] = W2[(32 + (lane & 31)) * 64 + 2 * s + (lane >> 5)];
+  }
+  const float sc1 = s1[lane], sh1 = t1[lane];
+  float za0 = 0.f, zb0 = 0.f, za1 = 0.f, zb1 = 0.f;  // mode 1: per-lane sums (channel lane&31 / +32)
+  const long units = total_points / ET_PTS;
+  for (long u = blockIdx.x; u < units; u += gridDim.x) {
+    const long pt0 = u * ET_PTS;
+    const long cloud0 = (pt0 / N) * N;
+    {
+      const int my_idx = idx[pt0 * K + 32 * w + (lane & 31)];
+      float* hrow = H + (32 * w) * ET_LD;
+#pragma unroll 8
+      for (int t = 0; t < 32; ++t) {
+        const int j = __builtin_amdgcn_readlane(my_idx, t);
+        const int pi = (32 * w + t) / K;
+        const float p = PQ[(cloud0 + j) * 128 + lane];
+        const float q = PQ[(pt0 + pi) * 128 + 64 + lane];
+        hrow[t * ET_LD + lane] = lrelu(sc1 * (p + q) + sh1);
+      }
+    }
+    f32x16 a0, a1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+    {
+      const float* ap = H + (32 * w + (lane & 31)) * ET_LD + (lane >> 5);
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        const float a = ap[2 * s];
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[s], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[s], a1, 0, 0, 0);
+      }
+    }
+    if (MODE == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { za0 += a0[r]; zb0 += a0[r] * a0[r]; za1 += a1[r]; zb1 += a1[r] * a1[r]; }
+    } else {
+      // raw z2 back into this wave's LDS rows; BN2 + LeakyReLU are applied in the max loop so that the
+      // winner's z2 can be saved for the backward pass
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * w + r3d_acc_row(r, lane);
+        H[row * ET_LD + (lane & 31)] = a0[r];
+        H[row * ET_LD + 32 + (lane & 31)] = a1[r];
+      }
+      __syncthreads();
+      for (int o = tid; o < ET_PTS * 64; o += blockDim.x) {
+        const int pt = o >> 6, ch = o & 63;
+        const float sc = s2[ch], sh = t2[ch];
+        const float* hp = H + (pt * K) * ET_LD + ch;
+        float zb = hp[0];
+        float m = lrelu(sc * zb + sh);
+        int am = 0;
+        for (int t = 1; t < K; ++t) {
+          const float z = hp[t * ET_LD];
+          const float v = lrelu(sc * z + sh);
+          if (v > m) { m = v; am = t; zb = z; }
+        }
+        out[(pt0 + pt) * ldo + ch] = m;
+        if (argmax_out) argmax_out[(pt0 + pt) * 64 + ch] = am;
+        if (zmax_out) zmax_out[(pt0 + pt) * 64 + ch] = zb;
+      }
+      __syncthreads();
+    }
+  }
+  if (MODE == 1) {
+    // combine the two lane halves (same channel), then the waves, in a fixed order
+    za0 += __shfl_xor(za0, 32); zb0 += __shfl_xor(zb0, 32);
+    za1 += __shfl_xor(za1, 32); zb1 += __shfl_xor(zb1, 32);
+    if (lane < 32) { ps[w][0][lane] = za0; ps[w][1][lane] = zb0; ps[w][0][32 + lane] = za1; ps[w][1][32 + lane] = zb1; }
+    __syncthreads();
+    if (tid < 128) {
+      const int v = tid >> 6, c = tid & 63;
+      float s = 0.f;
+      for (int q = 0; q < nwaves; ++q) s += ps[q][v][c];
+      part[((long)blockIdx.x * 2 + v) * 64 + c] = s;
+    }
+  }
+}
+
+// ---- backward pass B1 -------------------------------------------------------------------------
+// part layout per block: [0] dW2 partial 64*64, then [4096 + v*64 + c], v = 0: sum dy1, 1: sum dy1*ehat1
+#define ET_PART (64 * 64 + 2 * 64)
+__global__ __launch_bounds__(512) void r3d_edgeconv_bwd1_kernel(
+    const float* __restrict__ PQ, const int* __restrict__ idx, const float* __restrict__ s1, const float* __restrict__ t1,
+    const float* __restrict__ mean1, const float* __restrict__ invstd1, const float* __restrict__ W2,
+    const float* __restrict__ s2, const float* __restrict__ t2, const float* __restrict__ mean2,
+    const float* __restrict__ invstd2, const float* __restrict__ bn2_sums /* [2][64]: sum dy2, sum dy2 zhat2 */,
+    const float* __restrict__ dout, long lddo, const int* __restrict__ argmax, int N, int K, long total_points,
+    float* __restrict__ DY1 /* (total_points*K, 64) */, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int EK = ET_PTS * K;
+  float* H = smem;                       // [8K][ET_LD] h1
+  float* G = smem + EK * ET_LD;          // [8K][ET_LD] dz2, later dy1
+  float* dsm = G + EK * ET_LD;           // [8][64] dout of the unit
+  int* asm_ = (int*)(dsm + ET_PTS * 64); // [8][64] argmax of the unit
+  __shared__ float ps[16][2][64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nwaves = blockDim.x >> 6;
+  const int h = lane >> 5, j = lane & 31;
+  float b0[32], b1[32], wb0[32], wb1[32];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {
+    b0[s] = W2[j * 64 + 2 * s + h];             // B[k][jo] = W2[jo][k]   (z2 = W2 h1)
+    b1[s] = W2[(32 + j) * 64 + 2 * s + h];
+    wb0[s] = W2[(2 * s + h) * 64 + j];          // B[k = c][ji] = W2[c][ji] (dh1 = dz2 W2)
+    wb1[s] = W2[(2 * s + h) * 64 + 32 + j];
+  }
+  const float sc1 = s1[lane], sh1 = t1[lane], mu1 = mean1[lane], is1 = invstd1[lane];
+  const double E = (double)total_points * K;
+  // channel constants in the accumulator layout (column = j, +32 for the second tile)
+  const float s2a = s2[j], t2a = t2[j], mu2a = mean2[j], is2a = invstd2[j];
+  const float s2b = s2[32 + j], t2b = t2[32 + j], mu2b = mean2[32 + j], is2b = invstd2[32 + j];
+  const float m1a = (float)((double)bn2_sums[j] / E), m2a = (float)((double)bn2_sums[64 + j] / E);
+  const float m1b = (float)((double)bn2_sums[32 + j] / E), m2b = (float)((double)bn2_sums[96 + j] / E);
+  f32x16 dw;  // waves 0..3: dW2 tile (ti = w>>1: rows c, tj = w&1: cols ji)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dw[r] = 0.f;
+  float sdy = 0.f, sdye = 0.f;
+  const long units = total_points / ET_PTS;
+  for (long u = blockIdx.x; u < units; u += gridDim.x) {
+    const long pt0 = u * ET_PTS;
+    const long cloud0 = (pt0 / N) * N;
+    for (int o = tid; o < ET_PTS * 64; o += blockDim.x) {
+      dsm[o] = dout[(pt0 + (o >> 6)) * lddo + (o & 63)];
+      asm_[o] = argmax[(pt0 + (o >> 6)) * 64 + (o & 63)];
+    }
+    float eh[32];  // ehat1 of this wave's 32 edges, channel = lane
+    {
+      const int my_idx = idx[pt0 * K + 32 * w + j];
+      float* hrow = H + (32 * w) * ET_LD;
+#pragma unroll
+      for (int t = 0; t < 32; ++t) {
+        const int jn = __builtin_amdgcn_readlane(my_idx, t);
+        const int pi = (32 * w + t) / K;
+        const float e1 = PQ[(cloud0 + jn) * 128 + lane] + PQ[(pt0 + pi) * 128 + 64 + lane];
+        eh[t] = (e1 - mu1) * is1;
+        hrow[t * ET_LD + lane] = lrelu(sc1 * e1 + sh1);
+      }
+    }
+    f32x16 a0, a1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+    {
+      const float* ap = H + (32 * w + j) * ET_LD + h;
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        const float a = ap[2 * s];
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[s], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[s], a1, 0, 0, 0);
+      }
+    }
+    __syncthreads();  // dsm / asm_ visible
+    // dz2 into G (this wave's rows)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int e = 32 * w + r3d_acc_row(r, lane);
+      const int pt = e / K, t = e - pt * K;
+      {
+        const float z = a0[r];
+        const float uu = s2a * z + t2a;
+        float dy = (asm_[pt * 64 + j] == t) ? dsm[pt * 64 + j] * (uu > 0.f ? 1.f : 0.2f) : 0.f;
+        G[e * ET_LD + j] = s2a * (dy - m1a - ((z - mu2a) * is2a) * m2a);
+      }
+      {
+        const float z = a1[r];
+        const float uu = s2b * z + t2b;
+        float dy = (asm_[pt * 64 + 32 + j] == t) ? dsm[pt * 64 + 32 + j] * (uu > 0.f ? 1.f : 0.2f) : 0.f;
+        G[e * ET_LD + 32 + j] = s2b * (dy - m1b - ((z - mu2b) * is2b) * m2b);
+      }
+    }
+    __syncthreads();  // G and H complete for every wave
+    // dh1 = dz2 W2 (own rows), dy1 = dh1 * lrelu'(u1)  (u1 > 0  <=>  h1 > 0)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+    {
+      const float* gp = G + (32 * w + j) * ET_LD + h;
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        const float a = gp[2 * s];
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb0[s], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb1[s], a1, 0, 0, 0);
+      }
+    }
+    // dW2 += dz2^T h1 over the unit's 8K edges (waves 0..3, one 32x32 tile each)
+    if (w < 4) {
+      const int ti = w >> 1, tj = w & 1;
+      for (int s = 0; s < EK / 2; ++s) {
+        const int e = 2 * s + h;
+        dw = __builtin_amdgcn_mfma_f32_32x32x2f32(G[e * ET_LD + 32 * ti + j], H[e * ET_LD + 32 * tj + j], dw, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int e = 32 * w + r3d_acc_row(r, lane);
+      a0[r] *= (H[e * ET_LD + j] > 0.f) ? 1.f : 0.2f;
+      a1[r] *= (H[e * ET_LD + 32 + j] > 0.f) ? 1.f : 0.2f;
+    }
+    __syncthreads();  // every read of G (dz2) and H is done
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int e = 32 * w + r3d_acc_row(r, lane);
+      G[e * ET_LD + j] = a0[r];
+      G[e * ET_LD + 32 + j] = a1[r];
+    }
+    // same wave reads its rows back channel-per-lane: store dy1 rows, BN1 partial sums
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+      const float v = G[(32 * w + t) * ET_LD + lane];
+      DY1[(pt0 * K + 32 * w + t) * 64 + lane] = v;
+      sdy += v;
+      sdye += v * eh[t];
+    }
+    __syncthreads();  // before the next unit overwrites H / G / dsm
+  }
+  // per-block partials
+  ps[w][0][lane] = sdy;
+  ps[w][1][lane] = sdye;
+  __syncthreads();
+  float* mypart = part + (long)blockIdx.x * ET_PART;
+  if (tid < 128) {
+    const int v = tid >> 6, c = tid & 63;
+    float s = 0.f;
+    for (int q = 0; q < nwaves; ++q) s += ps[q][v][c];
+    mypart[4096 + v * 64 + c] = s;
+  }
+  if (w < 4) {
+    const int ti = w >> 1, tj = w & 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mypart[(32 * ti + r3d_acc_row(r, lane)) * 64 + 32 * tj + j] = dw[r];
+  }
+}
+
+__global__ void r3d_part_reduce_kernel(const float* __restrict__ part, int nblk, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int k = 0; k < nblk; ++k) s += (double)part[(long)k * n + i];
+  out[i] = (float)s;
+}
+
+// ---- backward pass B2: de1 -> dQ (sum over K), dP (scatter-add) ------------------------------------
+__global__ __launch_bounds__(256) void r3d_edgeconv_bwd2_kernel(
+    const float* __restrict__ PQ, const int* __restrict__ idx, const float* __restrict__ s1, const float* __restrict__ mean1,
+    const float* __restrict__ invstd1, const float* __restrict__ bn1_sums /* [2][64] */, const float* __restrict__ DY1,
+    int N, int K, long total_points, float* __restrict__ dPQ /* (M,128), zero-initialised */) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const double E = (double)total_points * K;
+  const float sc1 = s1[lane], mu1 = mean1[lane], is1 = invstd1[lane];
+  const float n1 = (float)((double)bn1_sums[lane] / E), n2 = (float)((double)bn1_sums[64 + lane] / E);
+  for (long pt = (long)blockIdx.x * 4 + w; pt < total_points; pt += (long)gridDim.x * 4) {
+    const long cloud0 = (pt / N) * N;
+    const float q = PQ[pt * 128 + 64 + lane];
+    const int my_idx = idx[pt * K + min(lane, K - 1)];
+    float dq = 0.f;
+    for (int t = 0; t < K; ++t) {
+      const int jn = __builtin_amdgcn_readlane(my_idx, t);
+      const float e1 = PQ[(cloud0 + jn) * 128 + lane] + q;
+      const float de = sc1 * (DY1[(pt * K + t) * 64 + lane] - n1 - ((e1 - mu1) * is1) * n2);
+      dq += de;
+      atomicAdd(&dPQ[(cloud0 + jn) * 128 + lane], de);
+    }
+    atomicAdd(&dPQ[pt * 128 + 64 + lane], dq);
+  }
+}
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+static int et_check(const char* fn, int B, int N, int K) {
+  if (B <= 0 || N <= 0 || N % ET_PTS != 0 || K < 4 || K > 32 || K % 4 != 0) {
+    r3d_set_error("%s: unsupported shape B=%d N=%d K=%d (N %% 8 == 0, K %% 4 == 0, 4..32)", fn, B, N, K);
+    return R3D_ERR_ARG;
+  }
+  return 0;
+}
+static int et_grid(long units) { return (int)(units < ET_MAXBLK ? units : ET_MAXBLK); }
+
+extern "C" long r3d_edgeconv_train_ws_words(void) { return (long)(ET_MAXBLK + 1) * ET_PART + 64; }
+
+// sums_out [2][64] = (sum e1, sum e1^2) over all B*N*K edges
+extern "C" int r3d_edge_stats1(const float* PQ, const int32_t* idx, int B, int N, int K, float* sums_out, float* ws,
+                               void* stream) {
+  R3D_REQUIRE(PQ && idx && sums_out && ws, "r3d_edge_stats1: null pointer");
+  int rc = et_check("r3d_edge_stats1", B, N, K);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = 512;
+  hipLaunchKernelGGL(r3d_edge_stats1_kernel, dim3(grid), dim3(256), 0, st, PQ, idx, N, K, (long)B * N, ws);
+  hipLaunchKernelGGL(r3d_part_reduce64_kernel, dim3(1), dim3(128), 0, st, ws, grid, 2, sums_out);
+  R3D_LAUNCH_CHECK("r3d_edge_stats1");
+  return R3D_OK;
+}
+
+// mode 1: sums_out [2][64] = (sum z2, sum z2^2); mode 0: out (B*N, ldo), argmax (B*N,64) int32, zmax (B*N,64)
+extern "C" int r3d_edgeconv_train_fwd(const float* PQ, const int32_t* idx, const float* s1, const float* t1,
+                                      const float* W2, const float* s2, const float* t2, int mode, float* out, long ldo,
+                                      int B, int N, int K, int32_t* argmax_out, float* zmax_out, float* sums_out,
+                                      float* ws, void* stream) {
+  R3D_REQUIRE(PQ && idx && s1 && t1 && W2 && ws, "r3d_edgeconv_train_fwd: null pointer");
+  int rc = et_check("r3d_edgeconv_train_fwd", B, N, K);
+  if (rc) return rc;
+  const int waves = ET_PTS * K / 32;
+  const size_t lds = sizeof(float) * (size_t)ET_PTS * K * ET_LD;
+  const long units = (long)B * N / ET_PTS;
+  const int grid = et_grid(units);
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 1) {
+    R3D_REQUIRE(sums_out, "r3d_edgeconv_train_fwd: mode 1 needs sums_out");
+    hipLaunchKernelGGL(r3d_edgeconv_train_fwd_kernel<1>, dim3(grid), dim3(64 * waves), lds, st, PQ, idx, s1, t1, W2, s2, t2,
+                       out, ldo, N, K, (long)B * N, argmax_out, zmax_out, ws);
+    hipLaunchKernelGGL(r3d_part_reduce64_kernel, dim3(1), dim3(128), 0, st, ws, grid, 2, sums_out);
+  } else {
+    R3D_REQUIRE(out && s2 && t2 && ldo >= 64, "r3d_edgeconv_train_fwd: mode 0 needs out, s2, t2");
+    hipLaunchKernelGGL(r3d_edgeconv_train_fwd_kernel<0>, dim3(grid), dim3(64 * waves), lds, st, PQ, idx, s1, t1, W2, s2, t2,
+                       out, ldo, N, K, (long)B * N, argmax_out, zmax_out, ws);
+  }
+  R3D_LAUNCH_CHECK("r3d_edgeconv_train_fwd");
+  return R3D_OK;
+}
+
+// Backward.  bn2_sums [2][64] = (sum dy2, sum dy2*zhat2) (from the point-level winners, computed by the
+// caller with r3d_colstats mode 1 on zmax).  Outputs: dW2 (64,64), bn1_sums [2][64] (sum dy1, sum dy1*ehat1),
+// dPQ (B*N,128) (zero-initialised by this call).  DY1 scratch: B*N*K*64 floats.
+extern "C" int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float* s1, const float* t1, const float* mean1,
+                                const float* invstd1, const float* W2, const float* s2, const float* t2,
+                                const float* mean2, const float* invstd2, const float* bn2_sums, const float* dout,
+                                long lddo, const int32_t* argmax, int B, int N, int K, float* DY1, float* dW2,
+                                float* bn1_sums, float* dPQ, float* ws, void* stream) {
+  R3D_REQUIRE(PQ && idx && s1 && t1 && mean1 && invstd1 && W2 && s2 && t2 && mean2 && invstd2 && bn2_sums && dout &&
+                  argmax && DY1 && dW2 && bn1_sums && dPQ && ws,
+              "r3d_edgeconv_bwd: null pointer");
+  int rc = et_check("r3d_edgeconv_bwd", B, N, K);
+  if (rc) return rc;
+  const int waves = ET_PTS * K / 32;
+  const int EK = ET_PTS * K;
+  const size_t lds = sizeof(float) * ((size_t)2 * EK * ET_LD + 2 * ET_PTS * 64);
+  const long units = (long)B * N / ET_PTS;
+  const int grid = et_grid(units);
+  hipStream_t st = (hipStream_t)stream;
+  static size_t attr = 0;
+  if (lds > attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)r3d_edgeconv_bwd1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    R3D_REQUIRE(e == hipSuccess, "r3d_edgeconv_bwd: cannot reserve %zu B of LDS", lds);
+    attr = lds;
+  }
+  hipLaunchKernelGGL(r3d_edgeconv_bwd1_kernel, dim3(grid), dim3(64 * waves), lds, st, PQ, idx, s1, t1, mean1, invstd1, W2,
+                     s2, t2, mean2, invstd2, bn2_sums, dout, lddo, argmax, N, K, (long)B * N, DY1, ws);
+  // partial layout: dW2 (4096) | sum dy1 (64) | sum dy1*ehat1 (64)
+  float* red = ws + (long)grid * ET_PART;  // ET_PART floats of headroom are part of r3d_edgeconv_train_ws_words
+  hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(r3d_cdiv(ET_PART, 256)), dim3(256), 0, st, ws, grid, ET_PART, red);
+  hipMemcpyAsync(dW2, red, sizeof(float) * 4096, hipMemcpyDeviceToDevice, st);
+  hipMemcpyAsync(bn1_sums, red + 4096, sizeof(float) * 128, hipMemcpyDeviceToDevice, st);
+  hipMemsetAsync(dPQ, 0, sizeof(float) * (size_t)B * N * 128, st);
+  hipLaunchKernelGGL(r3d_edgeconv_bwd2_kernel, dim3(1024), dim3(256), 0, st, PQ, idx, s1, mean1, invstd1, bn1_sums, DY1, N,
+                     K, (long)B * N, dPQ);
+  R3D_LAUNCH_CHECK("r3d_edgeconv_bwd");
+  return R3D_OK;
+}

@@ -27,7 +27,7 @@ enum { R3D_ACT_NONE = 0, R3D_ACT_RELU = 1, R3D_ACT_LRELU02 = 2 };
 __global__ __launch_bounds__(256) void r3d_pointwise_gemm_kernel(
     const float* __restrict__ X, long ldx, const float* __restrict__ W, int M, int K, int Co,
     const float* __restrict__ scale, const float* __restrict__ shift, int act,
-    float* __restrict__ Out, long ldo) {
+    float* __restrict__ Out, long ldo, int accumulate) {
   __shared__ float Xs[G_BM * G_LD];
   __shared__ float Ws[G_BN * G_LD];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -77,20 +77,35 @@ __global__ __launch_bounds__(256) void r3d_pointwise_gemm_kernel(
     float v = sc * acc[r] + sh;
     if (act == R3D_ACT_RELU) v = fmaxf(v, 0.f);
     else if (act == R3D_ACT_LRELU02) v = v > 0.f ? v : 0.2f * v;
-    Out[m * ldo + j] = v;
+    Out[m * ldo + j] = accumulate ? Out[m * ldo + j] + v : v;
   }
 }
+
+static int pointwise_launch(const float* X, long ldx, const float* W, long M, int K, int Co, const float* scale,
+                            const float* shift, int act, float* Out, long ldo, int accumulate, void* stream);
 
 extern "C" int r3d_pointwise_conv(const float* X, long ldx, const float* W, long M, int K, int Co,
                                   const float* scale, const float* shift, int act, float* Out,
                                   long ldo, void* stream) {
+  return pointwise_launch(X, ldx, W, M, K, Co, scale, shift, act, Out, ldo, 0, stream);
+}
+
+// Out += act(scale * X W^T + shift): gradient accumulation into a (slice of a) wider buffer
+extern "C" int r3d_pointwise_conv_acc(const float* X, long ldx, const float* W, long M, int K, int Co,
+                                      const float* scale, const float* shift, int act, float* Out,
+                                      long ldo, void* stream) {
+  return pointwise_launch(X, ldx, W, M, K, Co, scale, shift, act, Out, ldo, 1, stream);
+}
+
+static int pointwise_launch(const float* X, long ldx, const float* W, long M, int K, int Co, const float* scale,
+                            const float* shift, int act, float* Out, long ldo, int accumulate, void* stream) {
   R3D_REQUIRE(X && W && Out, "r3d_pointwise_conv: null pointer");
   R3D_REQUIRE(M > 0 && K > 0 && Co > 0 && ldx >= K && ldo >= Co,
               "r3d_pointwise_conv: bad shape M=%ld K=%d Co=%d ldx=%ld ldo=%ld", M, K, Co, ldx, ldo);
   R3D_REQUIRE(act >= 0 && act <= 2, "r3d_pointwise_conv: unknown activation %d", act);
   dim3 grid(r3d_cdiv(M, G_BM), r3d_cdiv(Co, G_BN));
   hipLaunchKernelGGL(r3d_pointwise_gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, W,
-                     (int)M, K, Co, scale, shift, act, Out, ldo);
+                     (int)M, K, Co, scale, shift, act, Out, ldo, accumulate);
   R3D_LAUNCH_CHECK("r3d_pointwise_conv");
   return R3D_OK;
 }

@@ -1,0 +1,302 @@
+"""Training-mode launch orchestration (forward with batch-statistics BatchNorm + backward).
+
+Two torch.autograd.Function objects wrap the HIP kernels so that the reference's
+``loss.backward(); optimizer.step()`` (models/mpti_learner.py:68-70) works unchanged:
+``EncoderTrainFn`` (DGCNN + BaseLearner + SelfAttention, i.e. getFeatures, models/mpti.py:579-589)
+and, in head_train.py, the transductive head with its losses.  Nothing here computes: every tensor
+operation is a call into libr3d_hip.so; torch provides memory, the autograd graph edge and Adam.
+"""
+import ctypes
+
+import torch
+
+from . import _lib, ops
+from .ops import _p, _rows, _st
+
+BN_EPS, BN_MOM = 1e-5, 0.1
+
+
+def _f(n, dev):
+    return torch.empty(n, device=dev, dtype=torch.float32)
+
+
+# ----------------------------------------------------------------------------- thin wrappers
+def colstats(X, C, mode=0, DY=None, bn=None, act=0):
+    M, ldx = _rows(X)
+    dev = X.device
+    lib = _lib.load()
+    sums = _f(2 * C, dev)
+    ws = _f(lib.r3d_colstats_ws_words(M, C), dev)
+    lddy = DY.stride(0) if DY is not None else 0
+    sc, sh, mu, is_ = bn if bn is not None else (None, None, None, None)
+    _lib.check(lib.r3d_colstats(_p(X), ldx, _p(DY), lddy, M, C, mode, _p(sc), _p(sh), _p(mu), _p(is_), act, _p(sums),
+                                _p(ws), _st()))
+    return sums
+
+
+def bn_fold(sums, count, bnmod, bias=None):
+    """Batch mean / invstd -> (scale, shift, mean, invstd); updates the module's running statistics like
+    nn.BatchNorm in train mode.  `bias`: conv bias folded away by the mean subtraction (it only shifts the
+    running mean)."""
+    C = bnmod.num_features
+    dev = sums.device
+    mean, invstd, scale, shift = _f(C, dev), _f(C, dev), _f(C, dev), _f(C, dev)
+    _lib.check(_lib.load().r3d_bn_fold(_p(sums), float(count), C, _p(bnmod.weight), _p(bnmod.bias), BN_EPS, BN_MOM,
+                                       _p(bnmod.running_mean), _p(bnmod.running_var), _p(mean), _p(invstd), _p(scale),
+                                       _p(shift), _st()))
+    if bias is not None:
+        bnmod.running_mean.add_(BN_MOM * bias.detach())
+    bnmod.num_batches_tracked += 1
+    return scale, shift, mean, invstd
+
+
+def affine_act(Z, scale, shift, act, out=None):
+    M, ldz = _rows(Z)
+    C = Z.shape[1]
+    if out is None:
+        out = torch.empty(M, C, device=Z.device, dtype=torch.float32)
+    _lib.check(_lib.load().r3d_affine_act(_p(Z), ldz, M, C, _p(scale), _p(shift), act, _p(out), out.stride(0), _st()))
+    return out
+
+
+def bn_bwd_apply(Z, DY, bn, act, sums, count):
+    M, ldz = _rows(Z)
+    C = Z.shape[1]
+    DZ = torch.empty(M, C, device=Z.device, dtype=torch.float32)
+    sc, sh, mu, is_ = bn
+    _lib.check(_lib.load().r3d_bn_bwd_apply(_p(Z), ldz, _p(DY), DY.stride(0), M, C, _p(sc), _p(sh), _p(mu), _p(is_), act,
+                                            _p(sums), float(count), _p(DZ), C, _st()))
+    return DZ
+
+
+def gemm_tn(A, B):
+    """A^T B: (M, Ca), (M, Cb) -> (Ca, Cb)."""
+    M, lda = _rows(A)
+    M2, ldb = _rows(B)
+    assert M == M2
+    Ca, Cb = A.shape[1], B.shape[1]
+    lib = _lib.load()
+    out = torch.empty(Ca, Cb, device=A.device, dtype=torch.float32)
+    ws = _f(lib.r3d_gemm_tn_ws_words(M, Ca, Cb), A.device)
+    _lib.check(lib.r3d_gemm_tn(_p(A), lda, _p(B), ldb, M, Ca, Cb, 1.0, _p(out), 0, _p(ws), _st()))
+    return out
+
+
+def conv_acc(X, W, out):
+    """out += X W^T."""
+    M, ldx = _rows(X)
+    _lib.check(_lib.load().r3d_pointwise_conv_acc(_p(X), ldx, _p(W), M, X.shape[1], W.shape[0], None, None, 0, _p(out),
+                                                  out.stride(0), _st()))
+
+
+def add_cols(src, dst):
+    M, lds = _rows(src)
+    _lib.check(_lib.load().r3d_add_cols(_p(src), lds, _p(dst), dst.stride(0), M, src.shape[1], _st()))
+
+
+# ----------------------------------------------------------------------------- conv + BN + act layer
+def conv_bn_fwd(X, W2d, bnmod, act, bias=None, out=None):
+    """Returns (y, saved) with saved = (X, W2d, z, bn vectors, act)."""
+    z = ops.pointwise_conv(X, W2d)  # raw; a conv bias cancels under batch statistics
+    C = W2d.shape[0]
+    sums = colstats(z, C)
+    bn = bn_fold(sums, z.shape[0], bnmod, bias)
+    y = affine_act(z, bn[0], bn[1], act, out=out)
+    return y, (X, W2d, z, bn, act)
+
+
+def conv_bn_bwd(saved, dY, want_dx=True, dx_acc=None):
+    """Returns (dW, dgamma, dbeta, dbias, dX).  dX is accumulated into dx_acc when given."""
+    X, W2d, z, bn, act = saved
+    C = W2d.shape[0]
+    M = z.shape[0]
+    sums = colstats(z, C, mode=1, DY=dY, bn=bn, act=act)
+    dz = bn_bwd_apply(z, dY, bn, act, sums, M)
+    dW = gemm_tn(dz, X)
+    dbias = colstats(dz, C)[:C]
+    dX = None
+    if want_dx:
+        Wt = W2d.t().contiguous()
+        if dx_acc is not None:
+            conv_acc(dz, Wt, dx_acc)
+        else:
+            dX = ops.pointwise_conv(dz, Wt)
+    return dW, sums[C:], sums[:C], dbias, dX
+
+
+# ----------------------------------------------------------------------------- EdgeConv layer
+def edgeconv_train_fwd(inp, idx, ec, B, N, out):
+    lib = _lib.load()
+    dev = inp.device
+    W1 = ec.layer[0].weight.reshape(64, -1)
+    C = W1.shape[1] // 2
+    Wpq = torch.cat((W1[:, :C], W1[:, C:] - W1[:, :C]), 0).contiguous()
+    PQ = ops.pointwise_conv(inp, Wpq)
+    K = idx.shape[-1]
+    E = B * N * K
+    ws = _f(lib.r3d_edgeconv_train_ws_words(), dev)
+    sums1 = _f(128, dev)
+    _lib.check(lib.r3d_edge_stats1(_p(PQ), _p(idx), B, N, K, _p(sums1), _p(ws), _st()))
+    bn1 = bn_fold(sums1, E, ec.layer[1])
+    W2 = ec.layer[3].weight.reshape(64, 64).contiguous()
+    sums2 = _f(128, dev)
+    _lib.check(lib.r3d_edgeconv_train_fwd(_p(PQ), _p(idx), _p(bn1[0]), _p(bn1[1]), _p(W2), None, None, 1, None, 64, B, N, K,
+                                          None, None, _p(sums2), _p(ws), _st()))
+    bn2 = bn_fold(sums2, E, ec.layer[4])
+    argmax = torch.empty(B * N, 64, device=dev, dtype=torch.int32)
+    zmax = torch.empty(B * N, 64, device=dev, dtype=torch.float32)
+    _lib.check(lib.r3d_edgeconv_train_fwd(_p(PQ), _p(idx), _p(bn1[0]), _p(bn1[1]), _p(W2), _p(bn2[0]), _p(bn2[1]), 0,
+                                          _p(out), out.stride(0), B, N, K, _p(argmax), _p(zmax), None, _p(ws), _st()))
+    return (inp, idx, Wpq, PQ, W2, bn1, bn2, argmax, zmax, C)
+
+
+def edgeconv_train_bwd(saved, dout, B, N, dx_acc):
+    """Returns (dW1 (64,2C,1,1), dg1, db1, dW2 (64,64,1,1), dg2, db2); input gradient accumulated into dx_acc."""
+    inp, idx, Wpq, PQ, W2, bn1, bn2, argmax, zmax, C = saved
+    lib = _lib.load()
+    dev = PQ.device
+    K = idx.shape[-1]
+    M = B * N
+    bn2_sums = colstats(zmax, 64, mode=1, DY=dout, bn=bn2, act=ops.ACT_LRELU)
+    DY1 = _f(M * K * 64, dev)
+    dW2, bn1_sums, dPQ = _f(64 * 64, dev), _f(128, dev), _f(M * 128, dev).view(M, 128)
+    ws = _f(lib.r3d_edgeconv_train_ws_words(), dev)
+    _lib.check(lib.r3d_edgeconv_bwd(_p(PQ), _p(idx), _p(bn1[0]), _p(bn1[1]), _p(bn1[2]), _p(bn1[3]), _p(W2), _p(bn2[0]),
+                                    _p(bn2[1]), _p(bn2[2]), _p(bn2[3]), _p(bn2_sums), _p(dout), dout.stride(0), _p(argmax),
+                                    B, N, K, _p(DY1), _p(dW2), _p(bn1_sums), _p(dPQ), _p(ws), _st()))
+    dWpq = gemm_tn(dPQ, inp)  # (128, C): rows 0..63 = dP^T x, rows 64..127 = dQ^T x
+    dW1 = torch.cat((dWpq[:64] - dWpq[64:], dWpq[64:]), 1).reshape(64, 2 * C, 1, 1)
+    if dx_acc is not None:
+        conv_acc(dPQ, Wpq.t().contiguous(), dx_acc)
+    return dW1, bn1_sums[64:], bn1_sums[:64], dW2.view(64, 64, 1, 1), bn2_sums[64:], bn2_sums[:64]
+
+
+# ----------------------------------------------------------------------------- encoder
+class EncoderTrainFn(torch.autograd.Function):
+    """getFeatures in training mode.  forward(x (B,C_in,N), model, seed, *params) -> feat (B*N, 192)."""
+
+    @staticmethod
+    def forward(ctx, x, model, seed, *params):
+        enc, base, att = model.encoder, model.base_learner, model.att_learner
+        lib = _lib.load()
+        B, _, N = x.shape
+        M = B * N
+        dev = x.device
+        x = x.contiguous().float()
+        x_pm = ops.cm_to_pm(x)
+        cat = torch.empty(M, 64 * enc.n_edgeconv, device=dev, dtype=torch.float32)
+        inp, ec_saved = x_pm, []
+        for l in range(enc.n_edgeconv):
+            idx = ops.knn(inp, B, N, enc.k, x_cm=x if l == 0 else None)
+            out = cat[:, 64 * l:64 * (l + 1)]
+            ec_saved.append(edgeconv_train_fwd(inp, idx, enc.edge_convs[l], B, N, out))
+            inp = out
+        h, mlp_saved = cat, []
+        for jn in range(len(enc.conv.layer_dims)):
+            W = enc.conv.layer[3 * jn].weight
+            h, sv = conv_bn_fwd(h, W.reshape(W.shape[0], -1).contiguous(), enc.conv.layer[3 * jn + 1], ops.ACT_LRELU)
+            mlp_saved.append(sv)
+        level2 = h
+        feat = torch.empty(M, model.feat_dim, device=dev, dtype=torch.float32)
+        ops.copy_cols(cat[:, :64], feat[:, :64])
+        hb, base_saved = level2, []
+        for i, seq in enumerate(base.convs):
+            last = i == base.num_convs - 1
+            W = seq[0].weight
+            hb, sv = conv_bn_fwd(hb, W.reshape(W.shape[0], -1).contiguous(), seq[1], ops.ACT_NONE if last else ops.ACT_RELU,
+                                 bias=seq[0].bias, out=feat[:, 128:] if last else None)
+            base_saved.append(sv)
+        Wqkv, qscale = att._fold()
+        qkv = ops.pointwise_conv(level2, Wqkv, qscale, None, ops.ACT_NONE)
+        lse = torch.empty(M, device=dev, dtype=torch.float32)
+        p_drop = float(att.dropout.p)
+        _lib.check(lib.r3d_attention_fwd_train(_p(qkv), 192, B, N, _p(feat[:, 64:128]), feat.stride(0), _p(lse), p_drop,
+                                               ctypes.c_uint(seed & 0xffffffff), _st()))
+        ctx.model, ctx.dims = model, (B, N, seed, p_drop)
+        model._dbg_idx = [sv[1] for sv in ec_saved]  # neighbour lists of this pass (parity tests inject them into the oracle)
+        ctx.saved = (ec_saved, mlp_saved, base_saved, cat, level2, Wqkv, qkv, lse, feat)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        model = ctx.model
+        enc, base, att = model.encoder, model.base_learner, model.att_learner
+        B, N, seed, p_drop = ctx.dims
+        ec_saved, mlp_saved, base_saved, cat, level2, Wqkv, qkv, lse, feat = ctx.saved
+        lib = _lib.load()
+        dev = dfeat.device
+        M = B * N
+        dfeat = dfeat.contiguous()
+        class _G(dict):  # gradients keyed by parameter identity
+            def __setitem__(self, k, v):
+                dict.__setitem__(self, id(k), v)
+        g = _G()
+        dlevel2 = torch.zeros(M, level2.shape[1], device=dev, dtype=torch.float32)
+        # --- BaseLearner (mpti.py:35-40)
+        d = dfeat[:, 128:]
+        for i in reversed(range(base.num_convs)):
+            seq = base.convs[i]
+            dW, dg, db, dbias, dX = conv_bn_bwd(base_saved[i], d, want_dx=True, dx_acc=dlevel2 if i == 0 else None)
+            g[seq[0].weight] = dW.view_as(seq[0].weight)
+            g[seq[0].bias] = dbias
+            g[seq[1].weight], g[seq[1].bias] = dg, db
+            d = dX
+        # --- SelfAttention (attention.py:39-46)
+        dqkv = torch.empty(M, 192, device=dev, dtype=torch.float32)
+        ws = _f(M, dev)
+        _lib.check(lib.r3d_attention_bwd(_p(qkv), 192, B, N, _p(feat[:, 64:128]), feat.stride(0), _p(dfeat[:, 64:128]),
+                                         dfeat.stride(0), _p(lse), p_drop, ctypes.c_uint(seed & 0xffffffff),
+                                         1.0 / att.temperature, _p(dqkv), 192, _p(ws), _st()))
+        dWqkv = gemm_tn(dqkv, level2)
+        for k, m in enumerate((att.q_map, att.k_map, att.v_map)):
+            g[m.weight] = dWqkv[64 * k:64 * (k + 1)].reshape(m.weight.shape)
+        Wraw = torch.cat([m.weight.reshape(64, -1) for m in (att.q_map, att.k_map, att.v_map)], 0)
+        conv_acc(dqkv, Wraw.t().contiguous(), dlevel2)
+        # --- point MLP (dgcnn.py:121-122)
+        dcat = torch.zeros(M, cat.shape[1], device=dev, dtype=torch.float32)
+        add_cols(dfeat[:, :64], dcat[:, :64])
+        d = dlevel2
+        for jn in reversed(range(len(mlp_saved))):
+            conv, bnm = enc.conv.layer[3 * jn], enc.conv.layer[3 * jn + 1]
+            dW, dg, db, _, dX = conv_bn_bwd(mlp_saved[jn], d, want_dx=True, dx_acc=dcat if jn == 0 else None)
+            g[conv.weight] = dW.view_as(conv.weight)
+            g[bnm.weight], g[bnm.bias] = dg, db
+            d = dX
+        # --- EdgeConv stack, last layer first (dgcnn.py:115-119)
+        for l in reversed(range(enc.n_edgeconv)):
+            ec = enc.edge_convs[l]
+            dx_acc = dcat[:, 64 * (l - 1):64 * l] if l > 0 else None
+            dW1, dg1, db1, dW2, dg2, db2 = edgeconv_train_bwd(ec_saved[l], dcat[:, 64 * l:64 * (l + 1)], B, N, dx_acc)
+            g[ec.layer[0].weight], g[ec.layer[1].weight], g[ec.layer[1].bias] = dW1, dg1, db1
+            g[ec.layer[3].weight], g[ec.layer[4].weight], g[ec.layer[4].bias] = dW2, dg2, db2
+        ctx.saved = None
+        return (None, None, None) + tuple(g.get(id(p)) for p in ctx.param_list)
+
+
+def encoder_params(model):
+    ps = list(model.encoder.parameters()) + list(model.base_learner.parameters()) + list(model.att_learner.parameters())
+    return ps
+
+
+def get_features_train(model, x, seed):
+    """feat (B*N, 192) with gradient edges to the encoder / base / attention parameters."""
+    params = encoder_params(model)
+
+    class _Fn(EncoderTrainFn):
+        @staticmethod
+        def forward(ctx, x, *ps):
+            ctx.param_list = params  # the module's own Parameter objects (gradient dict is keyed by identity)
+            return EncoderTrainFn.forward(ctx, x, model, seed, *ps)
+
+        @staticmethod
+        def backward(ctx, dfeat):
+            out = EncoderTrainFn.backward(ctx, dfeat)
+            return (None,) + out[3:]
+
+    return _Fn.apply(x, *params)
+
+
+def mpti_train_forward(model, support_x, support_y, query_x, query_y, gt_support_y, gt_query_y, logger, support_flag):
+    from . import head_train
+    return head_train.mpti_train_forward(model, support_x, support_y, query_x, query_y, gt_support_y, gt_query_y, logger,
+                                         support_flag)

@@ -1,0 +1,125 @@
+"""GPU parity of the TRAINING path: forward with batch-statistics BatchNorm and every gradient,
+against torch-CPU autograd through the oracle restatement (same neighbour lists injected)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import r3d_oracle as O
+from r3dfsseg_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return (a - b).abs().max().item() / max(1e-12, b.abs().max().item())
+
+
+def test_conv_bn_layer_fwd_bwd():
+    from r3dfsseg_amd import ops, train_ops as T
+    rs = np.random.RandomState(0)
+    M, K, C = 3000, 192, 512
+    x = torch.from_numpy(rs.randn(M, K).astype(np.float32))
+    W = torch.from_numpy((rs.randn(C, K) / np.sqrt(K)).astype(np.float32))
+    bn = torch.nn.BatchNorm1d(C)
+    bn.weight.data = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32))
+    bn.bias.data = torch.from_numpy(rs.uniform(-0.2, 0.2, C).astype(np.float32))
+    R = torch.from_numpy(rs.randn(M, C).astype(np.float32))
+    # reference: torch autograd on CPU
+    xr, Wr = x.clone().requires_grad_(), W.clone().requires_grad_()
+    bnr = torch.nn.BatchNorm1d(C)
+    bnr.load_state_dict(bn.state_dict())
+    y = torch.nn.functional.leaky_relu(bnr(xr @ Wr.t()), 0.2)
+    (y * R).sum().backward()
+    bng = bn.cuda()
+    yg, saved = T.conv_bn_fwd(x.cuda(), W.cuda(), bng, ops.ACT_LRELU)
+    np.testing.assert_allclose(yg.cpu().numpy(), y.detach().numpy(), atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(bng.running_mean.cpu().numpy(), bnr.running_mean.numpy(), atol=1e-6)
+    np.testing.assert_allclose(bng.running_var.cpu().numpy(), bnr.running_var.numpy(), atol=1e-5, rtol=1e-5)
+    dW, dg, db, dbias, dX = T.conv_bn_bwd(saved, R.cuda())
+    assert _rel(dW.cpu(), Wr.grad) < 2e-4
+    assert _rel(dX.cpu(), xr.grad) < 2e-4
+    assert _rel(dg.cpu(), bnr.weight.grad) < 2e-4 and _rel(db.cpu(), bnr.bias.grad) < 2e-4
+    assert dbias.abs().max().item() < 1e-2  # a bias in front of batch-stat BN has zero gradient
+
+
+def _encoder_setup(B, N, p_drop=0.0):
+    from r3dfsseg_amd.mpti import MPTI_SelfAtten
+    cfg = S.make_cfg(n_way=2, k_shot=1, pc_npts=N)
+    sd = S.make_state_dict(cfg, 123, feat_scale=1.0)
+    m = MPTI_SelfAtten(SimpleNamespace(**cfg))
+    m.load_state_dict(sd)
+    m.cuda().train()
+    m.att_learner.dropout.p = p_drop
+    pc = torch.from_numpy(np.stack([S._cloud(np.random.RandomState(90 + i), N, 0.0).T for i in range(B)]).copy())
+    return cfg, sd, m, pc
+
+
+def test_encoder_train_forward_and_gradients():
+    from r3dfsseg_amd import ops, train_ops as T
+    B, N = 2, 512
+    cfg, sd, m, pc = _encoder_setup(B, N)
+    R = torch.from_numpy(np.random.RandomState(5).randn(B * N, 192).astype(np.float32))
+    feat = T.get_features_train(m, pc.cuda(), seed=7)
+    (feat * R.cuda()).sum().backward()
+    idx = [i.cpu().to(torch.int64) for i in m._dbg_idx]
+    # oracle: same neighbour lists, torch-CPU autograd
+    sdr = {k: (v.clone().requires_grad_() if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd.items()}
+    ns = {}
+    fo = O.get_features(sdr, pc, cfg, train=True, new_stats=ns, idx_override=idx)  # (B,192,N)
+    fo_pm = fo.transpose(1, 2).reshape(B * N, 192)
+    np.testing.assert_allclose(feat.detach().cpu().numpy(), fo_pm.detach().numpy(), atol=5e-4, rtol=1e-3)
+    (fo_pm * R).sum().backward()
+    worst = []
+    for name, p in m.named_parameters():
+        if name.startswith("proj."):
+            continue
+        gref = sdr[name].grad
+        assert p.grad is not None, name
+        if name.startswith("base_learner") and name.endswith(".0.bias"):
+            # a conv bias in front of batch-statistics BN has an exactly zero gradient (only rounding noise)
+            assert p.grad.abs().max().item() < 1e-3 and gref.abs().max().item() < 1e-3
+            continue
+        err = _rel(p.grad.cpu(), gref)
+        worst.append((err, name))
+    print("gradient errors:", sorted(worst))
+    # fp32 everywhere; the largest deviations come from max-pool winners that differ between the two
+    # implementations when two neighbours' activations agree to the last bits
+    assert max(e for e, _ in worst) < 3e-2, sorted(worst)[-4:]
+    assert np.median([e for e, _ in worst]) < 2e-3
+    for k, v in ns.items():  # running statistics follow nn.BatchNorm's update
+        got = dict(m.named_buffers())[k].cpu()
+        np.testing.assert_allclose(got.numpy(), v.numpy(), atol=1e-5, rtol=1e-4)
+
+
+def test_attention_dropout_mask_and_backward():
+    """Dropout mask is a stateless hash: replicate it on the host, feed it to the oracle."""
+    from r3dfsseg_amd import ops, _lib
+    import ctypes
+    B, N, p, seed = 1, 256, 0.1, 12345
+    rs = np.random.RandomState(3)
+    qkv = torch.from_numpy(rs.randn(B * N, 192).astype(np.float32) * 0.7).requires_grad_()
+    R = torch.from_numpy(rs.randn(B * N, 64).astype(np.float32))
+    row = np.arange(B * N, dtype=np.uint32)[:, None]
+    key = np.arange(N, dtype=np.uint32)[None, :]
+    with np.errstate(over="ignore"):
+        x = row * np.uint32(0x9E3779B1) ^ key * np.uint32(0x85EBCA77) ^ np.uint32(seed)
+        x ^= x >> np.uint32(16); x *= np.uint32(0x7feb352d); x ^= x >> np.uint32(15); x *= np.uint32(0x846ca68b); x ^= x >> np.uint32(16)
+    keep = torch.from_numpy((x >= np.uint32(int(p * 4294967296.0))).astype(np.float32)) / (1 - p)
+    q, k, v = qkv[:, :64], qkv[:, 64:128], qkv[:, 128:]
+    attn = torch.softmax(q @ k.t(), -1) * keep
+    y = attn @ v
+    (y * R).sum().backward()
+    lib = _lib.load()
+    qg = qkv.detach().cuda()
+    out = torch.empty(B * N, 64, device="cuda"); lse = torch.empty(B * N, device="cuda")
+    st = ops._st()
+    _lib.check(lib.r3d_attention_fwd_train(ops._p(qg), 192, B, N, ops._p(out), 64, ops._p(lse), p, ctypes.c_uint(seed), st))
+    np.testing.assert_allclose(out.cpu().numpy(), y.detach().numpy(), atol=1e-4, rtol=1e-4)
+    assert 0.08 < 1 - (keep > 0).float().mean().item() < 0.12
+    dqkv = torch.empty(B * N, 192, device="cuda"); ws = torch.empty(B * N, device="cuda")
+    Rg = R.cuda()
+    _lib.check(lib.r3d_attention_bwd(ops._p(qg), 192, B, N, ops._p(out), 64, ops._p(Rg), 64, ops._p(lse), p, ctypes.c_uint(seed),
+                                     1.0, ops._p(dqkv), 192, ops._p(ws), st))
+    assert _rel(dqkv.cpu(), qkv.grad) < 1e-3
