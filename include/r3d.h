@@ -150,6 +150,33 @@ int r3d_attention_bwd(const float* qkv, long ld, int B, int N, const float* O, l
                       const float* lse, float p_drop, unsigned seed, float q_scale, float* dqkv, long ldd, float* ws,
                       void* stream);
 
+/* head backward (reference: autograd through models/mpti.py:488-512,571).  r3d_ce_grad -> G = dL/dZ (scaled by the
+ * device scalar *gscale); r3d_label_propagate_bwd: adjoint CG solve on the graph r3d_label_propagate left in ws,
+ * then gradients w.r.t. the node features; r3d_head_prototypes_bwd: cluster-mean / query-row backward. */
+int r3d_ce_grad(const float* Z, const int32_t* n_proto_dev, int n_cap, int n_query_pts, int n_classes,
+                const int64_t* labels, const float* gscale_dev, float* G, void* stream);
+int r3d_label_propagate_bwd(const float* nodes, long ldn, int D, int kp1, const float* Z, const float* G,
+                            const int32_t* n_dev, int n_cap, float sigma, float alpha, int max_iter, float tol, float* lam,
+                            float* dnodes, long ldd, int32_t* ws, int32_t* stats_out, void* stream);
+int r3d_head_prototypes_bwd(const float* dnodes, long ldd, int n_way, int k_shot, int N, int D, int n_query_pts,
+                            const int32_t* desc, const int32_t* assign, const int32_t* cluster_count, const int32_t* ws,
+                            float* dsfeat, long lds_, float* dqfeat, long ldq, void* stream);
+
+/* per-way supervised contrastive loss, train only (models/mpti.py:226-313): per shot FPS(4) prototypes of the
+ * foreground points -> proj Linear(D,128) -> L2 normalise -> SupCon(temp); mean over ways.  ws keeps what
+ * r3d_contrast_bwd needs (prototype gradients, assignments, per-way parameter gradients). */
+long r3d_contrast_ws_words(int n_way, int k_shot, int N);
+int r3d_contrast_fwd(const float* feat, long ldf, int D, const int32_t* support_y, const int32_t* support_flag, int n_way,
+                     int k_shot, int N, const float* W, const float* bias, float temp, float* loss_out, float* ws,
+                     void* stream);
+int r3d_contrast_bwd(int D, int n_way, int k_shot, int N, const float* gscale_dev, float* dfeat, long ldd, float* dW,
+                     float* db, float* ws, void* stream);
+/* training-only debug metrics (mpti.py:515-568): out4 = query_acc_LP, query_acc_original, clean_ratio_LP_avg,
+ * clean_ratio_original_avg */
+int r3d_train_metrics(const int32_t* pred, const int64_t* query_y, const int64_t* gt_query_y, int n_query_pts, const float* Z,
+                      const int32_t* desc, const int32_t* proto_ws, const int32_t* assign, const int32_t* gt_support_y,
+                      int n_way, int k_shot, int N, float* out4, void* stream);
+
 /* ---- clean-shot detection, eval only (models/mpti.py:87-223, 316-371) -----------------
  * Per shot: box means of foreground features at scales (1,1,1) and (2,2,1) -> cosine map ->
  * majority vote -> shot_keep (n_way*k_shot) int32 (0 = drop the shot's foreground). */

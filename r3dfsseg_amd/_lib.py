@@ -56,6 +56,13 @@ _SIGS = {
     "r3d_edgeconv_bwd": (c_i, [c_f] * 13 + [c_l, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f]),
     "r3d_attention_fwd_train": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_fl, c_u, c_f]),
     "r3d_attention_bwd": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_l, c_f, c_fl, c_u, c_fl, c_f, c_l, c_f, c_f]),
+    "r3d_ce_grad": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),
+    "r3d_label_propagate_bwd": (c_i, [c_f, c_l, c_i, c_i, c_f, c_f, c_f, c_i, c_fl, c_fl, c_i, c_fl, c_f, c_f, c_l, c_f, c_f, c_f]),
+    "r3d_head_prototypes_bwd": (c_i, [c_f, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_l, c_f, c_l, c_f]),
+    "r3d_contrast_ws_words": (c_l, [c_i, c_i, c_i]),
+    "r3d_contrast_fwd": (c_i, [c_f, c_l, c_i, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_fl, c_f, c_f, c_f]),
+    "r3d_contrast_bwd": (c_i, [c_i, c_i, c_i, c_i, c_f, c_f, c_l, c_f, c_f, c_f, c_f]),
+    "r3d_train_metrics": (c_i, [c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f]),
     "r3d_clean_ws_words": (c_l, [c_i, c_i]),
     "r3d_clean_shot_detect": (c_i, [c_f, c_l, c_i, c_f, c_i, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),
     "r3d_protonet_head": (c_i, [c_f, c_l, c_f, c_l, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_f, c_f, c_f]),

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libr3d_hip.so")
 SOURCES = ["error.hip", "knn.hip", "gemm.hip", "edgeconv.hip", "attention.hip", "head_proto.hip",
-           "head_graph.hip", "aux_heads.hip", "train_ops.hip", "edgeconv_train.hip"]
+           "head_graph.hip", "aux_heads.hip", "train_ops.hip", "edgeconv_train.hip", "contrast.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value"]
 

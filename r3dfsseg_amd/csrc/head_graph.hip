@@ -442,6 +442,60 @@ extern "C" long r3d_lp_ws_words(int n_cap, int kp1) {
 // nodes (n_cap, ldn), nbr (n_cap, kp1) from r3d_knn_topk (mode L2), Y (n_cap, 4) one-hot
 // rows for prototypes / zeros for queries.  Z (n_cap, 4) out.  n_dev: device int = n.
 // stats_out (optional, device, 2 ints): {converged flag, iterations}.
+struct LpWs {
+  unsigned *outb, *sym;
+  int *row_len, *row_ptr, *col;
+  float *val, *dinv;
+  float4 *r, *p0, *p1, *q, *part_rr, *part_pq;
+  CgState* cg;
+  long words;
+};
+
+static LpWs lp_carve(int32_t* ws, int n_cap, int kp1) {
+  LpWs L;
+  L.words = (n_cap + 31) / 32;
+  const long nnz_cap = 2L * n_cap * (kp1 - 1);
+  int32_t* wp = ws;
+  L.outb = (unsigned*)wp; wp += n_cap * L.words;
+  L.sym = (unsigned*)wp; wp += n_cap * L.words;
+  L.row_len = wp; wp += n_cap + 8;
+  L.row_ptr = wp; wp += n_cap + 8;
+  L.col = wp; wp += nnz_cap;
+  L.val = (float*)wp; wp += nnz_cap;
+  L.dinv = (float*)wp; wp += n_cap;
+  wp += (4 - ((wp - ws) & 3)) & 3;  // float4 alignment (ws itself must be 16-B aligned)
+  L.r = (float4*)wp; wp += 4L * n_cap;
+  L.p0 = (float4*)wp; wp += 4L * n_cap;
+  L.p1 = (float4*)wp; wp += 4L * n_cap;
+  L.q = (float4*)wp; wp += 4L * n_cap;
+  L.part_rr = (float4*)wp; wp += 4L * HG_MAX_PART;
+  L.part_pq = (float4*)wp; wp += 4L * HG_MAX_PART;
+  L.cg = (CgState*)wp;
+  return L;
+}
+
+// CG on the already built graph: X = (I - alpha S)^-1 RHS
+static int lp_solve(const LpWs& L, const float* RHS, const int32_t* n_dev, int n_cap, float alpha, int max_iter, float tol,
+                    float* X, int32_t* stats_out, hipStream_t st) {
+  const int nblk_v = r3d_cdiv(n_cap, 256);
+  const int nblk_s = r3d_cdiv(n_cap, HG_ROWS_PER_BLOCK);
+  R3D_REQUIRE(nblk_s <= HG_MAX_PART, "r3d_label_propagate: n_cap too large");
+  float4* x = (float4*)X;
+  hipLaunchKernelGGL(r3d_cg_init_kernel, dim3(nblk_v), dim3(256), 0, st, (const float4*)RHS, n_dev, n_cap, x, L.r, L.p0,
+                     L.part_rr, L.cg);
+  const float tol2 = tol * tol;
+  for (int it = 0; it < max_iter; ++it) {
+    float4* pold = (it & 1) ? L.p1 : L.p0;
+    float4* pnew = (it & 1) ? L.p0 : L.p1;
+    hipLaunchKernelGGL(r3d_cg_spmv_kernel, dim3(nblk_s), dim3(256), 0, st, L.row_ptr, L.col, L.val, n_dev, n_cap, alpha,
+                       it, nblk_v, tol2, L.r, pold, pnew, L.q, L.part_rr, L.part_pq, L.cg);
+    hipLaunchKernelGGL(r3d_cg_update_kernel, dim3(nblk_v), dim3(256), 0, st, n_dev, n_cap, it, nblk_s, tol2, pnew, L.q,
+                       x, L.r, L.part_pq, L.part_rr, L.cg);
+  }
+  if (stats_out) hipMemcpyAsync(stats_out, &L.cg->done, 2 * sizeof(int), hipMemcpyDeviceToDevice, st);
+  return R3D_OK;
+}
+
 extern "C" int r3d_label_propagate(const float* nodes, long ldn, int D, const int32_t* nbr, int kp1,
                                    const float* Y, const int32_t* n_dev, int n_cap, float sigma,
                                    float alpha, int max_iter, float tol, float* Z, int32_t* ws,
@@ -450,58 +504,186 @@ extern "C" int r3d_label_propagate(const float* nodes, long ldn, int D, const in
   R3D_REQUIRE(n_cap > 0 && n_cap <= 32768 && D > 0 && D <= 256 && kp1 >= 2,
               "r3d_label_propagate: unsupported n_cap=%d D=%d kp1=%d", n_cap, D, kp1);
   R3D_REQUIRE(max_iter > 0 && max_iter <= HG_MAX_ITER && sigma > 0.f, "r3d_label_propagate: bad solver parameters");
-  hipStream_t st = (hipStream_t)stream;
-  const long words = (n_cap + 31) / 32;
-  const long nnz_cap = 2L * n_cap * (kp1 - 1);
-  int32_t* wp = ws;
-  unsigned* outb = (unsigned*)wp; wp += n_cap * words;
-  unsigned* sym = (unsigned*)wp; wp += n_cap * words;
-  int* row_len = wp; wp += n_cap + 8;
-  int* row_ptr = wp; wp += n_cap + 8;
-  int* col = wp; wp += nnz_cap;
-  float* val = (float*)wp; wp += nnz_cap;
-  float* dinv = (float*)wp; wp += n_cap;
-  wp += (4 - ((wp - ws) & 3)) & 3;  // float4 alignment (ws itself must be 16-B aligned)
-  float4* r = (float4*)wp; wp += 4L * n_cap;
-  float4* p0 = (float4*)wp; wp += 4L * n_cap;
-  float4* p1 = (float4*)wp; wp += 4L * n_cap;
-  float4* q = (float4*)wp; wp += 4L * n_cap;
-  float4* part_rr = (float4*)wp; wp += 4L * HG_MAX_PART;
-  float4* part_pq = (float4*)wp; wp += 4L * HG_MAX_PART;
-  CgState* cg = (CgState*)wp;
   R3D_REQUIRE(((uintptr_t)ws & 15) == 0 && ((uintptr_t)Y & 15) == 0 && ((uintptr_t)Z & 15) == 0,
               "r3d_label_propagate: ws, Y and Z must be 16-byte aligned");
-
-  hipMemsetAsync(outb, 0, sizeof(unsigned) * 2 * n_cap * words, st);
+  hipStream_t st = (hipStream_t)stream;
+  const LpWs L = lp_carve(ws, n_cap, kp1);
+  const long words = L.words;
+  hipMemsetAsync(L.outb, 0, sizeof(unsigned) * 2 * n_cap * words, st);
   const long edges = (long)n_cap * (kp1 - 1);
   hipLaunchKernelGGL(r3d_graph_bits_kernel, dim3(r3d_cdiv(edges, 256)), dim3(256), 0, st, nbr, kp1, n_dev, n_cap,
-                     (int)words, outb, sym);
-  hipLaunchKernelGGL(r3d_graph_rowlen_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, sym, (int)words, n_dev,
-                     n_cap, row_len);
-  hipLaunchKernelGGL(r3d_scan_kernel, dim3(1), dim3(1024), 0, st, row_len, n_cap, row_ptr);
-  hipLaunchKernelGGL(r3d_graph_cols_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, sym, (int)words, n_dev,
-                     n_cap, row_ptr, col);
-  hipLaunchKernelGGL(r3d_graph_weights_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, nodes, ldn, D, outb,
-                     (int)words, n_dev, n_cap, row_ptr, col, sigma, val, dinv);
-  hipLaunchKernelGGL(r3d_graph_normalize_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, row_ptr, col, dinv,
-                     n_dev, n_cap, val);
-  const int nblk_v = r3d_cdiv(n_cap, 256);
-  const int nblk_s = r3d_cdiv(n_cap, HG_ROWS_PER_BLOCK);
-  R3D_REQUIRE(nblk_s <= HG_MAX_PART, "r3d_label_propagate: n_cap too large");
-  float4* x = (float4*)Z;
-  hipLaunchKernelGGL(r3d_cg_init_kernel, dim3(nblk_v), dim3(256), 0, st, (const float4*)Y, n_dev, n_cap, x, r, p0,
-                     part_rr, cg);
-  const float tol2 = tol * tol;
-  for (int it = 0; it < max_iter; ++it) {
-    float4* pold = (it & 1) ? p1 : p0;
-    float4* pnew = (it & 1) ? p0 : p1;
-    hipLaunchKernelGGL(r3d_cg_spmv_kernel, dim3(nblk_s), dim3(256), 0, st, row_ptr, col, val, n_dev, n_cap, alpha,
-                       it, nblk_v, tol2, r, pold, pnew, q, part_rr, part_pq, cg);
-    hipLaunchKernelGGL(r3d_cg_update_kernel, dim3(nblk_v), dim3(256), 0, st, n_dev, n_cap, it, nblk_s, tol2, pnew, q,
-                       x, r, part_pq, part_rr, cg);
-  }
-  if (stats_out) hipMemcpyAsync(stats_out, &cg->done, 2 * sizeof(int), hipMemcpyDeviceToDevice, st);
+                     (int)words, L.outb, L.sym);
+  hipLaunchKernelGGL(r3d_graph_rowlen_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, L.sym, (int)words, n_dev,
+                     n_cap, L.row_len);
+  hipLaunchKernelGGL(r3d_scan_kernel, dim3(1), dim3(1024), 0, st, L.row_len, n_cap, L.row_ptr);
+  hipLaunchKernelGGL(r3d_graph_cols_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, L.sym, (int)words, n_dev,
+                     n_cap, L.row_ptr, L.col);
+  hipLaunchKernelGGL(r3d_graph_weights_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, nodes, ldn, D, L.outb,
+                     (int)words, n_dev, n_cap, L.row_ptr, L.col, sigma, L.val, L.dinv);
+  hipLaunchKernelGGL(r3d_graph_normalize_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, L.row_ptr, L.col, L.dinv,
+                     n_dev, n_cap, L.val);
+  int rc = lp_solve(L, Y, n_dev, n_cap, alpha, max_iter, tol, Z, stats_out, st);
+  if (rc) return rc;
   R3D_LAUNCH_CHECK("r3d_label_propagate");
+  return R3D_OK;
+}
+
+// ---------------------------------------------------------------------------
+// backward of the head's graph part (training): reference autograd through mpti.py:739-776
+//   G = dL/dZ ; lambda = (I - alpha S)^-1 G (S symmetric) ; dL/dS_ij = alpha <lambda_i, Z_j>
+//   S = dinv_i A_ij dinv_j, dinv = (D + eps)^-1/2, D_i = sum_j A_ij, A = W + W^T,
+//   w_ij = exp(-0.5 ||x_i - x_j + eps||^2 / sigma^2) for j in nbr(i)
+// Both passes walk the symmetric CSR rows (gather only, no atomics, fixed order).
+// ---------------------------------------------------------------------------
+static __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+// pass 1: dD_i = -1/2 dinv_i^3 * sum_j (dS_ij + dS_ji) A_ij dinv_j      (A_ij dinv_j = S_ij / dinv_i)
+__global__ __launch_bounds__(256) void r3d_lp_bwd_dd_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col,
+                                                            const float* __restrict__ val, const float* __restrict__ dinv,
+                                                            const int* __restrict__ n_dev, int n_cap, float alpha,
+                                                            const float4* __restrict__ lam, const float4* __restrict__ Z,
+                                                            float* __restrict__ dD) {
+  const int n = min(*n_dev, n_cap);
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const float4 li = lam[i], zi = Z[i];
+  const float di = dinv[i];
+  float g = 0.f;
+  for (int e = row_ptr[i] + lane; e < row_ptr[i + 1]; e += 64) {
+    const int j = col[e];
+    const float ds = alpha * (dot4(li, Z[j]) + dot4(lam[j], zi));
+    g += ds * (val[e] / di);
+  }
+  g = r3d_wave_sum(g);
+  if (lane == 0) dD[i] = -0.5f * di * di * di * g;
+}
+
+// pass 2: dx_i = sum over the row of c_ij (x_i - x_j + eps) + c_ji (x_i - x_j - eps)
+__global__ __launch_bounds__(256) void r3d_lp_bwd_dx_kernel(
+    const float* __restrict__ nodes, long ldn, int D, const unsigned* __restrict__ outb, int words,
+    const int* __restrict__ row_ptr, const int* __restrict__ col, const float* __restrict__ dinv,
+    const int* __restrict__ n_dev, int n_cap, float sigma, float alpha, const float4* __restrict__ lam,
+    const float4* __restrict__ Z, const float* __restrict__ dD, float* __restrict__ dnodes, long ldd) {
+  __shared__ __attribute__((aligned(16))) float xs[4][256];
+  const int n = min(*n_dev, n_cap);
+  const int w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + w;
+  const int lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const float* xi = nodes + (long)i * ldn;
+  for (int c = lane; c < 256; c += 64) xs[w][c] = c < D ? xi[c] : 0.f;
+  __builtin_amdgcn_wave_barrier();
+  const float4 li = lam[i], zi = Z[i];
+  const float di = dinv[i], ddi = dD[i];
+  const int beg = row_ptr[i], end = row_ptr[i + 1];
+  const int D4 = D >> 2;
+  const float inv_s2 = 1.f / (sigma * sigma);
+  float U = 0.f, V = 0.f;                  // sum (c_ij + c_ji), sum (c_ij - c_ji)
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // sum_j u_j x_j[c], channels lane, lane+64, ...
+  for (int e0 = beg; e0 < end; e0 += 64) {
+    const int e = e0 + lane;
+    const bool ok = e < end;
+    const int j = col[min(e, end - 1)];
+    const float* xj = nodes + (long)j * ldn;
+    float a = 0.f, b = 0.f;
+    for (int c4 = 0; c4 < D4; ++c4) {
+      const float4 y = *reinterpret_cast<const float4*>(xj + 4 * c4);
+      const float4 x = *reinterpret_cast<const float4*>(&xs[w][4 * c4]);
+      float d1, d2;
+      d1 = (x.x - y.x) + 1e-6f; d2 = (y.x - x.x) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b);
+      d1 = (x.y - y.y) + 1e-6f; d2 = (y.y - x.y) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b);
+      d1 = (x.z - y.z) + 1e-6f; d2 = (y.z - x.z) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b);
+      d1 = (x.w - y.w) + 1e-6f; d2 = (y.w - x.w) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b);
+    }
+    for (int c = 4 * D4; c < D; ++c) {
+      const float y = xj[c], x = xs[w][c];
+      const float d1 = (x - y) + 1e-6f, d2 = (y - x) + 1e-6f;
+      a = __builtin_fmaf(d1, d1, a);
+      b = __builtin_fmaf(d2, d2, b);
+    }
+    const float dj = dinv[j];
+    const float T = alpha * (dot4(li, Z[j]) + dot4(lam[j], zi)) * di * dj + ddi + dD[j];  // dA_ij + dA_ji
+    const bool out_ij = (outb[(long)i * words + (j >> 5)] >> (j & 31)) & 1u;
+    const bool out_ji = (outb[(long)j * words + (i >> 5)] >> (i & 31)) & 1u;
+    float cij = 0.f, cji = 0.f;
+    if (ok && out_ij) cij = -T * expf(-0.5f * a * inv_s2) * inv_s2;
+    if (ok && out_ji) cji = -T * expf(-0.5f * b * inv_s2) * inv_s2;
+    const float u = cij + cji;
+    U += u;
+    V += cij - cji;
+    // weighted neighbour sum: the wave walks this chunk's entries, all lanes add one row each step
+    const int cnt = min(64, end - e0);
+    for (int t = 0; t < cnt; ++t) {
+      const float ut = r3d_readlane_f(u, t);
+      const int jt = __builtin_amdgcn_readlane(j, t);
+      const float* xr = nodes + (long)jt * ldn;
+      if (lane < D) a0 += ut * xr[lane];
+      if (lane + 64 < D) a1 += ut * xr[lane + 64];
+      if (lane + 128 < D) a2 += ut * xr[lane + 128];
+      if (lane + 192 < D) a3 += ut * xr[lane + 192];
+    }
+  }
+  U = r3d_wave_sum(U);
+  V = r3d_wave_sum(V);
+  float* dr = dnodes + (long)i * ldd;
+  if (lane < D) dr[lane] = xs[w][lane] * U - a0 + 1e-6f * V;
+  if (lane + 64 < D) dr[lane + 64] = xs[w][lane + 64] * U - a1 + 1e-6f * V;
+  if (lane + 128 < D) dr[lane + 128] = xs[w][lane + 128] * U - a2 + 1e-6f * V;
+  if (lane + 192 < D) dr[lane + 192] = xs[w][lane + 192] * U - a3 + 1e-6f * V;
+}
+
+// dL/dZ of the mean cross entropy over the query rows (mpti.py:778-781), scaled by *gscale
+__global__ void r3d_ce_grad_kernel(const float4* __restrict__ Z, const int* __restrict__ n_proto_dev, int n_cap, int n_qpts,
+                                   int n_classes, const long long* __restrict__ labels, const float* __restrict__ gscale,
+                                   float4* __restrict__ G) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_cap) return;
+  const int n_proto = *n_proto_dev;
+  const int q = i - n_proto;
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  if (q >= 0 && q < n_qpts) {
+    const float4 z = Z[i];
+    const float zv[4] = {z.x, z.y, z.z, z.w};
+    float mx = zv[0];
+    for (int c = 1; c < n_classes; ++c) mx = fmaxf(mx, zv[c]);
+    float se = 0.f;
+    for (int c = 0; c < n_classes; ++c) se += expf(zv[c] - mx);
+    const int lab = (int)labels[q];
+    const float sc = gscale[0] / (float)n_qpts;
+    for (int c = 0; c < n_classes; ++c) g[c] = (expf(zv[c] - mx) / se - (c == lab ? 1.f : 0.f)) * sc;
+  }
+  G[i] = make_float4(g[0], g[1], g[2], g[3]);
+}
+
+// Backward through label propagation + affinity.  Requires ws exactly as r3d_label_propagate left it.
+// G (n_cap,4) = dL/dZ (from r3d_ce_grad); lam scratch (n_cap,4); dnodes (n_cap, ldd) out.
+extern "C" int r3d_label_propagate_bwd(const float* nodes, long ldn, int D, int kp1, const float* Z, const float* G,
+                                       const int32_t* n_dev, int n_cap, float sigma, float alpha, int max_iter, float tol,
+                                       float* lam, float* dnodes, long ldd, int32_t* ws, int32_t* stats_out, void* stream) {
+  R3D_REQUIRE(nodes && Z && G && n_dev && lam && dnodes && ws, "r3d_label_propagate_bwd: null pointer");
+  R3D_REQUIRE(n_cap > 0 && n_cap <= 32768 && D > 0 && D <= 256 && max_iter > 0 && max_iter <= HG_MAX_ITER,
+              "r3d_label_propagate_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const LpWs L = lp_carve(ws, n_cap, kp1);
+  int rc = lp_solve(L, G, n_dev, n_cap, alpha, max_iter, tol, lam, stats_out, st);
+  if (rc) return rc;
+  float* dD = (float*)L.q;  // the CG vectors are free again after the solve
+  hipLaunchKernelGGL(r3d_lp_bwd_dd_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, L.row_ptr, L.col, L.val, L.dinv, n_dev,
+                     n_cap, alpha, (const float4*)lam, (const float4*)Z, dD);
+  hipLaunchKernelGGL(r3d_lp_bwd_dx_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, nodes, ldn, D, L.outb, (int)L.words,
+                     L.row_ptr, L.col, L.dinv, n_dev, n_cap, sigma, alpha, (const float4*)lam, (const float4*)Z, dD, dnodes,
+                     ldd);
+  R3D_LAUNCH_CHECK("r3d_label_propagate_bwd");
+  return R3D_OK;
+}
+
+extern "C" int r3d_ce_grad(const float* Z, const int32_t* n_proto_dev, int n_cap, int n_query_pts, int n_classes,
+                           const int64_t* labels, const float* gscale_dev, float* G, void* stream) {
+  R3D_REQUIRE(Z && n_proto_dev && labels && gscale_dev && G, "r3d_ce_grad: null pointer");
+  hipLaunchKernelGGL(r3d_ce_grad_kernel, dim3(r3d_cdiv(n_cap, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)Z,
+                     n_proto_dev, n_cap, n_query_pts, n_classes, (const long long*)labels, gscale_dev, (float4*)G);
+  R3D_LAUNCH_CHECK("r3d_ce_grad");
   return R3D_OK;
 }
 

@@ -553,6 +553,57 @@ extern "C" int r3d_head_prototypes(const int32_t* support_y, const int32_t* shot
   return R3D_OK;
 }
 
+// ---------------------------------------------------------------------------
+// backward of the cluster means (training): every listed support point receives
+// dproto[cluster] / |cluster| ; query rows copy through.  One wave per list position.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(HP_BLOCK) void r3d_proto_bwd_kernel(const float* __restrict__ dnodes, long ldd, int D, SegGeom g,
+                                                                 const int* __restrict__ comp, const int* __restrict__ desc,
+                                                                 const int* __restrict__ assign,
+                                                                 const int* __restrict__ cluster_count,
+                                                                 float* __restrict__ dsfeat, long lds_) {
+  int blk0;
+  const int seg = g.seg_of_block(blockIdx.x, &blk0);
+  const int count = desc[HD_SEG_COUNT + seg];
+  const int bis = blockIdx.x - blk0;
+  if ((long)bis * HP_BLOCK >= count) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int poff = desc[HD_SEG_POFF + seg];
+  for (int pos = bis * HP_BLOCK + w; pos < min(count, (bis + 1) * HP_BLOCK); pos += 4) {
+    const int gp = comp[g.off(seg) + pos];
+    const int row = poff + assign[g.off(seg) + pos];
+    const float inv = 1.f / (float)cluster_count[row];
+    for (int c = lane; c < D; c += 64) dsfeat[(long)gp * lds_ + c] = dnodes[(long)row * ldd + c] * inv;
+  }
+}
+
+__global__ void r3d_query_bwd_kernel(const float* __restrict__ dnodes, long ldd, int D, int nq_pts,
+                                     const int* __restrict__ desc, float* __restrict__ dqfeat, long ldq) {
+  const int n_proto = desc[HD_N_PROTO];
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)nq_pts * D) return;
+  const long r = i / D;
+  const int c = (int)(i - r * D);
+  dqfeat[r * ldq + c] = dnodes[(n_proto + r) * ldd + c];
+}
+
+// dsfeat (S*N, lds) must be zero-initialised by the caller (points in no list keep a zero gradient)
+extern "C" int r3d_head_prototypes_bwd(const float* dnodes, long ldd, int n_way, int k_shot, int N, int D, int n_query_pts,
+                                       const int32_t* desc, const int32_t* assign, const int32_t* cluster_count,
+                                       const int32_t* ws, float* dsfeat, long lds_, float* dqfeat, long ldq, void* stream) {
+  R3D_REQUIRE(dnodes && desc && assign && cluster_count && ws && dsfeat && dqfeat, "r3d_head_prototypes_bwd: null pointer");
+  int rc = check_geom("r3d_head_prototypes_bwd", n_way, k_shot, N, D);
+  if (rc) return rc;
+  SegGeom g{n_way, k_shot, N};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(r3d_proto_bwd_kernel, dim3(g.total_blocks()), dim3(HP_BLOCK), 0, st, dnodes, ldd, D, g, ws /* comp */,
+                     desc, assign, cluster_count, dsfeat, lds_);
+  hipLaunchKernelGGL(r3d_query_bwd_kernel, dim3(r3d_cdiv((long)n_query_pts * D, 256)), dim3(256), 0, st, dnodes, ldd, D,
+                     n_query_pts, desc, dqfeat, ldq);
+  R3D_LAUNCH_CHECK("r3d_head_prototypes_bwd");
+  return R3D_OK;
+}
+
 // Word offsets of the scratch sub-arrays inside ws (for tests that inspect the
 // intermediate index results): comp, mind, assign, cand, sel, seeds.
 extern "C" int r3d_head_proto_ws_offsets(int n_way, int k_shot, int N, long* out6) {

@@ -188,6 +188,7 @@ class HeadBuffers:
         self.cluster_count = torch.zeros(self.n_cap, **i32)
         self.stats = torch.zeros(2, **i32)
         self.knn_status = torch.zeros(1, **i32)
+        self.stats_bwd = torch.zeros(2, **i32)
         off = (ctypes.c_long * 6)()
         lib.r3d_head_proto_ws_offsets(n_way, k_shot, N, off)
         self.ws_off = list(off)

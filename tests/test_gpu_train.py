@@ -123,3 +123,76 @@ def test_attention_dropout_mask_and_backward():
     _lib.check(lib.r3d_attention_bwd(ops._p(qg), 192, B, N, ops._p(out), 64, ops._p(Rg), 64, ops._p(lse), p, ctypes.c_uint(seed),
                                      1.0, ops._p(dqkv), 192, ops._p(ws), st))
     assert _rel(dqkv.cpu(), qkv.grad) < 1e-3
+
+
+def _train_episode(n_way=2, k_shot=2, N=512, seed=3, noise=0.0):
+    from r3dfsseg_amd.mpti import MPTI_SelfAtten
+    cfg = S.make_cfg(n_way=n_way, k_shot=k_shot, pc_npts=N)
+    sd = S.make_state_dict(cfg, 123)
+    m = MPTI_SelfAtten(SimpleNamespace(**cfg))
+    m.load_state_dict(sd)
+    m.cuda().train()
+    m.att_learner.dropout.p = 0.0  # parity needs a shared mask; the mask itself is tested above
+    data, _ = S.make_episode(cfg, seed, noise_ratio=noise, train=True)
+    return cfg, sd, m, data
+
+
+def test_head_losses_and_feature_gradients():
+    """LP loss + contrastive loss and their gradients w.r.t. the features and proj, given equal features."""
+    from r3dfsseg_amd import contrast, head_train
+    cfg, sd, m, data = _train_episode()
+    sx, sy, qx, qy = data[:4]
+    flag = data[10]
+    rs = np.random.RandomState(11)
+    Sn, N = 4, 512
+    sfeat = torch.from_numpy((rs.randn(Sn * N, 192) * 0.08).astype(np.float32))
+    qfeat = torch.from_numpy((rs.randn(2 * N, 192) * 0.08).astype(np.float32))
+    # --- device
+    sg, qg = sfeat.cuda().requires_grad_(), qfeat.cuda().requires_grad_()
+    closs = contrast.per_way_contrast_loss(m, sg, sy.cuda(), flag.cuda())
+    lploss = head_train.HeadLPFn.apply(sg, qg, m, sy.cuda(), qy.cuda())
+    (lploss + 0.1 * closs).backward()
+    assert m._head[1].stats.cpu().tolist()[0] == 1 and m._head[1].stats_bwd.cpu().tolist()[0] == 1
+    # --- oracle (torch-CPU autograd through the restated head)
+    so, qo = sfeat.clone().requires_grad_(), qfeat.clone().requires_grad_()
+    sdr = {k: v.clone() for k, v in sd.items()}
+    sdr["proj.weight"].requires_grad_(); sdr["proj.bias"].requires_grad_()
+    sf4 = so.view(2, 2, N, 192).transpose(2, 3)  # (n_way, k_shot, d, N)
+    c_ref = O.per_way_contrast_loss(sdr, sf4, sy, flag, 4, 0.1)
+    fg_p, fg_l, _, _ = O.get_foreground_prototypes(sf4, sy, 100, 3)
+    bg_p, bg_l, _, _ = O.get_background_prototypes(sf4, torch.logical_not(sy), 100, 3)
+    protos = torch.cat((bg_p, fg_p), 0)
+    Y = torch.zeros(protos.shape[0] + 2 * N, 3)
+    Y[:protos.shape[0]] = torch.cat((bg_l, fg_l), 0)
+    node = torch.cat((protos, qo), 0)
+    A = O.affinity(node, 200, 1.0)
+    Z = O.label_propagate(A, Y)
+    qpred = Z[protos.shape[0]:].view(-1, N, 3).transpose(1, 2)
+    lp_ref = torch.nn.functional.cross_entropy(qpred, qy)
+    (lp_ref + 0.1 * c_ref).backward()
+    assert abs(closs.item() - c_ref.item()) < 1e-4 * max(1, abs(c_ref.item())), (closs.item(), c_ref.item())
+    assert abs(lploss.item() - lp_ref.item()) < 1e-4 * max(1, abs(lp_ref.item())), (lploss.item(), lp_ref.item())
+    e_s, e_q = _rel(sg.grad.cpu(), so.grad), _rel(qg.grad.cpu(), qo.grad)
+    e_w, e_b = _rel(m.proj.weight.grad.cpu(), sdr["proj.weight"].grad), _rel(m.proj.bias.grad.cpu(), sdr["proj.bias"].grad)
+    print("head gradient errors: sfeat %.2e qfeat %.2e proj.w %.2e proj.b %.2e" % (e_s, e_q, e_w, e_b))
+    assert e_s < 2e-3 and e_q < 2e-3 and e_w < 1e-3 and e_b < 1e-3
+
+
+def test_learner_train_step_runs_and_descends():
+    """MPTILearner_V3.train (mpti_learner.py:50-78): 8-tuple, finite, loss decreases over a few steps."""
+    from r3dfsseg_amd.mpti_learner import MPTILearner_V3
+    cfg = S.make_cfg(n_way=2, k_shot=2, pc_npts=512, pretrain_checkpoint_path="synthetic", model_checkpoint_path=None,
+                     lr=1e-3, step_size=5000, gamma=0.5)
+    L = MPTILearner_V3(SimpleNamespace(**cfg), mode="train")
+    data, _ = S.make_episode(cfg, 5, noise_ratio=0.5, train=True)
+    data = [t.cuda() for t in data]
+    losses = []
+    for it in range(6):
+        out = L.train(data, None)
+        assert len(out) == 8
+        loss, lp, con, acc = out[0], out[1], out[2], out[3]
+        assert torch.isfinite(loss) and torch.isfinite(lp) and torch.isfinite(con) and 0.0 <= acc <= 1.0
+        losses.append(loss.item())
+    print("train losses:", losses)
+    assert losses[-1] < losses[0]
+    assert int(L.model.encoder.conv.layer[1].num_batches_tracked.item()) == 12  # two getFeatures calls per step
