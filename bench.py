@@ -93,26 +93,42 @@ def main():
     model = MPTI_SelfAtten(SimpleNamespace(**cfg))
     model.load_state_dict(S.make_state_dict(cfg, 123))
     model.to(dev)
-    if args.mode == "train":
-        raise SystemExit("train mode bench lands with the backward kernels (see DESIGN.md, next)")
-    model.eval()
-
+    train = args.mode == "train"
     n_pool = 8  # distinct episodes per rank, resident in HBM before timing starts
     pool = []
     for e in range(n_pool):
-        data, _ = S.make_episode(cfg, seed=1000 * rank + e)
-        pool.append([t.to(dev) for t in data[:4]])
+        data, _ = S.make_episode(cfg, seed=1000 * rank + e, noise_ratio=0.2 if train else 0.0, train=train)
+        pool.append([t.to(dev) for t in (data if train else data[:4])])
     torch.cuda.synchronize()
 
     lp_flags = []
+    if train:
+        # forward + backward + single flat-bucket gradient all-reduce + Adam (mpti_learner.py:60-72)
+        from r3dfsseg_amd.dp_train import DPTrainer
+        targs = SimpleNamespace(lr=1e-3, step_size=5000, gamma=0.5, **cfg)
+        learner = SimpleNamespace(model=model)
+        learner.optimizer = torch.optim.Adam(
+            [{'params': model.encoder.parameters(), 'lr': 0.0001}, {'params': model.base_learner.parameters()},
+             {'params': model.att_learner.parameters()}, {'params': model.proj.parameters()}], lr=targs.lr)
+        learner.lr_scheduler = torch.optim.lr_scheduler.StepLR(learner.optimizer, step_size=targs.step_size, gamma=targs.gamma)
+        trainer = DPTrainer(learner)
+        model.train()
 
-    def step(i):
-        sx, sy, qx, qy = pool[i % n_pool]
-        with torch.no_grad():
-            logits, loss = model(sx, sy, qx, qy)
-        hb = model._head[1]
-        lp_flags.append(torch.cat((hb.stats, hb.knn_status)))  # (CG converged, CG iterations, kNN overflow)
-        return logits, loss
+        def step(i):
+            loss = trainer.step([pool[i % n_pool]])
+            hb = model._head[1]
+            lp_flags.append(torch.cat((hb.stats * hb.stats_bwd[:1].clamp(max=1), hb.knn_status)))
+            return loss
+    else:
+        model.eval()
+
+        def step(i):
+            sx, sy, qx, qy = pool[i % n_pool]
+            with torch.no_grad():
+                logits, loss = model(sx, sy, qx, qy)
+            hb = model._head[1]
+            lp_flags.append(torch.cat((hb.stats, hb.knn_status)))  # (CG converged, CG iterations, kNN overflow)
+            return logits, loss
 
     for i in range(args.warmup):
         step(i)
@@ -193,7 +209,8 @@ def main():
 
     eps = args.steps * world / elapsed
     out = {
-        "metric": "episodes/sec S3DIS 2-way 5-shot 2048-pt (MPTI+attention, %s forward)" % args.mode,
+        "metric": "episodes/sec S3DIS 2-way 5-shot 2048-pt (MPTI+attention, %s)" % (
+            "train: forward+backward+grad all-reduce+Adam" if train else "eval forward"),
         "value": eps, "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -47,13 +47,22 @@ __global__ __launch_bounds__(256) void r3d_edge_stats1_kernel(const float* __res
   }
 }
 
-__global__ void r3d_part_reduce64_kernel(const float* __restrict__ part, int nblk, int nvec, float* __restrict__ out) {
-  // out[v][c] = sum over blocks of part[blk][v][c], c < 64, in fp64, ascending block order
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nvec * 64) return;
+static __device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// out[i] = sum over blocks of part[blk][i] in fp64: one wave per output, lane l adds blocks l, l+64, ...
+// (a fixed partition and a fixed shuffle tree: deterministic)
+__global__ void r3d_part_reduce_kernel(const float* __restrict__ part, int nblk, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= n) return;
   double s = 0.0;
-  for (int k = 0; k < nblk; ++k) s += (double)part[(long)k * nvec * 64 + i];
-  out[i] = (float)s;
+  for (int k = lane; k < nblk; k += 64) s += (double)part[(long)k * n + i];
+  s = wave_sum_d(s);
+  if (lane == 0) out[i] = (float)s;
 }
 
 // ---- forward: mode 0 = output (+argmax, z at argmax); mode 1 = statistics of z2 -------------------
@@ -303,14 +312,6 @@ __global__ __launch_bounds__(512) void r3d_edgeconv_bwd1_kernel(
   }
 }
 
-__global__ void r3d_part_reduce_kernel(const float* __restrict__ part, int nblk, int n, float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double s = 0.0;
-  for (int k = 0; k < nblk; ++k) s += (double)part[(long)k * n + i];
-  out[i] = (float)s;
-}
-
 // ---- backward pass B2: de1 -> dQ (sum over K), dP (scatter-add) ------------------------------------
 __global__ __launch_bounds__(256) void r3d_edgeconv_bwd2_kernel(
     const float* __restrict__ PQ, const int* __restrict__ idx, const float* __restrict__ s1, const float* __restrict__ mean1,
@@ -359,7 +360,7 @@ extern "C" int r3d_edge_stats1(const float* PQ, const int32_t* idx, int B, int N
   hipStream_t st = (hipStream_t)stream;
   const int grid = 512;
   hipLaunchKernelGGL(r3d_edge_stats1_kernel, dim3(grid), dim3(256), 0, st, PQ, idx, N, K, (long)B * N, ws);
-  hipLaunchKernelGGL(r3d_part_reduce64_kernel, dim3(1), dim3(128), 0, st, ws, grid, 2, sums_out);
+  hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(128 / 4), dim3(256), 0, st, ws, grid, 128, sums_out);
   R3D_LAUNCH_CHECK("r3d_edge_stats1");
   return R3D_OK;
 }
@@ -381,7 +382,7 @@ extern "C" int r3d_edgeconv_train_fwd(const float* PQ, const int32_t* idx, const
     R3D_REQUIRE(sums_out, "r3d_edgeconv_train_fwd: mode 1 needs sums_out");
     hipLaunchKernelGGL(r3d_edgeconv_train_fwd_kernel<1>, dim3(grid), dim3(64 * waves), lds, st, PQ, idx, s1, t1, W2, s2, t2,
                        out, ldo, N, K, (long)B * N, argmax_out, zmax_out, ws);
-    hipLaunchKernelGGL(r3d_part_reduce64_kernel, dim3(1), dim3(128), 0, st, ws, grid, 2, sums_out);
+    hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(128 / 4), dim3(256), 0, st, ws, grid, 128, sums_out);
   } else {
     R3D_REQUIRE(out && s2 && t2 && ldo >= 64, "r3d_edgeconv_train_fwd: mode 0 needs out, s2, t2");
     hipLaunchKernelGGL(r3d_edgeconv_train_fwd_kernel<0>, dim3(grid), dim3(64 * waves), lds, st, PQ, idx, s1, t1, W2, s2, t2,
@@ -420,7 +421,7 @@ extern "C" int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float
                      s2, t2, mean2, invstd2, bn2_sums, dout, lddo, argmax, N, K, (long)B * N, DY1, ws);
   // partial layout: dW2 (4096) | sum dy1 (64) | sum dy1*ehat1 (64)
   float* red = ws + (long)grid * ET_PART;  // ET_PART floats of headroom are part of r3d_edgeconv_train_ws_words
-  hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(r3d_cdiv(ET_PART, 256)), dim3(256), 0, st, ws, grid, ET_PART, red);
+  hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(r3d_cdiv(ET_PART, 4)), dim3(256), 0, st, ws, grid, ET_PART, red);
   hipMemcpyAsync(dW2, red, sizeof(float) * 4096, hipMemcpyDeviceToDevice, st);
   hipMemcpyAsync(bn1_sums, red + 4096, sizeof(float) * 128, hipMemcpyDeviceToDevice, st);
   hipMemsetAsync(dPQ, 0, sizeof(float) * (size_t)B * N * 128, st);

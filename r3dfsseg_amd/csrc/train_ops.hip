@@ -132,9 +132,19 @@ __global__ void r3d_bn_bwd_apply_kernel(const float* __restrict__ Z, long ldz, c
 // (weight gradients: A = dz (M, Ca), B = X (M, Cb) -> dW (Ca, Cb)).  64 x 64 tile per workgroup on the
 // fp32 matrix core, the M axis split in chunks of TN_ROWS with per-chunk partial tiles that a second
 // kernel adds in ascending chunk order (deterministic, no float atomics).
-#define TN_ROWS 1024
+#define TN_ROWS_MAX 1024
+static int tn_rows(long M, int Ca, int Cb) {
+  // enough workgroups to fill the chip even for 64 x 64 outputs, chunks of at least 128 rows
+  const long tiles = (long)((Ca + 63) / 64) * ((Cb + 63) / 64);
+  long chunks = (1024 + tiles - 1) / tiles;
+  long rows = (M + chunks - 1) / chunks;
+  rows = ((rows + 31) / 32) * 32;
+  if (rows < 128) rows = 128;
+  if (rows > TN_ROWS_MAX) rows = TN_ROWS_MAX;
+  return (int)rows;
+}
 __global__ __launch_bounds__(256) void r3d_gemm_tn_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B,
-                                                          long ldb, long M, int Ca, int Cb,
+                                                          long ldb, long M, int Ca, int Cb, int TN_ROWS,
                                                           float* __restrict__ part /* [chunks][Ca][Cb] */) {
   __shared__ float As[32 * 65];  // [m][i]
   __shared__ float Bs[32 * 65];  // [m][j]
@@ -183,7 +193,15 @@ __global__ void r3d_chunk_reduce_kernel(const float* __restrict__ part, int chun
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float s = 0.f;
-  for (int k = 0; k < chunks; ++k) s += part[(long)k * n + i];
+  int k = 0;
+  for (; k + 8 <= chunks; k += 8) {  // 8 loads in flight; summation order stays ascending
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(long)(k + u) * n + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; k < chunks; ++k) s += part[(long)k * n + i];
   out[i] = accumulate ? out[i] + alpha * s : alpha * s;
 }
 
@@ -246,16 +264,20 @@ extern "C" int r3d_bn_bwd_apply(const float* Z, long ldz, const float* DY, long 
   return R3D_OK;
 }
 
-extern "C" long r3d_gemm_tn_ws_words(long M, int Ca, int Cb) { return ((M + TN_ROWS - 1) / TN_ROWS) * (long)Ca * Cb + 16; }
+extern "C" long r3d_gemm_tn_ws_words(long M, int Ca, int Cb) {
+  const int rows = tn_rows(M, Ca, Cb);
+  return ((M + rows - 1) / rows) * (long)Ca * Cb + 16;
+}
 
 // out (Ca, Cb) = alpha * A^T B  (+ out if accumulate)
 extern "C" int r3d_gemm_tn(const float* A, long lda, const float* B, long ldb, long M, int Ca, int Cb, float alpha,
                            float* out, int accumulate, float* ws, void* stream) {
   R3D_REQUIRE(A && B && out && ws && M > 0 && Ca > 0 && Cb > 0 && lda >= Ca && ldb >= Cb, "r3d_gemm_tn: bad arguments");
-  const int chunks = r3d_cdiv(M, TN_ROWS);
+  const int rows = tn_rows(M, Ca, Cb);
+  const int chunks = r3d_cdiv(M, rows);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(r3d_gemm_tn_kernel, dim3(r3d_cdiv(Ca, 64), r3d_cdiv(Cb, 64), chunks), dim3(256), 0, st, A, lda, B, ldb,
-                     M, Ca, Cb, ws);
+                     M, Ca, Cb, rows, ws);
   hipLaunchKernelGGL(r3d_chunk_reduce_kernel, dim3(r3d_cdiv((long)Ca * Cb, 256)), dim3(256), 0, st, ws, chunks,
                      (long)Ca * Cb, alpha, out, accumulate);
   R3D_LAUNCH_CHECK("r3d_gemm_tn");

@@ -17,11 +17,13 @@ class HeadLPFn(torch.autograd.Function):
         sfeatT = ops.pm_to_cm(sfeat, S, N)
         sy = support_y.reshape(S, N).to(torch.int32).contiguous()
         ops.head_prototypes(hb, sy, None, sfeat, sfeatT, qfeat)
-        # training always runs the full CG budget and the always-exact insertion kNN: there is a host
-        # sync per step anyway (loss.item() in the reference's train loop)
         nbr = ops.knn(hb.nodes, 1, hb.n_cap, hb.kp1, mode=ops.SCORE_L2, n_valid=hb.desc[ops.HD_N_NODES:],
                       status=hb.knn_status)
-        ops.label_propagate(hb, nbr, model.sigma, 0.99, model.lp_max_iter, model.lp_tol)
+        # same launch-budget policy as eval (mpti.py: _lp_next_budget); the training loop's own host sync
+        # (loss.item(), mpti_train_noise.py:107) is where lp_converged() can be checked
+        ctx.budget = model._lp_next_budget()
+        ops.label_propagate(hb, nbr, model.sigma, 0.99, ctx.budget, model.lp_tol)
+        model._lp_post(hb)
         labels = query_y.to(torch.int64).contiguous()
         logits, loss, pred = ops.query_logits_ce(hb, n_q, model.n_classes, labels)
         ctx.model, ctx.hb, ctx.labels, ctx.n_q = model, hb, labels, n_q
@@ -43,7 +45,8 @@ class HeadLPFn(torch.autograd.Function):
         dnodes = torch.empty(hb.n_cap, D, device=dev, dtype=torch.float32)
         _lib.check(lib.r3d_label_propagate_bwd(_p(hb.nodes), hb.nodes.stride(0), D, hb.kp1, _p(hb.Z), _p(G),
                                                _p(hb.desc[ops.HD_N_NODES:]), hb.n_cap, float(model.sigma), 0.99,
-                                               int(model.lp_max_iter), float(model.lp_tol), _p(lam), _p(dnodes), D,
+                                               int(min(model.lp_max_iter, 2 * ctx.budget)), float(model.lp_tol), _p(lam),
+                                               _p(dnodes), D,
                                                _p(hb.lp_ws), _p(hb.stats_bwd), _st()))
         dsfeat = torch.zeros(ctx.shapes[0], device=dev, dtype=torch.float32)
         dqfeat = torch.empty(ctx.shapes[1], device=dev, dtype=torch.float32)
