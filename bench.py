@@ -3,12 +3,16 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
-A "step" is one pass of the hot path over one episode per rank (configs[1] of BASELINE.json:
-S3DIS S0 2-way 5-shot 2048 pts, MPTI + attention), inputs resident in HBM.  Episodes are
-independent: ranks shard them with no data-path collective in eval mode
-(weak scaling).  Prints ONE JSON line on rank 0, with
-  roofline     -- dominant kernel timed live with HIP events on its launch stream
-  cpu_baseline -- the CPU oracle (a port of the reference path) on this box's host cores
+A "step" is one pass of the hot path over one episode per rank (configs[1] of BASELINE.json: S3DIS S0
+2-way 5-shot 2048 pts, MPTI + attention), inputs resident in HBM.
+  --mode train (default): forward + backward + ONE flat-bucket RCCL gradient all-reduce + Adam, i.e. the
+                          reference's MPTILearner_V3.train step (models/mpti_learner.py:60-72);
+  --mode eval           : forward only, MPTILearner_V3.test without its host sync.
+Episodes are independent: ranks take disjoint episodes (weak scaling); the only collective is
+the 1.5 MB gradient all-reduce of train mode.  ONE JSON line on rank 0, with
+  roofline     -- the entry point taking most time, priced with its ALGORITHMIC work over
+                  its HIP-event launch time (events recorded on the launch stream, second pass of the K steps)
+  cpu_baseline -- the CPU oracle (a port of the reference path) on this box's host cores, eval forward
 """
 import argparse
 import json
@@ -25,38 +29,52 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector peak
 
+OPS = ["knn_topk", "knn_topk_l2", "pointwise_conv", "edgeconv", "attention", "head_prototypes", "label_propagate",
+       "gemm_tn", "edgeconv_bwd", "attention_bwd", "bn_stats", "label_propagate_bwd"]
 
-OPS = ["knn_topk", "knn_topk_l2", "pointwise_conv", "edgeconv", "attention", "head_prototypes", "label_propagate"]
 
-
-def algorithmic_work(op, cfg, n_nodes, cg_iters):
-    """ALGORITHMIC (flops, bytes) of ONE step's launches of an entry point and the roofline that bounds
-    it (DESIGN.md "kernels"; per-unit figures from SURVEY.md 8d).  bytes = read every input once + write
-    every output once, fp32 / int32."""
+def algorithmic_work(op, cfg, n_nodes, cg_iters, train):
+    """ALGORITHMIC (flops, bytes, bound, launches) of ONE step's calls of an entry point (DESIGN.md section 4;
+    per-unit figures from SURVEY.md 8d).  bytes = every input read once + every output written once (fp32 /
+    int32).  In train mode getFeatures runs twice (support clouds, query clouds) with the same totals."""
     n_way, k_shot, N = cfg["n_way"], cfg["k_shot"], cfg["pc_npts"]
     S_ = n_way * k_shot
-    B = S_ + n_way * cfg.get("n_queries", 1)
+    n_q = n_way * cfg.get("n_queries", 1)
     K, D = cfg["dgcnn_k"], 192
-    M = B * N
-    if op == "knn_topk":  # 3 launches: C = 9, 64, 64
+    M = (S_ + n_q) * N
+    passes = 2 if train else 1
+    conv_shapes = [(cfg["pc_in_dim"], 128), (64, 128), (64, 128), (192, 512), (512, 256), (256, 128), (128, 64), (256, 192)]
+    if op == "knn_topk":  # per pass 3 launches: C = 9, 64, 64; sum over clouds of 2 N^2 C
         Cs = [cfg["pc_in_dim"], 64, 64]
-        return sum(2.0 * B * N * N * C for C in Cs), sum(M * C * 4 + M * K * 4 for C in Cs), "mfma", 3
+        return sum(2.0 * (S_ + n_q) * N * N * C for C in Cs), sum(M * C * 4 + M * K * 4 for C in Cs), "mfma", 3 * passes
     if op == "knn_topk_l2":
         kp1 = cfg["k_connect"] + 1
         return 2.0 * n_nodes * n_nodes * D, n_nodes * D * 4 + n_nodes * kp1 * 4, "mfma", 1
-    if op == "edgeconv":  # 3 launches
-        return 3 * M * K * (2.0 * 64 * 64 + 3 * 64), 3 * (M * 128 * 4 + M * K * 4 + M * 64 * 4), "mfma", 3
-    if op == "pointwise_conv":  # PQ x3, mlp x2, base x2, qkv
-        shapes = [(cfg["pc_in_dim"], 128), (64, 128), (64, 128), (192, 512), (512, 256), (256, 128), (128, 64), (256, 192)]
-        return (sum(2.0 * M * k * co for k, co in shapes), sum(M * k * 4 + M * co * 4 + k * co * 4 for k, co in shapes),
-                "mfma", len(shapes))
+    if op == "edgeconv":  # eval: 3 fused launches; train: stats1 + stats pass + output pass per layer
+        f = 3 * M * K * (2.0 * 64 * 64 + 3 * 64)
+        b = 3 * (M * 128 * 4 + M * K * 4 + M * 64 * 4)
+        return (f * 2, b * 3, "mfma", 9 * passes) if train else (f, b, "mfma", 3)
+    if op == "pointwise_conv":
+        f = sum(2.0 * M * k * co for k, co in conv_shapes)
+        b = sum(M * k * 4 + M * co * 4 + k * co * 4 for k, co in conv_shapes)
+        return (f * 2, b * 2, "mfma", 2 * len(conv_shapes) * passes) if train else (f, b, "mfma", len(conv_shapes))
     if op == "attention":
-        return 4.0 * B * N * N * 64, M * 192 * 4 + M * 64 * 4, "mfma", 1
+        return 4.0 * (S_ + n_q) * N * N * 64, M * 192 * 4 + M * 64 * 4, "mfma", passes
+    if op == "attention_bwd":  # S recomputed twice, dP twice, dV, dK, dQ: 14 N^2 d per cloud
+        return 14.0 * (S_ + n_q) * N * N * 64, M * (192 + 64 + 64 + 192) * 4, "mfma", passes
+    if op == "gemm_tn":  # weight gradients of every conv: 2 M K Co each
+        shapes = conv_shapes[:]
+        return (sum(2.0 * M * k * co for k, co in shapes), sum(M * (k + co) * 4 + k * co * 4 for k, co in shapes), "mfma",
+                len(shapes) * passes)
+    if op == "edgeconv_bwd":  # three edge GEMMs (z2 recompute, dh1, dW2) + dy1 round trip
+        return 3 * M * K * (3 * 2.0 * 64 * 64), 3 * (M * 128 * 4 * 2 + 2 * M * K * 64 * 4 + M * 64 * 8), "mfma", 3 * passes
+    if op == "bn_stats":  # column statistics: every activation / gradient matrix read once
+        cols = [512, 256, 128, 64]
+        return 4.0 * M * sum(cols) * 3, 3 * M * sum(cols) * 4, "hbm", 3 * len(cols) * passes
     if op == "head_prototypes":  # FPS + assignment + means: features read once per pass
         pts = S_ * N
-        ksub = cfg["n_subprototypes"]
-        return 3.0 * ksub * pts * D * 2, 3 * pts * D * 4, "hbm", 1
-    if op == "label_propagate":  # bitmap + CSR build + cg_iters SpMVs over <= 2*k nnz per row
+        return 3.0 * cfg["n_subprototypes"] * pts * D * 2, 3 * pts * D * 4, "hbm", 1
+    if op in ("label_propagate", "label_propagate_bwd"):  # graph build + cg_iters SpMVs over <= 2 k nnz per row
         nnz = 2.0 * n_nodes * cfg["k_connect"]
         return (n_nodes * cfg["k_connect"] * D * 6 + cg_iters * nnz * 8,
                 n_nodes * D * 4 + nnz * 8 + cg_iters * (nnz * 8 + n_nodes * 16 * 4), "hbm", 1)
@@ -69,7 +87,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="S", choices=["S", "C", "P"])
-    ap.add_argument("--mode", default="eval", choices=["eval", "train"])
+    ap.add_argument("--mode", default="train", choices=["eval", "train"])
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-kernel", default="auto", help="entry point to price (auto = the one taking most time)")
     args = ap.parse_args()
@@ -79,12 +98,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path in the product)")
+    if os.environ.get("R3D_BENCH_ONE_DEVICE"):  # rehearsal of the N > 1 code path on a one-GPU box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from r3dfsseg_amd import ops, synthetic as S
     from r3dfsseg_amd.mpti import MPTI_SelfAtten
@@ -93,87 +118,101 @@ def main():
     model = MPTI_SelfAtten(SimpleNamespace(**cfg))
     model.load_state_dict(S.make_state_dict(cfg, 123))
     model.to(dev)
-    train = args.mode == "train"
+
     n_pool = 8  # distinct episodes per rank, resident in HBM before timing starts
     pool = []
     for e in range(n_pool):
-        data, _ = S.make_episode(cfg, seed=1000 * rank + e, noise_ratio=0.2 if train else 0.0, train=train)
-        pool.append([t.to(dev) for t in (data if train else data[:4])])
+        data, _ = S.make_episode(cfg, seed=1000 * rank + e, noise_ratio=0.2, train=True)
+        pool.append([t.to(dev) for t in data])
     torch.cuda.synchronize()
 
+    from r3dfsseg_amd.dp_train import DPTrainer
+    learner = SimpleNamespace(model=model)
+    learner.optimizer = torch.optim.Adam(
+        [{'params': model.encoder.parameters(), 'lr': 0.0001}, {'params': model.base_learner.parameters()},
+         {'params': model.att_learner.parameters()}, {'params': model.proj.parameters()}], lr=1e-3)
+    learner.lr_scheduler = torch.optim.lr_scheduler.StepLR(learner.optimizer, step_size=5000, gamma=0.5)
+    trainer = DPTrainer(learner)
     lp_flags = []
-    if train:
-        # forward + backward + single flat-bucket gradient all-reduce + Adam (mpti_learner.py:60-72)
-        from r3dfsseg_amd.dp_train import DPTrainer
-        targs = SimpleNamespace(lr=1e-3, step_size=5000, gamma=0.5, **cfg)
-        learner = SimpleNamespace(model=model)
-        learner.optimizer = torch.optim.Adam(
-            [{'params': model.encoder.parameters(), 'lr': 0.0001}, {'params': model.base_learner.parameters()},
-             {'params': model.att_learner.parameters()}, {'params': model.proj.parameters()}], lr=targs.lr)
-        learner.lr_scheduler = torch.optim.lr_scheduler.StepLR(learner.optimizer, step_size=targs.step_size, gamma=targs.gamma)
-        trainer = DPTrainer(learner)
-        model.train()
 
-        def step(i):
-            loss = trainer.step([pool[i % n_pool]])
-            hb = model._head[1]
-            lp_flags.append(torch.cat((hb.stats * hb.stats_bwd[:1].clamp(max=1), hb.knn_status)))
-            return loss
+    def head_flags():
+        hb = model._head[1]
+        return torch.cat((hb.stats, hb.knn_status))  # (CG converged, CG iterations, kNN overflow)
+
+    def train_step(i):
+        trainer.step([pool[i % n_pool]])
+        hb = model._head[1]
+        f = head_flags()
+        f[0] = f[0] * hb.stats_bwd[0].clamp(max=1)  # forward AND adjoint solve converged
+        lp_flags.append(f)
+
+    def eval_step(i):
+        sx, sy, qx, qy = pool[i % n_pool][:4]
+        with torch.no_grad():
+            model(sx, sy, qx, qy)
+        lp_flags.append(head_flags())
+
+    def timed(step_fn, steps, warmup):
+        for i in range(warmup):
+            step_fn(i)
+        del lp_flags[:]
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step_fn(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t.item()
+        lp = torch.stack(lp_flags).cpu()
+        if int(lp[:, 2].max()) != 0:
+            raise SystemExit("bench invalid: 201-NN survivor buffer overflowed")
+        if int(lp[:, 0].min()) != 1:
+            raise SystemExit("bench invalid: label propagation did not converge in %d timed episode(s)" % int((lp[:, 0] != 1).sum()))
+        return el, lp
+
+    train = args.mode == "train"
+    if train:
+        model.train()
+        elapsed, lp = timed(train_step, args.steps, args.warmup)
+        model.eval()
+        other_el, _ = timed(eval_step, max(args.steps // 2, 1), 3)
+        other = ("eval_forward_episodes_per_sec", max(args.steps // 2, 1) * world / other_el)
+        model.train()
+        step_fn = train_step
     else:
         model.eval()
+        elapsed, lp = timed(eval_step, args.steps, args.warmup)
+        other = None
+        step_fn = eval_step
 
-        def step(i):
-            sx, sy, qx, qy = pool[i % n_pool]
-            with torch.no_grad():
-                logits, loss = model(sx, sy, qx, qy)
-            hb = model._head[1]
-            lp_flags.append(torch.cat((hb.stats, hb.knn_status)))  # (CG converged, CG iterations, kNN overflow)
-            return logits, loss
-
-    for i in range(args.warmup):
-        step(i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-    # roofline leg: the same K steps again with HIP events around every entry point (events are
-    # recorded on the launch stream = torch's current stream); kept out of the timed region above
+    # roofline leg: the same K steps again with HIP events around every entry point (recorded on the launch stream
+    # = torch's current stream); kept out of the timed region above
     timer = ops.KernelTimer(OPS)
     ops.set_timer(timer)
     for i in range(args.steps):
-        step(i)
+        step_fn(i)
     ops.set_timer(None)
     ksum_all = timer.summary()
-    lp = torch.stack(lp_flags[args.warmup:args.warmup + args.steps]).cpu()
-    if int(lp[:, 2].max()) != 0:
-        raise SystemExit("bench invalid: 201-NN survivor buffer overflowed")
-    if int(lp[:, 0].min()) != 1:
-        raise SystemExit("bench invalid: label propagation did not converge in %d timed episode(s)" % int((lp[:, 0] != 1).sum()))
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
-    S_ = cfg["n_way"] * cfg["k_shot"]
-    B = S_ + cfg["n_way"] * cfg.get("n_queries", 1)
     N = cfg["pc_npts"]
+    B = cfg["n_way"] * cfg["k_shot"] + cfg["n_way"] * cfg.get("n_queries", 1)
     n_nodes = int(model._head[1].desc[ops.HD_N_NODES].item())
     cg_mean = float(lp[:, 1].float().mean())
-    per_step_ms = {k: v["total_ms"] / args.steps for k, v in ksum_all.items()}
+    per_step_ms = {k: v["total_ms"] / args.steps for k, v in ksum_all.items() if v["launches"]}
     kern = max(per_step_ms, key=per_step_ms.get) if args.roofline_kernel == "auto" else args.roofline_kernel
-    fl, by, bound, launches = algorithmic_work(kern, cfg, n_nodes, cg_mean)
+    fl, by, bound, launches = algorithmic_work(kern, cfg, n_nodes, cg_mean, train)
     t_launch = per_step_ms[kern] * 1e-3 / launches
     if bound == "mfma":
         ach, peak, unit = fl / launches / t_launch / 1e12, F32_MFMA_PEAK_TF, "TFLOP/s"
@@ -205,12 +244,12 @@ def main():
                 break
         c1 = time.perf_counter()
         cpu = dict(value=n_cpu / (c1 - c0), unit="episodes/s", cores=ncores, kind="port",
-                   sample="%d full %s episode(s), eval forward, CPU oracle (C + torch-CPU, %d threads)" % (n_cpu, args.workload, ncores))
+                   sample="%d full %s episode(s), EVAL FORWARD only, CPU oracle (C + torch-CPU, %d threads)" % (n_cpu, args.workload, ncores))
 
     eps = args.steps * world / elapsed
     out = {
         "metric": "episodes/sec S3DIS 2-way 5-shot 2048-pt (MPTI+attention, %s)" % (
-            "train: forward+backward+grad all-reduce+Adam" if train else "eval forward"),
+            "train step: forward+backward+grad all-reduce+Adam" if train else "eval forward"),
         "value": eps, "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -218,8 +257,10 @@ def main():
             args.workload, cfg["n_way"], cfg["k_shot"], N, B, args.mode), "episodes_per_step": world},
         "roofline": roof, "cpu_baseline": cpu,
         "entry_point_ms_per_step": breakdown,
-        "lp_cg_iterations": {"mean": float(lp[:, 1].float().mean()), "max": int(lp[:, 1].max())},
+        "lp_cg_iterations": {"mean": cg_mean, "max": int(lp[:, 1].max())},
     }
+    if other:
+        out[other[0]] = other[1]
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

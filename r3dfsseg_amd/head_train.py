@@ -3,7 +3,7 @@ autograd edge of the transductive head.  Compute lives in libr3d_hip.so; this fi
 import torch
 
 from . import _lib, ops, train_ops as T
-from .ops import _p, _st
+from .ops import _p, _st, _timed
 
 
 class HeadLPFn(torch.autograd.Function):
@@ -43,7 +43,8 @@ class HeadLPFn(torch.autograd.Function):
                                    _p(gs), _p(G), _st()))
         lam = torch.empty(hb.n_cap, 4, device=dev, dtype=torch.float32)
         dnodes = torch.empty(hb.n_cap, D, device=dev, dtype=torch.float32)
-        _lib.check(lib.r3d_label_propagate_bwd(_p(hb.nodes), hb.nodes.stride(0), D, hb.kp1, _p(hb.Z), _p(G),
+        with _timed("label_propagate_bwd"):
+          _lib.check(lib.r3d_label_propagate_bwd(_p(hb.nodes), hb.nodes.stride(0), D, hb.kp1, _p(hb.Z), _p(G),
                                                _p(hb.desc[ops.HD_N_NODES:]), hb.n_cap, float(model.sigma), 0.99,
                                                int(min(model.lp_max_iter, 2 * ctx.budget)), float(model.lp_tol), _p(lam),
                                                _p(dnodes), D,

@@ -11,7 +11,7 @@ import ctypes
 import torch
 
 from . import _lib, ops
-from .ops import _p, _rows, _st
+from .ops import _p, _rows, _st, _timed
 
 BN_EPS, BN_MOM = 1e-5, 0.1
 
@@ -29,8 +29,9 @@ def colstats(X, C, mode=0, DY=None, bn=None, act=0):
     ws = _f(lib.r3d_colstats_ws_words(M, C), dev)
     lddy = DY.stride(0) if DY is not None else 0
     sc, sh, mu, is_ = bn if bn is not None else (None, None, None, None)
-    _lib.check(lib.r3d_colstats(_p(X), ldx, _p(DY), lddy, M, C, mode, _p(sc), _p(sh), _p(mu), _p(is_), act, _p(sums),
-                                _p(ws), _st()))
+    with _timed("bn_stats"):
+        _lib.check(lib.r3d_colstats(_p(X), ldx, _p(DY), lddy, M, C, mode, _p(sc), _p(sh), _p(mu), _p(is_), act, _p(sums),
+                                    _p(ws), _st()))
     return sums
 
 
@@ -78,7 +79,8 @@ def gemm_tn(A, B):
     lib = _lib.load()
     out = torch.empty(Ca, Cb, device=A.device, dtype=torch.float32)
     ws = _f(lib.r3d_gemm_tn_ws_words(M, Ca, Cb), A.device)
-    _lib.check(lib.r3d_gemm_tn(_p(A), lda, _p(B), ldb, M, Ca, Cb, 1.0, _p(out), 0, _p(ws), _st()))
+    with _timed("gemm_tn"):
+        _lib.check(lib.r3d_gemm_tn(_p(A), lda, _p(B), ldb, M, Ca, Cb, 1.0, _p(out), 0, _p(ws), _st()))
     return out
 
 
@@ -136,17 +138,20 @@ def edgeconv_train_fwd(inp, idx, ec, B, N, out):
     E = B * N * K
     ws = _f(lib.r3d_edgeconv_train_ws_words(), dev)
     sums1 = _f(128, dev)
-    _lib.check(lib.r3d_edge_stats1(_p(PQ), _p(idx), B, N, K, _p(sums1), _p(ws), _st()))
+    with _timed("edgeconv"):
+        _lib.check(lib.r3d_edge_stats1(_p(PQ), _p(idx), B, N, K, _p(sums1), _p(ws), _st()))
     bn1 = bn_fold(sums1, E, ec.layer[1])
     W2 = ec.layer[3].weight.reshape(64, 64).contiguous()
     sums2 = _f(128, dev)
-    _lib.check(lib.r3d_edgeconv_train_fwd(_p(PQ), _p(idx), _p(bn1[0]), _p(bn1[1]), _p(W2), None, None, 1, None, 64, B, N, K,
-                                          None, None, _p(sums2), _p(ws), _st()))
+    with _timed("edgeconv"):
+        _lib.check(lib.r3d_edgeconv_train_fwd(_p(PQ), _p(idx), _p(bn1[0]), _p(bn1[1]), _p(W2), None, None, 1, None, 64, B, N,
+                                              K, None, None, _p(sums2), _p(ws), _st()))
     bn2 = bn_fold(sums2, E, ec.layer[4])
     argmax = torch.empty(B * N, 64, device=dev, dtype=torch.int32)
     zmax = torch.empty(B * N, 64, device=dev, dtype=torch.float32)
-    _lib.check(lib.r3d_edgeconv_train_fwd(_p(PQ), _p(idx), _p(bn1[0]), _p(bn1[1]), _p(W2), _p(bn2[0]), _p(bn2[1]), 0,
-                                          _p(out), out.stride(0), B, N, K, _p(argmax), _p(zmax), None, _p(ws), _st()))
+    with _timed("edgeconv"):
+        _lib.check(lib.r3d_edgeconv_train_fwd(_p(PQ), _p(idx), _p(bn1[0]), _p(bn1[1]), _p(W2), _p(bn2[0]), _p(bn2[1]), 0,
+                                              _p(out), out.stride(0), B, N, K, _p(argmax), _p(zmax), None, _p(ws), _st()))
     return (inp, idx, Wpq, PQ, W2, bn1, bn2, argmax, zmax, C)
 
 
@@ -161,9 +166,10 @@ def edgeconv_train_bwd(saved, dout, B, N, dx_acc):
     DY1 = _f(M * K * 64, dev)
     dW2, bn1_sums, dPQ = _f(64 * 64, dev), _f(128, dev), _f(M * 128, dev).view(M, 128)
     ws = _f(lib.r3d_edgeconv_train_ws_words(), dev)
-    _lib.check(lib.r3d_edgeconv_bwd(_p(PQ), _p(idx), _p(bn1[0]), _p(bn1[1]), _p(bn1[2]), _p(bn1[3]), _p(W2), _p(bn2[0]),
-                                    _p(bn2[1]), _p(bn2[2]), _p(bn2[3]), _p(bn2_sums), _p(dout), dout.stride(0), _p(argmax),
-                                    B, N, K, _p(DY1), _p(dW2), _p(bn1_sums), _p(dPQ), _p(ws), _st()))
+    with _timed("edgeconv_bwd"):
+        _lib.check(lib.r3d_edgeconv_bwd(_p(PQ), _p(idx), _p(bn1[0]), _p(bn1[1]), _p(bn1[2]), _p(bn1[3]), _p(W2), _p(bn2[0]),
+                                        _p(bn2[1]), _p(bn2[2]), _p(bn2[3]), _p(bn2_sums), _p(dout), dout.stride(0),
+                                        _p(argmax), B, N, K, _p(DY1), _p(dW2), _p(bn1_sums), _p(dPQ), _p(ws), _st()))
     dWpq = gemm_tn(dPQ, inp)  # (128, C): rows 0..63 = dP^T x, rows 64..127 = dQ^T x
     dW1 = torch.cat((dWpq[:64] - dWpq[64:], dWpq[64:]), 1).reshape(64, 2 * C, 1, 1)
     if dx_acc is not None:
@@ -210,8 +216,9 @@ class EncoderTrainFn(torch.autograd.Function):
         qkv = ops.pointwise_conv(level2, Wqkv, qscale, None, ops.ACT_NONE)
         lse = torch.empty(M, device=dev, dtype=torch.float32)
         p_drop = float(att.dropout.p)
-        _lib.check(lib.r3d_attention_fwd_train(_p(qkv), 192, B, N, _p(feat[:, 64:128]), feat.stride(0), _p(lse), p_drop,
-                                               ctypes.c_uint(seed & 0xffffffff), _st()))
+        with _timed("attention"):
+            _lib.check(lib.r3d_attention_fwd_train(_p(qkv), 192, B, N, _p(feat[:, 64:128]), feat.stride(0), _p(lse), p_drop,
+                                                   ctypes.c_uint(seed & 0xffffffff), _st()))
         ctx.model, ctx.dims = model, (B, N, seed, p_drop)
         model._dbg_idx = [sv[1] for sv in ec_saved]  # neighbour lists of this pass (parity tests inject them into the oracle)
         ctx.saved = (ec_saved, mlp_saved, base_saved, cat, level2, Wqkv, qkv, lse, feat)
@@ -244,9 +251,10 @@ class EncoderTrainFn(torch.autograd.Function):
         # --- SelfAttention (attention.py:39-46)
         dqkv = torch.empty(M, 192, device=dev, dtype=torch.float32)
         ws = _f(M, dev)
-        _lib.check(lib.r3d_attention_bwd(_p(qkv), 192, B, N, _p(feat[:, 64:128]), feat.stride(0), _p(dfeat[:, 64:128]),
-                                         dfeat.stride(0), _p(lse), p_drop, ctypes.c_uint(seed & 0xffffffff),
-                                         1.0 / att.temperature, _p(dqkv), 192, _p(ws), _st()))
+        with _timed("attention_bwd"):
+            _lib.check(lib.r3d_attention_bwd(_p(qkv), 192, B, N, _p(feat[:, 64:128]), feat.stride(0), _p(dfeat[:, 64:128]),
+                                             dfeat.stride(0), _p(lse), p_drop, ctypes.c_uint(seed & 0xffffffff),
+                                             1.0 / att.temperature, _p(dqkv), 192, _p(ws), _st()))
         dWqkv = gemm_tn(dqkv, level2)
         for k, m in enumerate((att.q_map, att.k_map, att.v_map)):
             g[m.weight] = dWqkv[64 * k:64 * (k + 1)].reshape(m.weight.shape)
