@@ -3,16 +3,22 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
-A "step" is one pass of the hot path over one episode per rank (configs[1] of BASELINE.json: S3DIS S0
-2-way 5-shot 2048 pts, MPTI + attention), inputs resident in HBM.
-  --mode train (default): forward + backward + ONE flat-bucket RCCL gradient all-reduce + Adam, i.e. the
-                          reference's MPTILearner_V3.train step (models/mpti_learner.py:60-72);
+A "step" is one pass of the hot path over one batch of E episodes per rank (--episodes-per-rank, default 32 =
+BASELINE.json configs[4]'s 256-episode batch over 8 GPUs; each episode is configs[1]: S3DIS S0 2-way 5-shot
+2048 pts, MPTI + attention), inputs resident in HBM.
+  --mode train (default): E x (forward + backward) + ONE flat-bucket RCCL gradient all-reduce + Adam.  With
+                          E = 1 this is the reference's MPTILearner_V3.train step (models/mpti_learner.py:60-72).
   --mode eval           : forward only, MPTILearner_V3.test without its host sync.
+  --slots G (default 4) : episodes in flight per GPU -- every slot is a captured hipGraph replayed on its own HIP
+                          stream (r3dfsseg_amd/episode_graph.py); --slots 0 = eager launches, one episode at a time.
 Episodes are independent: ranks take disjoint episodes (weak scaling); the only collective is
 the 1.5 MB gradient all-reduce of train mode.  ONE JSON line on rank 0, with
   roofline     -- the entry point taking most time, priced with its ALGORITHMIC work over
-                  its HIP-event launch time (events recorded on the launch stream, second pass of the K steps)
+                  its HIP-event launch time (events recorded on the launch stream, in a separate pass of
+                  single-episode EAGER steps: one episode in flight, so launches do not overlap)
   cpu_baseline -- the CPU oracle (a port of the reference path) on this box's host cores, eval forward
+Extra fields: single_episode_eager_step_episodes_per_sec (E = 1, eager: the reference's own schedule) and
+eval_forward_episodes_per_sec.
 """
 import argparse
 import json
@@ -84,10 +90,14 @@ def algorithmic_work(op, cfg, n_nodes, cg_iters, train):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="S", choices=["S", "C", "P"])
     ap.add_argument("--mode", default="train", choices=["eval", "train"])
+    ap.add_argument("--episodes-per-rank", type=int, default=32,
+                    help="episodes of one step on every rank (BASELINE configs[4]: 256-episode batch / 8 GPUs)")
+    ap.add_argument("--slots", type=int, default=4, help="episodes in flight per GPU (hipGraphs on HIP streams); 0 = eager")
+    ap.add_argument("--lp-budget", type=int, default=None, help="CG launches frozen into each episode graph")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-kernel", default="auto", help="entry point to price (auto = the one taking most time)")
@@ -119,7 +129,8 @@ def main():
     model.load_state_dict(S.make_state_dict(cfg, 123))
     model.to(dev)
 
-    n_pool = 8  # distinct episodes per rank, resident in HBM before timing starts
+    E, G = args.episodes_per_rank, args.slots
+    n_pool = max(8, min(E, 32))  # distinct episodes per rank, resident in HBM before timing starts
     pool = []
     for e in range(n_pool):
         data, _ = S.make_episode(cfg, seed=1000 * rank + e, noise_ratio=0.2, train=True)
@@ -127,35 +138,54 @@ def main():
     torch.cuda.synchronize()
 
     from r3dfsseg_amd.dp_train import DPTrainer
+    from r3dfsseg_amd.episode_graph import EpisodeGraphs
     learner = SimpleNamespace(model=model)
     learner.optimizer = torch.optim.Adam(
         [{'params': model.encoder.parameters(), 'lr': 0.0001}, {'params': model.base_learner.parameters()},
          {'params': model.att_learner.parameters()}, {'params': model.proj.parameters()}], lr=1e-3)
     learner.lr_scheduler = torch.optim.lr_scheduler.StepLR(learner.optimizer, step_size=5000, gamma=0.5)
-    trainer = DPTrainer(learner)
+    train = args.mode == "train"
+    model.train(train)
+    trainer = DPTrainer(learner, n_slots=G if train else 0, example=pool[0], lp_budget=args.lp_budget) if train else None
+    eval_graphs = EpisodeGraphs(model, pool[0][:4], n_slots=G, train=False, lp_budget=args.lp_budget) if G else None
     lp_flags = []
+
+    def batch(i, n):
+        return [pool[(i * n + j) % n_pool] for j in range(n)]
 
     def head_flags():
         hb = model._head[1]
         return torch.cat((hb.stats, hb.knn_status))  # (CG converged, CG iterations, kNN overflow)
 
-    def train_step(i):
-        trainer.step([pool[i % n_pool]])
+    def train_step(i):  # E episodes in flight as hipGraphs -> gradient rows -> ONE all-reduce -> Adam
+        trainer.step(batch(i, E))
+
+    def train_step_eager(i):  # the reference's schedule: one episode, eager launches, all-reduce, Adam
+        saved, trainer.graphs = trainer.graphs, None
+        trainer.step(batch(i, 1))
+        trainer.graphs = saved
         hb = model._head[1]
         f = head_flags()
         f[0] = f[0] * hb.stats_bwd[0].clamp(max=1)  # forward AND adjoint solve converged
         lp_flags.append(f)
 
     def eval_step(i):
+        model.eval()
+        eval_graphs.run([ep[:4] for ep in batch(i, E)])
+
+    def eval_step_eager(i):
+        model.eval()
         sx, sy, qx, qy = pool[i % n_pool][:4]
         with torch.no_grad():
             model(sx, sy, qx, qy)
         lp_flags.append(head_flags())
 
-    def timed(step_fn, steps, warmup):
+    def timed(step_fn, steps, warmup, graphs=None):
         for i in range(warmup):
             step_fn(i)
         del lp_flags[:]
+        if graphs is not None:
+            graphs.check()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -170,36 +200,52 @@ def main():
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = t.item()
+        if graphs is not None:
+            bad, it_sum, it_max = graphs.check()
+            if bad:
+                raise SystemExit("bench invalid: %d timed episode(s) with unconverged label propagation / kNN overflow" % bad)
+            return el, (it_sum / (steps * E), it_max)
         lp = torch.stack(lp_flags).cpu()
         if int(lp[:, 2].max()) != 0:
             raise SystemExit("bench invalid: 201-NN survivor buffer overflowed")
         if int(lp[:, 0].min()) != 1:
             raise SystemExit("bench invalid: label propagation did not converge in %d timed episode(s)" % int((lp[:, 0] != 1).sum()))
-        return el, lp
+        return el, (float(lp[:, 1].float().mean()), int(lp[:, 1].max()))
 
-    train = args.mode == "train"
+    extra = {}
     if train:
-        model.train()
-        elapsed, lp = timed(train_step, args.steps, args.warmup)
-        model.eval()
-        other_el, _ = timed(eval_step, max(args.steps // 2, 1), 3)
-        other = ("eval_forward_episodes_per_sec", max(args.steps // 2, 1) * world / other_el)
-        model.train()
-        step_fn = train_step
+        if G:
+            elapsed, cg = timed(train_step, args.steps, args.warmup, trainer.graphs)
+            n_e = max(args.steps * E // 4, 8)
+            el1, _ = timed(train_step_eager, n_e, 3)
+            extra["single_episode_eager_step_episodes_per_sec"] = n_e * world / el1
+        else:
+            E = 1
+            elapsed, cg = timed(train_step_eager, args.steps, args.warmup)
+        step_fn = train_step_eager
     else:
-        model.eval()
-        elapsed, lp = timed(eval_step, args.steps, args.warmup)
-        other = None
-        step_fn = eval_step
+        if G:
+            elapsed, cg = timed(eval_step, args.steps, args.warmup, eval_graphs)
+        else:
+            E = 1
+            elapsed, cg = timed(eval_step_eager, args.steps, args.warmup)
+        step_fn = eval_step_eager
+    if train and G:
+        n_ev = max(args.steps // 2, 1)
+        el_ev, _ = timed(eval_step, n_ev, 2, eval_graphs)
+        extra["eval_forward_episodes_per_sec"] = n_ev * E * world / el_ev
+        model.train()
 
-    # roofline leg: the same K steps again with HIP events around every entry point (recorded on the launch stream
-    # = torch's current stream); kept out of the timed region above
+    # roofline leg: single-episode EAGER steps with HIP events around every entry point (recorded on the launch
+    # stream = torch's current stream); kept out of the timed region above
+    n_roof = max(min(args.steps * E, 40), 10)
     timer = ops.KernelTimer(OPS)
     ops.set_timer(timer)
-    for i in range(args.steps):
+    for i in range(n_roof):
         step_fn(i)
     ops.set_timer(None)
     ksum_all = timer.summary()
+    cg_mean, cg_max = cg
 
     if rank != 0:
         if world > 1:
@@ -209,8 +255,7 @@ def main():
     N = cfg["pc_npts"]
     B = cfg["n_way"] * cfg["k_shot"] + cfg["n_way"] * cfg.get("n_queries", 1)
     n_nodes = int(model._head[1].desc[ops.HD_N_NODES].item())
-    cg_mean = float(lp[:, 1].float().mean())
-    per_step_ms = {k: v["total_ms"] / args.steps for k, v in ksum_all.items() if v["launches"]}
+    per_step_ms = {k: v["total_ms"] / n_roof for k, v in ksum_all.items() if v["launches"]}
     kern = max(per_step_ms, key=per_step_ms.get) if args.roofline_kernel == "auto" else args.roofline_kernel
     fl, by, bound, launches = algorithmic_work(kern, cfg, n_nodes, cg_mean, train)
     t_launch = per_step_ms[kern] * 1e-3 / launches
@@ -246,21 +291,22 @@ def main():
         cpu = dict(value=n_cpu / (c1 - c0), unit="episodes/s", cores=ncores, kind="port",
                    sample="%d full %s episode(s), EVAL FORWARD only, CPU oracle (C + torch-CPU, %d threads)" % (n_cpu, args.workload, ncores))
 
-    eps = args.steps * world / elapsed
+    eps = args.steps * E * world / elapsed
     out = {
         "metric": "episodes/sec S3DIS 2-way 5-shot 2048-pt (MPTI+attention, %s)" % (
             "train step: forward+backward+grad all-reduce+Adam" if train else "eval forward"),
         "value": eps, "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %d-way %d-shot %d pts, %d clouds/episode, 1 episode/step/rank, mode=%s" % (
-            args.workload, cfg["n_way"], cfg["k_shot"], N, B, args.mode), "episodes_per_step": world},
+        "config": {"workload": "%s: %d-way %d-shot %d pts, %d clouds/episode, %d episode(s)/step/rank (%s), mode=%s" % (
+            args.workload, cfg["n_way"], cfg["k_shot"], N, B, E,
+            "%d in flight as hipGraphs on HIP streams" % G if G else "eager launches", args.mode),
+            "episodes_per_step": E * world, "episodes_per_rank": E, "slots": G},
         "roofline": roof, "cpu_baseline": cpu,
         "entry_point_ms_per_step": breakdown,
-        "lp_cg_iterations": {"mean": cg_mean, "max": int(lp[:, 1].max())},
+        "lp_cg_iterations": {"mean": cg_mean, "max": cg_max},
     }
-    if other:
-        out[other[0]] = other[1]
+    out.update(extra)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -144,11 +144,12 @@ int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float* s1, const
                      float* ws, void* stream);
 
 /* attention with dropout on the weights (attention.py:45) and flash-style backward */
+/* effective dropout seed = seed + *seed_dev (seed_dev may be NULL); a captured hipGraph bumps *seed_dev per replay */
 int r3d_attention_fwd_train(const float* qkv, long ld, int B, int N, float* out, long ldo, float* lse_out, float p_drop,
-                            unsigned seed, void* stream);
+                            unsigned seed, const unsigned* seed_dev, void* stream);
 int r3d_attention_bwd(const float* qkv, long ld, int B, int N, const float* O, long ldo, const float* dO, long lddo,
-                      const float* lse, float p_drop, unsigned seed, float q_scale, float* dqkv, long ldd, float* ws,
-                      void* stream);
+                      const float* lse, float p_drop, unsigned seed, const unsigned* seed_dev, float q_scale, float* dqkv,
+                      long ldd, float* ws, void* stream);
 
 /* head backward (reference: autograd through models/mpti.py:488-512,571).  r3d_ce_grad -> G = dL/dZ (scaled by the
  * device scalar *gscale); r3d_label_propagate_bwd: adjoint CG solve on the graph r3d_label_propagate left in ws,

@@ -31,7 +31,8 @@ static __device__ __forceinline__ bool attn_keep(unsigned seed, unsigned row, un
 
 __global__ __launch_bounds__(256) void r3d_attention_fwd_kernel(
     const float* __restrict__ qkv, long ld, int N, float* __restrict__ out, long ldo,
-    float* __restrict__ lse_out, float p_drop, unsigned seed) {
+    float* __restrict__ lse_out, float p_drop, unsigned seed, const unsigned* __restrict__ seed_dev) {
+  if (seed_dev) seed += *seed_dev;  // per-replay seed of a captured hipGraph lives in device memory
   const unsigned thresh = p_drop > 0.f ? (unsigned)(p_drop * 4294967296.0) : 0u;
   const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   __shared__ float Ks[2][32 * AT_LD];
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void r3d_attention_fwd_kernel(
 // out: (B*N, ldo) point-major, 64 columns written; lse_out optional (B*N) log-sum-exp
 // per query (saved for the backward pass).
 static int attention_launch(const float* qkv, long ld, int B, int N, float* out, long ldo, float* lse_out, float p_drop,
-                            unsigned seed, void* stream) {
+                            unsigned seed, const unsigned* seed_dev, void* stream) {
   R3D_REQUIRE(qkv && out, "r3d_attention_fwd: null pointer");
   R3D_REQUIRE(B > 0 && N > 0 && ld >= 192 && ld % 4 == 0 && ldo >= 64,
               "r3d_attention_fwd: bad shape B=%d N=%d ld=%ld ldo=%ld", B, N, ld, ldo);
@@ -161,21 +162,22 @@ static int attention_launch(const float* qkv, long ld, int B, int N, float* out,
   dim3 grid(r3d_cdiv(N, 128), B);
   R3D_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "r3d_attention_fwd: dropout probability %f out of range", p_drop);
   hipLaunchKernelGGL(r3d_attention_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, ld, N, out,
-                     ldo, lse_out, p_drop, seed);
+                     ldo, lse_out, p_drop, seed, seed_dev);
   R3D_LAUNCH_CHECK("r3d_attention_fwd");
   return R3D_OK;
 }
 
 extern "C" int r3d_attention_fwd(const float* qkv, long ld, int B, int N, float* out, long ldo, float* lse_out,
                                  void* stream) {
-  return attention_launch(qkv, ld, B, N, out, ldo, lse_out, 0.f, 0u, stream);
+  return attention_launch(qkv, ld, B, N, out, ldo, lse_out, 0.f, 0u, nullptr, stream);
 }
 
-// training forward: dropout p_drop on the attention weights with the stateless mask of attn_keep
+// training forward: dropout p_drop on the attention weights with the stateless mask of attn_keep.
+// Effective seed = seed + *seed_dev (seed_dev may be NULL): a captured hipGraph bumps the device word per replay.
 extern "C" int r3d_attention_fwd_train(const float* qkv, long ld, int B, int N, float* out, long ldo, float* lse_out,
-                                       float p_drop, unsigned seed, void* stream) {
+                                       float p_drop, unsigned seed, const unsigned* seed_dev, void* stream) {
   R3D_REQUIRE(lse_out, "r3d_attention_fwd_train: lse_out is required (saved for the backward pass)");
-  return attention_launch(qkv, ld, B, N, out, ldo, lse_out, p_drop, seed, stream);
+  return attention_launch(qkv, ld, B, N, out, ldo, lse_out, p_drop, seed, seed_dev, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -197,7 +199,9 @@ __global__ void r3d_attention_rowdot_kernel(const float* __restrict__ dO, long l
 
 __global__ __launch_bounds__(256) void r3d_attention_bwd_kv_kernel(
     const float* __restrict__ qkv, long ld, int N, const float* __restrict__ dO, long lddo, const float* __restrict__ lse,
-    const float* __restrict__ Dv, float* __restrict__ dqkv, long ldd, float p_drop, unsigned seed) {
+    const float* __restrict__ Dv, float* __restrict__ dqkv, long ldd, float p_drop, unsigned seed,
+    const unsigned* __restrict__ seed_dev) {
+  if (seed_dev) seed += *seed_dev;
   __shared__ float Qs[2][32 * AT_LD];
   __shared__ float Gs[2][32 * AT_LD];  // dO tile
   __shared__ float Ls[2][32], Ds[2][32];
@@ -310,7 +314,9 @@ __global__ __launch_bounds__(256) void r3d_attention_bwd_kv_kernel(
 
 __global__ __launch_bounds__(256) void r3d_attention_bwd_q_kernel(
     const float* __restrict__ qkv, long ld, int N, const float* __restrict__ dO, long lddo, const float* __restrict__ lse,
-    const float* __restrict__ Dv, float* __restrict__ dqkv, long ldd, float p_drop, unsigned seed, float q_scale) {
+    const float* __restrict__ Dv, float* __restrict__ dqkv, long ldd, float p_drop, unsigned seed,
+    const unsigned* __restrict__ seed_dev, float q_scale) {
+  if (seed_dev) seed += *seed_dev;
   __shared__ float Ks[2][32 * AT_LD];
   __shared__ float Vs[2][32 * AT_LD];
   const unsigned thresh = p_drop > 0.f ? (unsigned)(p_drop * 4294967296.0) : 0u;
@@ -410,8 +416,8 @@ __global__ __launch_bounds__(256) void r3d_attention_bwd_q_kernel(
 // dqkv (B*N, ldd >= 192): gradients of the q | k | v GEMM outputs (before the 1/sqrt(d) scale of q).
 // O: forward output (B*N, ldo); lse: saved log-sum-exp; ws: B*N floats.
 extern "C" int r3d_attention_bwd(const float* qkv, long ld, int B, int N, const float* O, long ldo, const float* dO,
-                                 long lddo, const float* lse, float p_drop, unsigned seed, float q_scale, float* dqkv,
-                                 long ldd, float* ws, void* stream) {
+                                 long lddo, const float* lse, float p_drop, unsigned seed, const unsigned* seed_dev,
+                                 float q_scale, float* dqkv, long ldd, float* ws, void* stream) {
   R3D_REQUIRE(qkv && O && dO && lse && dqkv && ws, "r3d_attention_bwd: null pointer");
   R3D_REQUIRE(B > 0 && N > 0 && ld >= 192 && ld % 4 == 0 && lddo % 4 == 0 && ldd >= 192 && ldo >= 64,
               "r3d_attention_bwd: bad shape");
@@ -421,9 +427,9 @@ extern "C" int r3d_attention_bwd(const float* qkv, long ld, int B, int N, const 
   hipLaunchKernelGGL(r3d_attention_rowdot_kernel, dim3(r3d_cdiv(M, 4)), dim3(256), 0, st, dO, lddo, O, ldo, M, ws);
   dim3 grid(r3d_cdiv(N, 128), B);
   hipLaunchKernelGGL(r3d_attention_bwd_kv_kernel, grid, dim3(256), 0, st, qkv, ld, N, dO, lddo, lse, ws, dqkv, ldd, p_drop,
-                     seed);
+                     seed, seed_dev);
   hipLaunchKernelGGL(r3d_attention_bwd_q_kernel, grid, dim3(256), 0, st, qkv, ld, N, dO, lddo, lse, ws, dqkv, ldd, p_drop,
-                     seed, q_scale);
+                     seed, seed_dev, q_scale);
   R3D_LAUNCH_CHECK("r3d_attention_bwd");
   return R3D_OK;
 }

@@ -64,3 +64,25 @@ static __device__ __forceinline__ float r3d_keep(float v, bool keep) {
 }
 
 static inline int r3d_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Device-to-device fill / copy as plain KERNELS.  The library's launch sequences are frozen into hipGraphs
+// (episode_graph.py); hipMemsetAsync / hipMemcpyAsync would become memset / memcpy graph nodes, and on this
+// stack (ROCm 7.2, measured with tools/fault_probe.py) a graph holding such nodes replayed wrongly once the
+// device had been synchronised between replays: stale neighbour bitmaps and status words, then a GPU memory
+// fault in r3d_graph_weights_kernel.  With kernel nodes only the replays are stable, so every byte the
+// library clears or moves goes through these two kernels.  Sizes are in 32-bit words.
+static __global__ void r3d_fill_words_kernel(unsigned* __restrict__ p, unsigned v, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+static __global__ void r3d_copy_words_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+static inline void r3d_zero_words(void* p, long n_words, hipStream_t st) {
+  const int g = (int)(n_words < 256L * 2048 ? (n_words + 255) / 256 : 2048);
+  hipLaunchKernelGGL(r3d_fill_words_kernel, dim3(g > 0 ? g : 1), dim3(256), 0, st, (unsigned*)p, 0u, n_words);
+}
+static inline void r3d_copy_words(void* dst, const void* src, long n_words, hipStream_t st) {
+  const int g = (int)(n_words < 256L * 2048 ? (n_words + 255) / 256 : 2048);
+  hipLaunchKernelGGL(r3d_copy_words_kernel, dim3(g > 0 ? g : 1), dim3(256), 0, st, (unsigned*)dst, (const unsigned*)src,
+                     n_words);
+}

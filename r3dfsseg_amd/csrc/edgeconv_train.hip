@@ -175,18 +175,16 @@ __global__ __launch_bounds__(512) void r3d_edgeconv_bwd1_kernel(
   float* G = smem + EK * ET_LD;          // [8K][ET_LD] dz2, later dy1
   float* dsm = G + EK * ET_LD;           // [8][64] dout of the unit
   int* asm_ = (int*)(dsm + ET_PTS * 64); // [8][64] argmax of the unit
-  __shared__ float ps[16][2][64];
+  float* W2s = (float*)(asm_ + ET_PTS * 64);  // [64][ET_LD] W2: both MFMA B operands are read from here (holding
+                                              // them in registers cost 128 VGPRs and spilled to scratch)
+  float (*ps)[2][64] = (float (*)[2][64])smem;  // [waves][2][64] block partials; aliases H after the unit loop
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int nwaves = blockDim.x >> 6;
   const int h = lane >> 5, j = lane & 31;
-  float b0[32], b1[32], wb0[32], wb1[32];
-#pragma unroll
-  for (int s = 0; s < 32; ++s) {
-    b0[s] = W2[j * 64 + 2 * s + h];             // B[k][jo] = W2[jo][k]   (z2 = W2 h1)
-    b1[s] = W2[(32 + j) * 64 + 2 * s + h];
-    wb0[s] = W2[(2 * s + h) * 64 + j];          // B[k = c][ji] = W2[c][ji] (dh1 = dz2 W2)
-    wb1[s] = W2[(2 * s + h) * 64 + 32 + j];
-  }
+  int* ept = (int*)(W2s + 64 * ET_LD);        // [8K] point of edge e within the unit (no runtime division in the loops)
+  for (int o = tid; o < 64 * 64; o += blockDim.x) W2s[(o >> 6) * ET_LD + (o & 63)] = W2[o];
+  for (int o = tid; o < EK; o += blockDim.x) ept[o] = o / K;
+  __syncthreads();
   const float sc1 = s1[lane], sh1 = t1[lane], mu1 = mean1[lane], is1 = invstd1[lane];
   const double E = (double)total_points * K;
   // channel constants in the accumulator layout (column = j, +32 for the second tile)
@@ -211,12 +209,21 @@ __global__ __launch_bounds__(512) void r3d_edgeconv_bwd1_kernel(
       const int my_idx = idx[pt0 * K + 32 * w + j];
       float* hrow = H + (32 * w) * ET_LD;
 #pragma unroll
-      for (int t = 0; t < 32; ++t) {
-        const int jn = __builtin_amdgcn_readlane(my_idx, t);
-        const int pi = (32 * w + t) / K;
-        const float e1 = PQ[(cloud0 + jn) * 128 + lane] + PQ[(pt0 + pi) * 128 + 64 + lane];
-        eh[t] = (e1 - mu1) * is1;
-        hrow[t * ET_LD + lane] = lrelu(sc1 * e1 + sh1);
+      for (int t0 = 0; t0 < 32; t0 += 8) {  // 16 gathers in flight per step
+        float pv[8], qv[8];
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+          const int jn = __builtin_amdgcn_readlane(my_idx, t0 + tt);
+          const int pi = ept[32 * w + t0 + tt];
+          pv[tt] = PQ[(cloud0 + jn) * 128 + lane];
+          qv[tt] = PQ[(pt0 + pi) * 128 + 64 + lane];
+        }
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+          const float e1 = pv[tt] + qv[tt];
+          eh[t0 + tt] = (e1 - mu1) * is1;
+          hrow[(t0 + tt) * ET_LD + lane] = lrelu(sc1 * e1 + sh1);
+        }
       }
     }
     f32x16 a0, a1;
@@ -224,11 +231,13 @@ __global__ __launch_bounds__(512) void r3d_edgeconv_bwd1_kernel(
     for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
     {
       const float* ap = H + (32 * w + j) * ET_LD + h;
-#pragma unroll
+      const float* bp0 = W2s + j * ET_LD + h;         // B[k][jo] = W2[jo][k]   (z2 = W2 h1)
+      const float* bp1 = W2s + (32 + j) * ET_LD + h;
+#pragma unroll 8
       for (int s = 0; s < 32; ++s) {
         const float a = ap[2 * s];
-        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[s], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[s], a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp0[2 * s], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp1[2 * s], a1, 0, 0, 0);
       }
     }
     __syncthreads();  // dsm / asm_ visible
@@ -236,7 +245,7 @@ __global__ __launch_bounds__(512) void r3d_edgeconv_bwd1_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int e = 32 * w + r3d_acc_row(r, lane);
-      const int pt = e / K, t = e - pt * K;
+      const int pt = ept[e], t = e - pt * K;
       {
         const float z = a0[r];
         const float uu = s2a * z + t2a;
@@ -256,11 +265,12 @@ __global__ __launch_bounds__(512) void r3d_edgeconv_bwd1_kernel(
     for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
     {
       const float* gp = G + (32 * w + j) * ET_LD + h;
-#pragma unroll
+      const float* wp = W2s + h * ET_LD + j;          // B[k = c][ji] = W2[c][ji] (dh1 = dz2 W2)
+#pragma unroll 8
       for (int s = 0; s < 32; ++s) {
         const float a = gp[2 * s];
-        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb0[s], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb1[s], a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wp[2 * s * ET_LD], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wp[2 * s * ET_LD + 32], a1, 0, 0, 0);
       }
     }
     // dW2 += dz2^T h1 over the unit's 8K edges (waves 0..3, one 32x32 tile each)
@@ -285,12 +295,16 @@ __global__ __launch_bounds__(512) void r3d_edgeconv_bwd1_kernel(
       G[e * ET_LD + 32 + j] = a1[r];
     }
     // same wave reads its rows back channel-per-lane: store dy1 rows, BN1 partial sums
+    {
+      float* drow = DY1 + (pt0 * K + 32 * w) * 64 + lane;
+      const float* grow = G + (32 * w) * ET_LD + lane;
 #pragma unroll
-    for (int t = 0; t < 32; ++t) {
-      const float v = G[(32 * w + t) * ET_LD + lane];
-      DY1[(pt0 * K + 32 * w + t) * 64 + lane] = v;
-      sdy += v;
-      sdye += v * eh[t];
+      for (int t = 0; t < 32; ++t) {
+        const float v = grow[t * ET_LD];
+        drow[t * 64] = v;
+        sdy += v;
+        sdye += v * eh[t];
+      }
     }
     __syncthreads();  // before the next unit overwrites H / G / dsm
   }
@@ -407,7 +421,7 @@ extern "C" int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float
   if (rc) return rc;
   const int waves = ET_PTS * K / 32;
   const int EK = ET_PTS * K;
-  const size_t lds = sizeof(float) * ((size_t)2 * EK * ET_LD + 2 * ET_PTS * 64);
+  const size_t lds = sizeof(float) * ((size_t)2 * EK * ET_LD + 2 * ET_PTS * 64 + 64 * ET_LD + EK);
   const long units = (long)B * N / ET_PTS;
   const int grid = et_grid(units);
   hipStream_t st = (hipStream_t)stream;
@@ -422,9 +436,9 @@ extern "C" int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float
   // partial layout: dW2 (4096) | sum dy1 (64) | sum dy1*ehat1 (64)
   float* red = ws + (long)grid * ET_PART;  // ET_PART floats of headroom are part of r3d_edgeconv_train_ws_words
   hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(r3d_cdiv(ET_PART, 4)), dim3(256), 0, st, ws, grid, ET_PART, red);
-  hipMemcpyAsync(dW2, red, sizeof(float) * 4096, hipMemcpyDeviceToDevice, st);
-  hipMemcpyAsync(bn1_sums, red + 4096, sizeof(float) * 128, hipMemcpyDeviceToDevice, st);
-  hipMemsetAsync(dPQ, 0, sizeof(float) * (size_t)B * N * 128, st);
+  r3d_copy_words(dW2, red, 4096, st);
+  r3d_copy_words(bn1_sums, red + 4096, 128, st);
+  r3d_zero_words(dPQ, (long)B * N * 128, st);
   hipLaunchKernelGGL(r3d_edgeconv_bwd2_kernel, dim3(1024), dim3(256), 0, st, PQ, idx, s1, mean1, invstd1, bn1_sums, DY1, N,
                      K, (long)B * N, dPQ);
   R3D_LAUNCH_CHECK("r3d_edgeconv_bwd");

@@ -492,7 +492,7 @@ static int lp_solve(const LpWs& L, const float* RHS, const int32_t* n_dev, int n
     hipLaunchKernelGGL(r3d_cg_update_kernel, dim3(nblk_v), dim3(256), 0, st, n_dev, n_cap, it, nblk_s, tol2, pnew, L.q,
                        x, L.r, L.part_pq, L.part_rr, L.cg);
   }
-  if (stats_out) hipMemcpyAsync(stats_out, &L.cg->done, 2 * sizeof(int), hipMemcpyDeviceToDevice, st);
+  if (stats_out) r3d_copy_words(stats_out, &L.cg->done, 2, st);
   return R3D_OK;
 }
 
@@ -509,7 +509,7 @@ extern "C" int r3d_label_propagate(const float* nodes, long ldn, int D, const in
   hipStream_t st = (hipStream_t)stream;
   const LpWs L = lp_carve(ws, n_cap, kp1);
   const long words = L.words;
-  hipMemsetAsync(L.outb, 0, sizeof(unsigned) * 2 * n_cap * words, st);
+  r3d_zero_words(L.outb, 2L * n_cap * words, st);
   const long edges = (long)n_cap * (kp1 - 1);
   hipLaunchKernelGGL(r3d_graph_bits_kernel, dim3(r3d_cdiv(edges, 256)), dim3(256), 0, st, nbr, kp1, n_dev, n_cap,
                      (int)words, L.outb, L.sym);

@@ -816,7 +816,7 @@ extern "C" int r3d_knn_topk(const float* x, long ldx, const float* x_cm, int B, 
       xT = cm_ws;
     }
     hipLaunchKernelGGL(r3d_sqnorm_cm_kernel, dim3(r3d_cdiv(N, 256), B), dim3(256), 0, st, xT, ldT, C, N, norm_ws);
-    hipMemsetAsync(status, 0, sizeof(int), st);
+    r3d_zero_words(status, 1, st);
     static size_t big_attr = 0;  // static __shared__ arrays count against the 160 KiB too: ask for what is used
     if (knn_big_lds_bytes(C) > big_attr) {
       hipError_t e = hipFuncSetAttribute((const void*)r3d_knn_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -54,6 +54,25 @@ def _fold_bn(bn, conv_bias=None):
     return scale.contiguous(), shift.contiguous()
 
 
+def _refresh(old, new):
+    """Write newly folded tensors INTO the storage of the previous cache entry where shapes allow: captured
+    episode hipGraphs (episode_graph.py) hold raw pointers to the folded weights, so a weight update must
+    refresh them in place instead of replacing (and freeing) them."""
+    if isinstance(new, torch.Tensor):
+        if (isinstance(old, torch.Tensor) and old.shape == new.shape and old.device == new.device
+                and old.dtype == new.dtype):
+            if old.data_ptr() != new.data_ptr():
+                old.copy_(new)
+            return old
+        return new
+    if isinstance(new, dict):
+        return {k: _refresh(old.get(k) if isinstance(old, dict) else None, v) for k, v in new.items()}
+    if isinstance(new, (list, tuple)):
+        o = old if isinstance(old, (list, tuple)) and len(old) == len(new) else [None] * len(new)
+        return type(new)(_refresh(a, b) for a, b in zip(o, new))
+    return new
+
+
 class DGCNN(nn.Module):
     """DGCNN encoder (dgcnn.py:83-127): 3 x {kNN on current features -> EdgeConv -> max over K},
     concat -> point MLP.  forward_pm works on point-major matrices (rows = points)."""
@@ -98,6 +117,7 @@ class DGCNN(nn.Module):
                 W = W.reshape(W.shape[0], -1).contiguous()
                 s, t = _fold_bn(self.conv.layer[3 * j + 1])
                 f["mlp"].append((W, s, t))
+            f = _refresh(self._folded[1] if self._folded is not None else None, f)
         self._folded = (key, f)
         return f
 
@@ -158,7 +178,8 @@ class SelfAttention(nn.Module):
             W = torch.cat([m.weight.reshape(self.out_channel, -1) for m in (self.q_map, self.k_map, self.v_map)], 0).contiguous()
             scale = torch.ones(3 * self.out_channel, device=W.device)
             scale[: self.out_channel] = 1.0 / self.temperature  # q / sqrt(d), exact for d = 64
-        self._folded = (key, (W, scale))
+            f = _refresh(self._folded[1] if self._folded is not None else None, (W, scale))
+        self._folded = (key, f)
         return self._folded[1]
 
     def forward_pm(self, x_pm, B, N, out):
@@ -198,6 +219,7 @@ class BaseLearner(nn.Module):
                 W = seq[0].weight.reshape(seq[0].weight.shape[0], -1).contiguous()
                 s, t = _fold_bn(seq[1], seq[0].bias)
                 f.append((W, s, t))
+            f = _refresh(self._folded[1] if self._folded is not None else None, f)
         self._folded = (key, f)
         return f
 

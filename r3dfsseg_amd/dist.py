@@ -37,7 +37,9 @@ class FlatGradBucket:
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        # one extra slot carries the episode count, so gradients AND their divisor travel in one all-reduce
+        self.store = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        self.flat = self.store[:n]
         off = 0
         for p in self.params:  # p.grad becomes a view into the bucket
             p.grad = self.flat[off:off + p.numel()].view_as(p)
@@ -48,10 +50,10 @@ class FlatGradBucket:
 
     def all_reduce_mean(self, n_local_episodes):
         """Sum gradients over ranks and divide by the total number of episodes of the step."""
-        total = torch.tensor([float(n_local_episodes)], device=self.flat.device)
+        total = self.store[-1:]
+        total.fill_(float(n_local_episodes))  # a fill kernel: no host->device copy, no host sync
         if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            dist.all_reduce(total, op=dist.ReduceOp.SUM)
+            dist.all_reduce(self.store, op=dist.ReduceOp.SUM)
         self.flat.div_(total)
         return self.flat
 

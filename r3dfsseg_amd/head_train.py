@@ -62,13 +62,70 @@ def mpti_train_forward(model, support_x, support_y, query_x, query_y, gt_support
     query_acc_original, clean_ratio_LP_avg, clean_ratio_original_avg."""
     from . import contrast
     S, N = model.n_way * model.k_shot, model.n_points
-    model._drop_seed = getattr(model, "_drop_seed", 0) + 2
+    slot = model._slot
+    if slot.seed_dev is not None:  # captured launch sequence: the seed advances in device memory
+        slot.seed_dev.add_(2)
+        seed = 0
+    else:
+        model._drop_seed = getattr(model, "_drop_seed", 0) + 2
+        seed = model._drop_seed
     sx = support_x.reshape(S, model.in_channels, N)
     # two getFeatures calls, each with its own BatchNorm batch statistics (mpti.py:434,436)
-    sfeat = T.get_features_train(model, sx, model._drop_seed)
-    qfeat = T.get_features_train(model, query_x, model._drop_seed + 1)
+    sfeat = T.get_features_train(model, sx, seed)
+    qfeat = T.get_features_train(model, query_x, seed + 1)
     contrast_loss = contrast.per_way_contrast_loss(model, sfeat, support_y, support_flag)
     lp_loss = HeadLPFn.apply(sfeat, qfeat, model, support_y, query_y)
     logits = model._train_logits
     metrics = contrast.train_debug_metrics(model, support_y, gt_support_y, query_y, gt_query_y, logger)
     return (logits, lp_loss, contrast_loss) + metrics
+
+
+def explicit_train_episode(model, episode, grad_sink, loss_weight=0.1):
+    """One episode's forward + backward as a FIXED launch sequence without the autograd engine (the form that
+    episode_graph.EpisodeGraphs freezes into a hipGraph): the forward halves of the three autograd Functions run
+    with plain namespaces as their ctx, then their backward halves in dependency order, and every parameter
+    gradient is ADDED into grad_sink[i] (views in the order of model.parameters(), requires_grad only).
+    Same kernels, same results as ``loss = lp + loss_weight * contrast; loss.backward()``
+    (models/mpti_learner.py:66-68).  Returns (loss, logits, metrics[4])."""
+    from types import SimpleNamespace
+    from . import contrast
+    (support_x, support_y, query_x, query_y, _sc, _qc, gt_support_y, gt_query_y, _bx, _by, support_flag) = episode
+    S, N = model.n_way * model.k_shot, model.n_points
+    with torch.no_grad():
+        slot = model._slot
+        if slot.seed_dev is not None:
+            slot.seed_dev.add_(2)
+            seed = 0
+        else:
+            model._drop_seed = getattr(model, "_drop_seed", 0) + 2
+            seed = model._drop_seed
+        params = T.encoder_params(model)
+        cs, cq, cc, ch = (SimpleNamespace(param_list=params) for _ in range(4))
+        sx = support_x.reshape(S, model.in_channels, N)
+        sfeat = T.EncoderTrainFn.forward(cs, sx, model, seed)
+        qfeat = T.EncoderTrainFn.forward(cq, query_x, model, seed + 1)
+        closs = contrast.ContrastFn.forward(cc, sfeat, model.proj.weight, model.proj.bias, model, support_y, support_flag)
+        lploss = HeadLPFn.forward(ch, sfeat, qfeat, model, support_y, query_y)
+        logits = model._train_logits
+        metrics = contrast.train_debug_metrics(model, support_y, gt_support_y, query_y, gt_query_y, None)
+        loss = lploss + loss_weight * closs
+        # ---- backward, in dependency order
+        one = torch.ones((), device=sfeat.device)
+        dsf_c, dWp, dbp = contrast.ContrastFn.backward(cc, one * loss_weight)[:3]
+        dsf, dqf = HeadLPFn.backward(ch, one)[:2]
+        dsf.add_(dsf_c)
+        gs = T.EncoderTrainFn.backward(cs, dsf)[3:]
+        gq = T.EncoderTrainFn.backward(cq, dqf)[3:]
+        index = {id(p): i for i, p in enumerate(q for q in model.parameters() if q.requires_grad)}
+        # two multi-tensor adds: a destination must not appear twice inside one foreach launch
+        for k, grads in enumerate((gs, gq)):
+            dst, src = [], []
+            for p, g in zip(params, grads):
+                if g is not None:
+                    dst.append(grad_sink[index[id(p)]])
+                    src.append(g.reshape(p.shape))
+            if k == 0:
+                dst += [grad_sink[index[id(model.proj.weight)]], grad_sink[index[id(model.proj.bias)]]]
+                src += [dWp, dbp]
+            torch._foreach_add_(dst, src)
+    return loss, logits, metrics

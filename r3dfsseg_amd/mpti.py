@@ -12,6 +12,20 @@ from . import ops
 from .dgcnn import DGCNN, BaseLearner, SelfAttention
 
 
+class EpisodeSlot:
+    """State owned by ONE in-flight episode: its head buffers, the device word behind the attention-dropout seed
+    and its CG launch budget.  Eager calls use the model's default slot; episode_graph.EpisodeGraphs gives every
+    captured hipGraph its own slot so that several episodes can be in flight on separate HIP streams."""
+
+    def __init__(self, sid=0):
+        self.id = sid
+        self.heads = {}
+        self.last = None            # (key, HeadBuffers) of the latest forward through this slot
+        self.seed_dev = None        # int32 device word added to the dropout seed (None: host-side counter)
+        self.fixed_budget = None    # CG launches per solve when the launch sequence is frozen in a graph
+        self.update_running = True  # does this slot's training forward update BatchNorm running statistics?
+
+
 class MPTI_SelfAtten(nn.Module):
     def __init__(self, args):
         super().__init__()
@@ -43,7 +57,7 @@ class MPTI_SelfAtten(nn.Module):
         self.lp_max_iter = getattr(args, "lp_max_iter", 200)
         self.lp_tol = getattr(args, "lp_tol", 1e-6)
         self.shot_level_clean_ratio = 0
-        self._head = None
+        self._slot = EpisodeSlot(0)
         # CG launch budget: iterations are enqueued without knowing when the solver converges
         # (no host sync in forward).  The budget follows the iteration count observed on earlier
         # episodes (read back asynchronously); callers that synchronise anyway (learner.test)
@@ -74,15 +88,22 @@ class MPTI_SelfAtten(nn.Module):
         return ops.pm_to_cm(self.getFeatures_pm(x), B, N)
 
     # ------------------------------------------------------------------ head buffers
+    @property
+    def _head(self):
+        return self._slot.last
+
     def _head_buffers(self, n_q, device):
         key = (n_q, str(device))
-        if self._head is None or self._head[0] != key:
-            hb = ops.HeadBuffers(self.n_way, self.k_shot, self.n_points, n_q * self.n_points,
-                                 self.n_subprototypes, self.k_connect, self.feat_dim, device)
-            self._head = (key, hb)
-        return self._head[1]
+        slot = self._slot
+        if key not in slot.heads:
+            slot.heads = {key: ops.HeadBuffers(self.n_way, self.k_shot, self.n_points, n_q * self.n_points,
+                                               self.n_subprototypes, self.k_connect, self.feat_dim, device)}
+        slot.last = (key, slot.heads[key])
+        return slot.heads[key]
 
     def _lp_next_budget(self):
+        if self._slot.fixed_budget is not None:
+            return min(self.lp_max_iter, self._slot.fixed_budget)
         if self._lp_probe is not None:
             host, ev = self._lp_probe
             if ev.query():
@@ -95,6 +116,8 @@ class MPTI_SelfAtten(nn.Module):
         return self._lp_budget
 
     def _lp_post(self, hb):
+        if self._slot.fixed_budget is not None:  # frozen launch sequence: convergence is checked by the graph owner
+            return
         if self._lp_probe is None:
             host = torch.empty(2, dtype=torch.int32, pin_memory=True)
             host.copy_(hb.stats, non_blocking=True)

@@ -14,6 +14,9 @@ from . import _lib, ops
 from .ops import _p, _rows, _st, _timed
 
 BN_EPS, BN_MOM = 1e-5, 0.1
+# False while a training forward must leave the BatchNorm running statistics alone (episode slots other than
+# slot 0 of episode_graph.EpisodeGraphs: concurrent read-modify-write of the shared buffers would race)
+update_running_stats = True
 
 
 def _f(n, dev):
@@ -42,12 +45,14 @@ def bn_fold(sums, count, bnmod, bias=None):
     C = bnmod.num_features
     dev = sums.device
     mean, invstd, scale, shift = _f(C, dev), _f(C, dev), _f(C, dev), _f(C, dev)
+    upd = update_running_stats
     _lib.check(_lib.load().r3d_bn_fold(_p(sums), float(count), C, _p(bnmod.weight), _p(bnmod.bias), BN_EPS, BN_MOM,
-                                       _p(bnmod.running_mean), _p(bnmod.running_var), _p(mean), _p(invstd), _p(scale),
-                                       _p(shift), _st()))
-    if bias is not None:
-        bnmod.running_mean.add_(BN_MOM * bias.detach())
-    bnmod.num_batches_tracked += 1
+                                       _p(bnmod.running_mean) if upd else None, _p(bnmod.running_var) if upd else None,
+                                       _p(mean), _p(invstd), _p(scale), _p(shift), _st()))
+    if upd:
+        if bias is not None:
+            bnmod.running_mean.add_(BN_MOM * bias.detach())
+        bnmod.num_batches_tracked += 1
     return scale, shift, mean, invstd
 
 
@@ -218,8 +223,8 @@ class EncoderTrainFn(torch.autograd.Function):
         p_drop = float(att.dropout.p)
         with _timed("attention"):
             _lib.check(lib.r3d_attention_fwd_train(_p(qkv), 192, B, N, _p(feat[:, 64:128]), feat.stride(0), _p(lse), p_drop,
-                                                   ctypes.c_uint(seed & 0xffffffff), _st()))
-        ctx.model, ctx.dims = model, (B, N, seed, p_drop)
+                                                   ctypes.c_uint(seed & 0xffffffff), _p(model._slot.seed_dev), _st()))
+        ctx.model, ctx.dims, ctx.seed_dev = model, (B, N, seed, p_drop), model._slot.seed_dev
         model._dbg_idx = [sv[1] for sv in ec_saved]  # neighbour lists of this pass (parity tests inject them into the oracle)
         ctx.saved = (ec_saved, mlp_saved, base_saved, cat, level2, Wqkv, qkv, lse, feat)
         return feat
@@ -254,7 +259,7 @@ class EncoderTrainFn(torch.autograd.Function):
         with _timed("attention_bwd"):
             _lib.check(lib.r3d_attention_bwd(_p(qkv), 192, B, N, _p(feat[:, 64:128]), feat.stride(0), _p(dfeat[:, 64:128]),
                                              dfeat.stride(0), _p(lse), p_drop, ctypes.c_uint(seed & 0xffffffff),
-                                             1.0 / att.temperature, _p(dqkv), 192, _p(ws), _st()))
+                                             _p(ctx.seed_dev), 1.0 / att.temperature, _p(dqkv), 192, _p(ws), _st()))
         dWqkv = gemm_tn(dqkv, level2)
         for k, m in enumerate((att.q_map, att.k_map, att.v_map)):
             g[m.weight] = dWqkv[64 * k:64 * (k + 1)].reshape(m.weight.shape)

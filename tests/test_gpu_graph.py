@@ -1,0 +1,102 @@
+"""Episodes replayed as captured hipGraphs on several HIP streams (r3dfsseg_amd/episode_graph.py) must give the
+results of the eager launch sequence: logits for evaluation, the summed gradient for training."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from r3dfsseg_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(cfg, train):
+    from r3dfsseg_amd.mpti import MPTI_SelfAtten
+    m = MPTI_SelfAtten(SimpleNamespace(**cfg))
+    m.load_state_dict(S.make_state_dict(cfg, 123))
+    m.cuda().train(train)
+    m.att_learner.dropout.p = 0.0  # eager and graph mode advance their dropout seeds differently
+    return m
+
+
+def _episodes(cfg, n):
+    out = []
+    for e in range(n):
+        data, _ = S.make_episode(cfg, seed=40 + e, noise_ratio=0.2, train=True)
+        out.append([t.cuda() for t in data])
+    return out
+
+
+def test_eval_graphs_match_eager():
+    from r3dfsseg_amd.episode_graph import EpisodeGraphs
+    cfg = S.make_cfg(n_way=2, k_shot=2, pc_npts=512)
+    m = _model(cfg, False)
+    eps = _episodes(cfg, 5)
+    eager = []
+    with torch.no_grad():
+        for ep in eps:
+            logits, _ = m(*ep[:4], lp_iters=m.lp_max_iter)
+            assert m.lp_converged()
+            eager.append(logits.clone())
+    g = EpisodeGraphs(m, eps[0][:4], n_slots=2, train=False, lp_budget=120)
+    out = torch.empty(len(eps), *eager[0].shape, device="cuda")
+    for _ in range(2):  # the second pass replays graphs whose buffers hold another episode's leftovers
+        loss_sum = g.run([ep[:4] for ep in eps], logits_out=out)
+    torch.cuda.synchronize()
+    bad, iters, mx = g.check()
+    assert bad == 0 and 0 < mx <= 120
+    for e in range(len(eps)):
+        np.testing.assert_allclose(out[e].cpu().numpy(), eager[e].cpu().numpy(), atol=2e-5, rtol=1e-5)
+        assert torch.equal(out[e].argmax(1), eager[e].argmax(1))
+    assert np.isfinite(float(loss_sum))
+    # the model's own eager path still works after capture (slot state restored)
+    with torch.no_grad():
+        logits, _ = m(*eps[1][:4], lp_iters=m.lp_max_iter)
+    np.testing.assert_allclose(logits.cpu().numpy(), eager[1].cpu().numpy(), atol=2e-5, rtol=1e-5)
+    # a weight update reaches the graphs: the folded weights they point at are refreshed in place
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.03)
+        want, _ = m(*eps[2][:4], lp_iters=m.lp_max_iter)
+    assert (want - eager[2]).abs().max().item() > 1e-3
+    g.run([eps[2][:4]], logits_out=out[:1])
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out[0].cpu().numpy(), want.cpu().numpy(), atol=2e-5, rtol=1e-5)
+
+
+def test_train_graphs_accumulate_the_eager_gradient():
+    from r3dfsseg_amd.dist import FlatGradBucket
+    from r3dfsseg_amd.episode_graph import EpisodeGraphs
+    cfg = S.make_cfg(n_way=2, k_shot=2, pc_npts=512)
+    m = _model(cfg, True)
+    eps = _episodes(cfg, 3)
+    bucket = FlatGradBucket(m.parameters())
+    running0 = m.encoder.conv.layer[1].running_mean.clone()
+    losses = []
+    for ep in eps:
+        out = m(ep[0], ep[1], ep[2], ep[3], gt_support_y=ep[6], gt_query_y=ep[7], train=True, support_flag=ep[10])
+        loss = out[1] + 0.1 * out[2]
+        loss.backward()
+        losses.append(float(loss))
+    want = bucket.flat.clone()
+    # restore the BatchNorm buffers: the graph run below starts from the same state
+    m.load_state_dict(S.make_state_dict(cfg, 123))
+    rows = torch.zeros(2, bucket.flat.numel(), device="cuda")
+    g = EpisodeGraphs(m, eps[0], n_slots=2, train=True, lp_budget=150, grad_rows=rows)
+    assert torch.equal(m.encoder.conv.layer[1].running_mean, running0)  # capture warm-up left no trace
+    total = g.run(eps)
+    torch.cuda.synchronize()
+    bad, iters, mx = g.check()
+    assert bad == 0
+    got = rows.sum(0)
+    assert abs(float(total) - sum(losses)) < 1e-4 * max(1.0, abs(sum(losses)))
+    err = (got - want).abs().max().item() / want.abs().max().item()
+    assert err < 2e-3, err
+    # slot 0 (episodes 0 and 2) is the one that updates the running statistics
+    assert not torch.equal(m.encoder.conv.layer[1].running_mean, running0)
+    # a second step reuses the graphs: rows are zeroed and re-accumulated
+    g.run(eps)
+    torch.cuda.synchronize()
+    err2 = (rows.sum(0) - want).abs().max().item() / want.abs().max().item()
+    assert err2 < 2e-3, err2  # batch statistics are per episode, so only float-atomic order differs
