@@ -111,6 +111,12 @@ int r3d_query_logits_ce(const float* Z, const int32_t* n_proto_dev, int n_q, int
  * Reference: nn.BatchNorm{1,2}d in train mode inside models/dgcnn.py:45-80, models/mpti.py:31-39. */
 int r3d_pointwise_conv_acc(const float* X, long ldx, const float* W, long M, int K, int Co, const float* scale,
                            const float* shift, int act, float* Out, long ldo, void* stream);
+/* z = X W^T together with its column sums (sum z, sum z^2) from the GEMM epilogue: the batch statistics of the
+ * layer without a second pass over z.  ws: r3d_pointwise_conv_stats_ws_words(M, Co) floats. */
+long r3d_pointwise_conv_stats_ws_words(long M, int Co);
+int r3d_pointwise_conv_stats(const float* X, long ldx, const float* W, long M, int K, int Co, float* Out, long ldo,
+                             float* sums_out /*[2][Co]*/, float* ws, void* stream);
+int r3d_colreduce(const float* part /*[chunks][2][C]*/, int chunks, int C, float* sums_out /*[2][C]*/, void* stream);
 long r3d_colstats_ws_words(long M, int C);
 int r3d_colstats(const float* X, long ldx, const float* DY, long lddy, long M, int C, int mode, const float* scale,
                  const float* shift, const float* mean, const float* invstd, int act, float* sums_out /*[2][C]*/,
@@ -137,6 +143,14 @@ int r3d_edgeconv_train_fwd(const float* PQ, const int32_t* idx, const float* s1,
                            const float* s2, const float* t2, int mode /*1: stats of z2, 0: output*/, float* out, long ldo,
                            int B, int N, int K, int32_t* argmax_out, float* zmax_out, float* sums_out, float* ws,
                            void* stream);
+/* one-pass training forward: z2 statistics + per point/channel max and min of z2 over the K edges; BatchNorm2 +
+ * LeakyReLU is monotone per channel, so r3d_edge_select finishes the layer once the statistics are folded */
+int r3d_edgeconv_train_fwd_minmax(const float* PQ, const int32_t* idx, const float* s1, const float* t1,
+                                  const float* W2, int B, int N, int K, float* zmax, float* zmin, int32_t* argmax,
+                                  int32_t* argmin, float* sums_out /*[2][64]*/, float* ws, void* stream);
+int r3d_edge_select(float* zmax /*in: max, out: selected z*/, const float* zmin, int32_t* argmax /*in/out*/,
+                    const int32_t* argmin, const float* s2, const float* t2, long M, float* out, long ldo,
+                    void* stream);
 int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float* s1, const float* t1, const float* mean1,
                      const float* invstd1, const float* W2, const float* s2, const float* t2, const float* mean2,
                      const float* invstd2, const float* bn2_sums, const float* dout, long lddo, const int32_t* argmax,

@@ -65,13 +65,17 @@ __global__ void r3d_part_reduce_kernel(const float* __restrict__ part, int nblk,
   if (lane == 0) out[i] = (float)s;
 }
 
-// ---- forward: mode 0 = output (+argmax, z at argmax); mode 1 = statistics of z2 -------------------
+// ---- forward: mode 0 = output (+argmax, z at argmax); mode 1 = statistics of z2;
+//      mode 2 = ONE pass for training: statistics of z2 AND, per point and channel, max / min of the raw z2 over
+//      the K edges with their positions.  BatchNorm2 + LeakyReLU is monotone per channel (increasing for
+//      gamma*invstd > 0, decreasing for < 0), so once the statistics are folded the layer output is
+//      lrelu(s2 * (s2 > 0 ? zmax : zmin) + t2) -- r3d_edge_select -- and the edge GEMM is not computed twice.
 template <int MODE>
 __global__ __launch_bounds__(512) void r3d_edgeconv_train_fwd_kernel(
     const float* __restrict__ PQ, const int* __restrict__ idx, const float* __restrict__ s1, const float* __restrict__ t1,
     const float* __restrict__ W2, const float* __restrict__ s2, const float* __restrict__ t2, float* __restrict__ out,
     long ldo, int N, int K, long total_points, int* __restrict__ argmax_out, float* __restrict__ zmax_out,
-    float* __restrict__ part /* mode 1: [grid][2][64] */) {
+    float* __restrict__ part /* mode 1, 2: [grid][2][64] */, float* __restrict__ zmin_out, int* __restrict__ argmin_out) {
   extern __shared__ __attribute__((aligned(16))) float H[];  // [8K][ET_LD]
   __shared__ float ps[16][2][64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -112,10 +116,36 @@ __global__ __launch_bounds__(512) void r3d_edgeconv_train_fwd_kernel(
         a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[s], a1, 0, 0, 0);
       }
     }
-    if (MODE == 1) {
+    if (MODE == 1 || MODE == 2) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { za0 += a0[r]; zb0 += a0[r] * a0[r]; za1 += a1[r]; zb1 += a1[r] * a1[r]; }
-    } else {
+    }
+    if (MODE == 2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * w + r3d_acc_row(r, lane);
+        H[row * ET_LD + (lane & 31)] = a0[r];
+        H[row * ET_LD + 32 + (lane & 31)] = a1[r];
+      }
+      __syncthreads();
+      for (int o = tid; o < ET_PTS * 64; o += blockDim.x) {
+        const int pt = o >> 6, ch = o & 63;
+        const float* hp = H + (pt * K) * ET_LD + ch;
+        float zx = hp[0], zn = zx;
+        int ax = 0, an = 0;
+        for (int t = 1; t < K; ++t) {
+          const float z = hp[t * ET_LD];
+          if (z > zx) { zx = z; ax = t; }
+          if (z < zn) { zn = z; an = t; }
+        }
+        zmax_out[(pt0 + pt) * 64 + ch] = zx;
+        zmin_out[(pt0 + pt) * 64 + ch] = zn;
+        argmax_out[(pt0 + pt) * 64 + ch] = ax;
+        argmin_out[(pt0 + pt) * 64 + ch] = an;
+      }
+      __syncthreads();
+    }
+    if (MODE == 0) {
       // raw z2 back into this wave's LDS rows; BN2 + LeakyReLU are applied in the max loop so that the
       // winner's z2 can be saved for the backward pass
 #pragma unroll
@@ -144,7 +174,7 @@ __global__ __launch_bounds__(512) void r3d_edgeconv_train_fwd_kernel(
       __syncthreads();
     }
   }
-  if (MODE == 1) {
+  if (MODE == 1 || MODE == 2) {
     // combine the two lane halves (same channel), then the waves, in a fixed order
     za0 += __shfl_xor(za0, 32); zb0 += __shfl_xor(zb0, 32);
     za1 += __shfl_xor(za1, 32); zb1 += __shfl_xor(zb1, 32);
@@ -395,14 +425,60 @@ extern "C" int r3d_edgeconv_train_fwd(const float* PQ, const int32_t* idx, const
   if (mode == 1) {
     R3D_REQUIRE(sums_out, "r3d_edgeconv_train_fwd: mode 1 needs sums_out");
     hipLaunchKernelGGL(r3d_edgeconv_train_fwd_kernel<1>, dim3(grid), dim3(64 * waves), lds, st, PQ, idx, s1, t1, W2, s2, t2,
-                       out, ldo, N, K, (long)B * N, argmax_out, zmax_out, ws);
+                       out, ldo, N, K, (long)B * N, argmax_out, zmax_out, ws, nullptr, nullptr);
     hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(128 / 4), dim3(256), 0, st, ws, grid, 128, sums_out);
   } else {
     R3D_REQUIRE(out && s2 && t2 && ldo >= 64, "r3d_edgeconv_train_fwd: mode 0 needs out, s2, t2");
     hipLaunchKernelGGL(r3d_edgeconv_train_fwd_kernel<0>, dim3(grid), dim3(64 * waves), lds, st, PQ, idx, s1, t1, W2, s2, t2,
-                       out, ldo, N, K, (long)B * N, argmax_out, zmax_out, ws);
+                       out, ldo, N, K, (long)B * N, argmax_out, zmax_out, ws, nullptr, nullptr);
   }
   R3D_LAUNCH_CHECK("r3d_edgeconv_train_fwd");
+  return R3D_OK;
+}
+
+// One-pass training forward (mode 2 above): sums_out [2][64] = (sum z2, sum z2^2) over all edges; zmax / zmin /
+// argmax / argmin (B*N, 64) per point and channel.  Follow with r3d_bn_fold and r3d_edge_select.
+extern "C" int r3d_edgeconv_train_fwd_minmax(const float* PQ, const int32_t* idx, const float* s1, const float* t1,
+                                             const float* W2, int B, int N, int K, float* zmax, float* zmin,
+                                             int32_t* argmax, int32_t* argmin, float* sums_out, float* ws, void* stream) {
+  R3D_REQUIRE(PQ && idx && s1 && t1 && W2 && zmax && zmin && argmax && argmin && sums_out && ws,
+              "r3d_edgeconv_train_fwd_minmax: null pointer");
+  int rc = et_check("r3d_edgeconv_train_fwd_minmax", B, N, K);
+  if (rc) return rc;
+  const int waves = ET_PTS * K / 32;
+  const size_t lds = sizeof(float) * (size_t)ET_PTS * K * ET_LD;
+  const long units = (long)B * N / ET_PTS;
+  const int grid = et_grid(units);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(r3d_edgeconv_train_fwd_kernel<2>, dim3(grid), dim3(64 * waves), lds, st, PQ, idx, s1, t1, W2, nullptr,
+                     nullptr, nullptr, 0, N, K, (long)B * N, argmax, zmax, ws, zmin, argmin);
+  hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(128 / 4), dim3(256), 0, st, ws, grid, 128, sums_out);
+  R3D_LAUNCH_CHECK("r3d_edgeconv_train_fwd_minmax");
+  return R3D_OK;
+}
+
+// out[m][c] = lrelu(s2[c] * z + t2[c]) with z = zmax (s2[c] >= 0) or zmin (s2[c] < 0); IN PLACE zmax[m][c] := z and
+// argmax[m][c] := position of that edge (what the backward pass consumes).  Equal activations keep the
+// lowest edge position, like the reference's max over the K axis (dgcnn.py:78).
+__global__ void r3d_edge_select_kernel(float* __restrict__ zmax, const float* __restrict__ zmin, int* __restrict__ argmax,
+                                       const int* __restrict__ argmin, const float* __restrict__ s2,
+                                       const float* __restrict__ t2, long M, float* __restrict__ out, long ldo) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * 64) return;
+  const int c = (int)(i & 63);
+  const long m = i >> 6;
+  const float sc = s2[c];
+  const bool up = sc >= 0.f;
+  const float z = up ? zmax[i] : zmin[i];
+  if (!up) { zmax[i] = z; argmax[i] = argmin[i]; }
+  out[m * ldo + c] = lrelu(sc * z + t2[c]);
+}
+extern "C" int r3d_edge_select(float* zmax, const float* zmin, int32_t* argmax, const int32_t* argmin, const float* s2,
+                               const float* t2, long M, float* out, long ldo, void* stream) {
+  R3D_REQUIRE(zmax && zmin && argmax && argmin && s2 && t2 && out && M > 0 && ldo >= 64, "r3d_edge_select: bad arguments");
+  hipLaunchKernelGGL(r3d_edge_select_kernel, dim3(r3d_cdiv(M * 64, 256)), dim3(256), 0, (hipStream_t)stream, zmax, zmin,
+                     argmax, argmin, s2, t2, M, out, ldo);
+  R3D_LAUNCH_CHECK("r3d_edge_select");
   return R3D_OK;
 }
 

@@ -27,7 +27,7 @@ enum { R3D_ACT_NONE = 0, R3D_ACT_RELU = 1, R3D_ACT_LRELU02 = 2 };
 __global__ __launch_bounds__(256) void r3d_pointwise_gemm_kernel(
     const float* __restrict__ X, long ldx, const float* __restrict__ W, int M, int K, int Co,
     const float* __restrict__ scale, const float* __restrict__ shift, int act,
-    float* __restrict__ Out, long ldo, int accumulate) {
+    float* __restrict__ Out, long ldo, int accumulate, float* __restrict__ stats_part /* [tiles_m][2][Co] or NULL */) {
   __shared__ float Xs[G_BM * G_LD];
   __shared__ float Ws[G_BN * G_LD];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -67,45 +67,83 @@ __global__ __launch_bounds__(256) void r3d_pointwise_gemm_kernel(
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk], acc, 0, 0, 0);
   }
   const int j = n0 + 32 * wn + (lane & 31);
-  if (j >= Co) return;
-  const float sc = scale ? scale[j] : 1.f;
-  const float sh = shift ? shift[j] : 0.f;
+  const bool jok = j < Co;
+  const float sc = (scale && jok) ? scale[j] : 1.f;
+  const float sh = (shift && jok) ? shift[j] : 0.f;
+  float s1 = 0.f, s2 = 0.f;  // column sums of the values written (training: batch statistics of z)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const long m = m0 + 32 * wm + r3d_acc_row(r, lane);
-    if (m >= M) continue;
+    if (m >= M || !jok) continue;
     float v = sc * acc[r] + sh;
     if (act == R3D_ACT_RELU) v = fmaxf(v, 0.f);
     else if (act == R3D_ACT_LRELU02) v = v > 0.f ? v : 0.2f * v;
     Out[m * ldo + j] = accumulate ? Out[m * ldo + j] + v : v;
+    s1 += v;
+    s2 += v * v;
+  }
+  if (stats_part) {  // uniform over the workgroup
+    // rows of one column sit in lanes l and l^32 of the two wm waves: fixed-order combine, no atomics
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    __syncthreads();  // the MFMA loop is done with Xs
+    float* red = Xs;  // [wm][wn][2][32]
+    if (lane < 32) {
+      red[((wm * 2 + wn) * 2 + 0) * 32 + lane] = s1;
+      red[((wm * 2 + wn) * 2 + 1) * 32 + lane] = s2;
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, cc = tid & 63, wn2 = cc >> 5, l2 = cc & 31;
+      const int jj = n0 + cc;
+      if (jj < Co)
+        stats_part[((long)blockIdx.x * 2 + which) * Co + jj] =
+            red[((0 * 2 + wn2) * 2 + which) * 32 + l2] + red[((1 * 2 + wn2) * 2 + which) * 32 + l2];
+    }
   }
 }
 
 static int pointwise_launch(const float* X, long ldx, const float* W, long M, int K, int Co, const float* scale,
-                            const float* shift, int act, float* Out, long ldo, int accumulate, void* stream);
+                            const float* shift, int act, float* Out, long ldo, int accumulate, float* stats_part,
+                            void* stream);
 
 extern "C" int r3d_pointwise_conv(const float* X, long ldx, const float* W, long M, int K, int Co,
                                   const float* scale, const float* shift, int act, float* Out,
                                   long ldo, void* stream) {
-  return pointwise_launch(X, ldx, W, M, K, Co, scale, shift, act, Out, ldo, 0, stream);
+  return pointwise_launch(X, ldx, W, M, K, Co, scale, shift, act, Out, ldo, 0, nullptr, stream);
+}
+
+// Training forward of a conv + BatchNorm layer: Out = X W^T (raw) AND the column sums the batch statistics need,
+// sums_out[0..Co) = sum_m Out[m][c], sums_out[Co..2Co) = sum_m Out[m][c]^2, produced in the GEMM epilogue (one
+// partial per 64-row tile, added in ascending tile order in fp64) instead of a second pass over Out.
+// ws: r3d_pointwise_conv_stats_ws_words(M, Co) floats.
+extern "C" int r3d_colreduce(const float* part, int chunks, int C, float* sums_out, void* stream);
+extern "C" long r3d_pointwise_conv_stats_ws_words(long M, int Co) { return (long)r3d_cdiv(M, G_BM) * 2 * Co; }
+extern "C" int r3d_pointwise_conv_stats(const float* X, long ldx, const float* W, long M, int K, int Co, float* Out,
+                                        long ldo, float* sums_out, float* ws, void* stream) {
+  R3D_REQUIRE(sums_out && ws, "r3d_pointwise_conv_stats: null pointer");
+  int rc = pointwise_launch(X, ldx, W, M, K, Co, nullptr, nullptr, R3D_ACT_NONE, Out, ldo, 0, ws, stream);
+  if (rc) return rc;
+  return r3d_colreduce(ws, r3d_cdiv(M, G_BM), Co, sums_out, stream);
 }
 
 // Out += act(scale * X W^T + shift): gradient accumulation into a (slice of a) wider buffer
 extern "C" int r3d_pointwise_conv_acc(const float* X, long ldx, const float* W, long M, int K, int Co,
                                       const float* scale, const float* shift, int act, float* Out,
                                       long ldo, void* stream) {
-  return pointwise_launch(X, ldx, W, M, K, Co, scale, shift, act, Out, ldo, 1, stream);
+  return pointwise_launch(X, ldx, W, M, K, Co, scale, shift, act, Out, ldo, 1, nullptr, stream);
 }
 
 static int pointwise_launch(const float* X, long ldx, const float* W, long M, int K, int Co, const float* scale,
-                            const float* shift, int act, float* Out, long ldo, int accumulate, void* stream) {
+                            const float* shift, int act, float* Out, long ldo, int accumulate, float* stats_part,
+                            void* stream) {
   R3D_REQUIRE(X && W && Out, "r3d_pointwise_conv: null pointer");
   R3D_REQUIRE(M > 0 && K > 0 && Co > 0 && ldx >= K && ldo >= Co,
               "r3d_pointwise_conv: bad shape M=%ld K=%d Co=%d ldx=%ld ldo=%ld", M, K, Co, ldx, ldo);
   R3D_REQUIRE(act >= 0 && act <= 2, "r3d_pointwise_conv: unknown activation %d", act);
   dim3 grid(r3d_cdiv(M, G_BM), r3d_cdiv(Co, G_BN));
   hipLaunchKernelGGL(r3d_pointwise_gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, W,
-                     (int)M, K, Co, scale, shift, act, Out, ldo, accumulate);
+                     (int)M, K, Co, scale, shift, act, Out, ldo, accumulate, stats_part);
   R3D_LAUNCH_CHECK("r3d_pointwise_conv");
   return R3D_OK;
 }

@@ -56,16 +56,27 @@ __global__ __launch_bounds__(256) void r3d_colpartial_kernel(
   }
 }
 
-__global__ void r3d_colreduce_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ out /* [2][C] */) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// 64 columns per workgroup; the chunk axis is split over the 4 waves (chunks q, q+4, ...), each adding in
+// ascending order in fp64, and the four wave totals are combined in a fixed order: deterministic for any count.
+__global__ __launch_bounds__(256) void r3d_colreduce_kernel(const float* __restrict__ part, int chunks, int C,
+                                                            float* __restrict__ out /* [2][C] */) {
+  __shared__ double sa[4][64], sb[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   double a = 0.0, b = 0.0;
-  for (int k = 0; k < chunks; ++k) {
-    a += (double)part[((long)k * 2 + 0) * C + c];
-    b += (double)part[((long)k * 2 + 1) * C + c];
+  if (c < C) {
+    for (int k = w; k < chunks; k += 4) {
+      a += (double)part[((long)k * 2 + 0) * C + c];
+      b += (double)part[((long)k * 2 + 1) * C + c];
+    }
   }
-  out[c] = (float)a;
-  out[C + c] = (float)b;
+  sa[w][lane] = a;
+  sb[w][lane] = b;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    out[c] = (float)(((sa[0][lane] + sa[1][lane]) + sa[2][lane]) + sa[3][lane]);
+    out[C + c] = (float)(((sb[0][lane] + sb[1][lane]) + sb[2][lane]) + sb[3][lane]);
+  }
 }
 
 // ---- batch statistics -> affine, running statistics update ------------------------------------
@@ -230,8 +241,17 @@ extern "C" int r3d_colstats(const float* X, long ldx, const float* DY, long lddy
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(r3d_colpartial_kernel, dim3(r3d_cdiv(C, 64), chunks), dim3(256), 0, st, X, ldx, DY, lddy, M, C, mode,
                      scale, shift, mean, invstd, act, ws);
-  hipLaunchKernelGGL(r3d_colreduce_kernel, dim3(r3d_cdiv(C, 256)), dim3(256), 0, st, ws, chunks, C, sums_out);
+  hipLaunchKernelGGL(r3d_colreduce_kernel, dim3(r3d_cdiv(C, 64)), dim3(256), 0, st, ws, chunks, C, sums_out);
   R3D_LAUNCH_CHECK("r3d_colstats");
+  return R3D_OK;
+}
+
+// [chunks][2][C] partial column sums -> sums_out [2][C] (shared with the GEMM-epilogue statistics of gemm.hip)
+extern "C" int r3d_colreduce(const float* part, int chunks, int C, float* sums_out, void* stream) {
+  R3D_REQUIRE(part && sums_out && chunks > 0 && C > 0, "r3d_colreduce: bad arguments");
+  hipLaunchKernelGGL(r3d_colreduce_kernel, dim3(r3d_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, part, chunks, C,
+                     sums_out);
+  R3D_LAUNCH_CHECK("r3d_colreduce");
   return R3D_OK;
 }
 

@@ -104,9 +104,15 @@ def add_cols(src, dst):
 # ----------------------------------------------------------------------------- conv + BN + act layer
 def conv_bn_fwd(X, W2d, bnmod, act, bias=None, out=None):
     """Returns (y, saved) with saved = (X, W2d, z, bn vectors, act)."""
-    z = ops.pointwise_conv(X, W2d)  # raw; a conv bias cancels under batch statistics
+    # raw z (a conv bias cancels under batch statistics) and its column sums from the same GEMM launch
+    M, ldx = _rows(X)
     C = W2d.shape[0]
-    sums = colstats(z, C)
+    lib = _lib.load()
+    z = torch.empty(M, C, device=X.device, dtype=torch.float32)
+    sums = _f(2 * C, X.device)
+    ws = _f(lib.r3d_pointwise_conv_stats_ws_words(M, C), X.device)
+    with _timed("pointwise_conv"):
+        _lib.check(lib.r3d_pointwise_conv_stats(_p(X), ldx, _p(W2d), M, X.shape[1], C, _p(z), C, _p(sums), _p(ws), _st()))
     bn = bn_fold(sums, z.shape[0], bnmod, bias)
     y = affine_act(z, bn[0], bn[1], act, out=out)
     return y, (X, W2d, z, bn, act)
@@ -120,7 +126,9 @@ def conv_bn_bwd(saved, dY, want_dx=True, dx_acc=None):
     sums = colstats(z, C, mode=1, DY=dY, bn=bn, act=act)
     dz = bn_bwd_apply(z, dY, bn, act, sums, M)
     dW = gemm_tn(dz, X)
-    dbias = colstats(dz, C)[:C]
+    # a conv bias in front of a training-mode BatchNorm has gradient sum_m dz = 0 identically (dz is the
+    # BN backward output, whose column sums vanish); the reference's autograd returns round-off noise there
+    dbias = torch.zeros(C, device=z.device, dtype=torch.float32)
     dX = None
     if want_dx:
         Wt = W2d.t().contiguous()
@@ -148,15 +156,17 @@ def edgeconv_train_fwd(inp, idx, ec, B, N, out):
     bn1 = bn_fold(sums1, E, ec.layer[1])
     W2 = ec.layer[3].weight.reshape(64, 64).contiguous()
     sums2 = _f(128, dev)
-    with _timed("edgeconv"):
-        _lib.check(lib.r3d_edgeconv_train_fwd(_p(PQ), _p(idx), _p(bn1[0]), _p(bn1[1]), _p(W2), None, None, 1, None, 64, B, N,
-                                              K, None, None, _p(sums2), _p(ws), _st()))
-    bn2 = bn_fold(sums2, E, ec.layer[4])
     argmax = torch.empty(B * N, 64, device=dev, dtype=torch.int32)
+    argmin = torch.empty(B * N, 64, device=dev, dtype=torch.int32)
     zmax = torch.empty(B * N, 64, device=dev, dtype=torch.float32)
-    with _timed("edgeconv"):
-        _lib.check(lib.r3d_edgeconv_train_fwd(_p(PQ), _p(idx), _p(bn1[0]), _p(bn1[1]), _p(W2), _p(bn2[0]), _p(bn2[1]), 0,
-                                              _p(out), out.stride(0), B, N, K, _p(argmax), _p(zmax), None, _p(ws), _st()))
+    zmin = torch.empty(B * N, 64, device=dev, dtype=torch.float32)
+    with _timed("edgeconv"):  # ONE edge-GEMM pass: z2 statistics and per-point max / min of z2
+        _lib.check(lib.r3d_edgeconv_train_fwd_minmax(_p(PQ), _p(idx), _p(bn1[0]), _p(bn1[1]), _p(W2), B, N, K, _p(zmax),
+                                                     _p(zmin), _p(argmax), _p(argmin), _p(sums2), _p(ws), _st()))
+    bn2 = bn_fold(sums2, E, ec.layer[4])
+    with _timed("edgeconv"):  # BN2 + LeakyReLU is monotone per channel: pick max or min, in place
+        _lib.check(lib.r3d_edge_select(_p(zmax), _p(zmin), _p(argmax), _p(argmin), _p(bn2[0]), _p(bn2[1]), B * N, _p(out),
+                                       out.stride(0), _st()))
     return (inp, idx, Wpq, PQ, W2, bn1, bn2, argmax, zmax, C)
 
 
