@@ -203,7 +203,8 @@ def main():
         if graphs is not None:
             bad, it_sum, it_max = graphs.check()
             if bad:
-                raise SystemExit("bench invalid: %d timed episode(s) with unconverged label propagation / kNN overflow" % bad)
+                raise SystemExit("bench invalid: %d timed episode(s) with unconverged label propagation (CG max %d of budget %d), %d with 201-NN survivor overflow"
+                                 % (graphs.last_unconverged, it_max, graphs.lp_budget, graphs.last_knn_overflow))
             return el, (it_sum / (steps * E), it_max)
         lp = torch.stack(lp_flags).cpu()
         if int(lp[:, 2].max()) != 0:
@@ -236,14 +237,16 @@ def main():
         extra["eval_forward_episodes_per_sec"] = n_ev * E * world / el_ev
         model.train()
 
-    # roofline leg: single-episode EAGER steps with HIP events around every entry point (recorded on the launch
-    # stream = torch's current stream); kept out of the timed region above
-    n_roof = max(min(args.steps * E, 40), 10)
-    timer = ops.KernelTimer(OPS)
+    # roofline leg: single-episode EAGER steps; every entry point's library calls are launched again 8 times back
+    # to back between one HIP event pair (recorded on the launch stream = torch's current stream), so the
+    # per-launch time is device time, free of event packets and host launch gaps; outside the timed region above
+    n_roof = 10
+    timer = ops.KernelTimer(OPS, repeat=8)
     ops.set_timer(timer)
     for i in range(n_roof):
         step_fn(i)
     ops.set_timer(None)
+    timer.close()
     ksum_all = timer.summary()
     cg_mean, cg_max = cg
 

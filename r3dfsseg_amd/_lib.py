@@ -97,16 +97,45 @@ def load():
         raise RuntimeError(
             "r3dfsseg_amd: %s not found -- build it with `python -m r3dfsseg_amd.build` "
             "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+    cdll = ctypes.CDLL(LIB_PATH)
+    lib = _Bound()
+    lib._cdll = cdll
     for name, (res, args) in _SIGS.items():
         try:
-            fn = getattr(lib, name)
+            fn = getattr(cdll, name)
         except AttributeError:
             raise RuntimeError("r3dfsseg_amd: symbol %s missing from %s" % (name, LIB_PATH))
         fn.restype = res
         fn.argtypes = args
+        setattr(lib, name, fn)
     _lib = lib
     return lib
+
+
+class _Bound:
+    """The bound entry points as plain attributes (one per symbol of include/r3d.h)."""
+
+
+_call_log = None  # list collecting (fn, args) of the library calls of one timed region (bench.py's roofline leg)
+
+
+def record_calls(on):
+    """Route every entry point through a recorder (on=True) or back to the raw ctypes functions (on=False).
+    While on, calls made with `_call_log` set to a list are appended to it, so that a timed region can be
+    launched again back to back (ops.KernelTimer with repeat > 0)."""
+    lib = load()
+    for name in _SIGS:
+        raw = getattr(lib._cdll, name)
+        if not on:
+            setattr(lib, name, raw)
+            continue
+
+        def wrapper(*args, _raw=raw):
+            rc = _raw(*args)
+            if _call_log is not None:
+                _call_log.append((_raw, args))
+            return rc
+        setattr(lib, name, wrapper)
 
 
 def check(rc):

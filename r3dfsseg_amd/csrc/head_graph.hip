@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void r3d_graph_cols_kernel(const unsigned* __r
 __global__ __launch_bounds__(256) void r3d_graph_weights_kernel(
     const float* __restrict__ nodes, long ldn, int D, const unsigned* __restrict__ outb, int words,
     const int* __restrict__ n_dev, int n_cap, const int* __restrict__ row_ptr, const int* __restrict__ col,
-    float sigma, float* __restrict__ val, float* __restrict__ dinv) {
+    float sigma, float* __restrict__ val, float* __restrict__ dinv, float* __restrict__ wdir /* [nnz][2] */) {
   __shared__ __attribute__((aligned(16))) float xs[4][256];
   const int n = min(*n_dev, n_cap);
   const int w = threadIdx.x >> 6;
@@ -171,11 +171,13 @@ __global__ __launch_bounds__(256) void r3d_graph_weights_kernel(
     }
     const bool out_ij = (outb[(long)i * words + (j >> 5)] >> (j & 31)) & 1u;
     const bool out_ji = (outb[(long)j * words + (i >> 5)] >> (i & 31)) & 1u;
-    float wgt = 0.f;
-    if (out_ij) { const float d = sqrtf(a) / sigma; wgt += expf(-0.5f * (d * d)); }
-    if (out_ji) { const float d = sqrtf(b) / sigma; wgt += expf(-0.5f * (d * d)); }
+    float wij = 0.f, wji = 0.f;
+    if (out_ij) { const float d = sqrtf(a) / sigma; wij = expf(-0.5f * (d * d)); }
+    if (out_ji) { const float d = sqrtf(b) / sigma; wji = expf(-0.5f * (d * d)); }
+    const float wgt = wij + wji;
     if (ok) {
       val[e] = wgt;
+      *reinterpret_cast<float2*>(wdir + 2L * e) = make_float2(wij, wji);
       dsum += wgt;
     }
   }
@@ -200,6 +202,11 @@ __global__ void r3d_graph_normalize_kernel(const int* __restrict__ row_ptr, cons
 //    Two launches per iteration; scalar reductions are done redundantly by every block
 //    from per-block partials written by the previous launch (no grid barrier, no host
 //    sync, deterministic summation order).
+//    Why not one persistent kernel with a grid barrier: measured on MI355X (tools/probe/grid_barrier.hip) a
+//    device-wide barrier whose workgroups exchange data needs agent-scope release/acquire fences, i.e. an L2
+//    write-back + invalidate per workgroup, and costs 3 us at 32 workgroups, 7 us at 128 and 13 us at 256
+//    (43 us with a fence in every wave); a persistent CG with two such barriers per iteration ran 3x SLOWER
+//    (100 us / iteration) than these two launches (17 us / iteration back to back).
 // ---------------------------------------------------------------------------
 #define HG_MAX_ITER 1022
 struct CgState {            // device memory
@@ -432,6 +439,7 @@ extern "C" long r3d_lp_ws_words(int n_cap, int kp1) {
   t += n_cap + 8;                  // row_len
   t += n_cap + 8;                  // row_ptr
   t += nnz_cap * 2;                // col, val
+  t += nnz_cap * 2;                // wdir: directed gaussian weights (w_ij, w_ji) per entry, kept for the backward
   t += n_cap;                      // dinv
   t += 5L * n_cap * HG_NC;         // x(out is separate) r, p0, p1, q  (+1 spare)
   t += 2L * HG_MAX_PART * HG_NC;   // partials
@@ -445,7 +453,7 @@ extern "C" long r3d_lp_ws_words(int n_cap, int kp1) {
 struct LpWs {
   unsigned *outb, *sym;
   int *row_len, *row_ptr, *col;
-  float *val, *dinv;
+  float *val, *dinv, *wdir;
   float4 *r, *p0, *p1, *q, *part_rr, *part_pq;
   CgState* cg;
   long words;
@@ -462,6 +470,7 @@ static LpWs lp_carve(int32_t* ws, int n_cap, int kp1) {
   L.row_ptr = wp; wp += n_cap + 8;
   L.col = wp; wp += nnz_cap;
   L.val = (float*)wp; wp += nnz_cap;
+  L.wdir = (float*)wp; wp += 2 * nnz_cap;
   L.dinv = (float*)wp; wp += n_cap;
   wp += (4 - ((wp - ws) & 3)) & 3;  // float4 alignment (ws itself must be 16-B aligned)
   L.r = (float4*)wp; wp += 4L * n_cap;
@@ -519,7 +528,7 @@ extern "C" int r3d_label_propagate(const float* nodes, long ldn, int D, const in
   hipLaunchKernelGGL(r3d_graph_cols_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, L.sym, (int)words, n_dev,
                      n_cap, L.row_ptr, L.col);
   hipLaunchKernelGGL(r3d_graph_weights_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, nodes, ldn, D, L.outb,
-                     (int)words, n_dev, n_cap, L.row_ptr, L.col, sigma, L.val, L.dinv);
+                     (int)words, n_dev, n_cap, L.row_ptr, L.col, sigma, L.val, L.dinv, L.wdir);
   hipLaunchKernelGGL(r3d_graph_normalize_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, L.row_ptr, L.col, L.dinv,
                      n_dev, n_cap, L.val);
   int rc = lp_solve(L, Y, n_dev, n_cap, alpha, max_iter, tol, Z, stats_out, st);
@@ -559,78 +568,73 @@ __global__ __launch_bounds__(256) void r3d_lp_bwd_dd_kernel(const int* __restric
   if (lane == 0) dD[i] = -0.5f * di * di * di * g;
 }
 
-// pass 2: dx_i = sum over the row of c_ij (x_i - x_j + eps) + c_ji (x_i - x_j - eps)
+// pass 2: dx_i = sum over the row of c_ij (x_i - x_j + eps) + c_ji (x_i - x_j - eps),
+//   c_ij = -(dA_ij + dA_ji) w_ij / sigma^2 with the directed weights w_ij, w_ji the forward pass left in wdir
+//   (no distance is recomputed here).  One wave per row; lane-per-entry for the coefficients, then the wave
+//   walks the entries and every lane accumulates its channels of the weighted neighbour sum (coalesced rows).
 __global__ __launch_bounds__(256) void r3d_lp_bwd_dx_kernel(
-    const float* __restrict__ nodes, long ldn, int D, const unsigned* __restrict__ outb, int words,
+    const float* __restrict__ nodes, long ldn, int D, const float* __restrict__ wdir,
     const int* __restrict__ row_ptr, const int* __restrict__ col, const float* __restrict__ dinv,
     const int* __restrict__ n_dev, int n_cap, float sigma, float alpha, const float4* __restrict__ lam,
     const float4* __restrict__ Z, const float* __restrict__ dD, float* __restrict__ dnodes, long ldd) {
-  __shared__ __attribute__((aligned(16))) float xs[4][256];
   const int n = min(*n_dev, n_cap);
   const int w = threadIdx.x >> 6;
   const int i = blockIdx.x * 4 + w;
   const int lane = threadIdx.x & 63;
   if (i >= n) return;
   const float* xi = nodes + (long)i * ldn;
-  for (int c = lane; c < 256; c += 64) xs[w][c] = c < D ? xi[c] : 0.f;
-  __builtin_amdgcn_wave_barrier();
   const float4 li = lam[i], zi = Z[i];
   const float di = dinv[i], ddi = dD[i];
   const int beg = row_ptr[i], end = row_ptr[i + 1];
-  const int D4 = D >> 2;
   const float inv_s2 = 1.f / (sigma * sigma);
-  float U = 0.f, V = 0.f;                  // sum (c_ij + c_ji), sum (c_ij - c_ji)
+  const bool k0 = lane < D, k1 = lane + 64 < D, k2 = lane + 128 < D, k3 = lane + 192 < D;
+  const int c0 = min(lane, D - 1), c1 = min(lane + 64, D - 1), c2 = min(lane + 128, D - 1), c3 = min(lane + 192, D - 1);
+  float U = 0.f, V = 0.f;                        // sum (c_ij + c_ji), sum (c_ij - c_ji)
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // sum_j u_j x_j[c], channels lane, lane+64, ...
   for (int e0 = beg; e0 < end; e0 += 64) {
     const int e = e0 + lane;
     const bool ok = e < end;
-    const int j = col[min(e, end - 1)];
-    const float* xj = nodes + (long)j * ldn;
-    float a = 0.f, b = 0.f;
-    for (int c4 = 0; c4 < D4; ++c4) {
-      const float4 y = *reinterpret_cast<const float4*>(xj + 4 * c4);
-      const float4 x = *reinterpret_cast<const float4*>(&xs[w][4 * c4]);
-      float d1, d2;
-      d1 = (x.x - y.x) + 1e-6f; d2 = (y.x - x.x) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b);
-      d1 = (x.y - y.y) + 1e-6f; d2 = (y.y - x.y) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b);
-      d1 = (x.z - y.z) + 1e-6f; d2 = (y.z - x.z) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b);
-      d1 = (x.w - y.w) + 1e-6f; d2 = (y.w - x.w) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b);
-    }
-    for (int c = 4 * D4; c < D; ++c) {
-      const float y = xj[c], x = xs[w][c];
-      const float d1 = (x - y) + 1e-6f, d2 = (y - x) + 1e-6f;
-      a = __builtin_fmaf(d1, d1, a);
-      b = __builtin_fmaf(d2, d2, b);
-    }
+    const int ec = min(e, end - 1);
+    const int j = col[ec];
+    const float2 wd = *reinterpret_cast<const float2*>(wdir + 2L * ec);
     const float dj = dinv[j];
     const float T = alpha * (dot4(li, Z[j]) + dot4(lam[j], zi)) * di * dj + ddi + dD[j];  // dA_ij + dA_ji
-    const bool out_ij = (outb[(long)i * words + (j >> 5)] >> (j & 31)) & 1u;
-    const bool out_ji = (outb[(long)j * words + (i >> 5)] >> (i & 31)) & 1u;
-    float cij = 0.f, cji = 0.f;
-    if (ok && out_ij) cij = -T * expf(-0.5f * a * inv_s2) * inv_s2;
-    if (ok && out_ji) cji = -T * expf(-0.5f * b * inv_s2) * inv_s2;
+    const float cij = ok ? -T * wd.x * inv_s2 : 0.f;
+    const float cji = ok ? -T * wd.y * inv_s2 : 0.f;
     const float u = cij + cji;
     U += u;
     V += cij - cji;
-    // weighted neighbour sum: the wave walks this chunk's entries, all lanes add one row each step
     const int cnt = min(64, end - e0);
-    for (int t = 0; t < cnt; ++t) {
+    int t = 0;
+    for (; t + 4 <= cnt; t += 4) {  // 4 neighbour rows (up to 16 loads) in flight
+      float x0[4], x1[4], x2[4], x3[4], ut[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        ut[q] = r3d_readlane_f(u, t + q);
+        const float* xr = nodes + (long)__builtin_amdgcn_readlane(j, t + q) * ldn;
+        x0[q] = xr[c0]; x1[q] = xr[c1]; x2[q] = xr[c2];
+        x3[q] = D > 192 ? xr[c3] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a0 = __builtin_fmaf(ut[q], x0[q], a0); a1 = __builtin_fmaf(ut[q], x1[q], a1);
+        a2 = __builtin_fmaf(ut[q], x2[q], a2); a3 = __builtin_fmaf(ut[q], x3[q], a3);
+      }
+    }
+    for (; t < cnt; ++t) {
       const float ut = r3d_readlane_f(u, t);
-      const int jt = __builtin_amdgcn_readlane(j, t);
-      const float* xr = nodes + (long)jt * ldn;
-      if (lane < D) a0 += ut * xr[lane];
-      if (lane + 64 < D) a1 += ut * xr[lane + 64];
-      if (lane + 128 < D) a2 += ut * xr[lane + 128];
-      if (lane + 192 < D) a3 += ut * xr[lane + 192];
+      const float* xr = nodes + (long)__builtin_amdgcn_readlane(j, t) * ldn;
+      a0 = __builtin_fmaf(ut, xr[c0], a0); a1 = __builtin_fmaf(ut, xr[c1], a1);
+      a2 = __builtin_fmaf(ut, xr[c2], a2); a3 = __builtin_fmaf(ut, D > 192 ? xr[c3] : 0.f, a3);
     }
   }
   U = r3d_wave_sum(U);
   V = r3d_wave_sum(V);
   float* dr = dnodes + (long)i * ldd;
-  if (lane < D) dr[lane] = xs[w][lane] * U - a0 + 1e-6f * V;
-  if (lane + 64 < D) dr[lane + 64] = xs[w][lane + 64] * U - a1 + 1e-6f * V;
-  if (lane + 128 < D) dr[lane + 128] = xs[w][lane + 128] * U - a2 + 1e-6f * V;
-  if (lane + 192 < D) dr[lane + 192] = xs[w][lane + 192] * U - a3 + 1e-6f * V;
+  if (k0) dr[lane] = xi[c0] * U - a0 + 1e-6f * V;
+  if (k1) dr[lane + 64] = xi[c1] * U - a1 + 1e-6f * V;
+  if (k2) dr[lane + 128] = xi[c2] * U - a2 + 1e-6f * V;
+  if (k3) dr[lane + 192] = xi[c3] * U - a3 + 1e-6f * V;
 }
 
 // dL/dZ of the mean cross entropy over the query rows (mpti.py:778-781), scaled by *gscale
@@ -671,7 +675,7 @@ extern "C" int r3d_label_propagate_bwd(const float* nodes, long ldn, int D, int 
   float* dD = (float*)L.q;  // the CG vectors are free again after the solve
   hipLaunchKernelGGL(r3d_lp_bwd_dd_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, L.row_ptr, L.col, L.val, L.dinv, n_dev,
                      n_cap, alpha, (const float4*)lam, (const float4*)Z, dD);
-  hipLaunchKernelGGL(r3d_lp_bwd_dx_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, nodes, ldn, D, L.outb, (int)L.words,
+  hipLaunchKernelGGL(r3d_lp_bwd_dx_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, nodes, ldn, D, L.wdir,
                      L.row_ptr, L.col, L.dinv, n_dev, n_cap, sigma, alpha, (const float4*)lam, (const float4*)Z, dD, dnodes,
                      ldd);
   R3D_LAUNCH_CHECK("r3d_label_propagate_bwd");

@@ -49,8 +49,8 @@ class EpisodeGraphs:
             n = sum(p.numel() for p in self.params)
             self.grad_rows = grad_rows if grad_rows is not None else torch.zeros(n_slots, n, device=dev)
             assert self.grad_rows.shape[0] == n_slots and self.grad_rows.shape[1] >= n
-        if lp_budget is None:
-            lp_budget = 96 if train else 64
+        if lp_budget is None:  # CG iterations frozen into the graph; launches after convergence are no-ops (~3 us each)
+            lp_budget = min(model.lp_max_iter, 160 if train else 96)
         self.lp_budget = lp_budget
         self.slots = []
         self.ev_start = torch.cuda.Event()
@@ -88,7 +88,8 @@ class EpisodeGraphs:
             hb = model._slot.last[1]
             ok = hb.stats[0]
             sl.logits = logits
-        sl.bad += (1 - ok) + hb.knn_status[0].clamp(max=1)
+        sl.bad += 1 - ok
+        sl.knn_overflow += hb.knn_status[0].clamp(max=1)
         sl.cg_iters += hb.stats[1]
         torch.maximum(sl.cg_max, hb.stats[1], out=sl.cg_max)
 
@@ -100,6 +101,7 @@ class EpisodeGraphs:
         sl.inputs = [t.to(dev).clone() for t in example]
         sl.loss_sum = torch.zeros((), device=dev)
         sl.bad = torch.zeros((), device=dev, dtype=torch.int32)
+        sl.knn_overflow = torch.zeros((), device=dev, dtype=torch.int32)
         sl.cg_iters = torch.zeros((), device=dev, dtype=torch.int32)
         sl.cg_max = torch.zeros((), device=dev, dtype=torch.int32)
         st = EpisodeSlot(s)
@@ -178,9 +180,11 @@ class EpisodeGraphs:
     def check(self):
         """Host check (synchronises): (number of replays whose label propagation did not converge or whose
         201-NN survivor buffer overflowed since the last check, mean CG iterations, max CG iterations)."""
-        bad = int(sum(int(sl.bad.item()) for sl in self.slots))
+        self.last_unconverged = int(sum(int(sl.bad.item()) for sl in self.slots))
+        self.last_knn_overflow = int(sum(int(sl.knn_overflow.item()) for sl in self.slots))
+        bad = self.last_unconverged + self.last_knn_overflow
         it = [int(sl.cg_iters.item()) for sl in self.slots]
         mx = max(int(sl.cg_max.item()) for sl in self.slots)
         for sl in self.slots:
-            sl.bad.zero_(); sl.cg_iters.zero_(); sl.cg_max.zero_()
+            sl.bad.zero_(); sl.knn_overflow.zero_(); sl.cg_iters.zero_(); sl.cg_max.zero_()
         return bad, sum(it), mx

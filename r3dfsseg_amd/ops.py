@@ -20,17 +20,29 @@ def _p(t):
 
 class KernelTimer:
     """HIP-event timing of selected entry points on the stream they are launched on
-    (bench.py's roofline leg).  Disabled (None) by default: zero overhead."""
+    (bench.py's roofline leg).  Disabled (None) by default: zero overhead.
 
-    def __init__(self, names):
+    repeat = 0: one event pair around every call (includes the event packets and any host launch gap).
+    repeat = R > 0: after a timed region ran, its library calls are launched again R times back to back
+    between ONE event pair and the region is priced at elapsed / R: device time of the launches, with the
+    event and host overhead amortised (the calls are idempotent: same inputs, same outputs)."""
+
+    def __init__(self, names, repeat=0):
         self.names = set(names)
         self.events = {n: [] for n in names}
+        self.repeat = repeat
+        if repeat:
+            _lib.record_calls(True)
+
+    def close(self):
+        if self.repeat:
+            _lib.record_calls(False)
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
         for n, ev in self.events.items():
-            ms = [a.elapsed_time(b) for a, b in ev]
+            ms = [a.elapsed_time(b) / r for a, b, r in ev]
             out[n] = dict(launches=len(ms), total_ms=float(sum(ms)), avg_ms=float(sum(ms) / max(len(ms), 1)))
         return out
 
@@ -52,12 +64,25 @@ class _timed:
         if self.on:
             self.a = torch.cuda.Event(enable_timing=True)
             self.b = torch.cuda.Event(enable_timing=True)
-            self.a.record()
+            if _TIMER.repeat:
+                _lib._call_log = []
+            else:
+                self.a.record()
 
     def __exit__(self, *exc):
         if self.on:
-            self.b.record()
-            _TIMER.events[self.name].append((self.a, self.b))
+            if _TIMER.repeat:
+                calls, _lib._call_log = _lib._call_log, None
+                if exc[0] is None and calls:
+                    self.a.record()
+                    for _ in range(_TIMER.repeat):
+                        for fn, args in calls:
+                            fn(*args)
+                    self.b.record()
+                    _TIMER.events[self.name].append((self.a, self.b, _TIMER.repeat))
+            else:
+                self.b.record()
+                _TIMER.events[self.name].append((self.a, self.b, 1))
 
 
 def _st():

@@ -2,6 +2,7 @@
 #include "../../r3dfsseg_amd/csrc/error.hip"
 #include "../../r3dfsseg_amd/csrc/knn.hip"
 #include "../../r3dfsseg_amd/csrc/gemm.hip"
+extern "C" int r3d_colreduce(const float*, int, int, float*, void*) { return 0; }  // gemm.hip references it; not used here
 #include <vector>
 #include <cstdlib>
 int main(int argc, char** argv) {
