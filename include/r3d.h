@@ -82,12 +82,16 @@ int r3d_head_desc_words(void);
 int r3d_head_max_k(void);
 long r3d_head_proto_ws_words(int n_way, int k_shot, int N);
 int r3d_head_proto_ws_offsets(int n_way, int k_shot, int N, long* out6 /* comp,mind,assign,cand,sel,seeds */);
+/* flags: R3D_HEAD_FPS_ONE_LAUNCH = all FPS rounds in one persistent launch (points stay in registers; needs the
+ * grid co-resident: episodes in flight x support points / 256 <= ~384 workgroups; desc word 26 (HD_FPS_TIMEOUT) reports
+ * a wait time-out); 0 = one launch per round. */
+#define R3D_HEAD_FPS_ONE_LAUNCH 1
 int r3d_head_prototypes(const int32_t* support_y /*(n_way*k_shot,N)*/, const int32_t* shot_keep /*opt (n_way*k_shot)*/,
                         const float* feat /*(S*N,ldf)*/, long ldf, const float* featT /*(S,D,N)*/,
                         const float* qfeat /*(n_q*N,ldq)*/, long ldq, int n_way, int k_shot, int N, int D,
                         int n_query_pts, int k, float* nodes, long ldn, float* node_labels /*(n_cap,4)*/,
                         int32_t* desc, int32_t* assign_out /*opt (2*S*N)*/, int32_t* cluster_count /*opt (n_cap)*/,
-                        int32_t* ws, void* stream);
+                        int32_t* ws, int flags, void* stream);
 
 /* ---- affinity + label propagation (models/mpti.py:717-776) ---------------------------
  * nbr (n_cap, kp1) from r3d_knn_topk mode 1 (column 0 is dropped as in mpti.py:736).

@@ -27,6 +27,7 @@ enum {
   HD_SEG_POFF = 2 * HP_MAXSEG,          // [HP_MAXSEG] first node row of the segment's prototypes
   HD_N_PROTO = 3 * HP_MAXSEG,
   HD_N_NODES = 3 * HP_MAXSEG + 1,
+  HD_FPS_TIMEOUT = 3 * HP_MAXSEG + 2,   // != 0: a workgroup of the one-launch FPS gave up waiting for its peers
   HD_WORDS = 3 * HP_MAXSEG + 8
 };
 
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(1024) void r3d_head_compact_kernel(const int* __res
     __syncthreads();
   }
   if (tid == 0) desc[HD_SEG_COUNT + seg] = base_s;
+  if (tid == 0 && seg == 0) desc[HD_FPS_TIMEOUT] = 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -246,6 +248,114 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_fps_round_kernel(
     for (int i = 1; i < 4; ++i) cand_better(v, p, red_v[i], red_p[i]);
     Cand c; c.v = v; c.pos = p;
     cand_next[blockIdx.x] = c;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 2b. the same sampling as ONE launch: every workgroup keeps its 256 points (all channels) in registers for
+//     all k rounds instead of re-reading them every round (the per-round launches above fetch the whole
+//     compacted feature matrix from the memory side each round: 100 x 16 MB per episode on the S workload).
+//     Per round a workgroup publishes its best candidate as ONE 64-bit word (score bits << 32 | position + 1;
+//     0 = not yet written; the slot array is zeroed before the launch) with a relaxed agent-scope atomic
+//     store and reads the words of its segment's workgroups with atomic loads: the words are the only data
+//     exchanged, so no fence / cache write-back is needed (cf. profiles/r01_experiments.md: a fenced grid
+//     barrier costs 3-13 us, this exchange ~1-2 us).
+//     Co-residency: all workgroups of a grid that hold points must be resident together (one workgroup waits
+//     for its peers).  A workgroup needs ~200 VGPRs, i.e. 2 workgroups fit a CU, 512 on the chip; the caller
+//     selects this kernel only when (episodes in flight) x (support points / 256) stays below that
+//     (flags & R3D_HEAD_FPS_ONE_LAUNCH).  A waiter that sees nothing for ~2 s sets desc[HD_FPS_TIMEOUT] and
+//     proceeds, so a mis-sized launch ends with an error flag instead of a hung GPU.
+// ---------------------------------------------------------------------------
+#define FPS_SPIN_LIMIT (1 << 22)
+template <int DP>
+__global__ __launch_bounds__(HP_BLOCK) void r3d_fps_persistent_kernel(
+    const float* __restrict__ featC, long pitch, int D, SegGeom g, int* __restrict__ desc, int k,
+    unsigned long long* __restrict__ xch /* [k][total_blocks] */, int total_blocks, int* __restrict__ sel) {
+  __shared__ float seedf[DP];
+  __shared__ float red_v[4];
+  __shared__ int red_p[4];
+  __shared__ int seed_pos_s;
+  int blk0;
+  const int seg = g.seg_of_block(blockIdx.x, &blk0);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int count = desc[HD_SEG_COUNT + seg];
+  if (count <= k) return;  // identity case (mpti.py:631-634): no sampling
+  const int bis = blockIdx.x - blk0;
+  if ((long)bis * HP_BLOCK >= count) return;
+  const int nblk = (count + HP_BLOCK - 1) / HP_BLOCK;
+  const int pos = bis * HP_BLOCK + tid;
+  const bool have = pos < count;
+  float xv[DP];
+  {
+    const float* fp = featC + g.off(seg) + min(pos, count - 1);
+#pragma unroll
+    for (int c = 0; c < DP; ++c) xv[c] = fp[(long)min(c, D - 1) * pitch];
+  }
+  float md = INFINITY;
+  int seed_pos = 0;
+  for (int round = 0; round < k; ++round) {
+    if (bis == 0 && tid == 0) sel[seg * HP_MAXK + round] = seed_pos;
+    if (round == k - 1) break;
+    __syncthreads();  // seedf / red_* of the previous round are no longer read
+    for (int c = tid; c < D; c += HP_BLOCK) seedf[c] = featC[(long)c * pitch + g.off(seg) + seed_pos];
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < DP; ++c) {
+      if (c < D) {
+        const float df = xv[c] - seedf[c];
+        acc = __builtin_fmaf(df, df, acc);
+      }
+    }
+    md = acc < md ? acc : md;
+    float v = have ? md : -INFINITY;
+    int p = have ? pos : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float v2 = __shfl_xor(v, o);
+      const int p2 = __shfl_xor(p, o);
+      cand_better(v, p, v2, p2);
+    }
+    if (lane == 0) { red_v[w] = v; red_p[w] = p; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int i = 1; i < 4; ++i) cand_better(v, p, red_v[i], red_p[i]);
+      const unsigned long long word = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(p + 1);
+      __hip_atomic_store(&xch[(long)round * total_blocks + blockIdx.x], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // gather the segment's candidates (every workgroup reads all of them: same election everywhere)
+    v = -INFINITY;
+    p = 0x7fffffff;
+    for (int i = tid; i < nblk; i += HP_BLOCK) {
+      const unsigned long long* src = &xch[(long)round * total_blocks + blk0 + i];
+      unsigned long long word = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int spins = 0;
+      while (word == 0ull && spins < FPS_SPIN_LIMIT) {
+        __builtin_amdgcn_s_sleep(2);
+        word = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ++spins;
+      }
+      if (word == 0ull) {
+        desc[HD_FPS_TIMEOUT] = 1;
+      } else {
+        cand_better(v, p, __uint_as_float((unsigned)(word >> 32)), (int)(unsigned)(word & 0xffffffffull) - 1);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float v2 = __shfl_xor(v, o);
+      const int p2 = __shfl_xor(p, o);
+      cand_better(v, p, v2, p2);
+    }
+    __syncthreads();  // red_* reuse
+    if (lane == 0) { red_v[w] = v; red_p[w] = p; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int i = 1; i < 4; ++i) cand_better(v, p, red_v[i], red_p[i]);
+      seed_pos_s = (p >= 0 && p < count) ? p : 0;  // stays a valid position even after a timeout
+    }
+    __syncthreads();
+    seed_pos = seed_pos_s;
   }
 }
 
@@ -490,7 +600,8 @@ extern "C" long r3d_head_proto_ws_words(int n_way, int k_shot, int N) {
   // comp + mind + assign + cand(2 x blocks x 2 words) + sel + seeds + cluster partial sums
   const long max_chunks = (g.cap(0) + CM_CHUNK - 1) / CM_CHUNK;
   return cap * 3 + 4L * g.total_blocks() + 2L * HP_MAXSEG * HP_MAXK + 64 +
-         (long)g.nseg() * HP_MAXK * max_chunks * 257 + 256L * (cap + 64);  // ... + featC (D <= 256 rows)
+         (long)g.nseg() * HP_MAXK * max_chunks * 257 + 256L * (cap + 64) +  // ... + featC (D <= 256 rows)
+         2L * HP_MAXK * g.total_blocks() + 8;                               // ... + one-launch FPS exchange words
 }
 
 // Builds prototypes into node rows [0, n_proto) and appends the query rows.
@@ -504,7 +615,7 @@ extern "C" int r3d_head_prototypes(const int32_t* support_y, const int32_t* shot
                                    long ldf, const float* featT, const float* qfeat, long ldq, int n_way,
                                    int k_shot, int N, int D, int n_query_pts, int k, float* nodes, long ldn,
                                    float* node_labels, int32_t* desc, int32_t* assign_out,
-                                   int32_t* cluster_count, int32_t* ws, void* stream) {
+                                   int32_t* cluster_count, int32_t* ws, int flags, void* stream) {
   R3D_REQUIRE(support_y && feat && featT && qfeat && nodes && node_labels && desc && ws,
               "r3d_head_prototypes: null pointer");
   int rc = check_geom("r3d_head_prototypes", n_way, k_shot, N, D);
@@ -525,19 +636,35 @@ extern "C" int r3d_head_prototypes(const int32_t* support_y, const int32_t* shot
   int* part_cnt = (int*)(part + (long)g.nseg() * HP_MAXK * max_chunks * 256);
   float* featC = (float*)(part_cnt + (long)g.nseg() * HP_MAXK * max_chunks);
   const long pitch = cap + 32;
+  long xoff = (featC + 256L * (cap + 64)) - (float*)ws;  // exchange words of the one-launch FPS, 8-byte aligned
+  xoff += xoff & 1;
+  unsigned long long* xch = (unsigned long long*)(ws + xoff);
   hipLaunchKernelGGL(r3d_head_compact_kernel, dim3(g.nseg()), dim3(1024), 0, st, support_y, shot_keep, g,
                      comp, desc);
   hipLaunchKernelGGL(r3d_head_gather_kernel, dim3(g.total_blocks()), dim3(HP_BLOCK), 0, st, feat, ldf, D, g, comp,
                      desc, featC, pitch);
-  for (int t = 0; t < k; ++t) {
-#define FPS_LAUNCH(DPAD)                                                                                          \
-    hipLaunchKernelGGL(r3d_fps_round_kernel<DPAD>, dim3(g.total_blocks()), dim3(HP_BLOCK), 0, st, featC, pitch, D, g, \
-                       desc, k, t, mind, (t & 1) ? cand0 : cand1, (t & 1) ? cand1 : cand0, sel)
-    if (D <= 64) FPS_LAUNCH(64);
-    else if (D <= 128) FPS_LAUNCH(128);
-    else if (D <= 192) FPS_LAUNCH(192);
-    else FPS_LAUNCH(256);
-#undef FPS_LAUNCH
+  if (flags & 1 /* R3D_HEAD_FPS_ONE_LAUNCH */) {
+    const int tb = g.total_blocks();
+    r3d_zero_words(xch, 2L * k * tb, st);
+#define FPS_ONE(DPAD)                                                                                                 \
+    hipLaunchKernelGGL(r3d_fps_persistent_kernel<DPAD>, dim3(tb), dim3(HP_BLOCK), 0, st, featC, pitch, D, g, desc, k, \
+                       xch, tb, sel)
+    if (D <= 64) FPS_ONE(64);
+    else if (D <= 128) FPS_ONE(128);
+    else if (D <= 192) FPS_ONE(192);
+    else FPS_ONE(256);
+#undef FPS_ONE
+  } else {
+    for (int t = 0; t < k; ++t) {
+  #define FPS_LAUNCH(DPAD)                                                                                          \
+      hipLaunchKernelGGL(r3d_fps_round_kernel<DPAD>, dim3(g.total_blocks()), dim3(HP_BLOCK), 0, st, featC, pitch, D, g, \
+                         desc, k, t, mind, (t & 1) ? cand0 : cand1, (t & 1) ? cand1 : cand0, sel)
+      if (D <= 64) FPS_LAUNCH(64);
+      else if (D <= 128) FPS_LAUNCH(128);
+      else if (D <= 192) FPS_LAUNCH(192);
+      else FPS_LAUNCH(256);
+  #undef FPS_LAUNCH
+    }
   }
   hipLaunchKernelGGL(r3d_fps_finalize_kernel, dim3(1), dim3(HP_MAXK), 0, st, g, k, n_query_pts, sel, seeds,
                      desc);

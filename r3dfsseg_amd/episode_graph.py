@@ -88,7 +88,7 @@ class EpisodeGraphs:
             hb = model._slot.last[1]
             ok = hb.stats[0]
             sl.logits = logits
-        sl.bad += 1 - ok
+        sl.bad += 1 - ok + hb.desc[ops.HD_FPS_TIMEOUT].clamp(max=1)
         sl.knn_overflow += hb.knn_status[0].clamp(max=1)
         sl.cg_iters += hb.stats[1]
         torch.maximum(sl.cg_max, hb.stats[1], out=sl.cg_max)
@@ -107,6 +107,9 @@ class EpisodeGraphs:
         st = EpisodeSlot(s)
         st.fixed_budget = self.lp_budget
         st.update_running = (s == 0)
+        # one-launch FPS only while all slots' FPS grids fit the chip together (head_proto.hip, 2b)
+        fps_blocks = (model.n_way * model.k_shot * model.n_points + 255) // 256 + model.n_way + 1
+        st.fps_one_launch = self.n_slots * fps_blocks <= 384
         if self.train:
             st.seed_dev = torch.full((1,), 7919 * (s + 1), device=dev, dtype=torch.int32)
             off, sl.grad_views = 0, []

@@ -24,6 +24,7 @@ class EpisodeSlot:
         self.seed_dev = None        # int32 device word added to the dropout seed (None: host-side counter)
         self.fixed_budget = None    # CG launches per solve when the launch sequence is frozen in a graph
         self.update_running = True  # does this slot's training forward update BatchNorm running statistics?
+        self.fps_one_launch = True  # persistent one-launch FPS (needs its grid co-resident, see head_proto.hip)
 
 
 class MPTI_SelfAtten(nn.Module):
@@ -98,6 +99,7 @@ class MPTI_SelfAtten(nn.Module):
         if key not in slot.heads:
             slot.heads = {key: ops.HeadBuffers(self.n_way, self.k_shot, self.n_points, n_q * self.n_points,
                                                self.n_subprototypes, self.k_connect, self.feat_dim, device)}
+        slot.heads[key].fps_one_launch = slot.fps_one_launch
         slot.last = (key, slot.heads[key])
         return slot.heads[key]
 
@@ -130,7 +132,8 @@ class MPTI_SelfAtten(nn.Module):
         201-NN append kernel stay inside its survivor buffer?  False -> call forward again with
         lp_iters=self.lp_max_iter (which also selects the always-exact insertion kNN kernel)."""
         hb = self._head[1]
-        return bool(hb.stats[0].item()) and int(hb.knn_status.item()) == 0
+        return (bool(hb.stats[0].item()) and int(hb.knn_status.item()) == 0
+                and int(hb.desc[ops.HD_FPS_TIMEOUT].item()) == 0)
 
     # ------------------------------------------------------------------ forward (mpti.py:414-577)
     def forward(self, support_x, support_y, query_x, query_y, gt_support_y=None, gt_query_y=None, train=False,
@@ -154,6 +157,8 @@ class MPTI_SelfAtten(nn.Module):
             from . import clean_detect
             shot_keep = clean_detect.shot_keep_flags(self, sfeat, sfeatT, support_x, support_y)
         hb = self._head_buffers(n_q, feat.device)
+        if lp_iters:  # the conservative re-run: one FPS launch per round as well
+            hb.fps_one_launch = False
         sy = support_y.reshape(S, N).to(torch.int32).contiguous()
         ops.head_prototypes(hb, sy, shot_keep, sfeat, sfeatT, qfeat)
         nbr = ops.knn(hb.nodes, 1, hb.n_cap, hb.kp1, mode=ops.SCORE_L2, n_valid=hb.desc[ops.HD_N_NODES:],

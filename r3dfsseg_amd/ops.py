@@ -11,7 +11,8 @@ from . import _lib
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 SCORE_DGCNN, SCORE_L2 = 0, 1
-HD_SEG_COUNT, HD_SEG_M, HD_SEG_POFF, HD_N_PROTO, HD_N_NODES = 0, 8, 16, 24, 25
+HD_SEG_COUNT, HD_SEG_M, HD_SEG_POFF, HD_N_PROTO, HD_N_NODES, HD_FPS_TIMEOUT = 0, 8, 16, 24, 25, 26
+HEAD_FPS_ONE_LAUNCH = 1
 
 
 def _p(t):
@@ -214,6 +215,10 @@ class HeadBuffers:
         self.stats = torch.zeros(2, **i32)
         self.knn_status = torch.zeros(1, **i32)
         self.stats_bwd = torch.zeros(2, **i32)
+        # all FPS rounds in one persistent launch: safe while (episodes in flight) x fps_blocks workgroups stay
+        # co-resident (~384 of the chip's 512 slots for this kernel); episode_graph.EpisodeGraphs decides per slot
+        self.fps_one_launch = True
+        self.fps_blocks = (n_way * k_shot * N + 255) // 256 + n_way + 1
         off = (ctypes.c_long * 6)()
         lib.r3d_head_proto_ws_offsets(n_way, k_shot, N, off)
         self.ws_off = list(off)
@@ -229,7 +234,7 @@ def head_prototypes(hb, support_y, shot_keep, sfeat_pm, sfeatT, qfeat_pm):
         _lib.check(_lib.load().r3d_head_prototypes(
             _p(support_y), _p(shot_keep), _p(sfeat_pm), ldf, _p(sfeatT), _p(qfeat_pm), ldq, hb.n_way, hb.k_shot,
             hb.N, hb.D, hb.n_q_pts, hb.k_sub, _p(hb.nodes), hb.nodes.stride(0), _p(hb.Y), _p(hb.desc),
-            _p(hb.assign), _p(hb.cluster_count), _p(hb.proto_ws), _st()))
+            _p(hb.assign), _p(hb.cluster_count), _p(hb.proto_ws), HEAD_FPS_ONE_LAUNCH if hb.fps_one_launch else 0, _st()))
 
 
 def label_propagate(hb, nbr, sigma, alpha=0.99, max_iter=200, tol=1e-6):

@@ -1,0 +1,22 @@
+"""Two eager episodes (one warm-up, one measured) of the S workload: a small launch count for PMC passes.
+usage: one_episode.py [train|eval]"""
+import os, sys
+from types import SimpleNamespace
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from r3dfsseg_amd import synthetic as S
+from r3dfsseg_amd.mpti import MPTI_SelfAtten
+mode = sys.argv[1] if len(sys.argv) > 1 else "eval"
+cfg = S.workload_cfg("S")
+m = MPTI_SelfAtten(SimpleNamespace(**cfg)); m.load_state_dict(S.make_state_dict(cfg, 123)); m.cuda().train(mode == "train")
+data, _ = S.make_episode(cfg, seed=1000, noise_ratio=0.2, train=True)
+ep = [t.cuda() for t in data]
+for it in range(2):
+    if mode == "train":
+        out = m(ep[0], ep[1], ep[2], ep[3], gt_support_y=ep[6], gt_query_y=ep[7], train=True, support_flag=ep[10])
+        (out[1] + 0.1 * out[2]).backward()
+    else:
+        with torch.no_grad():
+            m(*ep[:4])
+    torch.cuda.synchronize()
+    print("episode", it, "done", flush=True)
