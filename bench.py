@@ -9,7 +9,7 @@ BASELINE.json configs[4]'s 256-episode batch over 8 GPUs; each episode is config
   --mode train (default): E x (forward + backward) + ONE flat-bucket RCCL gradient all-reduce + Adam.  With
                           E = 1 this is the reference's MPTILearner_V3.train step (models/mpti_learner.py:60-72).
   --mode eval           : forward only, MPTILearner_V3.test without its host sync.
-  --slots G (default 4) : episodes in flight per GPU -- every slot is a captured hipGraph replayed on its own HIP
+  --slots G (6 / 4)     : episodes in flight per GPU -- every slot is a captured hipGraph replayed on its own HIP
                           stream (r3dfsseg_amd/episode_graph.py); --slots 0 = eager launches, one episode at a time.
 Episodes are independent: ranks take disjoint episodes (weak scaling); the only collective is
 the 1.5 MB gradient all-reduce of train mode.  ONE JSON line on rank 0, with
@@ -97,7 +97,10 @@ def main():
     ap.add_argument("--mode", default="train", choices=["eval", "train"])
     ap.add_argument("--episodes-per-rank", type=int, default=32,
                     help="episodes of one step on every rank (BASELINE configs[4]: 256-episode batch / 8 GPUs)")
-    ap.add_argument("--slots", type=int, default=4, help="episodes in flight per GPU (hipGraphs on HIP streams); 0 = eager")
+    ap.add_argument("--slots", type=int, default=None,
+                    help="episodes in flight per GPU (hipGraphs on HIP streams); 0 = eager; default 6 (train) / 4 (eval), "
+                         "the measured optima on MI355X")
+    ap.add_argument("--eval-slots", type=int, default=4, help="slots of the eval-forward leg of train mode")
     ap.add_argument("--lp-budget", type=int, default=None, help="CG launches frozen into each episode graph")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -130,6 +133,8 @@ def main():
     model.load_state_dict(S.make_state_dict(cfg, 123))
     model.to(dev)
 
+    if args.slots is None:
+        args.slots = 6 if args.mode == "train" else 4
     E, G = args.episodes_per_rank, args.slots
     n_pool = max(8, min(E, 32))  # distinct episodes per rank, resident in HBM before timing starts
     pool = []
@@ -148,7 +153,8 @@ def main():
     train = args.mode == "train"
     model.train(train)
     trainer = DPTrainer(learner, n_slots=G if train else 0, example=pool[0], lp_budget=args.lp_budget) if train else None
-    eval_graphs = EpisodeGraphs(model, pool[0][:4], n_slots=G, train=False, lp_budget=args.lp_budget) if G else None
+    G_eval = (args.eval_slots if train else G) if G else 0
+    eval_graphs = EpisodeGraphs(model, pool[0][:4], n_slots=G_eval, train=False, lp_budget=args.lp_budget) if G else None
     lp_flags = []
 
     def batch(i, n):

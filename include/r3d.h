@@ -71,7 +71,11 @@ int r3d_edgeconv_fwd(const float* PQ, const int32_t* idx, const float* W2, const
 /* ---- point self-attention, d = 64 (models/attention.py:43-46) ------------------------
  * qkv (B*N, ld): q*(1/8) | k | v at columns 0 | 64 | 128.  out (B*N, ldo) 64 columns.
  * lse_out optional (B*N). */
-int r3d_attention_fwd(const float* qkv, long ld, int B, int N, float* out, long ldo, float* lse_out, void* stream);
+/* ws (optional, r3d_attention_ws_words(B, N) floats): enables the streamed-axis split -- small grids (B*N/128
+ * workgroups) are cut along the key axis so that ~512 workgroups exist, partials merged in a fixed order */
+long r3d_attention_ws_words(int B, int N);
+int r3d_attention_fwd(const float* qkv, long ld, int B, int N, float* out, long ldo, float* lse_out, float* ws,
+                      void* stream);
 
 /* ---- multi-prototype extraction (models/mpti.py:597-715) -----------------------------
  * FPS (start index 0, ties lowest index) -> sorted unique seeds -> nearest-seed assignment ->
@@ -164,10 +168,10 @@ int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float* s1, const
 /* attention with dropout on the weights (attention.py:45) and flash-style backward */
 /* effective dropout seed = seed + *seed_dev (seed_dev may be NULL); a captured hipGraph bumps *seed_dev per replay */
 int r3d_attention_fwd_train(const float* qkv, long ld, int B, int N, float* out, long ldo, float* lse_out, float p_drop,
-                            unsigned seed, const unsigned* seed_dev, void* stream);
+                            unsigned seed, const unsigned* seed_dev, float* ws /*opt, as above*/, void* stream);
 int r3d_attention_bwd(const float* qkv, long ld, int B, int N, const float* O, long ldo, const float* dO, long lddo,
                       const float* lse, float p_drop, unsigned seed, const unsigned* seed_dev, float q_scale, float* dqkv,
-                      long ldd, float* ws, void* stream);
+                      long ldd, float* ws /* r3d_attention_ws_words(B, N) floats */, void* stream);
 
 /* head backward (reference: autograd through models/mpti.py:488-512,571).  r3d_ce_grad -> G = dL/dZ (scaled by the
  * device scalar *gscale); r3d_label_propagate_bwd: adjoint CG solve on the graph r3d_label_propagate left in ws,

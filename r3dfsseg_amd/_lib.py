@@ -31,7 +31,8 @@ _SIGS = {
     "r3d_knn_topk": (c_i, [c_f, c_l, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "r3d_pointwise_conv": (c_i, [c_f, c_l, c_f, c_l, c_i, c_i, c_f, c_f, c_i, c_f, c_l, c_f]),
     "r3d_edgeconv_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f, c_f]),
-    "r3d_attention_fwd": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_f]),
+    "r3d_attention_ws_words": (c_l, [c_i, c_i]),
+    "r3d_attention_fwd": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_f, c_f]),
     "r3d_head_desc_words": (c_i, []),
     "r3d_head_max_k": (c_i, []),
     "r3d_head_proto_ws_words": (c_l, [c_i, c_i, c_i]),
@@ -59,7 +60,7 @@ _SIGS = {
     "r3d_edge_stats1": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f]),
     "r3d_edgeconv_train_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_l, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f]),
     "r3d_edgeconv_bwd": (c_i, [c_f] * 13 + [c_l, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f]),
-    "r3d_attention_fwd_train": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_fl, c_u, c_f, c_f]),
+    "r3d_attention_fwd_train": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_fl, c_u, c_f, c_f, c_f]),
     "r3d_attention_bwd": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_l, c_f, c_fl, c_u, c_f, c_fl, c_f, c_l, c_f, c_f]),
     "r3d_ce_grad": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),
     "r3d_label_propagate_bwd": (c_i, [c_f, c_l, c_i, c_i, c_f, c_f, c_f, c_i, c_fl, c_fl, c_i, c_fl, c_f, c_f, c_l, c_f, c_f, c_f]),

@@ -31,7 +31,8 @@ static __device__ __forceinline__ bool attn_keep(unsigned seed, unsigned row, un
 
 __global__ __launch_bounds__(256) void r3d_attention_fwd_kernel(
     const float* __restrict__ qkv, long ld, int N, float* __restrict__ out, long ldo,
-    float* __restrict__ lse_out, float p_drop, unsigned seed, const unsigned* __restrict__ seed_dev) {
+    float* __restrict__ lse_out, float p_drop, unsigned seed, const unsigned* __restrict__ seed_dev,
+    int tiles_per_split, float* __restrict__ part /* split > 1: [split][M][66] = unnormalised o | m | l */) {
   if (seed_dev) seed += *seed_dev;  // per-replay seed of a captured hipGraph lives in device memory
   const unsigned thresh = p_drop > 0.f ? (unsigned)(p_drop * 4294967296.0) : 0u;
   const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
@@ -80,11 +81,13 @@ __global__ __launch_bounds__(256) void r3d_attention_fwd_kernel(
     }
   };
 
-  const int ntiles = (N + 31) / 32;
-  load_tile(0);
-  store_tile(0);
+  // key tiles [t_beg, t_end) of this workgroup (blockIdx.z = split of the key axis: more workgroups for small grids)
+  const int t_beg = blockIdx.z * tiles_per_split;
+  const int ntiles = min((N + 31) / 32, t_beg + tiles_per_split);
+  load_tile(32 * t_beg);
+  store_tile(t_beg & 1);
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
+  for (int t = t_beg; t < ntiles; ++t) {
     const int buf = t & 1;
     if (t + 1 < ntiles) load_tile(32 * (t + 1));
     // S^T = K Q^T
@@ -139,6 +142,17 @@ __global__ __launch_bounds__(256) void r3d_attention_fwd_kernel(
     __syncthreads();
   }
   if (!q_ok) return;
+  if (part) {  // partial (o, m, l) of this key range; r3d_attention_combine_kernel merges the splits
+    float* prow = part + ((long)blockIdx.z * gridDim.y * N + base + q_row) * 66;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ch = r3d_acc_row(r, lane);
+      prow[ch] = o0[r];
+      prow[32 + ch] = o1[r];
+    }
+    if (lane < 32) { prow[64] = m_run; prow[65] = l_run; }
+    return;
+  }
   const float inv = 1.f / l_run;
   float* orow = out + (base + q_row) * ldo;
 #pragma unroll
@@ -150,34 +164,79 @@ __global__ __launch_bounds__(256) void r3d_attention_fwd_kernel(
   if (lse_out && lane < 32) lse_out[base + q_row] = m_run + __logf(l_run);
 }
 
+// merge the key splits of the forward: m = max m_z, l = sum l_z e^(m_z - m), o = sum o_z e^(m_z - m) / l
+__global__ void r3d_attention_combine_kernel(const float* __restrict__ part, int nsplit, long M, float* __restrict__ out,
+                                             long ldo, float* __restrict__ lse_out) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  float m = -INFINITY;
+  for (int z = 0; z < nsplit; ++z) m = fmaxf(m, part[((long)z * M + row) * 66 + 64]);
+  float l = 0.f, o = 0.f;
+  for (int z = 0; z < nsplit; ++z) {
+    const float* pr = part + ((long)z * M + row) * 66;
+    const float sc = __expf(pr[64] - m);
+    l += pr[65] * sc;
+    o += pr[lane] * sc;
+  }
+  out[row * ldo + lane] = o / l;
+  if (lse_out && lane == 0) lse_out[row] = m + __logf(l);
+}
+
 // qkv: (B*N, ld) with q (pre-scaled by 1/sqrt(64)) | k | v at columns 0 | 64 | 128;
 // out: (B*N, ldo) point-major, 64 columns written; lse_out optional (B*N) log-sum-exp
 // per query (saved for the backward pass).
+// Streamed-axis split: one workgroup per 128 rows leaves small grids (B * N / 128 workgroups, 32 for the two query
+// clouds) with most CUs idle while every workgroup walks all N keys; the streamed axis is cut into `split` ranges
+// (blockIdx.z) so that ~512 workgroups exist, and the partial results are merged by a small kernel in a fixed
+// order (deterministic).  ws == NULL keeps the unsplit launch.
+static int attention_split(int B, int N) {
+  const int wgs = B * r3d_cdiv(N, 128), ntiles = r3d_cdiv(N, 32);
+  int split = r3d_cdiv(512, wgs);
+  if (split > 16) split = 16;
+  if (split > ntiles) split = ntiles;
+  return split < 1 ? 1 : split;
+}
+extern "C" long r3d_attention_ws_words(int B, int N) {
+  // forward: split * M * 66; backward: M (row dots) + split * M * 128 (dK | dV partials, reused for dQ)
+  return (long)B * N * (1 + 128L * attention_split(B, N)) + 64;
+}
+
 static int attention_launch(const float* qkv, long ld, int B, int N, float* out, long ldo, float* lse_out, float p_drop,
-                            unsigned seed, const unsigned* seed_dev, void* stream) {
+                            unsigned seed, const unsigned* seed_dev, float* ws, void* stream) {
   R3D_REQUIRE(qkv && out, "r3d_attention_fwd: null pointer");
   R3D_REQUIRE(B > 0 && N > 0 && ld >= 192 && ld % 4 == 0 && ldo >= 64,
               "r3d_attention_fwd: bad shape B=%d N=%d ld=%ld ldo=%ld", B, N, ld, ldo);
   R3D_REQUIRE(((uintptr_t)qkv & 15) == 0, "r3d_attention_fwd: qkv must be 16-byte aligned");
-  dim3 grid(r3d_cdiv(N, 128), B);
   R3D_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "r3d_attention_fwd: dropout probability %f out of range", p_drop);
+  const int split = ws ? attention_split(B, N) : 1;
+  const int ntiles = r3d_cdiv(N, 32);
+  const int tps = r3d_cdiv(ntiles, split);
+  const int nz = r3d_cdiv(ntiles, tps);  // no empty split
+  dim3 grid(r3d_cdiv(N, 128), B, nz);
   hipLaunchKernelGGL(r3d_attention_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, ld, N, out,
-                     ldo, lse_out, p_drop, seed, seed_dev);
+                     ldo, lse_out, p_drop, seed, seed_dev, tps, nz > 1 ? ws : nullptr);
+  if (nz > 1) {
+    const long M = (long)B * N;
+    hipLaunchKernelGGL(r3d_attention_combine_kernel, dim3(r3d_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, ws, nz, M,
+                       out, ldo, lse_out);
+  }
   R3D_LAUNCH_CHECK("r3d_attention_fwd");
   return R3D_OK;
 }
 
 extern "C" int r3d_attention_fwd(const float* qkv, long ld, int B, int N, float* out, long ldo, float* lse_out,
+                                 float* ws /* opt: r3d_attention_ws_words(B, N) floats enable the key split */,
                                  void* stream) {
-  return attention_launch(qkv, ld, B, N, out, ldo, lse_out, 0.f, 0u, nullptr, stream);
+  return attention_launch(qkv, ld, B, N, out, ldo, lse_out, 0.f, 0u, nullptr, ws, stream);
 }
 
 // training forward: dropout p_drop on the attention weights with the stateless mask of attn_keep.
 // Effective seed = seed + *seed_dev (seed_dev may be NULL): a captured hipGraph bumps the device word per replay.
 extern "C" int r3d_attention_fwd_train(const float* qkv, long ld, int B, int N, float* out, long ldo, float* lse_out,
-                                       float p_drop, unsigned seed, const unsigned* seed_dev, void* stream) {
+                                       float p_drop, unsigned seed, const unsigned* seed_dev, float* ws, void* stream) {
   R3D_REQUIRE(lse_out, "r3d_attention_fwd_train: lse_out is required (saved for the backward pass)");
-  return attention_launch(qkv, ld, B, N, out, ldo, lse_out, p_drop, seed, seed_dev, stream);
+  return attention_launch(qkv, ld, B, N, out, ldo, lse_out, p_drop, seed, seed_dev, ws, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -200,7 +259,7 @@ __global__ void r3d_attention_rowdot_kernel(const float* __restrict__ dO, long l
 __global__ __launch_bounds__(256) void r3d_attention_bwd_kv_kernel(
     const float* __restrict__ qkv, long ld, int N, const float* __restrict__ dO, long lddo, const float* __restrict__ lse,
     const float* __restrict__ Dv, float* __restrict__ dqkv, long ldd, float p_drop, unsigned seed,
-    const unsigned* __restrict__ seed_dev) {
+    const unsigned* __restrict__ seed_dev, int tiles_per_split, float* __restrict__ part /* [split][M][128] or NULL */) {
   if (seed_dev) seed += *seed_dev;
   __shared__ float Qs[2][32 * AT_LD];
   __shared__ float Gs[2][32 * AT_LD];  // dO tile
@@ -253,11 +312,12 @@ __global__ __launch_bounds__(256) void r3d_attention_bwd_kv_kernel(
     }
     if (tid < 32) { Ls[buf][tid] = lreg; Ds[buf][tid] = dreg; }
   };
-  const int ntiles = (N + 31) / 32;
-  load_tile(0);
-  store_tile(0);
+  const int t_beg = blockIdx.z * tiles_per_split;
+  const int ntiles = min((N + 31) / 32, t_beg + tiles_per_split);
+  load_tile(32 * t_beg);
+  store_tile(t_beg & 1);
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
+  for (int t = t_beg; t < ntiles; ++t) {
     const int buf = t & 1;
     if (t + 1 < ntiles) load_tile(32 * (t + 1));
     // S[query][key] = Q' K^T ; dP~[query][key] = dO V^T   (rows = queries of the tile, column = this lane's key)
@@ -301,7 +361,7 @@ __global__ __launch_bounds__(256) void r3d_attention_bwd_kv_kernel(
     __syncthreads();
   }
   if (!key_ok) return;
-  float* drow = dqkv + (base + key) * ldd;
+  float* drow = part ? part + ((long)blockIdx.z * gridDim.y * N + base + key) * 128 - 64 : dqkv + (base + key) * ldd;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int c = r3d_acc_row(r, lane);
@@ -312,10 +372,23 @@ __global__ __launch_bounds__(256) void r3d_attention_bwd_kv_kernel(
   }
 }
 
+// out[row][col0 + c] = scale * sum_z part[z][row][c], z ascending (fixed order), c < width
+__global__ void r3d_attention_sum_kernel(const float* __restrict__ part, int nsplit, long M, int width, float scale,
+                                         float* __restrict__ out, long ldo, int col0) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * width) return;
+  const long row = i / width;
+  const int c = (int)(i - row * width);
+  float s = 0.f;
+  for (int z = 0; z < nsplit; ++z) s += part[((long)z * M + row) * width + c];
+  out[row * ldo + col0 + c] = s * scale;
+}
+
 __global__ __launch_bounds__(256) void r3d_attention_bwd_q_kernel(
     const float* __restrict__ qkv, long ld, int N, const float* __restrict__ dO, long lddo, const float* __restrict__ lse,
     const float* __restrict__ Dv, float* __restrict__ dqkv, long ldd, float p_drop, unsigned seed,
-    const unsigned* __restrict__ seed_dev, float q_scale) {
+    const unsigned* __restrict__ seed_dev, float q_scale, int tiles_per_split,
+    float* __restrict__ part /* [split][M][64] unscaled, or NULL */) {
   if (seed_dev) seed += *seed_dev;
   __shared__ float Ks[2][32 * AT_LD];
   __shared__ float Vs[2][32 * AT_LD];
@@ -362,11 +435,12 @@ __global__ __launch_bounds__(256) void r3d_attention_bwd_q_kernel(
       vd[0] = vreg[i].x; vd[1] = vreg[i].y; vd[2] = vreg[i].z; vd[3] = vreg[i].w;
     }
   };
-  const int ntiles = (N + 31) / 32;
-  load_tile(0);
-  store_tile(0);
+  const int t_beg = blockIdx.z * tiles_per_split;
+  const int ntiles = min((N + 31) / 32, t_beg + tiles_per_split);
+  load_tile(32 * t_beg);
+  store_tile(t_beg & 1);
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
+  for (int t = t_beg; t < ntiles; ++t) {
     const int buf = t & 1;
     if (t + 1 < ntiles) load_tile(32 * (t + 1));
     // S^T[key][query] = K Q'^T ; dP~^T[key][query] = V dO^T
@@ -404,17 +478,19 @@ __global__ __launch_bounds__(256) void r3d_attention_bwd_q_kernel(
     __syncthreads();
   }
   if (!q_ok) return;
-  float* drow = dqkv + (base + q_row) * ldd;
+  float* drow = part ? part + ((long)blockIdx.z * gridDim.y * N + base + q_row) * 64 : dqkv + (base + q_row) * ldd;
+  const float osc = part ? 1.f : q_scale;  // partials stay unscaled; r3d_attention_sum_kernel applies q_scale
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int c = r3d_acc_row(r, lane);
-    drow[c] = dq0[r] * q_scale;  // gradient w.r.t. the UNscaled q map output (q' = q * q_scale)
-    drow[32 + c] = dq1[r] * q_scale;
+    drow[c] = dq0[r] * osc;  // gradient w.r.t. the UNscaled q map output (q' = q * q_scale)
+    drow[32 + c] = dq1[r] * osc;
   }
 }
 
 // dqkv (B*N, ldd >= 192): gradients of the q | k | v GEMM outputs (before the 1/sqrt(d) scale of q).
-// O: forward output (B*N, ldo); lse: saved log-sum-exp; ws: B*N floats.
+// O: forward output (B*N, ldo); lse: saved log-sum-exp; ws: r3d_attention_ws_words(B, N) floats (row dots + the
+// partial dK | dV / dQ of the streamed-axis split).
 extern "C" int r3d_attention_bwd(const float* qkv, long ld, int B, int N, const float* O, long ldo, const float* dO,
                                  long lddo, const float* lse, float p_drop, unsigned seed, const unsigned* seed_dev,
                                  float q_scale, float* dqkv, long ldd, float* ws, void* stream) {
@@ -425,11 +501,21 @@ extern "C" int r3d_attention_bwd(const float* qkv, long ld, int B, int N, const 
   hipStream_t st = (hipStream_t)stream;
   const long M = (long)B * N;
   hipLaunchKernelGGL(r3d_attention_rowdot_kernel, dim3(r3d_cdiv(M, 4)), dim3(256), 0, st, dO, lddo, O, ldo, M, ws);
-  dim3 grid(r3d_cdiv(N, 128), B);
+  const int ntiles = r3d_cdiv(N, 32);
+  const int tps = r3d_cdiv(ntiles, attention_split(B, N));
+  const int nz = r3d_cdiv(ntiles, tps);
+  float* part = nz > 1 ? ws + M : nullptr;
+  dim3 grid(r3d_cdiv(N, 128), B, nz);
   hipLaunchKernelGGL(r3d_attention_bwd_kv_kernel, grid, dim3(256), 0, st, qkv, ld, N, dO, lddo, lse, ws, dqkv, ldd, p_drop,
-                     seed, seed_dev);
+                     seed, seed_dev, tps, part);
+  if (part)
+    hipLaunchKernelGGL(r3d_attention_sum_kernel, dim3(r3d_cdiv(M * 128, 256)), dim3(256), 0, st, part, nz, M, 128, 1.f, dqkv,
+                       ldd, 64);
   hipLaunchKernelGGL(r3d_attention_bwd_q_kernel, grid, dim3(256), 0, st, qkv, ld, N, dO, lddo, lse, ws, dqkv, ldd, p_drop,
-                     seed, seed_dev, q_scale);
+                     seed, seed_dev, q_scale, tps, part);
+  if (part)
+    hipLaunchKernelGGL(r3d_attention_sum_kernel, dim3(r3d_cdiv(M * 64, 256)), dim3(256), 0, st, part, nz, M, 64, q_scale, dqkv,
+                       ldd, 0);
   R3D_LAUNCH_CHECK("r3d_attention_bwd");
   return R3D_OK;
 }

@@ -109,7 +109,7 @@ class EpisodeGraphs:
         st.update_running = (s == 0)
         # one-launch FPS only while all slots' FPS grids fit the chip together (head_proto.hip, 2b)
         fps_blocks = (model.n_way * model.k_shot * model.n_points + 255) // 256 + model.n_way + 1
-        st.fps_one_launch = self.n_slots * fps_blocks <= 384
+        st.fps_one_launch = self.n_slots * fps_blocks <= 500  # 512 workgroup slots at 2 waves per SIMD
         if self.train:
             st.seed_dev = torch.full((1,), 7919 * (s + 1), device=dev, dtype=torch.int32)
             off, sl.grad_views = 0, []

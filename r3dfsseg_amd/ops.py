@@ -188,8 +188,10 @@ def attention(qkv, B, N, out, want_lse=False):
     M2, ldo = _rows(out)
     assert M == B * N and M2 == M and qkv.shape[1] == 192 and out.shape[1] == 64
     lse = torch.empty(M, device=qkv.device, dtype=torch.float32) if want_lse else None
+    lib = _lib.load()
+    ws = torch.empty(lib.r3d_attention_ws_words(B, N), device=qkv.device, dtype=torch.float32)
     with _timed("attention"):
-        _lib.check(_lib.load().r3d_attention_fwd(_p(qkv), ld, B, N, _p(out), ldo, _p(lse), _st()))
+        _lib.check(lib.r3d_attention_fwd(_p(qkv), ld, B, N, _p(out), ldo, _p(lse), _p(ws), _st()))
     return lse
 
 

@@ -231,9 +231,10 @@ class EncoderTrainFn(torch.autograd.Function):
         qkv = ops.pointwise_conv(level2, Wqkv, qscale, None, ops.ACT_NONE)
         lse = torch.empty(M, device=dev, dtype=torch.float32)
         p_drop = float(att.dropout.p)
+        aws = _f(lib.r3d_attention_ws_words(B, N), dev)
         with _timed("attention"):
             _lib.check(lib.r3d_attention_fwd_train(_p(qkv), 192, B, N, _p(feat[:, 64:128]), feat.stride(0), _p(lse), p_drop,
-                                                   ctypes.c_uint(seed & 0xffffffff), _p(model._slot.seed_dev), _st()))
+                                                   ctypes.c_uint(seed & 0xffffffff), _p(model._slot.seed_dev), _p(aws), _st()))
         ctx.model, ctx.dims, ctx.seed_dev = model, (B, N, seed, p_drop), model._slot.seed_dev
         model._dbg_idx = [sv[1] for sv in ec_saved]  # neighbour lists of this pass (parity tests inject them into the oracle)
         ctx.saved = (ec_saved, mlp_saved, base_saved, cat, level2, Wqkv, qkv, lse, feat)
@@ -265,7 +266,7 @@ class EncoderTrainFn(torch.autograd.Function):
             d = dX
         # --- SelfAttention (attention.py:39-46)
         dqkv = torch.empty(M, 192, device=dev, dtype=torch.float32)
-        ws = _f(M, dev)
+        ws = _f(lib.r3d_attention_ws_words(B, N), dev)
         with _timed("attention_bwd"):
             _lib.check(lib.r3d_attention_bwd(_p(qkv), 192, B, N, _p(feat[:, 64:128]), feat.stride(0), _p(dfeat[:, 64:128]),
                                              dfeat.stride(0), _p(lse), p_drop, ctypes.c_uint(seed & 0xffffffff),

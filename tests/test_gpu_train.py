@@ -117,11 +117,12 @@ def test_attention_dropout_mask_and_backward():
     st = ops._st()
     # effective seed = immediate + device word (the word is what a captured episode graph bumps per replay)
     sdev = torch.tensor([1000], dtype=torch.int32, device="cuda")
+    aws = torch.empty(lib.r3d_attention_ws_words(B, N), device="cuda")  # enables the key-axis split (8 ranges here)
     _lib.check(lib.r3d_attention_fwd_train(ops._p(qg), 192, B, N, ops._p(out), 64, ops._p(lse), p, ctypes.c_uint(seed - 1000),
-                                           ops._p(sdev), st))
+                                           ops._p(sdev), ops._p(aws), st))
     np.testing.assert_allclose(out.cpu().numpy(), y.detach().numpy(), atol=1e-4, rtol=1e-4)
     assert 0.08 < 1 - (keep > 0).float().mean().item() < 0.12
-    dqkv = torch.empty(B * N, 192, device="cuda"); ws = torch.empty(B * N, device="cuda")
+    dqkv = torch.empty(B * N, 192, device="cuda"); ws = torch.empty(lib.r3d_attention_ws_words(B, N), device="cuda")
     Rg = R.cuda()
     _lib.check(lib.r3d_attention_bwd(ops._p(qg), 192, B, N, ops._p(out), 64, ops._p(Rg), 64, ops._p(lse), p, ctypes.c_uint(seed),
                                      None, 1.0, ops._p(dqkv), 192, ops._p(ws), st))
