@@ -348,7 +348,8 @@ def main():
 
     eps = args.steps * E * world / elapsed
     out = {
-        "metric": "episodes/sec S3DIS 2-way 5-shot 2048-pt (MPTI+attention, %s)" % (
+        "metric": "episodes/sec %s %d-way %d-shot %d-pt (MPTI+attention, %s)" % (
+            "ScanNet" if args.workload == "C" else "S3DIS", cfg["n_way"], cfg["k_shot"], N,
             "train step: forward+backward+grad all-reduce+Adam" if train else "eval forward"),
         "value": eps, "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
