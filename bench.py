@@ -117,13 +117,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("R3D_BENCH_FORCE_DIST"):  # FORCE_DIST: rehearse the RCCL path with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from r3dfsseg_amd import ops, synthetic as S
     from r3dfsseg_amd.mpti import MPTI_SelfAtten
@@ -193,17 +194,17 @@ def main():
         del lp_flags[:]
         if graphs is not None:
             graphs.check()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
             step_fn(i)
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         el = time.perf_counter() - t0
-        if world > 1:
+        if dist is not None:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = t.item()
@@ -258,7 +259,7 @@ def main():
     cg_mean, cg_max = cg
 
     if rank != 0:
-        if world > 1:
+        if dist is not None:
             dist.destroy_process_group()
         return
 
@@ -364,7 +365,7 @@ def main():
     }
     out.update(extra)
     print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

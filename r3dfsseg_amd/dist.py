@@ -52,7 +52,7 @@ class FlatGradBucket:
         """Sum gradients over ranks and divide by the total number of episodes of the step."""
         total = self.store[-1:]
         total.fill_(float(n_local_episodes))  # a fill kernel: no host->device copy, no host sync
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_initialized():  # also with one rank (cheap, and it keeps the single-rank path identical)
             dist.all_reduce(self.store, op=dist.ReduceOp.SUM)
         self.flat.div_(total)
         return self.flat

@@ -22,13 +22,9 @@ Frozen-sequence consequences, all checked or documented:
   * BatchNorm running statistics are updated by slot 0 only (shared buffers, concurrent slots would race);
     the batch statistics used for normalisation are per episode either way.
 """
-import os
-
 import torch
 
 from . import ops, train_ops
-
-_DBG = os.environ.get("R3D_EG_DEBUG", "")
 from .mpti import EpisodeSlot
 
 
@@ -109,7 +105,8 @@ class EpisodeGraphs:
         st.update_running = (s == 0)
         # one-launch FPS only while all slots' FPS grids fit the chip together (head_proto.hip, 2b)
         fps_blocks = (model.n_way * model.k_shot * model.n_points + 255) // 256 + model.n_way + 1
-        st.fps_one_launch = self.n_slots * fps_blocks <= 500  # 512 workgroup slots at 2 waves per SIMD
+        # 2 workgroups of the one-launch FPS fit a CU at D <= 192 (234 VGPRs), 1 above: 512 / 256 slots on the chip
+        st.fps_one_launch = self.n_slots * fps_blocks <= (500 if model.feat_dim <= 192 else 250)
         if self.train:
             st.seed_dev = torch.full((1,), 7919 * (s + 1), device=dev, dtype=torch.int32)
             off, sl.grad_views = 0, []
@@ -127,7 +124,10 @@ class EpisodeGraphs:
         cur.wait_stream(sl.stream)
         torch.cuda.synchronize()
         sl.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(sl.graph):
+        # thread-local capture mode: only this thread launches into the capture (no autograd engine threads in the
+        # explicit episode), while other threads -- e.g. the RCCL watchdog of torch.distributed polling its events --
+        # must stay free to call the HIP runtime
+        with torch.cuda.graph(sl.graph, capture_error_mode="thread_local"):
             self._run_once(sl)
         return sl
 
@@ -161,14 +161,13 @@ class EpisodeGraphs:
         G = self.n_slots
         for e, ep in enumerate(episodes):
             sl = self.slots[e % G]
-            with torch.cuda.stream(main if "mainstream" in _DBG else sl.stream):
-                if e < G and "mainstream" not in _DBG:
+            with torch.cuda.stream(sl.stream):
+                if e < G:
                     sl.stream.wait_event(self.ev_start)
-                if "nocopy" not in _DBG:
-                    for dst, src in zip(sl.inputs, ep):
-                        dst.copy_(src, non_blocking=True)
-                        if src.is_cuda and "norecord" not in _DBG:
-                            src.record_stream(sl.stream)
+                for dst, src in zip(sl.inputs, ep):
+                    dst.copy_(src, non_blocking=True)
+                    if src.is_cuda:
+                        src.record_stream(sl.stream)
                 sl.graph.replay()
                 if logits_out is not None:
                     logits_out[e].copy_(sl.logits, non_blocking=True)

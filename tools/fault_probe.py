@@ -1,4 +1,7 @@
-"""Bisect the replay-after-eager memory fault: each stage in its own process, progress markers after syncs."""
+"""Replay patterns of the episode hipGraphs, each stage in its own process with progress markers after syncs:
+run, synchronise, (eager work / weight update), run again.  With memset / memcpy nodes inside the captured
+sequence the second run faulted on ROCm 7.2 (profiles/r01_experiments.md); with kernel nodes only every stage
+passes."""
 import os, sys, subprocess
 from types import SimpleNamespace
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -45,7 +48,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         stage(sys.argv[1])
     else:
-        for n, env in [("T1", dict(SLOTS="1")), ("E1", dict(SLOTS="1")), ("T1", dict()), ("E1", dict())]:
+        for n, env in [("T1", dict(SLOTS="1")), ("E1", dict(SLOTS="1")), ("T1", dict()), ("T2", dict()), ("E1", dict()),
+                       ("E2", dict()), ("E3", dict())]:
             r = subprocess.run([sys.executable, __file__, n], capture_output=True, text=True, timeout=200, env=dict(os.environ, **env))
             print("==", n, env, "rc", r.returncode, "|", " / ".join(l for l in r.stdout.splitlines()), "|",
                   " ".join(l for l in r.stderr.splitlines() if "fault" in l.lower())[:200], flush=True)
