@@ -19,8 +19,8 @@
 #include "common.h"
 
 #define HG_NC 4                 // label columns carried (n_way + 1 <= 4), float4 per node
-#define HG_ROWS_PER_BLOCK 32    // CG: rows per 256-thread block (8 per wave)
-#define HG_MAX_PART 1024        // max CG blocks (n_cap <= 32768)
+#define HG_ROWS_PER_BLOCK_MIN 4 // CG SpMV: rows per 256-thread block (1 per wave; more when n_cap / 4 > HG_MAX_PART)
+#define HG_MAX_PART 2048        // max CG blocks
 
 // ---------------------------------------------------------------------------
 // 2. bitmaps: outb[i] = { j : j in nbr(i) } ; sym[i] = outb[i] | { j : i in nbr(j) }
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void r3d_cg_init_kernel(const float4* __restri
 // A: p_new = r + beta p_old ; q = (I - alpha S) p_new ; partial <p_new, q>
 __global__ __launch_bounds__(256) void r3d_cg_spmv_kernel(
     const int* __restrict__ row_ptr, const int* __restrict__ col, const float* __restrict__ val,
-    const int* __restrict__ n_dev, int n_cap, float alpha_lp, int it, int nblk_rr, float tol2,
+    const int* __restrict__ n_dev, int n_cap, float alpha_lp, int it, int nblk_rr, float tol2, int rows_per_block,
     const float4* __restrict__ r, const float4* __restrict__ p_old, float4* __restrict__ p_new,
     float4* __restrict__ q, const float4* __restrict__ part_rr, float4* __restrict__ part_pq,
     CgState* __restrict__ st) {
@@ -292,8 +292,10 @@ __global__ __launch_bounds__(256) void r3d_cg_spmv_kernel(
     rn[0] = rr.x; rn[1] = rr.y; rn[2] = rr.z; rn[3] = rr.w;
   }
   float4 acc_pq = f4_zero();
-  const int row0 = blockIdx.x * HG_ROWS_PER_BLOCK + w * (HG_ROWS_PER_BLOCK / 4);
-  for (int rr_i = 0; rr_i < HG_ROWS_PER_BLOCK / 4; ++rr_i) {
+  // few rows per wave: the SpMV is a chain of dependent loads per row (col -> gather), so its time is
+  // rows-per-wave x that latency: 1 row per wave at n = 4.4k (was 8) took the CG iteration from 21 to 16 us
+  const int row0 = blockIdx.x * rows_per_block + w * (rows_per_block / 4);
+  for (int rr_i = 0; rr_i < rows_per_block / 4; ++rr_i) {
     const int i = row0 + rr_i;
     if (i >= n) break;
     float4 s = f4_zero();
@@ -487,7 +489,9 @@ static LpWs lp_carve(int32_t* ws, int n_cap, int kp1) {
 static int lp_solve(const LpWs& L, const float* RHS, const int32_t* n_dev, int n_cap, float alpha, int max_iter, float tol,
                     float* X, int32_t* stats_out, hipStream_t st) {
   const int nblk_v = r3d_cdiv(n_cap, 256);
-  const int nblk_s = r3d_cdiv(n_cap, HG_ROWS_PER_BLOCK);
+  int rpb = HG_ROWS_PER_BLOCK_MIN;
+  while (r3d_cdiv(n_cap, rpb) > HG_MAX_PART) rpb += 4;
+  const int nblk_s = r3d_cdiv(n_cap, rpb);
   R3D_REQUIRE(nblk_s <= HG_MAX_PART, "r3d_label_propagate: n_cap too large");
   float4* x = (float4*)X;
   hipLaunchKernelGGL(r3d_cg_init_kernel, dim3(nblk_v), dim3(256), 0, st, (const float4*)RHS, n_dev, n_cap, x, L.r, L.p0,
@@ -497,7 +501,7 @@ static int lp_solve(const LpWs& L, const float* RHS, const int32_t* n_dev, int n
     float4* pold = (it & 1) ? L.p1 : L.p0;
     float4* pnew = (it & 1) ? L.p0 : L.p1;
     hipLaunchKernelGGL(r3d_cg_spmv_kernel, dim3(nblk_s), dim3(256), 0, st, L.row_ptr, L.col, L.val, n_dev, n_cap, alpha,
-                       it, nblk_v, tol2, L.r, pold, pnew, L.q, L.part_rr, L.part_pq, L.cg);
+                       it, nblk_v, tol2, rpb, L.r, pold, pnew, L.q, L.part_rr, L.part_pq, L.cg);
     hipLaunchKernelGGL(r3d_cg_update_kernel, dim3(nblk_v), dim3(256), 0, st, n_dev, n_cap, it, nblk_s, tol2, pnew, L.q,
                        x, L.r, L.part_pq, L.part_rr, L.cg);
   }
