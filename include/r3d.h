@@ -50,6 +50,7 @@ int r3d_copy_cols(const float* src, long ld_src, float* dst, long ld_dst, long M
  * append-and-rank kernel; bit 0 set afterwards means its survivor buffer overflowed and the
  * call must be repeated with status == NULL (insertion kernel, always exact). */
 int r3d_sqnorm(const float* x, long ldx, long rows, int C, float* out, void* stream);
+long r3d_knn_norm_ws_words(int B, int N);  /* floats of norm_ws: B*N norms + per-tile overflow flags */
 int r3d_knn_topk(const float* x, long ldx, const float* x_cm, int B, int N, int C, int k, int mode,
                  const int32_t* n_valid_dev, float* norm_ws, float* cm_ws, int32_t* idx_out, float* score_out,
                  int32_t* status, void* stream);

@@ -32,6 +32,7 @@ _SIGS = {
     "r3d_pointwise_conv": (c_i, [c_f, c_l, c_f, c_l, c_i, c_i, c_f, c_f, c_i, c_f, c_l, c_f]),
     "r3d_edgeconv_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f, c_f]),
     "r3d_attention_ws_words": (c_l, [c_i, c_i]),
+    "r3d_knn_norm_ws_words": (c_l, [c_i, c_i]),
     "r3d_attention_fwd": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_f, c_f]),
     "r3d_head_desc_words": (c_i, []),
     "r3d_head_max_k": (c_i, []),

@@ -16,6 +16,7 @@
 // 64 staged through LDS, writes the 32x128 score tile to LDS and lets each wave keep
 // the sorted top-(64*R) list of 8 rows in registers (list entry t lives in register
 // t/64 of lane t%64; insertion = ballot + popcount + lane shift).
+#include <stdlib.h>
 #include "common.h"
 
 #define KNN_Q 32
@@ -277,7 +278,9 @@ __device__ unsigned long long g_knn_dbg[16];
 template <int KS>
 __global__ __launch_bounds__(256) void r3d_knn_small_kernel(
     const float* __restrict__ xT, long ldT, int N, int C, int k, int mode, const int* __restrict__ n_dev,
-    const float* __restrict__ nrm, int* __restrict__ idx_out, float* __restrict__ score_out) {
+    const float* __restrict__ nrm, int* __restrict__ idx_out, float* __restrict__ score_out,
+    const int* __restrict__ tile_flags /* optional: only 32-row tiles with a non-zero flag are computed */) {
+  if (tile_flags && !tile_flags[(long)blockIdx.y * gridDim.x + blockIdx.x]) return;
   __shared__ float smem[32 * 129 > 2 * 32 * 128 ? 32 * 129 : 2 * 32 * 128];
   __shared__ float tau_s[32];
   const int b = blockIdx.y;
@@ -528,14 +531,18 @@ __global__ __launch_bounds__(256) void r3d_knn_small_kernel(
 // Channels run in chunks of 64 (32 MFMA k-pairs): fragments of the next chunk are in flight
 // behind the current chunk's MFMA chain; query fragments sit in LDS (conflict-free stride).
 // ---------------------------------------------------------------------------
-#define KB_WAVES 8
-#define KB_CAP 384
-#define KB_GROUPS (KB_WAVES * 32)
-
-__global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_big_kernel(
+// Two configurations of the same kernel:
+//   big <8 waves, 384 slots, top-2 per group>: 32 < k <= 256 (the head's 201-NN); overflow -> *status bit 0.
+//   mid <4 waves, 128 slots, top-1 per group>: k <= 32 on 17..256 channels (DGCNN layers 2 and 3): half the
+//       threads and a third of the LDS, so two workgroups share a CU and overlap their phases; a 32-row tile whose
+//       buffer overflowed (> 128 candidates at or above tau: duplicated points tie exactly) sets tile_flags[tile]
+//       and is recomputed by the exact insertion kernel launched right behind (it returns at once elsewhere).
+template <int KB_WAVES, int KB_CAP, int KB_TOP, int KCH /* k-pairs per channel chunk: 32 (64 channels) or 8 (16) */>
+__global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_append_kernel(
     const float* __restrict__ xT, long ldT, int N, int C, int k, int mode, const int* __restrict__ n_dev,
     const float* __restrict__ nrm, int* __restrict__ idx_out, float* __restrict__ score_out,
-    int* __restrict__ status) {
+    int* __restrict__ status, int* __restrict__ tile_flags) {
+  constexpr int KB_GROUPS = KB_WAVES * 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int cnt_s[32];
   __shared__ float tau_s[32];
@@ -545,14 +552,14 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_big_kernel(
   if (q0 >= n) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, j = lane & 31;
-  const int nch = (C + 63) / 64;          // channel chunks of 64
-  const int Cs = nch * 64 + 1;            // LDS row stride of the query fragments (odd)
+  const int nch = (C + 2 * KCH - 1) / (2 * KCH);  // channel chunks of 2 KCH
+  const int Cs = nch * 2 * KCH + 1;               // LDS row stride of the query fragments (odd)
   float* Aq = smem;                       // [32][Cs]
   float* region = smem + 32 * Cs;         // pass A: gmax [32][2*KB_GROUPS + 1]; pass B: buffers
   const float* xb = xT + (long)b * C * ldT;
   const float* nb = nrm + (long)b * N;
 
-  for (int e = tid; e < 32 * nch * 64; e += 64 * KB_WAVES) {
+  for (int e = tid; e < 32 * nch * 2 * KCH; e += 64 * KB_WAVES) {
     const int c = e >> 5, jj = e & 31;
     const float v = xb[(long)min(c, C - 1) * ldT + min(q0 + jj, n - 1)];
     Aq[jj * Cs + c] = r3d_keep(v, c < C && q0 + jj < n);
@@ -570,27 +577,27 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_big_kernel(
   const int my_sub = (nsub - w + KB_WAVES - 1) / KB_WAVES;  // sub-tiles of this wave (w < nsub assumed below)
   const int T = (w < nsub) ? my_sub * nch : 0;              // (sub-tile, chunk) units
 
-  auto bload = [&](int t, float (&bf)[32]) {
+  auto bload = [&](int t, float (&bf)[KCH]) {
     const int st = w + KB_WAVES * (t / nch), ch = t % nch;
     const int cand = 32 * st + j;
     const bool ok = cand < n;
     const int cc = min(cand, n - 1);
 #pragma unroll
-    for (int s = 0; s < 32; ++s) {
-      const int c = 64 * ch + 2 * s + h;
+    for (int s = 0; s < KCH; ++s) {
+      const int c = 2 * KCH * ch + 2 * s + h;
       bf[s] = r3d_keep(xb[(long)min(c, C - 1) * ldT + cc], ok && c < C);
     }
   };
   f32x16 acc;
-  auto mma = [&](int t, const float (&bf)[32]) {
+  auto mma = [&](int t, const float (&bf)[KCH]) {
     const int ch = t % nch;
     if (ch == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     }
-    const float* ap = Aq + j * Cs + 64 * ch + h;
+    const float* ap = Aq + j * Cs + 2 * KCH * ch + h;
 #pragma unroll
-    for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bf[s], acc, 0, 0, 0);
+    for (int s = 0; s < KCH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bf[s], acc, 0, 0, 0);
   };
   auto scores = [&](int st, f32x16& sc) {
     const int cand = 32 * st + j;
@@ -612,7 +619,7 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_big_kernel(
     }
   };
 
-  float bfA[32], bfB[32];
+  float bfA[KCH], bfB[KCH];
   // ------------------------------------------------------------------ pass A: top-2 per group
   float g1[16], g2[16];
 #pragma unroll
@@ -624,9 +631,11 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_big_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float x = sc[r];
-      const float lo = fminf(g1[r], x);
+      if (KB_TOP == 2) {
+        const float lo = fminf(g1[r], x);
+        g2[r] = fmaxf(g2[r], lo);
+      }
       g1[r] = fmaxf(g1[r], x);
-      g2[r] = fmaxf(g2[r], lo);
     }
   };
   if (T > 0) bload(0, bfA);
@@ -640,25 +649,25 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_big_kernel(
     finishA(t + 1);
   }
   {
-    constexpr int GS = 2 * KB_GROUPS + 1;
+    constexpr int GS = KB_TOP * KB_GROUPS + 1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int q = r3d_acc_row(r, lane);
-      region[q * GS + 2 * (32 * w + j)] = g1[r];
-      region[q * GS + 2 * (32 * w + j) + 1] = g2[r];
+      region[q * GS + KB_TOP * (32 * w + j)] = g1[r];
+      if (KB_TOP == 2) region[q * GS + 2 * (32 * w + j) + 1] = g2[r];
     }
     __syncthreads();
     for (int qq = 0; qq < 32 / KB_WAVES; ++qq) {
       const int q = (32 / KB_WAVES) * w + qq;
-      unsigned key[2 * KB_GROUPS / 64];
+      unsigned key[KB_TOP * KB_GROUPS / 64];
 #pragma unroll
-      for (int i = 0; i < 2 * KB_GROUPS / 64; ++i) key[i] = f2key(region[q * GS + 64 * i + lane]) >> 16;
+      for (int i = 0; i < KB_TOP * KB_GROUPS / 64; ++i) key[i] = f2key(region[q * GS + 64 * i + lane]) >> 16;
       unsigned res = 0;  // largest 16-bit key prefix with at least k retained values at or above it
       for (int bit = 15; bit >= 0; --bit) {
         const unsigned cand = res | (1u << bit);
         int c = 0;
 #pragma unroll
-        for (int i = 0; i < 2 * KB_GROUPS / 64; ++i) c += __popcll(__ballot(key[i] >= cand));
+        for (int i = 0; i < KB_TOP * KB_GROUPS / 64; ++i) c += __popcll(__ballot(key[i] >= cand));
         if (c >= k) res = cand;
       }
       if (lane == 0) tau_s[q] = key2f(res << 16);  // truncation rounds DOWN in key order: still a lower bound
@@ -703,7 +712,10 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_big_kernel(
     mma(t + 1, bfB);
     finishB(t + 1);
   }
-  if (__any(overflow) && lane == 0 && status) atomicOr(status, 1);
+  if (__any(overflow) && lane == 0) {
+    if (status) atomicOr(status, 1);
+    if (tile_flags) tile_flags[(long)b * gridDim.x + blockIdx.x] = 1;
+  }
   __syncthreads();
 
   // ------------------------------------------------------------------ rank the survivors
@@ -737,13 +749,19 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_big_kernel(
   }
 }
 
-static size_t knn_big_lds_bytes(int C) {
-  const int nch = (C + 63) / 64;
-  const size_t a = 32 * (size_t)(nch * 64 + 1);
-  const size_t g = 32 * (size_t)(2 * KB_GROUPS + 1);
-  const size_t bsz = 2 * 32 * (size_t)KB_CAP;
+static size_t knn_append_lds_bytes(int C, int waves, int cap, int top, int kch = 32) {
+  const int nch = (C + 2 * kch - 1) / (2 * kch);
+  const size_t a = 32 * (size_t)(nch * 2 * kch + 1);
+  const size_t g = 32 * (size_t)(top * waves * 32 + 1);
+  const size_t bsz = 2 * 32 * (size_t)cap;
   return sizeof(float) * (a + (g > bsz ? g : bsz));
 }
+static size_t knn_big_lds_bytes(int C) { return knn_append_lds_bytes(C, 8, 384, 2); }
+#ifndef KM_WAVES  // mid configuration (overridable for tools/knnbench sweeps)
+#define KM_WAVES 4
+#define KM_CAP 128
+#define KM_TOP 1
+#endif
 
 static size_t knn_lds_bytes(int C) {
   const int Cp = (C + 1) & ~1;
@@ -764,8 +782,10 @@ extern "C" int r3d_pm_to_cm_pitched(const float* in, long ld, int B, int C, int 
 // row pitch of the internal channel-major copies: N + 32 floats, so that consecutive channels of
 // one point do not sit a power-of-two stride apart (same L2 channel for every load of a chain)
 extern "C" long r3d_cm_pitch(int N) { return (long)((N + 31) / 32) * 32 + 32; }
+// floats of norm_ws: the squared norms (B*N) + one overflow flag per 32-row tile (k <= 32 path) + padding
+extern "C" long r3d_knn_norm_ws_words(int B, int N) { return (long)B * N + (long)B * ((N + 31) / 32) + 64; }
 
-// x: (B*N, ldx) point-major fp32; norm_ws: (B*N) fp32 scratch; idx_out: (B, N, k) int32;
+// x: (B*N, ldx) point-major fp32; norm_ws: r3d_knn_norm_ws_words(B, N) fp32 scratch; idx_out: (B, N, k) int32;
 // score_out: optional (B, N, k) fp32; n_valid_dev: optional device int, rows >= *n are
 // neither queried nor offered as candidates (used by the head where the node count
 // is data dependent and stays on the device).
@@ -794,12 +814,41 @@ extern "C" int r3d_knn_topk(const float* x, long ldx, const float* x_cm, int B, 
     }
     hipLaunchKernelGGL(r3d_sqnorm_cm_kernel, dim3(r3d_cdiv(N, 256), B), dim3(256), 0, st, xT, ldT, C, N, norm_ws);
     dim3 g2(r3d_cdiv(N, 32), B);
-    if (C <= 16)
-      hipLaunchKernelGGL(r3d_knn_small_kernel<8>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, norm_ws,
-                         idx_out, score_out);
-    else
-      hipLaunchKernelGGL(r3d_knn_small_kernel<32>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, norm_ws,
-                         idx_out, score_out);
+    static const bool two_pass_only = getenv("R3D_KNN_TWO_PASS") != nullptr;  // A/B switch for tools/knnbench
+    int* tile_flags = (int*)(norm_ws + (long)B * N);  // r3d_knn_norm_ws_words reserves B * ceil(N/32) words here
+    if (two_pass_only) {
+      if (C <= 16)
+        hipLaunchKernelGGL(r3d_knn_small_kernel<8>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, norm_ws,
+                           idx_out, score_out, (const int*)nullptr);
+      else
+        hipLaunchKernelGGL(r3d_knn_small_kernel<32>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, norm_ws,
+                           idx_out, score_out, (const int*)nullptr);
+    } else {
+      // append-and-rank (mid configuration); tiles whose survivor buffer overflowed are redone by the exact
+      // sorted-insertion kernel in the same stream -- no host round trip, never a wrong result
+      r3d_zero_words(tile_flags, (long)B * g2.x, st);
+      const size_t lds = knn_append_lds_bytes(C, KM_WAVES, KM_CAP, KM_TOP, C <= 16 ? 8 : 32);
+      static size_t mid_attr[2] = {0, 0};
+      if (lds > mid_attr[C <= 16]) {
+        hipError_t e = C <= 16 ? hipFuncSetAttribute((const void*)r3d_knn_append_kernel<KM_WAVES, KM_CAP, KM_TOP, 8>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                               : hipFuncSetAttribute((const void*)r3d_knn_append_kernel<KM_WAVES, KM_CAP, KM_TOP, 32>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        R3D_REQUIRE(e == hipSuccess, "r3d_knn_topk(mid): cannot reserve %zu B of LDS", lds);
+        mid_attr[C <= 16] = lds;
+      }
+      if (C <= 16) {
+        hipLaunchKernelGGL((r3d_knn_append_kernel<KM_WAVES, KM_CAP, KM_TOP, 8>), g2, dim3(64 * KM_WAVES), lds, st, xT, ldT, N, C,
+                           k, mode, n_valid_dev, norm_ws, idx_out, score_out, (int*)nullptr, tile_flags);
+        hipLaunchKernelGGL(r3d_knn_small_kernel<8>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, norm_ws,
+                           idx_out, score_out, (const int*)tile_flags);
+      } else {
+        hipLaunchKernelGGL((r3d_knn_append_kernel<KM_WAVES, KM_CAP, KM_TOP, 32>), g2, dim3(64 * KM_WAVES), lds, st, xT, ldT, N, C,
+                           k, mode, n_valid_dev, norm_ws, idx_out, score_out, (int*)nullptr, tile_flags);
+        hipLaunchKernelGGL(r3d_knn_small_kernel<32>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, norm_ws,
+                           idx_out, score_out, (const int*)tile_flags);
+      }
+    }
     R3D_LAUNCH_CHECK("r3d_knn_topk(small)");
     return R3D_OK;
   }
@@ -819,14 +868,14 @@ extern "C" int r3d_knn_topk(const float* x, long ldx, const float* x_cm, int B, 
     r3d_zero_words(status, 1, st);
     static size_t big_attr = 0;  // static __shared__ arrays count against the 160 KiB too: ask for what is used
     if (knn_big_lds_bytes(C) > big_attr) {
-      hipError_t e = hipFuncSetAttribute((const void*)r3d_knn_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+      hipError_t e = hipFuncSetAttribute((const void*)r3d_knn_append_kernel<8, 384, 2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)knn_big_lds_bytes(C));
       R3D_REQUIRE(e == hipSuccess, "r3d_knn_topk(big): cannot reserve %zu B of LDS: %s", knn_big_lds_bytes(C),
                   hipGetErrorString(e));
       big_attr = knn_big_lds_bytes(C);
     }
-    hipLaunchKernelGGL(r3d_knn_big_kernel, dim3(r3d_cdiv(N, 32), B), dim3(64 * KB_WAVES), knn_big_lds_bytes(C), st,
-                       xT, ldT, N, C, k, mode, n_valid_dev, norm_ws, idx_out, score_out, status);
+    hipLaunchKernelGGL((r3d_knn_append_kernel<8, 384, 2, 32>), dim3(r3d_cdiv(N, 32), B), dim3(64 * 8), knn_big_lds_bytes(C), st,
+                       xT, ldT, N, C, k, mode, n_valid_dev, norm_ws, idx_out, score_out, status, (int*)nullptr);
     R3D_LAUNCH_CHECK("r3d_knn_topk(big)");
     return R3D_OK;
   }

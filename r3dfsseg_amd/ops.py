@@ -133,7 +133,7 @@ def knn(x_pm, B, N, k, mode=SCORE_DGCNN, n_valid=None, return_scores=False, x_cm
     C = x_pm.shape[1]
     assert M == B * N
     dev = x_pm.device
-    norm = torch.empty(M, device=dev, dtype=torch.float32)
+    norm = torch.empty(_lib.load().r3d_knn_norm_ws_words(B, N), device=dev, dtype=torch.float32)
     idx = torch.empty(B, N, k, device=dev, dtype=torch.int32)
     sc = torch.empty(B, N, k, device=dev, dtype=torch.float32) if return_scores else None
     cm_ws = None

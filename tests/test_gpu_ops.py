@@ -61,6 +61,21 @@ def test_knn_duplicate_points_ties(ops):
     assert np.array_equal(got.cpu().numpy().astype(np.int64), want.numpy())
 
 
+def test_knn_massive_duplicates_overflow_repair(ops):
+    """300 identical points in a 64-channel cloud: for those rows 300 candidates tie at the best score, far more than
+    the 128-slot survivor buffer of the append-and-rank kernel, so their tiles are redone by the exact insertion
+    kernel in the same stream.  The result must still be the oracle's (ties -> lower index), bit for bit."""
+    rs = np.random.RandomState(5)
+    x = rs.randn(2, 64, 1024).astype(np.float32)
+    dup = rs.permutation(1024)[:300]
+    x[0][:, dup] = x[0][:, dup[:1]]
+    x = torch.from_numpy(x)
+    want, wsc = O.knn(x, 20, return_dist=True)
+    got, gsc = ops.knn(ops.cm_to_pm(_dev(x)), 2, 1024, 20, return_scores=True)
+    assert np.array_equal(gsc.cpu().numpy(), wsc.numpy())
+    assert np.array_equal(got.cpu().numpy().astype(np.int64), want.numpy())
+
+
 def test_knn_full_size_properties(ops):
     """BASELINE size (12 clouds x 2048 x 64): size-independent properties + a sampled oracle check."""
     B, C, N, k = 12, 64, 2048, 20

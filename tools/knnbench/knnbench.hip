@@ -13,7 +13,7 @@ int main(int argc, char** argv) {
   for (auto& v : h) v = rand() / (float)RAND_MAX - 0.5f;
   float *x, *nrm, *cm; int* idx; int* status; hipMalloc(&status, 4);
   hipMalloc(&cm, (size_t)B * C * (N + 64) * 4);
-  hipMalloc(&x, h.size() * 4); hipMalloc(&nrm, (size_t)B * N * 4); hipMalloc(&idx, (size_t)B * N * k * 4);
+  hipMalloc(&x, h.size() * 4); hipMalloc(&nrm, (size_t)r3d_knn_norm_ws_words(B, N) * 4); hipMalloc(&idx, (size_t)B * N * k * 4);
   hipMemcpy(x, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int it = 0; it < 3; ++it) r3d_knn_topk(x, C, nullptr, B, N, C, k, mode, nullptr, nrm, cm, idx, nullptr, status, 0);
