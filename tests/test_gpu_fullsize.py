@@ -1,0 +1,102 @@
+"""Full-size runs (BASELINE.json configs[1], [2], [3]) checked through size-independent properties and, where the
+oracle finishes in seconds, against the oracle itself."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import r3d_oracle as O
+from r3dfsseg_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(cfg):
+    from r3dfsseg_amd.mpti import MPTI_SelfAtten
+    m = MPTI_SelfAtten(SimpleNamespace(**cfg))
+    m.load_state_dict(S.make_state_dict(cfg, 123))
+    return m.cuda().eval()
+
+
+def _lp_residual(model):
+    """|| Y - (I - alpha S) Z ||_F / || Y ||_F per label column, S rebuilt from the CSR the solver left in its workspace."""
+    from r3dfsseg_amd import ops
+    hb = model._head[1]
+    n = int(hb.desc[ops.HD_N_NODES].item())
+    words = (hb.n_cap + 31) // 32
+    nnz_cap = 2 * hb.n_cap * (hb.kp1 - 1)
+    o_rowptr = 2 * hb.n_cap * words + hb.n_cap + 8
+    o_col = o_rowptr + hb.n_cap + 8
+    o_val = o_col + nnz_cap
+    row_ptr = hb.lp_ws[o_rowptr:o_rowptr + n + 1].to(torch.int64)
+    nnz = int(row_ptr[-1].item())
+    col = hb.lp_ws[o_col:o_col + nnz].to(torch.int64)
+    val = hb.lp_ws[o_val:o_val + nnz].view(torch.float32)
+    Sm = torch.sparse_csr_tensor(row_ptr, col, val.double(), size=(n, n))
+    Z, Y = hb.Z[:n].double(), hb.Y[:n].double()
+    r = Y - (Z - 0.99 * (Sm @ Z))
+    # structure of the graph: symmetric, zero diagonal, every row has at least k_connect entries
+    dense_rows = (row_ptr[1:] - row_ptr[:-1])
+    assert int(dense_rows.min()) >= hb.kp1 - 1 - 1
+    return (r.norm(dim=0) / Y.norm(dim=0).clamp(min=1e-30)).cpu().numpy(), n, nnz
+
+
+@pytest.mark.parametrize("workload,noise", [("S", 0.0), ("S", 0.4), ("C", 0.2)])
+def test_full_size_eval_properties(workload, noise):
+    cfg = S.workload_cfg(workload)
+    m = _model(cfg)
+    data, _ = S.make_episode(cfg, seed=77, noise_ratio=noise)
+    sx, sy, qx, qy = [t.cuda() for t in data[:4]]
+    with torch.no_grad():
+        l1, loss1 = m(sx, sy, qx, qy)
+        iters = None
+        if not m.lp_converged():  # the caller's protocol (MPTILearner_V3.test): re-run with the full budget
+            iters = m.lp_max_iter
+            l1, loss1 = m(sx, sy, qx, qy, lp_iters=iters)
+            assert m.lp_converged()
+        res, n, nnz = _lp_residual(m)
+        l2, loss2 = m(sx, sy, qx, qy, lp_iters=iters)
+    assert torch.equal(l1, l2) and torch.equal(loss1, loss2)                  # deterministic, idempotent
+    assert torch.isfinite(l1).all() and l1.shape == (cfg["n_way"], cfg["n_way"] + 1, cfg["pc_npts"])
+    assert (res[:cfg["n_way"] + 1] < 2e-5).all(), res                          # Z solves (I - alpha S) Z = Y
+    assert n <= m._head[1].n_cap and nnz <= 2 * n * cfg["k_connect"]
+
+
+def test_full_size_S_against_oracle():
+    """configs[1] / [2] at full size: S3DIS 2-way 5-shot 2048 pts with 40 % noisy shots, one episode."""
+    cfg = S.workload_cfg("S")
+    sd = S.make_state_dict(cfg, 123)
+    m = _model(cfg)
+    data, _ = S.make_episode(cfg, seed=78, noise_ratio=0.4)
+    sx, sy, qx, qy = data[:4]
+    with torch.no_grad():
+        logits, loss = m(sx.cuda(), sy.cuda(), qx.cuda(), qy.cuda())
+    want_logits, want_loss = O.mpti_forward(sd, cfg, sx, sy, qx, qy)
+    agree = (logits.cpu().argmax(1) == want_logits.argmax(1)).float().mean().item()
+    assert agree >= 0.99, agree
+    assert abs(loss.item() - want_loss.item()) < 5e-3
+    # logits are O(1..3): 1e-4 relative to max(1, |value|).  Measured: median 1.4e-5, 99 % below 5e-5 relative; the
+    # tail (max 2e-3) sits behind fp32 near-ties of a neighbour choice in layers 2 / 3
+    d = (logits.cpu() - want_logits).abs() / want_logits.abs().clamp(min=1.0)
+    assert (d < 1e-4).float().mean().item() >= 0.99 and d.max().item() < 1e-2, (d.max().item(),)
+
+
+def test_full_size_graph_slots_match_eager():
+    from r3dfsseg_amd.episode_graph import EpisodeGraphs
+    cfg = S.workload_cfg("S")
+    m = _model(cfg)
+    eps = []
+    for e in range(6):
+        data, _ = S.make_episode(cfg, seed=90 + e, noise_ratio=0.2)
+        eps.append([t.cuda() for t in data[:4]])
+    with torch.no_grad():
+        eager = [m(*ep)[0].clone() for ep in eps]
+    g = EpisodeGraphs(m, eps[0], n_slots=4, train=False)
+    out = torch.empty(len(eps), *eager[0].shape, device="cuda")
+    g.run(eps, logits_out=out)
+    torch.cuda.synchronize()
+    bad, _, _ = g.check()
+    assert bad == 0
+    for e in range(len(eps)):
+        np.testing.assert_allclose(out[e].cpu().numpy(), eager[e].cpu().numpy(), atol=2e-5, rtol=1e-5)
