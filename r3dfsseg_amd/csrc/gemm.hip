@@ -28,8 +28,8 @@ __global__ __launch_bounds__(256) void r3d_pointwise_gemm_kernel(
     const float* __restrict__ X, long ldx, const float* __restrict__ W, int M, int K, int Co,
     const float* __restrict__ scale, const float* __restrict__ shift, int act,
     float* __restrict__ Out, long ldo, int accumulate, float* __restrict__ stats_part /* [tiles_m][2][Co] or NULL */) {
-  __shared__ float Xs[G_BM * G_LD];
-  __shared__ float Ws[G_BN * G_LD];
+  __shared__ float Xs[2][G_BM * G_LD];
+  __shared__ float Ws[2][G_BN * G_LD];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
   const long m0 = (long)blockIdx.x * G_BM;
@@ -38,10 +38,11 @@ __global__ __launch_bounds__(256) void r3d_pointwise_gemm_kernel(
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int srow = tid >> 5, scol = tid & 31;  // 8 rows x 32 cols per pass
-  for (int k0 = 0; k0 < K; k0 += G_BK) {
-    // phase 1: all global loads (unconditional, clamped addresses; common.h: r3d_keep);
-    // phase 2: all LDS writes -- written as two loops so the loads stay in flight together
-    float xv[G_BM / 8], wv[G_BN / 8];
+  // all global loads of a K-step first (unconditional, clamped addresses; common.h: r3d_keep), the LDS writes
+  // afterwards, and the NEXT K-step's loads in flight behind the current step's MFMAs (two LDS buffers, one
+  // barrier per step)
+  float xv[G_BM / 8], wv[G_BN / 8];
+  auto load_step = [&](int k0) {
     const int gk = k0 + scol;
     const int gkc = min(gk, K - 1);
 #pragma unroll
@@ -52,19 +53,29 @@ __global__ __launch_bounds__(256) void r3d_pointwise_gemm_kernel(
       xv[p] = r3d_keep(X[min(gm, (long)M - 1) * ldx + gkc], gm < M && gk < K);
       wv[p] = r3d_keep(W[(long)min(gj, Co - 1) * K + gkc], gj < Co && gk < K);
     }
-    __syncthreads();
+  };
+  auto store_step = [&](int buf) {
 #pragma unroll
     for (int p = 0; p < G_BM / 8; ++p) {
       const int row = srow + 8 * p;
-      Xs[row * G_LD + scol] = xv[p];
-      Ws[row * G_LD + scol] = wv[p];
+      Xs[buf][row * G_LD + scol] = xv[p];
+      Ws[buf][row * G_LD + scol] = wv[p];
     }
-    __syncthreads();
-    const float* ap = Xs + (32 * wm + (lane & 31)) * G_LD + (lane >> 5);
-    const float* bp = Ws + (32 * wn + (lane & 31)) * G_LD + (lane >> 5);
+  };
+  load_step(0);
+  store_step(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < K; k0 += G_BK, buf ^= 1) {
+    const bool more = k0 + G_BK < K;
+    if (more) load_step(k0 + G_BK);
+    const float* ap = Xs[buf] + (32 * wm + (lane & 31)) * G_LD + (lane >> 5);
+    const float* bp = Ws[buf] + (32 * wn + (lane & 31)) * G_LD + (lane >> 5);
 #pragma unroll
     for (int kk = 0; kk < G_BK; kk += 2)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk], acc, 0, 0, 0);
+    if (more) store_step(buf ^ 1);
+    __syncthreads();
   }
   const int j = n0 + 32 * wn + (lane & 31);
   const bool jok = j < Co;
@@ -87,7 +98,7 @@ __global__ __launch_bounds__(256) void r3d_pointwise_gemm_kernel(
     s1 += __shfl_xor(s1, 32);
     s2 += __shfl_xor(s2, 32);
     __syncthreads();  // the MFMA loop is done with Xs
-    float* red = Xs;  // [wm][wn][2][32]
+    float* red = Xs[0];  // [wm][wn][2][32]
     if (lane < 32) {
       red[((wm * 2 + wn) * 2 + 0) * 32 + lane] = s1;
       red[((wm * 2 + wn) * 2 + 1) * 32 + lane] = s2;

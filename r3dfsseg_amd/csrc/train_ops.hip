@@ -157,8 +157,8 @@ static int tn_rows(long M, int Ca, int Cb) {
 __global__ __launch_bounds__(256) void r3d_gemm_tn_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B,
                                                           long ldb, long M, int Ca, int Cb, int TN_ROWS,
                                                           float* __restrict__ part /* [chunks][Ca][Cb] */) {
-  __shared__ float As[32 * 65];  // [m][i]
-  __shared__ float Bs[32 * 65];  // [m][j]
+  __shared__ float As[2][32 * 65];  // [buffer][m][i]
+  __shared__ float Bs[2][32 * 65];  // [buffer][m][j]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wi = w >> 1, wj = w & 1;
   const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void r3d_gemm_tn_kernel(const float* __restric
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int srow = tid >> 6, scol = tid & 63;  // 4 rows x 64 cols per pass
-  for (long m0 = m_beg; m0 < m_end; m0 += 32) {
-    float av[8], bv[8];
+  float av[8], bv[8];
+  auto load_stage = [&](long m0) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const long m = m0 + srow + 4 * p;
@@ -176,20 +176,32 @@ __global__ __launch_bounds__(256) void r3d_gemm_tn_kernel(const float* __restric
       av[p] = r3d_keep(A[mc * lda + min(i0 + scol, Ca - 1)], m < m_end && i0 + scol < Ca);
       bv[p] = r3d_keep(B[mc * ldb + min(j0 + scol, Cb - 1)], m < m_end && j0 + scol < Cb);
     }
-    __syncthreads();
+  };
+  auto store_stage = [&](int buf) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-      As[(srow + 4 * p) * 65 + scol] = av[p];
-      Bs[(srow + 4 * p) * 65 + scol] = bv[p];
+      As[buf][(srow + 4 * p) * 65 + scol] = av[p];
+      Bs[buf][(srow + 4 * p) * 65 + scol] = bv[p];
     }
-    __syncthreads();
+  };
+  // software pipeline: the next 32-row stage is in flight (global -> registers) behind the MFMAs of the current
+  // one and lands in the other LDS buffer: one barrier per stage
+  load_stage(m_beg);
+  store_stage(0);
+  __syncthreads();
+  int buf = 0;
+  for (long m0 = m_beg; m0 < m_end; m0 += 32, buf ^= 1) {
+    const bool more = m0 + 32 < m_end;
+    if (more) load_stage(m0 + 32);
     // MFMA A operand: A^T[i][m] -> lane (i = lane&31, k = m): As[m][32*wi + i]
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int m = 2 * s + (lane >> 5);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[m * 65 + 32 * wi + (lane & 31)], Bs[m * 65 + 32 * wj + (lane & 31)],
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const int m = 2 * s2 + (lane >> 5);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][m * 65 + 32 * wi + (lane & 31)], Bs[buf][m * 65 + 32 * wj + (lane & 31)],
                                                  acc, 0, 0, 0);
     }
+    if (more) store_stage(buf ^ 1);
+    __syncthreads();
   }
   const int j = j0 + 32 * wj + (lane & 31);
 #pragma unroll
