@@ -188,6 +188,8 @@ def main():
             model(sx, sy, qx, qy)
         lp_flags.append(head_flags())
 
+    invalid = []  # reasons why a timed leg does not count (every episode must have a converged, exact head)
+
     def timed(step_fn, steps, warmup, graphs=None):
         for i in range(warmup):
             step_fn(i)
@@ -210,15 +212,16 @@ def main():
             el = t.item()
         if graphs is not None:
             bad, it_sum, it_max = graphs.check()
-            if bad:
-                raise SystemExit("bench invalid: %d timed episode(s) with unconverged label propagation (CG max %d of budget %d), %d with 201-NN survivor overflow"
-                                 % (graphs.last_unconverged, it_max, graphs.lp_budget, graphs.last_knn_overflow))
+            if bad:  # recorded, not fatal: an abort on one rank would leave the others in the next barrier
+                invalid.append("%s: %d episode(s) with unconverged label propagation / FPS time-out (CG max %d of budget %d), "
+                               "%d with 201-NN survivor overflow" % (step_fn.__name__, graphs.last_unconverged, it_max,
+                                                                     graphs.lp_budget, graphs.last_knn_overflow))
             return el, (it_sum / (steps * E), it_max)
         lp = torch.stack(lp_flags).cpu()
         if int(lp[:, 2].max()) != 0:
-            raise SystemExit("bench invalid: 201-NN survivor buffer overflowed")
+            invalid.append("%s: 201-NN survivor buffer overflowed" % step_fn.__name__)
         if int(lp[:, 0].min()) != 1:
-            raise SystemExit("bench invalid: label propagation did not converge in %d timed episode(s)" % int((lp[:, 0] != 1).sum()))
+            invalid.append("%s: label propagation did not converge in %d episode(s)" % (step_fn.__name__, int((lp[:, 0] != 1).sum())))
         return el, (float(lp[:, 1].float().mean()), int(lp[:, 1].max()))
 
     extra = {}
@@ -258,6 +261,9 @@ def main():
     ksum_all = timer.summary()
     cg_mean, cg_max = cg
 
+    n_invalid = torch.tensor([float(len(invalid))], device=dev)
+    if dist is not None:
+        dist.all_reduce(n_invalid)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -359,11 +365,14 @@ def main():
             args.workload, cfg["n_way"], cfg["k_shot"], N, B, E,
             "%d in flight as hipGraphs on HIP streams" % G if G else "eager launches", args.mode),
             "episodes_per_step": E * world, "episodes_per_rank": E, "slots": G},
+        "valid": int(n_invalid.item()) == 0, "invalid": invalid,
         "roofline": roof, "rooflines": rooflines, "cpu_baseline": cpu,
         "entry_point_ms_per_step": breakdown,
         "lp_cg_iterations": {"mean": cg_mean, "max": cg_max},
     }
     out.update(extra)
+    if not out["valid"]:
+        print("bench.py: WARNING, the line below is flagged invalid: %s" % "; ".join(invalid), file=sys.stderr)
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -46,7 +46,7 @@ class EpisodeGraphs:
             self.grad_rows = grad_rows if grad_rows is not None else torch.zeros(n_slots, n, device=dev)
             assert self.grad_rows.shape[0] == n_slots and self.grad_rows.shape[1] >= n
         if lp_budget is None:  # CG iterations frozen into the graph; launches after convergence are no-ops (~3 us each)
-            lp_budget = min(model.lp_max_iter, 160 if train else 96)
+            lp_budget = min(model.lp_max_iter, 200 if train else 128)
         self.lp_budget = lp_budget
         self.slots = []
         self.ev_start = torch.cuda.Event()
