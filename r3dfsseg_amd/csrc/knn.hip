@@ -537,7 +537,8 @@ __global__ __launch_bounds__(256) void r3d_knn_small_kernel(
 //       threads and a third of the LDS, so two workgroups share a CU and overlap their phases; a 32-row tile whose
 //       buffer overflowed (> 128 candidates at or above tau: duplicated points tie exactly) sets tile_flags[tile]
 //       and is recomputed by the exact insertion kernel launched right behind (it returns at once elsewhere).
-template <int KB_WAVES, int KB_CAP, int KB_TOP, int KCH /* k-pairs per channel chunk: 32 (64 channels) or 8 (16) */>
+template <int KB_WAVES, int KB_CAP, int KB_TOP, int KCH /* k-pairs per channel chunk: 32 (64 channels) or 8 (16) */,
+          int KB_SAMPLE /* pass A visits every KB_SAMPLE-th sub-tile of a wave: tau from a sample is still a lower bound */>
 __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_append_kernel(
     const float* __restrict__ xT, long ldT, int N, int C, int k, int mode, const int* __restrict__ n_dev,
     const float* __restrict__ nrm, int* __restrict__ idx_out, float* __restrict__ score_out,
@@ -577,8 +578,9 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_append_kernel(
   const int my_sub = (nsub - w + KB_WAVES - 1) / KB_WAVES;  // sub-tiles of this wave (w < nsub assumed below)
   const int T = (w < nsub) ? my_sub * nch : 0;              // (sub-tile, chunk) units
 
+  int stride = KB_SAMPLE;  // sub-tile stride of the running pass (pass A: the sample; pass B: 1)
   auto bload = [&](int t, float (&bf)[KCH]) {
-    const int st = w + KB_WAVES * (t / nch), ch = t % nch;
+    const int st = w + KB_WAVES * stride * (t / nch), ch = t % nch;
     const int cand = 32 * st + j;
     const bool ok = cand < n;
     const int cc = min(cand, n - 1);
@@ -627,7 +629,7 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_append_kernel(
   auto finishA = [&](int t) {
     if (t % nch != nch - 1) return;
     f32x16 sc;
-    scores(w + KB_WAVES * (t / nch), sc);
+    scores(w + KB_WAVES * stride * (t / nch), sc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float x = sc[r];
@@ -638,16 +640,18 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_append_kernel(
       g1[r] = fmaxf(g1[r], x);
     }
   };
-  if (T > 0) bload(0, bfA);
-  for (int t = 0; t < T; t += 2) {
-    if (t + 1 < T) bload(t + 1, bfB);
+  const int TA = (w < nsub) ? ((my_sub + KB_SAMPLE - 1) / KB_SAMPLE) * nch : 0;  // sampled units of pass A
+  if (TA > 0) bload(0, bfA);
+  for (int t = 0; t < TA; t += 2) {
+    if (t + 1 < TA) bload(t + 1, bfB);
     mma(t, bfA);
     finishA(t);
-    if (t + 1 >= T) break;
-    if (t + 2 < T) bload(t + 2, bfA);
+    if (t + 1 >= TA) break;
+    if (t + 2 < TA) bload(t + 2, bfA);
     mma(t + 1, bfB);
     finishA(t + 1);
   }
+  stride = 1;
   {
     constexpr int GS = KB_TOP * KB_GROUPS + 1;
 #pragma unroll
@@ -762,6 +766,10 @@ static size_t knn_big_lds_bytes(int C) { return knn_append_lds_bytes(C, 8, 384, 
 #define KM_CAP 128
 #define KM_TOP 1
 #endif
+#ifndef KM_SAMPLE
+#define KM_SAMPLE 2  // pass A on half of the candidates: ~2k survivors in pass B (40 of 128 slots at k = 20); measured
+                     // 277 us per call against 306 (no sampling), 324 (1/4, 192 slots) and 841 (1/8: repairs)
+#endif
 
 static size_t knn_lds_bytes(int C) {
   const int Cp = (C + 1) & ~1;
@@ -830,20 +838,20 @@ extern "C" int r3d_knn_topk(const float* x, long ldx, const float* x_cm, int B, 
       const size_t lds = knn_append_lds_bytes(C, KM_WAVES, KM_CAP, KM_TOP, C <= 16 ? 8 : 32);
       static size_t mid_attr[2] = {0, 0};
       if (lds > mid_attr[C <= 16]) {
-        hipError_t e = C <= 16 ? hipFuncSetAttribute((const void*)r3d_knn_append_kernel<KM_WAVES, KM_CAP, KM_TOP, 8>,
+        hipError_t e = C <= 16 ? hipFuncSetAttribute((const void*)r3d_knn_append_kernel<KM_WAVES, KM_CAP, KM_TOP, 8, KM_SAMPLE>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                               : hipFuncSetAttribute((const void*)r3d_knn_append_kernel<KM_WAVES, KM_CAP, KM_TOP, 32>,
+                               : hipFuncSetAttribute((const void*)r3d_knn_append_kernel<KM_WAVES, KM_CAP, KM_TOP, 32, KM_SAMPLE>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         R3D_REQUIRE(e == hipSuccess, "r3d_knn_topk(mid): cannot reserve %zu B of LDS", lds);
         mid_attr[C <= 16] = lds;
       }
       if (C <= 16) {
-        hipLaunchKernelGGL((r3d_knn_append_kernel<KM_WAVES, KM_CAP, KM_TOP, 8>), g2, dim3(64 * KM_WAVES), lds, st, xT, ldT, N, C,
+        hipLaunchKernelGGL((r3d_knn_append_kernel<KM_WAVES, KM_CAP, KM_TOP, 8, KM_SAMPLE>), g2, dim3(64 * KM_WAVES), lds, st, xT, ldT, N, C,
                            k, mode, n_valid_dev, norm_ws, idx_out, score_out, (int*)nullptr, tile_flags);
         hipLaunchKernelGGL(r3d_knn_small_kernel<8>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, norm_ws,
                            idx_out, score_out, (const int*)tile_flags);
       } else {
-        hipLaunchKernelGGL((r3d_knn_append_kernel<KM_WAVES, KM_CAP, KM_TOP, 32>), g2, dim3(64 * KM_WAVES), lds, st, xT, ldT, N, C,
+        hipLaunchKernelGGL((r3d_knn_append_kernel<KM_WAVES, KM_CAP, KM_TOP, 32, KM_SAMPLE>), g2, dim3(64 * KM_WAVES), lds, st, xT, ldT, N, C,
                            k, mode, n_valid_dev, norm_ws, idx_out, score_out, (int*)nullptr, tile_flags);
         hipLaunchKernelGGL(r3d_knn_small_kernel<32>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, norm_ws,
                            idx_out, score_out, (const int*)tile_flags);
@@ -868,13 +876,13 @@ extern "C" int r3d_knn_topk(const float* x, long ldx, const float* x_cm, int B, 
     r3d_zero_words(status, 1, st);
     static size_t big_attr = 0;  // static __shared__ arrays count against the 160 KiB too: ask for what is used
     if (knn_big_lds_bytes(C) > big_attr) {
-      hipError_t e = hipFuncSetAttribute((const void*)r3d_knn_append_kernel<8, 384, 2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      hipError_t e = hipFuncSetAttribute((const void*)r3d_knn_append_kernel<8, 384, 2, 32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)knn_big_lds_bytes(C));
       R3D_REQUIRE(e == hipSuccess, "r3d_knn_topk(big): cannot reserve %zu B of LDS: %s", knn_big_lds_bytes(C),
                   hipGetErrorString(e));
       big_attr = knn_big_lds_bytes(C);
     }
-    hipLaunchKernelGGL((r3d_knn_append_kernel<8, 384, 2, 32>), dim3(r3d_cdiv(N, 32), B), dim3(64 * 8), knn_big_lds_bytes(C), st,
+    hipLaunchKernelGGL((r3d_knn_append_kernel<8, 384, 2, 32, 1>), dim3(r3d_cdiv(N, 32), B), dim3(64 * 8), knn_big_lds_bytes(C), st,
                        xT, ldT, N, C, k, mode, n_valid_dev, norm_ws, idx_out, score_out, status, (int*)nullptr);
     R3D_LAUNCH_CHECK("r3d_knn_topk(big)");
     return R3D_OK;
