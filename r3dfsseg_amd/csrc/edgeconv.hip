@@ -46,15 +46,31 @@ __global__ __launch_bounds__(512) void r3d_edgeconv_kernel(
       const int e = 32 * w + (lane & 31);  // edge handled by this lane for the index load
       const int my_idx = idx[pt0 * K + e];  // (8 points x K) indices are contiguous
       float* hrow = H + (32 * w) * EC_LD;
-#pragma unroll 8
-      for (int t = 0; t < 32; ++t) {
-        const int j = __builtin_amdgcn_readlane(my_idx, t);
-        const int pi = (32 * w + t) / K;  // local point of edge t
-        const float p = PQ[(cloud0 + j) * 128 + lane];
-        const float q = PQ[(pt0 + pi) * 128 + 64 + lane];
-        float h = p + q;
-        h = h > 0.f ? h : 0.2f * h;
-        hrow[t * EC_LD + lane] = h;
+      // all 32 neighbour rows of the wave in flight at once (the gather is L2-latency bound: 8 at a time took
+      // four round trips per unit), then the adds / stores; the point's own Q row changes at most twice in 32 edges
+      float pv[32];
+#pragma unroll
+      for (int t = 0; t < 32; ++t) pv[t] = PQ[(cloud0 + __builtin_amdgcn_readlane(my_idx, t)) * 128 + lane];
+      const int p_first = (32 * w) / K, p_last = (32 * w + 31) / K;
+      const float q0 = PQ[(pt0 + p_first) * 128 + 64 + lane];
+      const float q1 = PQ[(pt0 + min(p_first + 1, p_last)) * 128 + 64 + lane];
+      const float q2 = PQ[(pt0 + p_last) * 128 + 64 + lane];
+      const int e1 = (p_first + 1) * K - 32 * w, e2 = (p_first + 2) * K - 32 * w;  // first edge of the 2nd / 3rd point
+      if (K >= 16) {  // 32 consecutive edges touch at most 3 points
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+          const float q = t < e1 ? q0 : (t < e2 ? q1 : q2);
+          float h = pv[t] + q;
+          h = h > 0.f ? h : 0.2f * h;
+          hrow[t * EC_LD + lane] = h;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+          float h = pv[t] + PQ[(pt0 + (32 * w + t) / K) * 128 + 64 + lane];
+          h = h > 0.f ? h : 0.2f * h;
+          hrow[t * EC_LD + lane] = h;
+        }
       }
     }
     // ---- second layer on the matrix core (wave-local rows: no barrier needed)

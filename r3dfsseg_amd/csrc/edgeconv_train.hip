@@ -31,11 +31,16 @@ __global__ __launch_bounds__(256) void r3d_edge_stats1_kernel(const float* __res
     const long cloud0 = (pt / N) * N;
     const float q = PQ[pt * 128 + 64 + lane];
     const int my_idx = idx[pt * K + min(lane, K - 1)];
-    for (int t = 0; t < K; ++t) {
-      const int j = __builtin_amdgcn_readlane(my_idx, t);
-      const float e = PQ[(cloud0 + j) * 128 + lane] + q;
-      a += e;
-      b += e * e;
+    for (int t = 0; t < K; t += 4) {  // K % 4 == 0: four neighbour rows in flight (was one: a chain of L2 round trips)
+      float pv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pv[u] = PQ[(cloud0 + __builtin_amdgcn_readlane(my_idx, t + u)) * 128 + lane];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float e = pv[u] + q;
+        a += e;
+        b += e * e;
+      }
     }
   }
   sa[w][lane] = a;
@@ -95,13 +100,18 @@ __global__ __launch_bounds__(512) void r3d_edgeconv_train_fwd_kernel(
     {
       const int my_idx = idx[pt0 * K + 32 * w + (lane & 31)];
       float* hrow = H + (32 * w) * ET_LD;
-#pragma unroll 8
-      for (int t = 0; t < 32; ++t) {
-        const int j = __builtin_amdgcn_readlane(my_idx, t);
-        const int pi = (32 * w + t) / K;
-        const float p = PQ[(cloud0 + j) * 128 + lane];
-        const float q = PQ[(pt0 + pi) * 128 + 64 + lane];
-        hrow[t * ET_LD + lane] = lrelu(sc1 * (p + q) + sh1);
+      // all 32 neighbour rows in flight at once (L2-latency bound gather); the point's own Q row per edge is an
+      // L1 hit and is loaded alongside
+#pragma unroll
+      for (int t0 = 0; t0 < 32; t0 += 16) {  // 32 loads in flight per step (two steps keep 3 waves per SIMD)
+        float pv[16], qv[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          pv[t] = PQ[(cloud0 + __builtin_amdgcn_readlane(my_idx, t0 + t)) * 128 + lane];
+          qv[t] = PQ[(pt0 + (32 * w + t0 + t) / K) * 128 + 64 + lane];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) hrow[(t0 + t) * ET_LD + lane] = lrelu(sc1 * (pv[t] + qv[t]) + sh1);
       }
     }
     f32x16 a0, a1;
@@ -239,17 +249,17 @@ __global__ __launch_bounds__(512) void r3d_edgeconv_bwd1_kernel(
       const int my_idx = idx[pt0 * K + 32 * w + j];
       float* hrow = H + (32 * w) * ET_LD;
 #pragma unroll
-      for (int t0 = 0; t0 < 32; t0 += 8) {  // 16 gathers in flight per step
-        float pv[8], qv[8];
+      for (int t0 = 0; t0 < 32; t0 += 16) {  // 32 gathers in flight per step
+        float pv[16], qv[16];
 #pragma unroll
-        for (int tt = 0; tt < 8; ++tt) {
+        for (int tt = 0; tt < 16; ++tt) {
           const int jn = __builtin_amdgcn_readlane(my_idx, t0 + tt);
           const int pi = ept[32 * w + t0 + tt];
           pv[tt] = PQ[(cloud0 + jn) * 128 + lane];
           qv[tt] = PQ[(pt0 + pi) * 128 + 64 + lane];
         }
 #pragma unroll
-        for (int tt = 0; tt < 8; ++tt) {
+        for (int tt = 0; tt < 16; ++tt) {
           const float e1 = pv[tt] + qv[tt];
           eh[t0 + tt] = (e1 - mu1) * is1;
           hrow[(t0 + tt) * ET_LD + lane] = lrelu(sc1 * e1 + sh1);
@@ -370,12 +380,22 @@ __global__ __launch_bounds__(256) void r3d_edgeconv_bwd2_kernel(
     const float q = PQ[pt * 128 + 64 + lane];
     const int my_idx = idx[pt * K + min(lane, K - 1)];
     float dq = 0.f;
-    for (int t = 0; t < K; ++t) {
-      const int jn = __builtin_amdgcn_readlane(my_idx, t);
-      const float e1 = PQ[(cloud0 + jn) * 128 + lane] + q;
-      const float de = sc1 * (DY1[(pt * K + t) * 64 + lane] - n1 - ((e1 - mu1) * is1) * n2);
-      dq += de;
-      atomicAdd(&dPQ[(cloud0 + jn) * 128 + lane], de);
+    for (int t = 0; t < K; t += 4) {  // K % 4 == 0: four rows of PQ and dy1 in flight
+      float pv[4], dv[4];
+      int jn[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        jn[u] = __builtin_amdgcn_readlane(my_idx, t + u);
+        pv[u] = PQ[(cloud0 + jn[u]) * 128 + lane];
+        dv[u] = DY1[(pt * K + t + u) * 64 + lane];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float e1 = pv[u] + q;
+        const float de = sc1 * (dv[u] - n1 - ((e1 - mu1) * is1) * n2);
+        dq += de;
+        atomicAdd(&dPQ[(cloud0 + jn[u]) * 128 + lane], de);
+      }
     }
     atomicAdd(&dPQ[pt * 128 + 64 + lane], dq);
   }

@@ -139,15 +139,15 @@ def test_pointwise_conv_strided_views(ops):
 
 
 # ------------------------------------------------------------------ a2+a3 EdgeConv (dgcnn.py:26-61,117-118)
-@pytest.mark.parametrize("B,C,N", [(2, 9, 512), (2, 64, 512)])
-def test_edgeconv_vs_oracle(ops, B, C, N):
+@pytest.mark.parametrize("B,C,N,K", [(2, 9, 512, 20), (1, 64, 1024, 20), (1, 64, 256, 8), (1, 64, 256, 12)])
+def test_edgeconv_vs_oracle(ops, B, C, N, K):
     from r3dfsseg_amd.dgcnn import DGCNN
     cfg = S.make_cfg()
     sd = S.make_state_dict(cfg, 123)
     layer = 0 if C == 9 else 1
     x = _rand((B, C, N), 51, 0.5)
-    idx = O.knn(x, 20)
-    e = O.get_edge_feature(x, 20, idx)
+    idx = O.knn(x, K)
+    e = O.get_edge_feature(x, K, idx)
     want = O.conv_block(sd, "encoder.edge_convs.%d" % layer, e, 2, 2).max(dim=-1)[0]  # (B,64,N)
     enc = DGCNN(cfg["edgeconv_widths"], cfg["dgcnn_mlp_widths"], 9, 20)
     enc.load_state_dict({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")})
@@ -159,7 +159,7 @@ def test_edgeconv_vs_oracle(ops, B, C, N):
     am = ops.edgeconv(PQ, _dev(idx.to(torch.int32)).contiguous(), W2, s2, t2, out, B, N, want_argmax=True)
     got = ops.pm_to_cm(out, B, N).cpu()
     np.testing.assert_allclose(got.numpy(), want.numpy(), atol=TOL, rtol=1e-4)
-    assert am.min() >= 0 and am.max() < 20
+    assert am.min() >= 0 and am.max() < K
 
 
 # ------------------------------------------------------------------ a7 attention (attention.py:32-48)
