@@ -13,7 +13,7 @@
 //
 // Work unit: 8 points = 8K edges (K % 4 == 0), one wave per 32 edges (K = 20: 5 waves).
 // Each wave gathers the P rows of its own 32 edges into LDS (256-B coalesced rows),
-// runs 2 x 32 MFMAs (32 edges x 64 outputs, W2 fragments resident in 64 VGPRs), writes
+// runs 2 x 32 MFMAs (32 edges x 64 outputs, W2 fragments read from LDS), writes
 // the activated 32 x 64 block back over its LDS rows; the max over each point's K rows
 // is then a plain LDS reduction.  Workgroups walk units with a grid stride.
 #include "common.h"
@@ -28,13 +28,11 @@ __global__ __launch_bounds__(512) void r3d_edgeconv_kernel(
   extern __shared__ __attribute__((aligned(16))) float H[];  // [8K][EC_LD]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int nthreads = blockDim.x;
-  // W2 fragments: B[k][j] = W2[j][k]; tile t covers outputs 32t .. 32t+31
-  float b0[32], b1[32];
-#pragma unroll
-  for (int s = 0; s < 32; ++s) {
-    b0[s] = W2[(lane & 31) * 64 + 2 * s + (lane >> 5)];
-    b1[s] = W2[(32 + (lane & 31)) * 64 + 2 * s + (lane >> 5)];
-  }
+  // W2 in LDS behind the edge rows: its MFMA B fragments (B[k][j] = W2[j][k]) would cost 64 VGPRs in registers
+  // and, with the 32-deep gather, one workgroup per CU; from LDS two fit and overlap gather and MFMA phases
+  float* W2s = H + EC_PTS * K * EC_LD;  // [64][EC_LD]
+  for (int o = tid; o < 64 * 64; o += nthreads) W2s[(o >> 6) * EC_LD + (o & 63)] = W2[o];
+  __syncthreads();
   const float sc0 = s2[lane & 31], sh0 = t2[lane & 31];
   const float sc1 = s2[32 + (lane & 31)], sh1 = t2[32 + (lane & 31)];
   const long units = total_points / EC_PTS;
@@ -79,11 +77,13 @@ __global__ __launch_bounds__(512) void r3d_edgeconv_kernel(
     for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
     {
       const float* ap = H + (32 * w + (lane & 31)) * EC_LD + (lane >> 5);
-#pragma unroll
+      const float* bp0 = W2s + (lane & 31) * EC_LD + (lane >> 5);
+      const float* bp1 = bp0 + 32 * EC_LD;
+#pragma unroll 8
       for (int s = 0; s < 32; ++s) {
         const float a = ap[2 * s];
-        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[s], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[s], a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp0[2 * s], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp1[2 * s], a1, 0, 0, 0);
       }
     }
     // ---- BN2 + LeakyReLU, back into this wave's LDS rows
@@ -127,7 +127,7 @@ extern "C" int r3d_edgeconv_fwd(const float* PQ, const int32_t* idx, const float
   R3D_REQUIRE(N % EC_PTS == 0, "r3d_edgeconv_fwd: N=%d must be a multiple of %d", N, EC_PTS);
   R3D_REQUIRE(K >= 4 && K <= 32 && K % 4 == 0, "r3d_edgeconv_fwd: K=%d unsupported (need K %% 4 == 0, 4..32)", K);
   const int waves = EC_PTS * K / 32;
-  const size_t lds = sizeof(float) * (size_t)EC_PTS * K * EC_LD;
+  const size_t lds = sizeof(float) * ((size_t)EC_PTS * K * EC_LD + 64 * EC_LD);
   const long units = (long)B * N / EC_PTS;
   int grid = (int)(units < 1024 ? units : 1024);
   static bool attr_set = false;

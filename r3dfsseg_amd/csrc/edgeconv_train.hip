@@ -81,16 +81,15 @@ __global__ __launch_bounds__(512) void r3d_edgeconv_train_fwd_kernel(
     const float* __restrict__ W2, const float* __restrict__ s2, const float* __restrict__ t2, float* __restrict__ out,
     long ldo, int N, int K, long total_points, int* __restrict__ argmax_out, float* __restrict__ zmax_out,
     float* __restrict__ part /* mode 1, 2: [grid][2][64] */, float* __restrict__ zmin_out, int* __restrict__ argmin_out) {
-  extern __shared__ __attribute__((aligned(16))) float H[];  // [8K][ET_LD]
+  extern __shared__ __attribute__((aligned(16))) float H[];  // [8K][ET_LD], then W2 [64][ET_LD]
   __shared__ float ps[16][2][64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int nwaves = blockDim.x >> 6;
-  float b0[32], b1[32];
-#pragma unroll
-  for (int s = 0; s < 32; ++s) {
-    b0[s] = W2[(lane & 31) * 64 + 2 * s + (lane >> 5)];
-    b1[s] = W2[(32 + (lane & 31)) * 64 + 2 * s + (lane >> 5)];
-  }
+  // W2 in LDS: its MFMA B fragments cost 64 VGPRs when held in registers, which together with the 32-deep gather
+  // left one workgroup per CU; from LDS two workgroups fit and overlap their gather / MFMA phases
+  float* W2s = H + ET_PTS * K * ET_LD;
+  for (int o = tid; o < 64 * 64; o += blockDim.x) W2s[(o >> 6) * ET_LD + (o & 63)] = W2[o];
+  __syncthreads();
   const float sc1 = s1[lane], sh1 = t1[lane];
   float za0 = 0.f, zb0 = 0.f, za1 = 0.f, zb1 = 0.f;  // mode 1: per-lane sums (channel lane&31 / +32)
   const long units = total_points / ET_PTS;
@@ -119,11 +118,13 @@ __global__ __launch_bounds__(512) void r3d_edgeconv_train_fwd_kernel(
     for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
     {
       const float* ap = H + (32 * w + (lane & 31)) * ET_LD + (lane >> 5);
-#pragma unroll
+      const float* bp0 = W2s + (lane & 31) * ET_LD + (lane >> 5);  // B[k][jo] = W2[jo][k]
+      const float* bp1 = bp0 + 32 * ET_LD;
+#pragma unroll 8
       for (int s = 0; s < 32; ++s) {
         const float a = ap[2 * s];
-        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[s], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[s], a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp0[2 * s], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp1[2 * s], a1, 0, 0, 0);
       }
     }
     if (MODE == 1 || MODE == 2) {
@@ -412,6 +413,20 @@ static int et_check(const char* fn, int B, int N, int K) {
   return 0;
 }
 static int et_grid(long units) { return (int)(units < ET_MAXBLK ? units : ET_MAXBLK); }
+// dynamic LDS above 64 KB (K > 20) needs the attribute on every instance of the forward kernel
+static int et_fwd_lds_attr(size_t lds) {
+  static size_t done = 0;
+  if (lds <= done) return 0;
+  hipError_t e0 = hipFuncSetAttribute((const void*)r3d_edgeconv_train_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e1 = hipFuncSetAttribute((const void*)r3d_edgeconv_train_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e2 = hipFuncSetAttribute((const void*)r3d_edgeconv_train_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess) {
+    r3d_set_error("r3d_edgeconv_train_fwd: cannot reserve %zu B of LDS", lds);
+    return R3D_ERR_LAUNCH;
+  }
+  done = lds;
+  return 0;
+}
 
 extern "C" long r3d_edgeconv_train_ws_words(void) { return (long)(ET_MAXBLK + 1) * ET_PART + 64; }
 
@@ -438,10 +453,12 @@ extern "C" int r3d_edgeconv_train_fwd(const float* PQ, const int32_t* idx, const
   int rc = et_check("r3d_edgeconv_train_fwd", B, N, K);
   if (rc) return rc;
   const int waves = ET_PTS * K / 32;
-  const size_t lds = sizeof(float) * (size_t)ET_PTS * K * ET_LD;
+  const size_t lds = sizeof(float) * ((size_t)ET_PTS * K * ET_LD + 64 * ET_LD);
   const long units = (long)B * N / ET_PTS;
   const int grid = et_grid(units);
   hipStream_t st = (hipStream_t)stream;
+  rc = et_fwd_lds_attr(lds);
+  if (rc) return rc;
   if (mode == 1) {
     R3D_REQUIRE(sums_out, "r3d_edgeconv_train_fwd: mode 1 needs sums_out");
     hipLaunchKernelGGL(r3d_edgeconv_train_fwd_kernel<1>, dim3(grid), dim3(64 * waves), lds, st, PQ, idx, s1, t1, W2, s2, t2,
@@ -466,10 +483,12 @@ extern "C" int r3d_edgeconv_train_fwd_minmax(const float* PQ, const int32_t* idx
   int rc = et_check("r3d_edgeconv_train_fwd_minmax", B, N, K);
   if (rc) return rc;
   const int waves = ET_PTS * K / 32;
-  const size_t lds = sizeof(float) * (size_t)ET_PTS * K * ET_LD;
+  const size_t lds = sizeof(float) * ((size_t)ET_PTS * K * ET_LD + 64 * ET_LD);
   const long units = (long)B * N / ET_PTS;
   const int grid = et_grid(units);
   hipStream_t st = (hipStream_t)stream;
+  rc = et_fwd_lds_attr(lds);
+  if (rc) return rc;
   hipLaunchKernelGGL(r3d_edgeconv_train_fwd_kernel<2>, dim3(grid), dim3(64 * waves), lds, st, PQ, idx, s1, t1, W2, nullptr,
                      nullptr, nullptr, 0, N, K, (long)B * N, argmax, zmax, ws, zmin, argmin);
   hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(128 / 4), dim3(256), 0, st, ws, grid, 128, sums_out);
