@@ -301,12 +301,24 @@ def main():
                                    for k in ("r3d_cg_spmv_kernel", "r3d_cg_update_kernel"))
         except (OSError, KeyError, ValueError):
             pass
+        rocprof_us = None  # per-kernel averages of the committed rocprofv3 --kernel-trace --stats summary of this command
+        try:
+            name = "r01_v10_rocprofv3_kernel_stats_%s_eager.txt" % ("train" if train else "eval")
+            rows = {l.split("(")[0].strip(): float(l.split()[-2]) for l in open(os.path.join(ROOT, "profiles", name))
+                    if l.startswith("r3d_cg_")}
+            rocprof_us = rows["r3d_cg_spmv_kernel"] + rows["r3d_cg_update_kernel"]
+        except (OSError, KeyError, ValueError, IndexError):
+            pass
         roof = dict(kernel="r3d_cg_spmv_kernel + r3d_cg_update_kernel (one CG iteration of label propagation)",
                     bound="hbm", achieved=by / t_iter / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t_iter / 1e9 / HBM_PEAK_GBS,
                     traffic=traffic, avg_launch_ms=t_iter * 1e3, algorithmic_mb_per_launch=by / 1e6,
                     algorithmic_gflop_per_launch=fl / 1e9, csr_nnz=nnz, nodes=n_nodes,
                     iterations_per_episode=cg_mean * (2 if train else 1),
-                    note=("one launch pair; traffic = FETCH_SIZE + WRITE_SIZE of the pair from the committed rocprofv3 PMC "
+                    rocprofv3_kernel_us=rocprof_us,
+                    frac_kernel_time_only=(by / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rocprof_us else None,
+                    note=("avg_launch_ms is event-measured over back-to-back DEPENDENT launches, so it contains the two launch "
+                          "gaps of an iteration; rocprofv3_kernel_us is the pair's in-kernel time from the committed "
+                          "--kernel-trace --stats summary.  traffic = FETCH_SIZE + WRITE_SIZE of the pair from the committed rocprofv3 PMC "
                           "passes (profiles/r01_pmc_traffic.json, raw counters); the matrix (%.1f MB) is L2 / Infinity-Cache "
                           "resident between launches" % (nnz * 8 / 1e6)))
     else:
