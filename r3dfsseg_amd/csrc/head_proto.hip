@@ -517,15 +517,29 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_cluster_partial_kernel(
     const int gp = cp[min(pos, end - 1)];
     unsigned long long mm = __ballot(f);
     cnt += __popcll(mm);
+    // the wave walks the matches in ascending position (fixed summation order), 8 feature rows in flight per
+    // step: one row at a time was a chain of L2 round trips, 200 us for a cluster holding most of a chunk
+    const int c0 = min(lane, D - 1), c1 = min(lane + 64, D - 1), c2 = min(lane + 128, D - 1), c3 = min(lane + 192, D - 1);
     while (mm) {
-      const int src = __ffsll((long long)mm) - 1;
-      mm &= mm - 1;
-      const long row = __builtin_amdgcn_readlane(gp, src);
-      const float* fr = feat + row * ldf;
-      if (lane < D) a0 += fr[lane];
-      if (lane + 64 < D) a1 += fr[lane + 64];
-      if (lane + 128 < D) a2 += fr[lane + 128];
-      if (lane + 192 < D) a3 += fr[lane + 192];
+      float v0[8], v1[8], v2[8], v3[8];
+      bool on[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        on[u] = mm != 0ull;  // wave-uniform
+        const int src = on[u] ? __ffsll((long long)mm) - 1 : 0;
+        mm &= mm - 1;        // 0 stays 0
+        const float* fr = feat + (long)__builtin_amdgcn_readlane(gp, src) * ldf;
+        v0[u] = fr[c0]; v1[u] = fr[c1]; v2[u] = fr[c2]; v3[u] = fr[c3];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (on[u]) {
+          if (lane < D) a0 += v0[u];
+          if (lane + 64 < D) a1 += v1[u];
+          if (lane + 128 < D) a2 += v2[u];
+          if (lane + 192 < D) a3 += v3[u];
+        }
+      }
     }
   }
   psum[w][lane] = a0; psum[w][lane + 64] = a1; psum[w][lane + 128] = a2; psum[w][lane + 192] = a3;
