@@ -32,18 +32,32 @@ __global__ __launch_bounds__(256) void r3d_colpartial_kernel(
   if (c < C) {
     float sc = 1.f, sh = 0.f, mu = 0.f, is = 1.f;
     if (mode == 1) { sc = scale[c]; sh = shift[c]; mu = mean[c]; is = invstd[c]; }
-    for (long r = r0 + w; r < r1; r += 4) {
-      const float x = X[r * ldx + c];
-      if (mode == 0) {
-        a += x;
-        b += x * x;
-      } else {
-        const float u = sc * x + sh;
-        float g = DY[r * lddy + c];
-        if (act == 1) g = u > 0.f ? g : 0.f;
-        else if (act == 2) g = u > 0.f ? g : 0.2f * g;
-        a += g;
-        b += g * ((x - mu) * is);
+    // 8 rows in flight per step (unconditional loads on clamped rows, masked afterwards: common.h r3d_keep); the
+    // row order of the sums is unchanged
+    for (long rb = r0 + w; rb < r1; rb += 32) {
+      float xv[8], gv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long r = min(rb + 4 * u, r1 - 1);
+        xv[u] = X[r * ldx + c];
+        gv[u] = mode == 1 ? DY[r * lddy + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (rb + 4 * u < r1) {
+          const float x = xv[u];
+          if (mode == 0) {
+            a += x;
+            b += x * x;
+          } else {
+            const float uu = sc * x + sh;
+            float g = gv[u];
+            if (act == 1) g = uu > 0.f ? g : 0.f;
+            else if (act == 2) g = uu > 0.f ? g : 0.2f * g;
+            a += g;
+            b += g * ((x - mu) * is);
+          }
+        }
       }
     }
   }
