@@ -264,7 +264,15 @@ __global__ void r3d_sqnorm_cm_kernel(const float* __restrict__ xT, long ldT, int
   if (i >= N) return;
   const float* p = xT + (long)b * C * ldT + i;
   float acc = 0.f;
-  for (int c = 0; c < C; ++c) acc = __builtin_fmaf(p[(long)c * ldT], p[(long)c * ldT], acc);
+  int c = 0;
+  for (; c + 8 <= C; c += 8) {  // 8 channel loads in flight; the chain stays channel-ascending
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(long)(c + u) * ldT];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_fmaf(v[u], v[u], acc);
+  }
+  for (; c < C; ++c) acc = __builtin_fmaf(p[(long)c * ldT], p[(long)c * ldT], acc);
   out[(long)b * N + i] = acc;
 }
 

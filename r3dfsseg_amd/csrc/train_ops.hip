@@ -79,7 +79,18 @@ __global__ __launch_bounds__(256) void r3d_colreduce_kernel(const float* __restr
   const int c = blockIdx.x * 64 + lane;
   double a = 0.0, b = 0.0;
   if (c < C) {
-    for (int k = w; k < chunks; k += 4) {
+    int k = w;
+    for (; k + 12 < chunks; k += 16) {  // 4 chunks (8 loads) in flight, added in the same ascending order
+      float va[4], vb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        va[u] = part[((long)(k + 4 * u) * 2 + 0) * C + c];
+        vb[u] = part[((long)(k + 4 * u) * 2 + 1) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a += (double)va[u]; b += (double)vb[u]; }
+    }
+    for (; k < chunks; k += 4) {
       a += (double)part[((long)k * 2 + 0) * C + c];
       b += (double)part[((long)k * 2 + 1) * C + c];
     }
