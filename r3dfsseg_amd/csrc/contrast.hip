@@ -80,7 +80,15 @@ __global__ __launch_bounds__(256) void r3d_contrast_protos_kernel(
         if (pos < nfg) {
           const float* xr = fb + (long)fg[pos] * ldf;
           float acc = 0.f;
-          for (int c = 0; c < D; ++c) { const float df = xr[c] - seedf[0][c]; acc = __builtin_fmaf(df, df, acc); }
+          int c = 0;
+          for (; c + 8 <= D; c += 8) {  // 8 channel loads in flight, chain stays channel-ascending
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = xr[c + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const float df = v[u] - seedf[0][c + u]; acc = __builtin_fmaf(df, df, acc); }
+          }
+          for (; c < D; ++c) { const float df = xr[c] - seedf[0][c]; acc = __builtin_fmaf(df, df, acc); }
           mind[i] = acc < mind[i] ? acc : mind[i];
           if (mind[i] > bv || (mind[i] == bv && pos < bp)) { bv = mind[i]; bp = pos; }
         }
@@ -123,11 +131,29 @@ __global__ __launch_bounds__(256) void r3d_contrast_protos_kernel(
     int best = 0;
     if (nfg > CT_K) {
       float bestd = INFINITY;
-      for (int s = 0; s < m; ++s) {
-        float acc = 0.f;
-        for (int c = 0; c < D; ++c) { const float df = (xr[c] - seedf[s][c]) + 1e-6f; acc = __builtin_fmaf(df, df, acc); }
-        const float d = sqrtf(acc);
-        if (d < bestd) { bestd = d; best = s; }
+      float acc[CT_K] = {0.f, 0.f, 0.f, 0.f};  // one pass over the point's channels feeds all (<= 4) seeds
+      int c = 0;
+      for (; c + 8 <= D; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = xr[c + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+          for (int s = 0; s < CT_K; ++s) { const float df = (v[u] - seedf[s][c + u]) + 1e-6f; acc[s] = __builtin_fmaf(df, df, acc[s]); }
+        }
+      }
+      for (; c < D; ++c) {
+        const float v = xr[c];
+#pragma unroll
+        for (int s = 0; s < CT_K; ++s) { const float df = (v - seedf[s][c]) + 1e-6f; acc[s] = __builtin_fmaf(df, df, acc[s]); }
+      }
+#pragma unroll
+      for (int s = 0; s < CT_K; ++s) {
+        if (s < m) {
+          const float d = sqrtf(acc[s]);
+          if (d < bestd) { bestd = d; best = s; }
+        }
       }
     } else {
       best = pos;
