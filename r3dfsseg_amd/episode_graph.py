@@ -22,6 +22,8 @@ Frozen-sequence consequences, all checked or documented:
   * BatchNorm running statistics are updated by slot 0 only (shared buffers, concurrent slots would race);
     the batch statistics used for normalisation are per episode either way.
 """
+import os
+
 import torch
 
 from . import ops, train_ops
@@ -105,8 +107,11 @@ class EpisodeGraphs:
         st.update_running = (s == 0)
         # one-launch FPS only while all slots' FPS grids fit the chip together (head_proto.hip, 2b)
         fps_blocks = (model.n_way * model.k_shot * model.n_points + 255) // 256 + model.n_way + 1
-        # 2 workgroups of the one-launch FPS fit a CU at D <= 192 (234 VGPRs), 1 above: 512 / 256 slots on the chip
-        st.fps_one_launch = self.n_slots * fps_blocks <= (500 if model.feat_dim <= 192 else 250)
+        # 2 workgroups of the one-launch FPS fit a CU at D <= 192 (234 VGPRs), 1 above: 512 / 256 slots on the chip.
+        # HIP runs the streams on GPU_MAX_HW_QUEUES (default 4) hardware queues, one kernel at a time per queue, so at
+        # most that many FPS grids are ever resident together, whatever the number of slots
+        in_flight = min(self.n_slots, int(os.environ.get("GPU_MAX_HW_QUEUES", "4")))
+        st.fps_one_launch = in_flight * fps_blocks <= (500 if model.feat_dim <= 192 else 250)
         if self.train:
             st.seed_dev = torch.full((1,), 7919 * (s + 1), device=dev, dtype=torch.int32)
             off, sl.grad_views = 0, []
