@@ -546,7 +546,8 @@ __global__ __launch_bounds__(256) void r3d_knn_small_kernel(
 //       buffer overflowed (> 128 candidates at or above tau: duplicated points tie exactly) sets tile_flags[tile]
 //       and is recomputed by the exact insertion kernel launched right behind (it returns at once elsewhere).
 template <int KB_WAVES, int KB_CAP, int KB_TOP, int KCH /* k-pairs per channel chunk: 32 (64 channels) or 8 (16) */,
-          int KB_SAMPLE /* pass A visits every KB_SAMPLE-th sub-tile of a wave: tau from a sample is still a lower bound */>
+          int KB_SAMPLE /* pass A visits every KB_SAMPLE-th sub-tile of a wave: tau from a sample is still a lower bound */,
+          bool FULLC /* C is a multiple of the chunk width: no channel clamping / masking in the fragment loads */>
 __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_append_kernel(
     const float* __restrict__ xT, long ldT, int N, int C, int k, int mode, const int* __restrict__ n_dev,
     const float* __restrict__ nrm, int* __restrict__ idx_out, float* __restrict__ score_out,
@@ -588,26 +589,41 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_append_kernel(
 
   int stride = KB_SAMPLE;  // sub-tile stride of the running pass (pass A: the sample; pass B: 1)
   auto bload = [&](int t, float (&bf)[KCH]) {
-    const int st = w + KB_WAVES * stride * (t / nch), ch = t % nch;
+    const int st = w + KB_WAVES * stride * (t / nch), ch = (t % nch);
     const int cand = 32 * st + j;
     const bool ok = cand < n;
     const int cc = min(cand, n - 1);
+    if (FULLC) {
+      // address arithmetic per load costs as much issue time as the MFMA it feeds: one base pointer, constant
+      // strides, no masks (a clamped candidate is a real one and is discarded at score time: `valid`)
+      const float* p = xb + (long)(2 * KCH * ch + h) * ldT + cc;
+      const long st2 = 2 * ldT;
 #pragma unroll
-    for (int s = 0; s < KCH; ++s) {
-      const int c = 2 * KCH * ch + 2 * s + h;
-      bf[s] = r3d_keep(xb[(long)min(c, C - 1) * ldT + cc], ok && c < C);
+      for (int s = 0; s < KCH; ++s) bf[s] = p[s * st2];
+    } else {
+#pragma unroll
+      for (int s = 0; s < KCH; ++s) {
+        const int c = 2 * KCH * ch + 2 * s + h;
+        bf[s] = r3d_keep(xb[(long)min(c, C - 1) * ldT + cc], ok && c < C);
+      }
     }
   };
   f32x16 acc;
   auto mma = [&](int t, const float (&bf)[KCH]) {
-    const int ch = t % nch;
+    const int ch = (t % nch);
     if (ch == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     }
     const float* ap = Aq + j * Cs + 2 * KCH * ch + h;
+    // all A fragments of the chunk into registers first: read-two / wait / two MFMAs / read-two ... (what hipcc
+    // emits for `mfma(ap[2 * s], ...)`) exposes the LDS latency between every pair of MFMAs
+    float av[KCH];
 #pragma unroll
-    for (int s = 0; s < KCH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bf[s], acc, 0, 0, 0);
+    for (int s = 0; s < KCH; ++s) av[s] = ap[2 * s];
+    __builtin_amdgcn_sched_barrier(0);  // keep the machine scheduler from sinking the reads back next to their uses
+#pragma unroll
+    for (int s = 0; s < KCH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bf[s], acc, 0, 0, 0);
   };
   auto scores = [&](int st, f32x16& sc) {
     const int cand = 32 * st + j;
@@ -635,7 +651,7 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_append_kernel(
 #pragma unroll
   for (int r = 0; r < 16; ++r) { g1[r] = -INFINITY; g2[r] = -INFINITY; }
   auto finishA = [&](int t) {
-    if (t % nch != nch - 1) return;
+    if ((t % nch) != nch - 1) return;
     f32x16 sc;
     scores(w + KB_WAVES * stride * (t / nch), sc);
 #pragma unroll
@@ -696,7 +712,7 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_append_kernel(
   int* bufi = (int*)(region + 32 * KB_CAP);  // [32][KB_CAP]
   bool overflow = false;
   auto finishB = [&](int t) {
-    if (t % nch != nch - 1) return;
+    if ((t % nch) != nch - 1) return;
     const int st = w + KB_WAVES * (t / nch);
     f32x16 sc;
     scores(st, sc);
@@ -785,6 +801,23 @@ static size_t knn_lds_bytes(int C) {
                           (size_t)KNN_Q * (KNN_CH + 1) + KNN_Q);
 }
 
+// launch one instance of the append-and-rank kernel (raising its dynamic-LDS limit once per instance)
+template <int WAVES, int CAP, int TOP, int KCH, int SAMPLE, bool FULLC>
+static int knn_append_launch(dim3 grid, size_t lds, hipStream_t st, const float* xT, long ldT, int N, int C, int k, int mode,
+                             const int* n_valid_dev, const float* nrm, int* idx_out, float* score_out, int* status,
+                             int* tile_flags) {
+  static size_t attr = 0;
+  if (lds > attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)r3d_knn_append_kernel<WAVES, CAP, TOP, KCH, SAMPLE, FULLC>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    R3D_REQUIRE(e == hipSuccess, "r3d_knn_topk: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+    attr = lds;
+  }
+  hipLaunchKernelGGL((r3d_knn_append_kernel<WAVES, CAP, TOP, KCH, SAMPLE, FULLC>), grid, dim3(64 * WAVES), lds, st, xT, ldT, N, C,
+                     k, mode, n_valid_dev, nrm, idx_out, score_out, status, tile_flags);
+  return R3D_OK;
+}
+
 extern "C" int r3d_sqnorm(const float* x, long ldx, long rows, int C, float* out, void* stream) {
   R3D_REQUIRE(x && out && rows > 0 && C > 0 && ldx >= C, "r3d_sqnorm: bad arguments");
   hipLaunchKernelGGL(r3d_sqnorm_kernel, dim3(r3d_cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, x,
@@ -844,23 +877,20 @@ extern "C" int r3d_knn_topk(const float* x, long ldx, const float* x_cm, int B, 
       // sorted-insertion kernel in the same stream -- no host round trip, never a wrong result
       r3d_zero_words(tile_flags, (long)B * g2.x, st);
       const size_t lds = knn_append_lds_bytes(C, KM_WAVES, KM_CAP, KM_TOP, C <= 16 ? 8 : 32);
-      static size_t mid_attr[2] = {0, 0};
-      if (lds > mid_attr[C <= 16]) {
-        hipError_t e = C <= 16 ? hipFuncSetAttribute((const void*)r3d_knn_append_kernel<KM_WAVES, KM_CAP, KM_TOP, 8, KM_SAMPLE>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                               : hipFuncSetAttribute((const void*)r3d_knn_append_kernel<KM_WAVES, KM_CAP, KM_TOP, 32, KM_SAMPLE>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        R3D_REQUIRE(e == hipSuccess, "r3d_knn_topk(mid): cannot reserve %zu B of LDS", lds);
-        mid_attr[C <= 16] = lds;
-      }
+      int rc;
       if (C <= 16) {
-        hipLaunchKernelGGL((r3d_knn_append_kernel<KM_WAVES, KM_CAP, KM_TOP, 8, KM_SAMPLE>), g2, dim3(64 * KM_WAVES), lds, st, xT, ldT, N, C,
-                           k, mode, n_valid_dev, norm_ws, idx_out, score_out, (int*)nullptr, tile_flags);
+        rc = knn_append_launch<KM_WAVES, KM_CAP, KM_TOP, 8, KM_SAMPLE, false>(g2, lds, st, xT, ldT, N, C, k, mode, n_valid_dev,
+                                                                              norm_ws, idx_out, score_out, nullptr, tile_flags);
+        if (rc) return rc;
         hipLaunchKernelGGL(r3d_knn_small_kernel<8>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, norm_ws,
                            idx_out, score_out, (const int*)tile_flags);
       } else {
-        hipLaunchKernelGGL((r3d_knn_append_kernel<KM_WAVES, KM_CAP, KM_TOP, 32, KM_SAMPLE>), g2, dim3(64 * KM_WAVES), lds, st, xT, ldT, N, C,
-                           k, mode, n_valid_dev, norm_ws, idx_out, score_out, (int*)nullptr, tile_flags);
+        rc = C % 64 == 0
+                 ? knn_append_launch<KM_WAVES, KM_CAP, KM_TOP, 32, KM_SAMPLE, true>(g2, lds, st, xT, ldT, N, C, k, mode, n_valid_dev,
+                                                                                    norm_ws, idx_out, score_out, nullptr, tile_flags)
+                 : knn_append_launch<KM_WAVES, KM_CAP, KM_TOP, 32, KM_SAMPLE, false>(g2, lds, st, xT, ldT, N, C, k, mode, n_valid_dev,
+                                                                                     norm_ws, idx_out, score_out, nullptr, tile_flags);
+        if (rc) return rc;
         hipLaunchKernelGGL(r3d_knn_small_kernel<32>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, norm_ws,
                            idx_out, score_out, (const int*)tile_flags);
       }
@@ -882,16 +912,15 @@ extern "C" int r3d_knn_topk(const float* x, long ldx, const float* x_cm, int B, 
     }
     hipLaunchKernelGGL(r3d_sqnorm_cm_kernel, dim3(r3d_cdiv(N, 256), B), dim3(256), 0, st, xT, ldT, C, N, norm_ws);
     r3d_zero_words(status, 1, st);
-    static size_t big_attr = 0;  // static __shared__ arrays count against the 160 KiB too: ask for what is used
-    if (knn_big_lds_bytes(C) > big_attr) {
-      hipError_t e = hipFuncSetAttribute((const void*)r3d_knn_append_kernel<8, 384, 2, 32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)knn_big_lds_bytes(C));
-      R3D_REQUIRE(e == hipSuccess, "r3d_knn_topk(big): cannot reserve %zu B of LDS: %s", knn_big_lds_bytes(C),
-                  hipGetErrorString(e));
-      big_attr = knn_big_lds_bytes(C);
+    {
+      const dim3 gb(r3d_cdiv(N, 32), B);
+      const int rc = C % 64 == 0
+                         ? knn_append_launch<8, 384, 2, 32, 1, true>(gb, knn_big_lds_bytes(C), st, xT, ldT, N, C, k, mode, n_valid_dev,
+                                                                     norm_ws, idx_out, score_out, status, nullptr)
+                         : knn_append_launch<8, 384, 2, 32, 1, false>(gb, knn_big_lds_bytes(C), st, xT, ldT, N, C, k, mode, n_valid_dev,
+                                                                      norm_ws, idx_out, score_out, status, nullptr);
+      if (rc) return rc;
     }
-    hipLaunchKernelGGL((r3d_knn_append_kernel<8, 384, 2, 32, 1>), dim3(r3d_cdiv(N, 32), B), dim3(64 * 8), knn_big_lds_bytes(C), st,
-                       xT, ldT, N, C, k, mode, n_valid_dev, norm_ws, idx_out, score_out, status, (int*)nullptr);
     R3D_LAUNCH_CHECK("r3d_knn_topk(big)");
     return R3D_OK;
   }
