@@ -42,16 +42,31 @@ __global__ __launch_bounds__(256) void r3d_pointwise_gemm_kernel(
   // afterwards, and the NEXT K-step's loads in flight behind the current step's MFMAs (two LDS buffers, one
   // barrier per step)
   float xv[G_BM / 8], wv[G_BN / 8];
+  // row pointers once per workgroup: rows beyond M / Co are clamped duplicates whose products only reach output
+  // elements that are never stored, so the only mask left is the K tail (address arithmetic and masks in the load
+  // loop cost as much issue time as the MFMAs they feed: tools/probe/mfma_feed.hip)
+  const float* xrow[G_BM / 8];
+  const float* wrow[G_BN / 8];
+#pragma unroll
+  for (int p = 0; p < G_BM / 8; ++p) {
+    xrow[p] = X + min(m0 + srow + 8 * p, (long)M - 1) * ldx;
+    wrow[p] = W + (long)min(n0 + srow + 8 * p, Co - 1) * K;
+  }
   auto load_step = [&](int k0) {
     const int gk = k0 + scol;
-    const int gkc = min(gk, K - 1);
+    if (k0 + G_BK <= K) {  // uniform: full K step, no masks
 #pragma unroll
-    for (int p = 0; p < G_BM / 8; ++p) {
-      const int row = srow + 8 * p;
-      const long gm = m0 + row;
-      const int gj = n0 + row;
-      xv[p] = r3d_keep(X[min(gm, (long)M - 1) * ldx + gkc], gm < M && gk < K);
-      wv[p] = r3d_keep(W[(long)min(gj, Co - 1) * K + gkc], gj < Co && gk < K);
+      for (int p = 0; p < G_BM / 8; ++p) {
+        xv[p] = xrow[p][gk];
+        wv[p] = wrow[p][gk];
+      }
+    } else {
+      const int gkc = min(gk, K - 1);
+#pragma unroll
+      for (int p = 0; p < G_BM / 8; ++p) {
+        xv[p] = r3d_keep(xrow[p][gkc], gk < K);
+        wv[p] = r3d_keep(wrow[p][gkc], gk < K);
+      }
     }
   };
   auto store_step = [&](int buf) {

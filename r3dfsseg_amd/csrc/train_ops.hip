@@ -193,13 +193,26 @@ __global__ __launch_bounds__(256) void r3d_gemm_tn_kernel(const float* __restric
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int srow = tid >> 6, scol = tid & 63;  // 4 rows x 64 cols per pass
   float av[8], bv[8];
+  // columns beyond Ca / Cb are clamped duplicates that only reach unstored outputs; rows beyond m_end must be
+  // zero (they enter every sum), so only the last stage of a chunk is masked
+  const float* acol = A + min(i0 + scol, Ca - 1);
+  const float* bcol = B + min(j0 + scol, Cb - 1);
   auto load_stage = [&](long m0) {
+    if (m0 + 32 <= m_end) {  // uniform: full stage, no masks
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const long m = m0 + srow + 4 * p;
-      const long mc = min(m, M - 1);
-      av[p] = r3d_keep(A[mc * lda + min(i0 + scol, Ca - 1)], m < m_end && i0 + scol < Ca);
-      bv[p] = r3d_keep(B[mc * ldb + min(j0 + scol, Cb - 1)], m < m_end && j0 + scol < Cb);
+      for (int p = 0; p < 8; ++p) {
+        const long m = m0 + srow + 4 * p;
+        av[p] = acol[m * lda];
+        bv[p] = bcol[m * ldb];
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const long m = m0 + srow + 4 * p;
+        const long mc = min(m, M - 1);
+        av[p] = r3d_keep(acol[mc * lda], m < m_end);
+        bv[p] = r3d_keep(bcol[mc * ldb], m < m_end);
+      }
     }
   };
   auto store_stage = [&](int buf) {
