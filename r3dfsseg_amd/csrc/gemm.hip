@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void r3d_pointwise_gemm_kernel(
   for (int k0 = 0; k0 < K; k0 += G_BK, buf ^= 1) {
     const bool more = k0 + G_BK < K;
     if (more) load_step(k0 + G_BK);
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch loads in front of the MFMAs (the scheduler sinks them to their use)
     const float* ap = Xs[buf] + (32 * wm + (lane & 31)) * G_LD + (lane >> 5);
     const float* bp = Ws[buf] + (32 * wn + (lane & 31)) * G_LD + (lane >> 5);
 #pragma unroll

@@ -575,6 +575,7 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_append_kernel(
     Aq[jj * Cs + c] = r3d_keep(v, c < C && q0 + jj < n);
   }
   if (tid < 32) cnt_s[tid] = 0;
+  KSTAMP(8);
   float nq[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -631,16 +632,13 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_append_kernel(
     const float nj = r3d_keep(nb[min(cand, n - 1)], valid);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float v;
-      if (mode == R3D_SCORE_DGCNN) {
-        const float inner = -2.f * acc[r];
-        const float tt = (-nj) - inner;
-        v = tt - nq[r];
-      } else {
-        float dis = (nq[r] + nj) - 2.f * acc[r];
-        if (dis < 0.f) dis = 0.f;
-        v = -dis;
-      }
+      // both score forms, selected without a branch (a uniform `if (mode)` inside the unrolled loop became 32
+      // branches per sub-tile)
+      const float inner = -2.f * acc[r];
+      const float v_dg = ((-nj) - inner) - nq[r];
+      const float dis = (nq[r] + nj) - 2.f * acc[r];
+      const float v_l2 = -fmaxf(dis, 0.f);
+      const float v = mode == R3D_SCORE_DGCNN ? v_dg : v_l2;
       sc[r] = valid ? v : -INFINITY;
     }
   };
@@ -664,17 +662,22 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_append_kernel(
       g1[r] = fmaxf(g1[r], x);
     }
   };
+  KSTAMP(9);
   const int TA = (w < nsub) ? ((my_sub + KB_SAMPLE - 1) / KB_SAMPLE) * nch : 0;  // sampled units of pass A
+  // one-unit prefetch: the next fragment's loads are issued in front of the current MFMA chain and handed over by
+  // register copies afterwards (tools/probe/mfma_feed.hip sustains 110 TFLOP/s this way).  The two-buffer form
+  // unrolled by hand compiled to chains that waited, through the single in-order vmcnt counter, on the loads
+  // issued right in front of them.
   if (TA > 0) bload(0, bfA);
-  for (int t = 0; t < TA; t += 2) {
+  for (int t = 0; t < TA; ++t) {
     if (t + 1 < TA) bload(t + 1, bfB);
+    __builtin_amdgcn_sched_barrier(0);
     mma(t, bfA);
     finishA(t);
-    if (t + 1 >= TA) break;
-    if (t + 2 < TA) bload(t + 2, bfA);
-    mma(t + 1, bfB);
-    finishA(t + 1);
+#pragma unroll
+    for (int s = 0; s < KCH; ++s) bfA[s] = bfB[s];
   }
+  KSTAMP(10);
   stride = 1;
   {
     constexpr int GS = KB_TOP * KB_GROUPS + 1;
@@ -702,6 +705,7 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_append_kernel(
     }
     __syncthreads();
   }
+  KSTAMP(11);
   float tauq[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) tauq[r] = tau_s[r3d_acc_row(r, lane)];
@@ -730,16 +734,20 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_append_kernel(
       }
     }
   };
+  // one-unit prefetch: the next fragment's loads are issued in front of the current MFMA chain and handed over by
+  // register copies afterwards (tools/probe/mfma_feed.hip sustains 110 TFLOP/s this way).  The two-buffer form
+  // unrolled by hand compiled to chains that waited, through the single in-order vmcnt counter, on the loads
+  // issued right in front of them.
   if (T > 0) bload(0, bfA);
-  for (int t = 0; t < T; t += 2) {
+  for (int t = 0; t < T; ++t) {
     if (t + 1 < T) bload(t + 1, bfB);
+    __builtin_amdgcn_sched_barrier(0);
     mma(t, bfA);
     finishB(t);
-    if (t + 1 >= T) break;
-    if (t + 2 < T) bload(t + 2, bfA);
-    mma(t + 1, bfB);
-    finishB(t + 1);
+#pragma unroll
+    for (int s = 0; s < KCH; ++s) bfA[s] = bfB[s];
   }
+  KSTAMP(12);
   if (__any(overflow) && lane == 0) {
     if (status) atomicOr(status, 1);
     if (tile_flags) tile_flags[(long)b * gridDim.x + blockIdx.x] = 1;
@@ -775,6 +783,7 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_append_kernel(
       }
     }
   }
+  KSTAMP(13);
 }
 
 static size_t knn_append_lds_bytes(int C, int waves, int cap, int top, int kch = 32) {

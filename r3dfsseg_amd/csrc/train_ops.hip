@@ -231,6 +231,7 @@ __global__ __launch_bounds__(256) void r3d_gemm_tn_kernel(const float* __restric
   for (long m0 = m_beg; m0 < m_end; m0 += 32, buf ^= 1) {
     const bool more = m0 + 32 < m_end;
     if (more) load_stage(m0 + 32);
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch loads in front of the MFMAs (the scheduler sinks them to their use)
     // MFMA A operand: A^T[i][m] -> lane (i = lane&31, k = m): As[m][32*wi + i]
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) {
