@@ -303,9 +303,10 @@ def main():
             pass
         rocprof_us = None  # per-kernel averages of the committed rocprofv3 --kernel-trace --stats summary of this command
         try:
-            name = "r01_v10_rocprofv3_kernel_stats_%s_eager.txt" % ("train" if train else "eval")
-            rows = {l.split("(")[0].strip(): float(l.split()[-2]) for l in open(os.path.join(ROOT, "profiles", name))
-                    if l.startswith("r3d_cg_")}
+            import glob
+            name = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_kernel_stats_%s_eager.txt" % (
+                "train" if train else "eval"))))[-1]  # the newest committed summary
+            rows = {l.split("(")[0].strip(): float(l.split()[-2]) for l in open(name) if l.startswith("r3d_cg_")}
             rocprof_us = rows["r3d_cg_spmv_kernel"] + rows["r3d_cg_update_kernel"]
         except (OSError, KeyError, ValueError, IndexError):
             pass
