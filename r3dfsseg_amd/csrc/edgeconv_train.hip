@@ -70,17 +70,18 @@ __global__ void r3d_part_reduce_kernel(const float* __restrict__ part, int nblk,
   if (lane == 0) out[i] = (float)s;
 }
 
-// ---- forward: mode 0 = output (+argmax, z at argmax); mode 1 = statistics of z2;
-//      mode 2 = ONE pass for training: statistics of z2 AND, per point and channel, max / min of the raw z2 over
-//      the K edges with their positions.  BatchNorm2 + LeakyReLU is monotone per channel (increasing for
-//      gamma*invstd > 0, decreasing for < 0), so once the statistics are folded the layer output is
-//      lrelu(s2 * (s2 > 0 ? zmax : zmin) + t2) -- r3d_edge_select -- and the edge GEMM is not computed twice.
+// ---- two-pass forward (8-point units, 32x32x2): mode 0 = output (+argmax, z at argmax); mode 1 = statistics of
+//      z2.  The training path uses the ONE-pass kernel r3d_edgeconv_train_fwd2_kernel below instead: statistics of z2
+//      AND, per point and channel, max / min of the raw z2 over the K edges with their positions.  BatchNorm2 +
+//      LeakyReLU is monotone per channel (increasing for gamma*invstd > 0, decreasing for < 0), so once the statistics
+//      are folded the layer output is lrelu(s2 * (s2 > 0 ? zmax : zmin) + t2) -- r3d_edge_select -- and the edge
+//      GEMM is not computed twice.
 template <int MODE>
 __global__ __launch_bounds__(512) void r3d_edgeconv_train_fwd_kernel(
     const float* __restrict__ PQ, const int* __restrict__ idx, const float* __restrict__ s1, const float* __restrict__ t1,
     const float* __restrict__ W2, const float* __restrict__ s2, const float* __restrict__ t2, float* __restrict__ out,
     long ldo, int N, int K, long total_points, int* __restrict__ argmax_out, float* __restrict__ zmax_out,
-    float* __restrict__ part /* mode 1, 2: [grid][2][64] */, float* __restrict__ zmin_out, int* __restrict__ argmin_out) {
+    float* __restrict__ part /* mode 1: [grid][2][64] */) {
   extern __shared__ __attribute__((aligned(16))) float H[];  // [8K][ET_LD], then W2 [64][ET_LD]
   __shared__ float ps[16][2][64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -127,34 +128,9 @@ __global__ __launch_bounds__(512) void r3d_edgeconv_train_fwd_kernel(
         a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp1[2 * s], a1, 0, 0, 0);
       }
     }
-    if (MODE == 1 || MODE == 2) {
+    if (MODE == 1) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { za0 += a0[r]; zb0 += a0[r] * a0[r]; za1 += a1[r]; zb1 += a1[r] * a1[r]; }
-    }
-    if (MODE == 2) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * w + r3d_acc_row(r, lane);
-        H[row * ET_LD + (lane & 31)] = a0[r];
-        H[row * ET_LD + 32 + (lane & 31)] = a1[r];
-      }
-      __syncthreads();
-      for (int o = tid; o < ET_PTS * 64; o += blockDim.x) {
-        const int pt = o >> 6, ch = o & 63;
-        const float* hp = H + (pt * K) * ET_LD + ch;
-        float zx = hp[0], zn = zx;
-        int ax = 0, an = 0;
-        for (int t = 1; t < K; ++t) {
-          const float z = hp[t * ET_LD];
-          if (z > zx) { zx = z; ax = t; }
-          if (z < zn) { zn = z; an = t; }
-        }
-        zmax_out[(pt0 + pt) * 64 + ch] = zx;
-        zmin_out[(pt0 + pt) * 64 + ch] = zn;
-        argmax_out[(pt0 + pt) * 64 + ch] = ax;
-        argmin_out[(pt0 + pt) * 64 + ch] = an;
-      }
-      __syncthreads();
     }
     if (MODE == 0) {
       // raw z2 back into this wave's LDS rows; BN2 + LeakyReLU are applied in the max loop so that the
@@ -185,7 +161,7 @@ __global__ __launch_bounds__(512) void r3d_edgeconv_train_fwd_kernel(
       __syncthreads();
     }
   }
-  if (MODE == 1 || MODE == 2) {
+  if (MODE == 1) {
     // combine the two lane halves (same channel), then the waves, in a fixed order
     za0 += __shfl_xor(za0, 32); zb0 += __shfl_xor(zb0, 32);
     za1 += __shfl_xor(za1, 32); zb1 += __shfl_xor(zb1, 32);
@@ -201,169 +177,249 @@ __global__ __launch_bounds__(512) void r3d_edgeconv_train_fwd_kernel(
 }
 
 // ---- backward pass B1 -------------------------------------------------------------------------
+// Unit = 4 points = 4K edge rows = RT row tiles of 16 (K = 4 RT), one workgroup of 4 waves per unit, on
+// v_mfma_f32_16x16x4_f32: wave w owns the 16 output channels 16w.. of the two edge GEMMs (its W2 fragments stay
+// in 32 registers) and 16 rows of dW2.  Against the earlier 8-point / 32x32x2 version (5 waves on 4 SIMDs, 102 KB
+// of LDS, one workgroup per CU) every phase is balanced over the 4 SIMDs and 46 KB of LDS at K = 20 leave room
+// for 3 workgroups per CU, whose gather / MFMA / store phases overlap.
+// LDS rows have stride 68 words and the k index of every MFMA is assigned so that the operand reads are
+// conflict-free: row-major operands read 16 consecutive k per lane as four b128 (lane group g takes k = 16g..16g+15),
+// the edge-contraction (dW2) takes edge 16(s>>2) + 4g + (s&3) at step s.  The summation order over k differs from
+// the ascending chain; nothing in the backward decides an index.
 // part layout per block: [0] dW2 partial 64*64, then [4096 + v*64 + c], v = 0: sum dy1, 1: sum dy1*ehat1
 #define ET_PART (64 * 64 + 2 * 64)
-__global__ __launch_bounds__(512) void r3d_edgeconv_bwd1_kernel(
+#define E2_PTS 4
+#define E2_LD 68
+static __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// acc[t] (rows 16t.., this wave's 16 columns) = A[rows][0..63] * B, A row-major in LDS, B fragments in registers
+template <int RT>
+static __device__ __forceinline__ void e2_rowgemm(const float* __restrict__ A, const float (&Bf)[16], int n, int g,
+                                                  f32x4 (&acc)[RT]) {
+#pragma unroll
+  for (int t = 0; t < RT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int qk = 0; qk < 4; ++qk) {  // four k per lane and step group: one b128 per row tile
+    float4 av[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) av[t] = *(const float4*)(A + (16 * t + n) * E2_LD + 16 * g + 4 * qk);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {  // RT independent accumulator chains back to back (40-cycle dependent latency)
+        const float a = s == 0 ? av[t].x : s == 1 ? av[t].y : s == 2 ? av[t].z : av[t].w;
+        acc[t] = mfma16(a, Bf[4 * qk + s], acc[t]);
+      }
+    }
+  }
+}
+
+template <int RT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT <= 5 ? 3 : 2))) void r3d_edgeconv_bwd1_kernel(
     const float* __restrict__ PQ, const int* __restrict__ idx, const float* __restrict__ s1, const float* __restrict__ t1,
     const float* __restrict__ mean1, const float* __restrict__ invstd1, const float* __restrict__ W2,
     const float* __restrict__ s2, const float* __restrict__ t2, const float* __restrict__ mean2,
     const float* __restrict__ invstd2, const float* __restrict__ bn2_sums /* [2][64]: sum dy2, sum dy2 zhat2 */,
-    const float* __restrict__ dout, long lddo, const int* __restrict__ argmax, int N, int K, long total_points,
+    const float* __restrict__ dout, long lddo, const int* __restrict__ argmax, int N, long total_points,
     float* __restrict__ DY1 /* (total_points*K, 64) */, float* __restrict__ part) {
+  constexpr int K = 4 * RT, R = 16 * RT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int EK = ET_PTS * K;
-  float* H = smem;                       // [8K][ET_LD] h1
-  float* G = smem + EK * ET_LD;          // [8K][ET_LD] dz2, later dy1
-  float* dsm = G + EK * ET_LD;           // [8][64] dout of the unit
-  int* asm_ = (int*)(dsm + ET_PTS * 64); // [8][64] argmax of the unit
-  float* W2s = (float*)(asm_ + ET_PTS * 64);  // [64][ET_LD] W2: both MFMA B operands are read from here (holding
-                                              // them in registers cost 128 VGPRs and spilled to scratch)
-  float (*ps)[2][64] = (float (*)[2][64])smem;  // [waves][2][64] block partials; aliases H after the unit loop
+  float* H = smem;                        // [R][E2_LD] h1
+  float* G = smem + R * E2_LD;            // [R][E2_LD] dz2, later dy1
+  float* dsm = G + R * E2_LD;             // [4][64] dout of the unit
+  int* asm_ = (int*)(dsm + E2_PTS * 64);  // [4][64] argmax of the unit
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int nwaves = blockDim.x >> 6;
-  const int h = lane >> 5, j = lane & 31;
-  int* ept = (int*)(W2s + 64 * ET_LD);        // [8K] point of edge e within the unit (no runtime division in the loops)
-  for (int o = tid; o < 64 * 64; o += blockDim.x) W2s[(o >> 6) * ET_LD + (o & 63)] = W2[o];
-  for (int o = tid; o < EK; o += blockDim.x) ept[o] = o / K;
-  __syncthreads();
+  const int n = lane & 15, g = lane >> 4;
+  const int c = 16 * w + n;  // this lane's column of the z2 / dh1 tiles
   const float sc1 = s1[lane], sh1 = t1[lane], mu1 = mean1[lane], is1 = invstd1[lane];
   const double E = (double)total_points * K;
-  // channel constants in the accumulator layout (column = j, +32 for the second tile)
-  const float s2a = s2[j], t2a = t2[j], mu2a = mean2[j], is2a = invstd2[j];
-  const float s2b = s2[32 + j], t2b = t2[32 + j], mu2b = mean2[32 + j], is2b = invstd2[32 + j];
-  const float m1a = (float)((double)bn2_sums[j] / E), m2a = (float)((double)bn2_sums[64 + j] / E);
-  const float m1b = (float)((double)bn2_sums[32 + j] / E), m2b = (float)((double)bn2_sums[96 + j] / E);
-  f32x16 dw;  // waves 0..3: dW2 tile (ti = w>>1: rows c, tj = w&1: cols ji)
+  const float s2c = s2[c], t2c = t2[c], mu2c = mean2[c], is2c = invstd2[c];
+  const float m1c = (float)((double)bn2_sums[c] / E), m2c = (float)((double)bn2_sums[64 + c] / E);
+  f32x4 dw[4];  // dW2 rows 16w + 4g + i, columns 4n + tj
 #pragma unroll
-  for (int r = 0; r < 16; ++r) dw[r] = 0.f;
+  for (int tj = 0; tj < 4; ++tj) dw[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
   float sdy = 0.f, sdye = 0.f;
-  const long units = total_points / ET_PTS;
+  const long units = total_points / E2_PTS;
   for (long u = blockIdx.x; u < units; u += gridDim.x) {
-    const long pt0 = u * ET_PTS;
+    const long pt0 = u * E2_PTS;
     const long cloud0 = (pt0 / N) * N;
-    for (int o = tid; o < ET_PTS * 64; o += blockDim.x) {
-      dsm[o] = dout[(pt0 + (o >> 6)) * lddo + (o & 63)];
-      asm_[o] = argmax[(pt0 + (o >> 6)) * 64 + (o & 63)];
-    }
-    float eh[32];  // ehat1 of this wave's 32 edges, channel = lane
+    dsm[tid] = dout[(pt0 + w) * lddo + lane];
+    asm_[tid] = argmax[(pt0 + w) * 64 + lane];
+    // W2 fragments are re-read (L1 / L2 hits) in the phase that uses them: holding both sets for the whole loop
+    // costs 32 registers and the third workgroup per CU.  The opaque zero keeps the loads inside the loop.
+    int keep = 0;
+    asm volatile("" : "+v"(keep));
+    float Bf[16];
     {
-      const int my_idx = idx[pt0 * K + 32 * w + j];
-      float* hrow = H + (32 * w) * ET_LD;
+      const float4* bz = (const float4*)(W2 + c * 64 + 16 * g + keep);  // z2[e][c] = sum_k h1[e][k] W2[c][k]
 #pragma unroll
-      for (int t0 = 0; t0 < 32; t0 += 16) {  // 32 gathers in flight per step
-        float pv[16], qv[16];
-#pragma unroll
-        for (int tt = 0; tt < 16; ++tt) {
-          const int jn = __builtin_amdgcn_readlane(my_idx, t0 + tt);
-          const int pi = ept[32 * w + t0 + tt];
-          pv[tt] = PQ[(cloud0 + jn) * 128 + lane];
-          qv[tt] = PQ[(pt0 + pi) * 128 + 64 + lane];
-        }
-#pragma unroll
-        for (int tt = 0; tt < 16; ++tt) {
-          const float e1 = pv[tt] + qv[tt];
-          eh[t0 + tt] = (e1 - mu1) * is1;
-          hrow[(t0 + tt) * ET_LD + lane] = lrelu(sc1 * e1 + sh1);
-        }
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const float4 v = bz[s4];
+        Bf[4 * s4] = v.x; Bf[4 * s4 + 1] = v.y; Bf[4 * s4 + 2] = v.z; Bf[4 * s4 + 3] = v.w;
       }
     }
-    f32x16 a0, a1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+    float eh[K];  // ehat1 of the K edges of point w (this wave's rows), channel = lane
     {
-      const float* ap = H + (32 * w + j) * ET_LD + h;
-      const float* bp0 = W2s + j * ET_LD + h;         // B[k][jo] = W2[jo][k]   (z2 = W2 h1)
-      const float* bp1 = W2s + (32 + j) * ET_LD + h;
-#pragma unroll 8
-      for (int s = 0; s < 32; ++s) {
-        const float a = ap[2 * s];
-        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp0[2 * s], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp1[2 * s], a1, 0, 0, 0);
+      const int my_idx = idx[(pt0 + w) * K + min(lane, K - 1)];
+      const float q = PQ[(pt0 + w) * 128 + 64 + lane];
+      float pv[K];
+#pragma unroll
+      for (int t = 0; t < K; ++t) pv[t] = PQ[(cloud0 + __builtin_amdgcn_readlane(my_idx, t)) * 128 + lane];
+      float* hrow = H + (K * w) * E2_LD + lane;
+#pragma unroll
+      for (int t = 0; t < K; ++t) {
+        const float e1 = pv[t] + q;
+        eh[t] = (e1 - mu1) * is1;
+        hrow[t * E2_LD] = lrelu(sc1 * e1 + sh1);
       }
     }
-    __syncthreads();  // dsm / asm_ visible
-    // dz2 into G (this wave's rows)
+    __syncthreads();  // H, dsm, asm_ complete
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[RT];
+    e2_rowgemm<RT>(H, Bf, n, g, acc);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int e = 32 * w + r3d_acc_row(r, lane);
-      const int pt = ept[e], t = e - pt * K;
-      {
-        const float z = a0[r];
-        const float uu = s2a * z + t2a;
-        float dy = (asm_[pt * 64 + j] == t) ? dsm[pt * 64 + j] * (uu > 0.f ? 1.f : 0.2f) : 0.f;
-        G[e * ET_LD + j] = s2a * (dy - m1a - ((z - mu2a) * is2a) * m2a);
-      }
-      {
-        const float z = a1[r];
-        const float uu = s2b * z + t2b;
-        float dy = (asm_[pt * 64 + 32 + j] == t) ? dsm[pt * 64 + 32 + j] * (uu > 0.f ? 1.f : 0.2f) : 0.f;
-        G[e * ET_LD + 32 + j] = s2b * (dy - m1b - ((z - mu2b) * is2b) * m2b);
+    for (int s = 0; s < 16; ++s) Bf[s] = W2[(16 * g + s) * 64 + c + keep];  // dh1[e][c] = sum_k dz2[e][k] W2[k][c]
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = 16 * t + 4 * g + i;
+        const int pt = e / K, tt = e - pt * K;
+        const float z = acc[t][i];
+        const float uu = s2c * z + t2c;
+        const float dy = (asm_[pt * 64 + c] == tt) ? dsm[pt * 64 + c] * (uu > 0.f ? 1.f : 0.2f) : 0.f;
+        G[e * E2_LD + c] = s2c * (dy - m1c - ((z - mu2c) * is2c) * m2c);
       }
     }
-    __syncthreads();  // G and H complete for every wave
-    // dh1 = dz2 W2 (own rows), dy1 = dh1 * lrelu'(u1)  (u1 > 0  <=>  h1 > 0)
+    __syncthreads();  // dz2 complete
+    __builtin_amdgcn_sched_barrier(0);
+    e2_rowgemm<RT>(G, Bf, n, g, acc);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+    for (int t = 0; t < RT; ++t) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[t][i] *= (H[(16 * t + 4 * g + i) * E2_LD + c] > 0.f) ? 1.f : 0.2f;  // u1 > 0 <=> h1 > 0
+    }
+    // dW2 += dz2^T h1 over the unit's edges
+#pragma unroll 4
+    for (int s = 0; s < 4 * RT; ++s) {
+      const int e = 16 * (s >> 2) + 4 * g + (s & 3);
+      const float a = G[e * E2_LD + 16 * w + n];
+      const float4 b = *(const float4*)(H + e * E2_LD + 4 * n);
+      dw[0] = mfma16(a, b.x, dw[0]);
+      dw[1] = mfma16(a, b.y, dw[1]);
+      dw[2] = mfma16(a, b.z, dw[2]);
+      dw[3] = mfma16(a, b.w, dw[3]);
+    }
+    __syncthreads();  // every read of dz2 is done
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) G[(16 * t + 4 * g + i) * E2_LD + c] = acc[t][i];
+    }
+    __syncthreads();  // dy1 complete
     {
-      const float* gp = G + (32 * w + j) * ET_LD + h;
-      const float* wp = W2s + h * ET_LD + j;          // B[k = c][ji] = W2[c][ji] (dh1 = dz2 W2)
-#pragma unroll 8
-      for (int s = 0; s < 32; ++s) {
-        const float a = gp[2 * s];
-        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wp[2 * s * ET_LD], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wp[2 * s * ET_LD + 32], a1, 0, 0, 0);
-      }
-    }
-    // dW2 += dz2^T h1 over the unit's 8K edges (waves 0..3, one 32x32 tile each)
-    if (w < 4) {
-      const int ti = w >> 1, tj = w & 1;
-      for (int s = 0; s < EK / 2; ++s) {
-        const int e = 2 * s + h;
-        dw = __builtin_amdgcn_mfma_f32_32x32x2f32(G[e * ET_LD + 32 * ti + j], H[e * ET_LD + 32 * tj + j], dw, 0, 0, 0);
-      }
-    }
+      float* drow = DY1 + ((pt0 + w) * K) * 64 + lane;
+      const float* grow = G + (K * w) * E2_LD + lane;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int e = 32 * w + r3d_acc_row(r, lane);
-      a0[r] *= (H[e * ET_LD + j] > 0.f) ? 1.f : 0.2f;
-      a1[r] *= (H[e * ET_LD + 32 + j] > 0.f) ? 1.f : 0.2f;
-    }
-    __syncthreads();  // every read of G (dz2) and H is done
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int e = 32 * w + r3d_acc_row(r, lane);
-      G[e * ET_LD + j] = a0[r];
-      G[e * ET_LD + 32 + j] = a1[r];
-    }
-    // same wave reads its rows back channel-per-lane: store dy1 rows, BN1 partial sums
-    {
-      float* drow = DY1 + (pt0 * K + 32 * w) * 64 + lane;
-      const float* grow = G + (32 * w) * ET_LD + lane;
-#pragma unroll
-      for (int t = 0; t < 32; ++t) {
-        const float v = grow[t * ET_LD];
+      for (int t = 0; t < K; ++t) {
+        const float v = grow[t * E2_LD];
         drow[t * 64] = v;
         sdy += v;
         sdye += v * eh[t];
       }
     }
-    __syncthreads();  // before the next unit overwrites H / G / dsm
+    // the next unit writes H / dsm / asm_ (last read before the third barrier) before its first barrier and G after it
   }
-  // per-block partials
-  ps[w][0][lane] = sdy;
-  ps[w][1][lane] = sdye;
+  __syncthreads();
+  // thread coordinates again from an opaque copy: carried across the loop they cost a register the loop needs
+  int tid2 = threadIdx.x;
+  asm volatile("" : "+v"(tid2));
+  const int lane2 = tid2 & 63, w2 = tid2 >> 6, n2 = tid2 & 15, g2 = (tid2 >> 4) & 3;
+  float (*ps)[2][64] = (float (*)[2][64])smem;  // [4][2][64] block partials (aliases H)
+  ps[w2][0][lane2] = sdy;
+  ps[w2][1][lane2] = sdye;
   __syncthreads();
   float* mypart = part + (long)blockIdx.x * ET_PART;
-  if (tid < 128) {
-    const int v = tid >> 6, c = tid & 63;
-    float s = 0.f;
-    for (int q = 0; q < nwaves; ++q) s += ps[q][v][c];
-    mypart[4096 + v * 64 + c] = s;
+  if (tid2 < 128) {
+    const int v = tid2 >> 6, cc = tid2 & 63;
+    mypart[4096 + v * 64 + cc] = ((ps[0][v][cc] + ps[1][v][cc]) + ps[2][v][cc]) + ps[3][v][cc];
   }
-  if (w < 4) {
-    const int ti = w >> 1, tj = w & 1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mypart[(32 * ti + r3d_acc_row(r, lane)) * 64 + 32 * tj + j] = dw[r];
+  for (int i = 0; i < 4; ++i)
+    *(float4*)(mypart + (16 * w2 + 4 * g2 + i) * 64 + 4 * n2) = float4{dw[0][i], dw[1][i], dw[2][i], dw[3][i]};
+}
+
+// ---- one-pass training forward on the same 4-point / 16x16x4 unit (replaces MODE 2 of the 8-point kernel) ------
+// statistics of z2 and, per point and channel, max / min of the raw z2 over the K edges with their positions
+template <int RT>
+__global__ __launch_bounds__(256) void r3d_edgeconv_train_fwd2_kernel(
+    const float* __restrict__ PQ, const int* __restrict__ idx, const float* __restrict__ s1, const float* __restrict__ t1,
+    const float* __restrict__ W2, int N, long total_points, int* __restrict__ argmax_out, float* __restrict__ zmax_out,
+    float* __restrict__ zmin_out, int* __restrict__ argmin_out, float* __restrict__ part /* [grid][2][64] */) {
+  constexpr int K = 4 * RT, R = 16 * RT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* H = smem;              // [R][E2_LD] h1
+  float* Z = smem + R * E2_LD;  // [R][E2_LD] z2
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int c = 16 * w + n;
+  float Bz[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) Bz[s] = W2[c * 64 + 16 * g + s];  // z2[e][c] = sum_k h1[e][k] W2[c][k]
+  const float sc1 = s1[lane], sh1 = t1[lane];
+  float za = 0.f, zb = 0.f;
+  const long units = total_points / E2_PTS;
+  for (long u = blockIdx.x; u < units; u += gridDim.x) {
+    const long pt0 = u * E2_PTS;
+    const long cloud0 = (pt0 / N) * N;
+    {
+      const int my_idx = idx[(pt0 + w) * K + min(lane, K - 1)];
+      const float q = PQ[(pt0 + w) * 128 + 64 + lane];
+      float pv[K];
+#pragma unroll
+      for (int t = 0; t < K; ++t) pv[t] = PQ[(cloud0 + __builtin_amdgcn_readlane(my_idx, t)) * 128 + lane];
+      float* hrow = H + (K * w) * E2_LD + lane;
+#pragma unroll
+      for (int t = 0; t < K; ++t) hrow[t * E2_LD] = lrelu(sc1 * (pv[t] + q) + sh1);
+    }
+    __syncthreads();  // H complete; every wave is done scanning the previous unit's Z
+    f32x4 acc[RT];
+    e2_rowgemm<RT>(H, Bz, n, g, acc);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float z = acc[t][i];
+        za += z;
+        zb += z * z;
+        Z[(16 * t + 4 * g + i) * E2_LD + c] = z;
+      }
+    }
+    __syncthreads();  // Z complete; H free for the next unit's gather
+    {
+      const float* zp = Z + (K * w) * E2_LD + lane;  // point w, channel lane
+      float zx = zp[0], zn = zx;
+      int ax = 0, an = 0;
+#pragma unroll
+      for (int t = 1; t < K; ++t) {
+        const float z = zp[t * E2_LD];
+        if (z > zx) { zx = z; ax = t; }
+        if (z < zn) { zn = z; an = t; }
+      }
+      const long o = (pt0 + w) * 64 + lane;
+      zmax_out[o] = zx;
+      zmin_out[o] = zn;
+      argmax_out[o] = ax;
+      argmin_out[o] = an;
+    }
+  }
+  // the four lane groups of a wave hold partial sums of the same 16 channels; wave w owns channels 16w..16w+15
+  za += __shfl_xor(za, 16); zb += __shfl_xor(zb, 16);
+  za += __shfl_xor(za, 32); zb += __shfl_xor(zb, 32);
+  if (g == 0) {
+    part[((long)blockIdx.x * 2 + 0) * 64 + c] = za;
+    part[((long)blockIdx.x * 2 + 1) * 64 + c] = zb;
   }
 }
 
@@ -419,8 +475,7 @@ static int et_fwd_lds_attr(size_t lds) {
   if (lds <= done) return 0;
   hipError_t e0 = hipFuncSetAttribute((const void*)r3d_edgeconv_train_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipError_t e1 = hipFuncSetAttribute((const void*)r3d_edgeconv_train_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipError_t e2 = hipFuncSetAttribute((const void*)r3d_edgeconv_train_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess) {
+  if (e0 != hipSuccess || e1 != hipSuccess) {
     r3d_set_error("r3d_edgeconv_train_fwd: cannot reserve %zu B of LDS", lds);
     return R3D_ERR_LAUNCH;
   }
@@ -462,18 +517,55 @@ extern "C" int r3d_edgeconv_train_fwd(const float* PQ, const int32_t* idx, const
   if (mode == 1) {
     R3D_REQUIRE(sums_out, "r3d_edgeconv_train_fwd: mode 1 needs sums_out");
     hipLaunchKernelGGL(r3d_edgeconv_train_fwd_kernel<1>, dim3(grid), dim3(64 * waves), lds, st, PQ, idx, s1, t1, W2, s2, t2,
-                       out, ldo, N, K, (long)B * N, argmax_out, zmax_out, ws, nullptr, nullptr);
+                       out, ldo, N, K, (long)B * N, argmax_out, zmax_out, ws);
     hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(128 / 4), dim3(256), 0, st, ws, grid, 128, sums_out);
   } else {
     R3D_REQUIRE(out && s2 && t2 && ldo >= 64, "r3d_edgeconv_train_fwd: mode 0 needs out, s2, t2");
     hipLaunchKernelGGL(r3d_edgeconv_train_fwd_kernel<0>, dim3(grid), dim3(64 * waves), lds, st, PQ, idx, s1, t1, W2, s2, t2,
-                       out, ldo, N, K, (long)B * N, argmax_out, zmax_out, ws, nullptr, nullptr);
+                       out, ldo, N, K, (long)B * N, argmax_out, zmax_out, ws);
   }
   R3D_LAUNCH_CHECK("r3d_edgeconv_train_fwd");
   return R3D_OK;
 }
 
-// One-pass training forward (mode 2 above): sums_out [2][64] = (sum z2, sum z2^2) over all edges; zmax / zmin /
+template <int RT>
+static int fwd2_launch_rt(long units, hipStream_t st, const float* PQ, const int32_t* idx, const float* s1, const float* t1,
+                          const float* W2, int N, long total_points, int32_t* argmax, float* zmax, float* zmin,
+                          int32_t* argmin, float* ws, int* grid_out) {
+  const size_t lds = sizeof(float) * ((size_t)2 * 16 * RT * E2_LD);
+  static int resident = 0;
+  if (!resident) {
+    hipError_t e = hipFuncSetAttribute((const void*)r3d_edgeconv_train_fwd2_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    R3D_REQUIRE(e == hipSuccess, "r3d_edgeconv_train_fwd_minmax: cannot reserve %zu B of LDS", lds);
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    R3D_REQUIRE(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, r3d_edgeconv_train_fwd2_kernel<RT>, 256, lds) == hipSuccess &&
+                    hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && per_cu > 0,
+                "r3d_edgeconv_train_fwd_minmax: occupancy query failed");
+    resident = per_cu * prop.multiProcessorCount;
+    if (resident > ET_MAXBLK) resident = ET_MAXBLK;
+  }
+  const int grid = (int)(units < resident ? units : resident);
+  hipLaunchKernelGGL(r3d_edgeconv_train_fwd2_kernel<RT>, dim3(grid), dim3(256), lds, st, PQ, idx, s1, t1, W2, N, total_points,
+                     argmax, zmax, zmin, argmin, ws);
+  *grid_out = grid;
+  return R3D_OK;
+}
+static int fwd2_launch(int K, long units, hipStream_t st, const float* PQ, const int32_t* idx, const float* s1, const float* t1,
+                       const float* W2, int N, long total_points, int32_t* argmax, float* zmax, float* zmin, int32_t* argmin,
+                       float* ws, int* grid_out) {
+#define E2_CASE(RT)                                                                                                       \
+  case RT:                                                                                                                \
+    return fwd2_launch_rt<RT>(units, st, PQ, idx, s1, t1, W2, N, total_points, argmax, zmax, zmin, argmin, ws, grid_out)
+  switch (K / 4) {
+    E2_CASE(1); E2_CASE(2); E2_CASE(3); E2_CASE(4); E2_CASE(5); E2_CASE(6); E2_CASE(7); E2_CASE(8);
+  }
+#undef E2_CASE
+  r3d_set_error("r3d_edgeconv_train_fwd_minmax: unsupported K=%d", K);
+  return R3D_ERR_ARG;
+}
+
+// One-pass training forward (r3d_edgeconv_train_fwd2_kernel): sums_out [2][64] = (sum z2, sum z2^2) over all edges; zmax / zmin /
 // argmax / argmin (B*N, 64) per point and channel.  Follow with r3d_bn_fold and r3d_edge_select.
 extern "C" int r3d_edgeconv_train_fwd_minmax(const float* PQ, const int32_t* idx, const float* s1, const float* t1,
                                              const float* W2, int B, int N, int K, float* zmax, float* zmin,
@@ -482,15 +574,10 @@ extern "C" int r3d_edgeconv_train_fwd_minmax(const float* PQ, const int32_t* idx
               "r3d_edgeconv_train_fwd_minmax: null pointer");
   int rc = et_check("r3d_edgeconv_train_fwd_minmax", B, N, K);
   if (rc) return rc;
-  const int waves = ET_PTS * K / 32;
-  const size_t lds = sizeof(float) * ((size_t)ET_PTS * K * ET_LD + 64 * ET_LD);
-  const long units = (long)B * N / ET_PTS;
-  const int grid = et_grid(units);
   hipStream_t st = (hipStream_t)stream;
-  rc = et_fwd_lds_attr(lds);
+  int grid = 0;
+  rc = fwd2_launch(K, (long)B * N / E2_PTS, st, PQ, idx, s1, t1, W2, N, (long)B * N, argmax, zmax, zmin, argmin, ws, &grid);
   if (rc) return rc;
-  hipLaunchKernelGGL(r3d_edgeconv_train_fwd_kernel<2>, dim3(grid), dim3(64 * waves), lds, st, PQ, idx, s1, t1, W2, nullptr,
-                     nullptr, nullptr, 0, N, K, (long)B * N, argmax, zmax, ws, zmin, argmin);
   hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(128 / 4), dim3(256), 0, st, ws, grid, 128, sums_out);
   R3D_LAUNCH_CHECK("r3d_edgeconv_train_fwd_minmax");
   return R3D_OK;
@@ -521,6 +608,46 @@ extern "C" int r3d_edge_select(float* zmax, const float* zmin, int32_t* argmax, 
   return R3D_OK;
 }
 
+template <int RT>
+static int bwd1_launch_rt(long units, hipStream_t st, const float* PQ, const int32_t* idx, const float* s1, const float* t1,
+                          const float* mean1, const float* invstd1, const float* W2, const float* s2, const float* t2,
+                          const float* mean2, const float* invstd2, const float* bn2_sums, const float* dout, long lddo,
+                          const int32_t* argmax, int N, long total_points, float* DY1, float* ws, int* grid_out) {
+  const size_t lds = sizeof(float) * ((size_t)2 * 16 * RT * E2_LD + 2 * E2_PTS * 64);
+  static int resident = 0;  // workgroups the chip holds at once (persistent loop over the units)
+  if (!resident) {
+    hipError_t e = hipFuncSetAttribute((const void*)r3d_edgeconv_bwd1_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    R3D_REQUIRE(e == hipSuccess, "r3d_edgeconv_bwd: cannot reserve %zu B of LDS", lds);
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    R3D_REQUIRE(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, r3d_edgeconv_bwd1_kernel<RT>, 256, lds) == hipSuccess &&
+                    hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && per_cu > 0,
+                "r3d_edgeconv_bwd: occupancy query failed");
+    resident = per_cu * prop.multiProcessorCount;
+    if (resident > ET_MAXBLK) resident = ET_MAXBLK;
+  }
+  const int grid = (int)(units < resident ? units : resident);
+  hipLaunchKernelGGL(r3d_edgeconv_bwd1_kernel<RT>, dim3(grid), dim3(256), lds, st, PQ, idx, s1, t1, mean1, invstd1, W2, s2, t2,
+                     mean2, invstd2, bn2_sums, dout, lddo, argmax, N, total_points, DY1, ws);
+  *grid_out = grid;
+  return R3D_OK;
+}
+static int bwd1_launch(int K, long units, hipStream_t st, const float* PQ, const int32_t* idx, const float* s1, const float* t1,
+                       const float* mean1, const float* invstd1, const float* W2, const float* s2, const float* t2,
+                       const float* mean2, const float* invstd2, const float* bn2_sums, const float* dout, long lddo,
+                       const int32_t* argmax, int N, long total_points, float* DY1, float* ws, int* grid_out) {
+#define E2_CASE(RT)                                                                                                       \
+  case RT:                                                                                                                \
+    return bwd1_launch_rt<RT>(units, st, PQ, idx, s1, t1, mean1, invstd1, W2, s2, t2, mean2, invstd2, bn2_sums, dout, lddo, \
+                              argmax, N, total_points, DY1, ws, grid_out)
+  switch (K / 4) {
+    E2_CASE(1); E2_CASE(2); E2_CASE(3); E2_CASE(4); E2_CASE(5); E2_CASE(6); E2_CASE(7); E2_CASE(8);
+  }
+#undef E2_CASE
+  r3d_set_error("r3d_edgeconv_bwd: unsupported K=%d", K);
+  return R3D_ERR_ARG;
+}
+
 // Backward.  bn2_sums [2][64] = (sum dy2, sum dy2*zhat2) (from the point-level winners, computed by the
 // caller with r3d_colstats mode 1 on zmax).  Outputs: dW2 (64,64), bn1_sums [2][64] (sum dy1, sum dy1*ehat1),
 // dPQ (B*N,128) (zero-initialised by this call).  DY1 scratch: B*N*K*64 floats.
@@ -534,20 +661,12 @@ extern "C" int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float
               "r3d_edgeconv_bwd: null pointer");
   int rc = et_check("r3d_edgeconv_bwd", B, N, K);
   if (rc) return rc;
-  const int waves = ET_PTS * K / 32;
-  const int EK = ET_PTS * K;
-  const size_t lds = sizeof(float) * ((size_t)2 * EK * ET_LD + 2 * ET_PTS * 64 + 64 * ET_LD + EK);
-  const long units = (long)B * N / ET_PTS;
-  const int grid = et_grid(units);
+  const long units = (long)B * N / E2_PTS;
   hipStream_t st = (hipStream_t)stream;
-  static size_t attr = 0;
-  if (lds > attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)r3d_edgeconv_bwd1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    R3D_REQUIRE(e == hipSuccess, "r3d_edgeconv_bwd: cannot reserve %zu B of LDS", lds);
-    attr = lds;
-  }
-  hipLaunchKernelGGL(r3d_edgeconv_bwd1_kernel, dim3(grid), dim3(64 * waves), lds, st, PQ, idx, s1, t1, mean1, invstd1, W2,
-                     s2, t2, mean2, invstd2, bn2_sums, dout, lddo, argmax, N, K, (long)B * N, DY1, ws);
+  int grid = 0;
+  rc = bwd1_launch(K, units, st, PQ, idx, s1, t1, mean1, invstd1, W2, s2, t2, mean2, invstd2, bn2_sums, dout, lddo, argmax, N,
+                   (long)B * N, DY1, ws, &grid);
+  if (rc) return rc;
   // partial layout: dW2 (4096) | sum dy1 (64) | sum dy1*ehat1 (64)
   float* red = ws + (long)grid * ET_PART;  // ET_PART floats of headroom are part of r3d_edgeconv_train_ws_words
   hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(r3d_cdiv(ET_PART, 4)), dim3(256), 0, st, ws, grid, ET_PART, red);

@@ -93,6 +93,53 @@ def test_encoder_train_forward_and_gradients():
         np.testing.assert_allclose(got.numpy(), v.numpy(), atol=1e-5, rtol=1e-4)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [4, 8, 12, 16, 20, 24, 28, 32])
+def test_edgeconv_train_layer_every_k(K):
+    """One EdgeConv layer in training mode (forward + backward kernels, one instantiation per K) against torch
+    autograd in fp64 on the same neighbour lists (models/dgcnn.py:26-61 with batch-statistics BatchNorm)."""
+    from r3dfsseg_amd import train_ops as T
+    B, N, C = 3, 72, 8
+    rs = np.random.RandomState(100 + K)
+    x = torch.from_numpy(rs.randn(B * N, C).astype(np.float32))
+    idx = torch.from_numpy(np.stack([[rs.permutation(N)[:K] for _ in range(N)] for _ in range(B)]).astype(np.int32))
+    conv1 = torch.nn.Conv2d(2 * C, 64, 1, bias=False)
+    conv2 = torch.nn.Conv2d(64, 64, 1, bias=False)
+    bn1, bn2 = torch.nn.BatchNorm2d(64), torch.nn.BatchNorm2d(64)
+    with torch.no_grad():
+        conv1.weight.copy_(torch.from_numpy(rs.randn(64, 2 * C, 1, 1).astype(np.float32) * 0.4))
+        conv2.weight.copy_(torch.from_numpy(rs.randn(64, 64, 1, 1).astype(np.float32) * 0.2))
+        for bn in (bn1, bn2):
+            bn.weight.copy_(torch.from_numpy(rs.uniform(-1.5, 1.5, 64).astype(np.float32)))  # both signs: max AND min winners
+            bn.bias.copy_(torch.from_numpy(rs.randn(64).astype(np.float32) * 0.3))
+    R = torch.from_numpy(rs.randn(B * N, 64).astype(np.float32))
+    # reference, fp64
+    xr = x.double().requires_grad_()
+    W1r, W2r = conv1.weight.detach().double().reshape(64, 2 * C).requires_grad_(), conv2.weight.detach().double().reshape(64, 64).requires_grad_()
+    g1, b1, g2, b2 = [t.detach().double().requires_grad_() for t in (bn1.weight, bn1.bias, bn2.weight, bn2.bias)]
+    xb = xr.view(B, N, C)
+    nb = torch.stack([xb[b][idx[b].long()] for b in range(B)])            # (B,N,K,C)
+    ctr = xb[:, :, None, :].expand(B, N, K, C)
+    e1 = torch.cat((nb - ctr, ctr), -1) @ W1r.t()                           # (B,N,K,64)
+
+    def bn_act(z, g, b):
+        mu, var = z.mean((0, 1, 2)), z.var((0, 1, 2), unbiased=False)
+        return torch.nn.functional.leaky_relu((z - mu) / torch.sqrt(var + 1e-5) * g + b, 0.2)
+    out_ref = bn_act(bn_act(e1, g1, b1) @ W2r.t(), g2, b2).max(2)[0].reshape(B * N, 64)
+    (out_ref * R.double()).sum().backward()
+    # device
+    ec = SimpleNamespace(layer=[conv1.cuda(), bn1.cuda().train(), None, conv2.cuda(), bn2.cuda().train()])
+    out = torch.empty(B * N, 64, device="cuda")
+    saved = T.edgeconv_train_fwd(x.cuda(), idx.cuda().contiguous(), ec, B, N, out)
+    np.testing.assert_allclose(out.cpu().numpy(), out_ref.detach().numpy(), atol=2e-4, rtol=2e-4)
+    dx = torch.zeros(B * N, C, device="cuda")
+    dW1, dg1, db1, dW2, dg2, db2 = T.edgeconv_train_bwd(saved, R.cuda(), B, N, dx)
+    torch.cuda.synchronize()
+    for name, got, ref in (("dW1", dW1.reshape(64, 2 * C), W1r.grad), ("dW2", dW2.reshape(64, 64), W2r.grad), ("dg1", dg1, g1.grad),
+                           ("db1", db1, b1.grad), ("dg2", dg2, g2.grad), ("db2", db2, b2.grad), ("dx", dx, xr.grad)):
+        assert _rel(got.cpu().double(), ref) < 5e-4, (name, K, _rel(got.cpu().double(), ref))
+
+
 def test_attention_dropout_mask_and_backward():
     """Dropout mask is a stateless hash: replicate it on the host, feed it to the oracle."""
     from r3dfsseg_amd import ops, _lib
