@@ -11,108 +11,88 @@
 // and only the second 64x64 layer runs per edge, on the matrix core:
 //   out[i] = max_j lrelu(s2 * (W2 h1(i, j)) + t2).
 //
-// Work unit: 8 points = 8K edges (K % 4 == 0), one wave per 32 edges (K = 20: 5 waves).
-// Each wave gathers the P rows of its own 32 edges into LDS (256-B coalesced rows),
-// runs 2 x 32 MFMAs (32 edges x 64 outputs, W2 fragments read from LDS), writes
-// the activated 32 x 64 block back over its LDS rows; the max over each point's K rows
-// is then a plain LDS reduction.  Workgroups walk units with a grid stride.
-#include "common.h"
+// Work unit: 4 points = 4K edges (K % 4 == 0), 4 waves (edge_tile.h): wave w gathers the K neighbour rows of point w
+// (256-B coalesced rows, all K in flight) into LDS, the 64x64 layer runs on 16x16x4 MFMAs with wave w owning output
+// channels 16w..16w+15 (W2 fragments in registers), the activated block goes to a second LDS tile and the max over
+// each point's K rows is a column scan (point w, channel lane).  Workgroups walk units with a grid stride; 44 KB of
+// LDS at K = 20 keep 3 workgroups per CU.
+#include "edge_tile.h"
 
-#define EC_PTS 8
-#define EC_LD 65
-
-__global__ __launch_bounds__(512) void r3d_edgeconv_kernel(
+template <int RT>
+__global__ __launch_bounds__(256) void r3d_edgeconv_kernel(
     const float* __restrict__ PQ, const int* __restrict__ idx, const float* __restrict__ W2,
     const float* __restrict__ s2, const float* __restrict__ t2, float* __restrict__ out, long ldo,
-    int N, int K, long total_points, int* __restrict__ argmax_out) {
-  extern __shared__ __attribute__((aligned(16))) float H[];  // [8K][EC_LD]
+    int N, long total_points, int* __restrict__ argmax_out) {
+  constexpr int K = 4 * RT, R = 16 * RT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* H = smem;              // [R][E2_LD] h1
+  float* Z = smem + R * E2_LD;  // [R][E2_LD] activated second layer
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int nthreads = blockDim.x;
-  // W2 in LDS behind the edge rows: its MFMA B fragments (B[k][j] = W2[j][k]) would cost 64 VGPRs in registers
-  // and, with the 32-deep gather, one workgroup per CU; from LDS two fit and overlap gather and MFMA phases
-  float* W2s = H + EC_PTS * K * EC_LD;  // [64][EC_LD]
-  for (int o = tid; o < 64 * 64; o += nthreads) W2s[(o >> 6) * EC_LD + (o & 63)] = W2[o];
-  __syncthreads();
-  const float sc0 = s2[lane & 31], sh0 = t2[lane & 31];
-  const float sc1 = s2[32 + (lane & 31)], sh1 = t2[32 + (lane & 31)];
-  const long units = total_points / EC_PTS;
+  const int n = lane & 15, g = lane >> 4;
+  const int c = 16 * w + n;
+  float Bz[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) Bz[s] = W2[c * 64 + 16 * g + s];  // z2[e][c] = sum_k h1[e][k] W2[c][k]
+  const float s2c = s2[c], t2c = t2[c];
+  const long units = total_points / E2_PTS;
   for (long u = blockIdx.x; u < units; u += gridDim.x) {
-    const long pt0 = u * EC_PTS;            // first point of the unit (global row)
-    const long cloud0 = (pt0 / N) * N;      // first row of its cloud
-    // ---- gather: this wave's 32 edges
+    const long pt0 = u * E2_PTS;        // first point of the unit (global row)
+    const long cloud0 = (pt0 / N) * N;  // first row of its cloud
     {
-      const int e = 32 * w + (lane & 31);  // edge handled by this lane for the index load
-      const int my_idx = idx[pt0 * K + e];  // (8 points x K) indices are contiguous
-      float* hrow = H + (32 * w) * EC_LD;
-      // all 32 neighbour rows of the wave in flight at once (the gather is L2-latency bound: 8 at a time took
-      // four round trips per unit), then the adds / stores; the point's own Q row changes at most twice in 32 edges
-      float pv[32];
+      const int my_idx = idx[(pt0 + w) * K + min(lane, K - 1)];
+      const float q = PQ[(pt0 + w) * 128 + 64 + lane];
+      float pv[K];
 #pragma unroll
-      for (int t = 0; t < 32; ++t) pv[t] = PQ[(cloud0 + __builtin_amdgcn_readlane(my_idx, t)) * 128 + lane];
-      const int p_first = (32 * w) / K, p_last = (32 * w + 31) / K;
-      const float q0 = PQ[(pt0 + p_first) * 128 + 64 + lane];
-      const float q1 = PQ[(pt0 + min(p_first + 1, p_last)) * 128 + 64 + lane];
-      const float q2 = PQ[(pt0 + p_last) * 128 + 64 + lane];
-      const int e1 = (p_first + 1) * K - 32 * w, e2 = (p_first + 2) * K - 32 * w;  // first edge of the 2nd / 3rd point
-      if (K >= 16) {  // 32 consecutive edges touch at most 3 points
+      for (int t = 0; t < K; ++t) pv[t] = PQ[(cloud0 + __builtin_amdgcn_readlane(my_idx, t)) * 128 + lane];
+      float* hrow = H + (K * w) * E2_LD + lane;
 #pragma unroll
-        for (int t = 0; t < 32; ++t) {
-          const float q = t < e1 ? q0 : (t < e2 ? q1 : q2);
-          float h = pv[t] + q;
-          h = h > 0.f ? h : 0.2f * h;
-          hrow[t * EC_LD + lane] = h;
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < 32; ++t) {
-          float h = pv[t] + PQ[(pt0 + (32 * w + t) / K) * 128 + 64 + lane];
-          h = h > 0.f ? h : 0.2f * h;
-          hrow[t * EC_LD + lane] = h;
-        }
+      for (int t = 0; t < K; ++t) {
+        const float h = pv[t] + q;
+        hrow[t * E2_LD] = h > 0.f ? h : 0.2f * h;
       }
     }
-    // ---- second layer on the matrix core (wave-local rows: no barrier needed)
-    f32x16 a0, a1;
+    __syncthreads();  // H complete; every wave is done scanning the previous unit's Z
+    f32x4 acc[RT];
+    e2_rowgemm<RT>(H, Bz, n, g, acc);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
-    {
-      const float* ap = H + (32 * w + (lane & 31)) * EC_LD + (lane >> 5);
-      const float* bp0 = W2s + (lane & 31) * EC_LD + (lane >> 5);
-      const float* bp1 = bp0 + 32 * EC_LD;
-#pragma unroll 8
-      for (int s = 0; s < 32; ++s) {
-        const float a = ap[2 * s];
-        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp0[2 * s], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp1[2 * s], a1, 0, 0, 0);
+    for (int t = 0; t < RT; ++t) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = s2c * acc[t][i] + t2c;  // BN2 + LeakyReLU
+        Z[(16 * t + 4 * g + i) * E2_LD + c] = v > 0.f ? v : 0.2f * v;
       }
     }
-    // ---- BN2 + LeakyReLU, back into this wave's LDS rows
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = 32 * w + r3d_acc_row(r, lane);
-      float v0 = sc0 * a0[r] + sh0;
-      v0 = v0 > 0.f ? v0 : 0.2f * v0;
-      float v1 = sc1 * a1[r] + sh1;
-      v1 = v1 > 0.f ? v1 : 0.2f * v1;
-      H[row * EC_LD + (lane & 31)] = v0;
-      H[row * EC_LD + 32 + (lane & 31)] = v1;
-    }
-    __syncthreads();
-    // ---- max over the K rows of each point (first maximum wins, as torch.max)
-    for (int o = tid; o < EC_PTS * 64; o += nthreads) {
-      const int pt = o >> 6, ch = o & 63;
-      const float* hp = H + (pt * K) * EC_LD + ch;
-      float m = hp[0];
+    __syncthreads();  // Z complete; H free for the next unit's gather
+    {
+      // max over the K rows of point w, channel lane (first maximum wins, as torch.max)
+      const float* zp = Z + (K * w) * E2_LD + lane;
+      float m = zp[0];
       int am = 0;
+#pragma unroll
       for (int t = 1; t < K; ++t) {
-        const float v = hp[t * EC_LD];
+        const float v = zp[t * E2_LD];
         if (v > m) { m = v; am = t; }
       }
-      out[(pt0 + pt) * ldo + ch] = m;
-      if (argmax_out) argmax_out[(pt0 + pt) * 64 + ch] = am;
+      out[(pt0 + w) * ldo + lane] = m;
+      if (argmax_out) argmax_out[(pt0 + w) * 64 + lane] = am;
     }
-    __syncthreads();
   }
+}
+
+template <int RT>
+static int edgeconv_launch_rt(const float* PQ, const int32_t* idx, const float* W2, const float* s2, const float* t2, float* out,
+                              long ldo, int N, long total_points, int32_t* argmax_out, hipStream_t st) {
+  const size_t lds = sizeof(float) * ((size_t)2 * 16 * RT * E2_LD);
+  static int resident = 0;  // workgroups the chip holds at once
+  if (!resident) {
+    resident = e2_resident_blocks(r3d_edgeconv_kernel<RT>, lds, 1024);
+    R3D_REQUIRE(resident > 0, "r3d_edgeconv_fwd: cannot reserve %zu B of LDS", lds);
+  }
+  const long units = total_points / E2_PTS;
+  const int grid = (int)(units < resident ? units : resident);
+  hipLaunchKernelGGL(r3d_edgeconv_kernel<RT>, dim3(grid), dim3(256), lds, st, PQ, idx, W2, s2, t2, out, ldo, N, total_points,
+                     argmax_out);
+  return R3D_OK;
 }
 
 // PQ: (B*N, 128) point-major [P | Q]; idx: (B, N, K) int32 neighbour ids local to the
@@ -124,20 +104,17 @@ extern "C" int r3d_edgeconv_fwd(const float* PQ, const int32_t* idx, const float
                                 int32_t* argmax_out, void* stream) {
   R3D_REQUIRE(PQ && idx && W2 && s2 && t2 && out, "r3d_edgeconv_fwd: null pointer");
   R3D_REQUIRE(B > 0 && N > 0 && ldo >= 64, "r3d_edgeconv_fwd: bad shape");
-  R3D_REQUIRE(N % EC_PTS == 0, "r3d_edgeconv_fwd: N=%d must be a multiple of %d", N, EC_PTS);
+  R3D_REQUIRE(N % E2_PTS == 0, "r3d_edgeconv_fwd: N=%d must be a multiple of %d", N, E2_PTS);
   R3D_REQUIRE(K >= 4 && K <= 32 && K % 4 == 0, "r3d_edgeconv_fwd: K=%d unsupported (need K %% 4 == 0, 4..32)", K);
-  const int waves = EC_PTS * K / 32;
-  const size_t lds = sizeof(float) * ((size_t)EC_PTS * K * EC_LD + 64 * EC_LD);
-  const long units = (long)B * N / EC_PTS;
-  int grid = (int)(units < 1024 ? units : 1024);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)r3d_edgeconv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        160 * 1024);
-    attr_set = true;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = R3D_ERR_ARG;
+#define E2_CASE(RT) \
+  case RT: rc = edgeconv_launch_rt<RT>(PQ, idx, W2, s2, t2, out, ldo, N, (long)B * N, argmax_out, st); break
+  switch (K / 4) {
+    E2_CASE(1); E2_CASE(2); E2_CASE(3); E2_CASE(4); E2_CASE(5); E2_CASE(6); E2_CASE(7); E2_CASE(8);
   }
-  hipLaunchKernelGGL(r3d_edgeconv_kernel, dim3(grid), dim3(64 * waves), lds, (hipStream_t)stream, PQ, idx,
-                     W2, s2, t2, out, ldo, N, K, (long)B * N, argmax_out);
+#undef E2_CASE
+  if (rc) return rc;
   R3D_LAUNCH_CHECK("r3d_edgeconv_fwd");
   return R3D_OK;
 }

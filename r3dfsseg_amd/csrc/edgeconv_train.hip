@@ -12,7 +12,7 @@
 //       dh1 = dz2 W2; dy1 = dh1 lrelu'(u1) -> stored per edge; partial sums of dy1, dy1 ehat1
 //   B2 (gather/scatter): de1 = s1 (dy1 - n1 - ehat1 n2); dQ[i] = sum_t de1; dP[j] += de1 (float atomics
 //       on whole 256-B rows, the shape the memory-side atomic units run at full rate).
-#include "common.h"
+#include "edge_tile.h"
 
 #define ET_PTS 8
 #define ET_LD 65
@@ -177,44 +177,10 @@ __global__ __launch_bounds__(512) void r3d_edgeconv_train_fwd_kernel(
 }
 
 // ---- backward pass B1 -------------------------------------------------------------------------
-// Unit = 4 points = 4K edge rows = RT row tiles of 16 (K = 4 RT), one workgroup of 4 waves per unit, on
-// v_mfma_f32_16x16x4_f32: wave w owns the 16 output channels 16w.. of the two edge GEMMs (its W2 fragments stay
-// in 32 registers) and 16 rows of dW2.  Against the earlier 8-point / 32x32x2 version (5 waves on 4 SIMDs, 102 KB
-// of LDS, one workgroup per CU) every phase is balanced over the 4 SIMDs and 46 KB of LDS at K = 20 leave room
-// for 3 workgroups per CU, whose gather / MFMA / store phases overlap.
-// LDS rows have stride 68 words and the k index of every MFMA is assigned so that the operand reads are
-// conflict-free: row-major operands read 16 consecutive k per lane as four b128 (lane group g takes k = 16g..16g+15),
-// the edge-contraction (dW2) takes edge 16(s>>2) + 4g + (s&3) at step s.  The summation order over k differs from
-// the ascending chain; nothing in the backward decides an index.
+// 4-point units on 16x16x4 MFMA (edge_tile.h).  The dW2 edge contraction takes edge 16(s>>2) + 4g + (s&3) at step s
+// (conflict-free b32 reads of dz2, one b128 of h1 feeding four column tiles).
 // part layout per block: [0] dW2 partial 64*64, then [4096 + v*64 + c], v = 0: sum dy1, 1: sum dy1*ehat1
 #define ET_PART (64 * 64 + 2 * 64)
-#define E2_PTS 4
-#define E2_LD 68
-static __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-// acc[t] (rows 16t.., this wave's 16 columns) = A[rows][0..63] * B, A row-major in LDS, B fragments in registers
-template <int RT>
-static __device__ __forceinline__ void e2_rowgemm(const float* __restrict__ A, const float (&Bf)[16], int n, int g,
-                                                  f32x4 (&acc)[RT]) {
-#pragma unroll
-  for (int t = 0; t < RT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int qk = 0; qk < 4; ++qk) {  // four k per lane and step group: one b128 per row tile
-    float4 av[RT];
-#pragma unroll
-    for (int t = 0; t < RT; ++t) av[t] = *(const float4*)(A + (16 * t + n) * E2_LD + 16 * g + 4 * qk);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-#pragma unroll
-      for (int t = 0; t < RT; ++t) {  // RT independent accumulator chains back to back (40-cycle dependent latency)
-        const float a = s == 0 ? av[t].x : s == 1 ? av[t].y : s == 2 ? av[t].z : av[t].w;
-        acc[t] = mfma16(a, Bf[4 * qk + s], acc[t]);
-      }
-    }
-  }
-}
-
 template <int RT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT <= 5 ? 3 : 2))) void r3d_edgeconv_bwd1_kernel(
     const float* __restrict__ PQ, const int* __restrict__ idx, const float* __restrict__ s1, const float* __restrict__ t1,
@@ -535,15 +501,8 @@ static int fwd2_launch_rt(long units, hipStream_t st, const float* PQ, const int
   const size_t lds = sizeof(float) * ((size_t)2 * 16 * RT * E2_LD);
   static int resident = 0;
   if (!resident) {
-    hipError_t e = hipFuncSetAttribute((const void*)r3d_edgeconv_train_fwd2_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    R3D_REQUIRE(e == hipSuccess, "r3d_edgeconv_train_fwd_minmax: cannot reserve %zu B of LDS", lds);
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    R3D_REQUIRE(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, r3d_edgeconv_train_fwd2_kernel<RT>, 256, lds) == hipSuccess &&
-                    hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && per_cu > 0,
-                "r3d_edgeconv_train_fwd_minmax: occupancy query failed");
-    resident = per_cu * prop.multiProcessorCount;
-    if (resident > ET_MAXBLK) resident = ET_MAXBLK;
+    resident = e2_resident_blocks(r3d_edgeconv_train_fwd2_kernel<RT>, lds, ET_MAXBLK);
+    R3D_REQUIRE(resident > 0, "r3d_edgeconv_train_fwd_minmax: cannot reserve %zu B of LDS", lds);
   }
   const int grid = (int)(units < resident ? units : resident);
   hipLaunchKernelGGL(r3d_edgeconv_train_fwd2_kernel<RT>, dim3(grid), dim3(256), lds, st, PQ, idx, s1, t1, W2, N, total_points,
@@ -616,15 +575,8 @@ static int bwd1_launch_rt(long units, hipStream_t st, const float* PQ, const int
   const size_t lds = sizeof(float) * ((size_t)2 * 16 * RT * E2_LD + 2 * E2_PTS * 64);
   static int resident = 0;  // workgroups the chip holds at once (persistent loop over the units)
   if (!resident) {
-    hipError_t e = hipFuncSetAttribute((const void*)r3d_edgeconv_bwd1_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    R3D_REQUIRE(e == hipSuccess, "r3d_edgeconv_bwd: cannot reserve %zu B of LDS", lds);
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    R3D_REQUIRE(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, r3d_edgeconv_bwd1_kernel<RT>, 256, lds) == hipSuccess &&
-                    hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && per_cu > 0,
-                "r3d_edgeconv_bwd: occupancy query failed");
-    resident = per_cu * prop.multiProcessorCount;
-    if (resident > ET_MAXBLK) resident = ET_MAXBLK;
+    resident = e2_resident_blocks(r3d_edgeconv_bwd1_kernel<RT>, lds, ET_MAXBLK);
+    R3D_REQUIRE(resident > 0, "r3d_edgeconv_bwd: cannot reserve %zu B of LDS", lds);
   }
   const int grid = (int)(units < resident ? units : resident);
   hipLaunchKernelGGL(r3d_edgeconv_bwd1_kernel<RT>, dim3(grid), dim3(256), lds, st, PQ, idx, s1, t1, mean1, invstd1, W2, s2, t2,

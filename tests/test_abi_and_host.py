@@ -35,7 +35,7 @@ def test_abi_argument_validation_without_gpu():
     rc = lib.r3d_knn_topk(None, 9, None, 1, 64, 9, 20, 0, None, None, None, None, None, None, None)
     assert rc != 0 and b"null" in lib.r3d_last_error_string()
     rc = lib.r3d_edgeconv_fwd(ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8),
-                              ctypes.c_void_p(8), ctypes.c_void_p(8), 64, 1, 100, 20, None, None)
+                              ctypes.c_void_p(8), ctypes.c_void_p(8), 64, 1, 102, 20, None, None)
     assert rc != 0 and b"multiple" in lib.r3d_last_error_string()
 
 
