@@ -58,16 +58,37 @@ static __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
-// out[i] = sum over blocks of part[blk][i] in fp64: one wave per output, lane l adds blocks l, l+64, ...
-// (a fixed partition and a fixed shuffle tree: deterministic)
-__global__ void r3d_part_reduce_kernel(const float* __restrict__ part, int nblk, int n, float* __restrict__ out) {
-  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (i >= n) return;
+// out[i] = sum over blocks of part[blk][i] in fp64.  64 consecutive outputs per workgroup (coalesced 256-B rows of
+// `part`), the block axis split over 16 waves (blocks w, w+16, ...; 8 loads in flight), wave totals combined in a
+// fixed order: deterministic.  (One wave per output with lanes striding over the blocks fetched a 128-B line per
+// 4 useful bytes: 20 us for the 768 x 4224 partials of the backward pass.)
+// Outputs i >= split go to out2[i - split] (the backward's dW2 | BN1 sums land in their own buffers).
+__global__ __launch_bounds__(1024) void r3d_part_reduce_kernel(const float* __restrict__ part, int nblk, int n,
+                                                               float* __restrict__ out, int split, float* __restrict__ out2) {
+  __shared__ double sm[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
   double s = 0.0;
-  for (int k = lane; k < nblk; k += 64) s += (double)part[(long)k * n + i];
-  s = wave_sum_d(s);
-  if (lane == 0) out[i] = (float)s;
+  if (i < n) {
+    int k = w;
+    for (; k + 7 * 16 < nblk; k += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(long)(k + 16 * u) * n + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; k < nblk; k += 16) s += (double)part[(long)k * n + i];
+  }
+  sm[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && i < n) {
+    double t = sm[0][lane];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += sm[q][lane];
+    if (i < split) out[i] = (float)t;
+    else out2[i - split] = (float)t;
+  }
 }
 
 // ---- two-pass forward (8-point units, 32x32x2): mode 0 = output (+argmax, z at argmax); mode 1 = statistics of
@@ -390,10 +411,12 @@ __global__ __launch_bounds__(256) void r3d_edgeconv_train_fwd2_kernel(
 }
 
 // ---- backward pass B2: de1 -> dQ (sum over K), dP (scatter-add) ------------------------------------
+template <int RT>
 __global__ __launch_bounds__(256) void r3d_edgeconv_bwd2_kernel(
     const float* __restrict__ PQ, const int* __restrict__ idx, const float* __restrict__ s1, const float* __restrict__ mean1,
     const float* __restrict__ invstd1, const float* __restrict__ bn1_sums /* [2][64] */, const float* __restrict__ DY1,
-    int N, int K, long total_points, float* __restrict__ dPQ /* (M,128), zero-initialised */) {
+    int N, long total_points, float* __restrict__ dPQ /* (M,128), zero-initialised */) {
+  constexpr int K = 4 * RT;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const double E = (double)total_points * K;
   const float sc1 = s1[lane], mu1 = mean1[lane], is1 = invstd1[lane];
@@ -402,23 +425,21 @@ __global__ __launch_bounds__(256) void r3d_edgeconv_bwd2_kernel(
     const long cloud0 = (pt / N) * N;
     const float q = PQ[pt * 128 + 64 + lane];
     const int my_idx = idx[pt * K + min(lane, K - 1)];
+    // all K neighbour rows and all K dy1 rows of the point in flight at once (four at a time was a chain of K/4
+    // memory round trips per point)
+    float pv[K], dv[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      pv[t] = PQ[(cloud0 + __builtin_amdgcn_readlane(my_idx, t)) * 128 + lane];
+      dv[t] = DY1[(pt * K + t) * 64 + lane];
+    }
     float dq = 0.f;
-    for (int t = 0; t < K; t += 4) {  // K % 4 == 0: four rows of PQ and dy1 in flight
-      float pv[4], dv[4];
-      int jn[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        jn[u] = __builtin_amdgcn_readlane(my_idx, t + u);
-        pv[u] = PQ[(cloud0 + jn[u]) * 128 + lane];
-        dv[u] = DY1[(pt * K + t + u) * 64 + lane];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float e1 = pv[u] + q;
-        const float de = sc1 * (dv[u] - n1 - ((e1 - mu1) * is1) * n2);
-        dq += de;
-        atomicAdd(&dPQ[(cloud0 + jn[u]) * 128 + lane], de);
-      }
+    for (int t = 0; t < K; ++t) {
+      const float e1 = pv[t] + q;
+      const float de = sc1 * (dv[t] - n1 - ((e1 - mu1) * is1) * n2);
+      dq += de;
+      atomicAdd(&dPQ[(cloud0 + __builtin_amdgcn_readlane(my_idx, t)) * 128 + lane], de);
     }
     atomicAdd(&dPQ[pt * 128 + 64 + lane], dq);
   }
@@ -460,7 +481,7 @@ extern "C" int r3d_edge_stats1(const float* PQ, const int32_t* idx, int B, int N
   hipStream_t st = (hipStream_t)stream;
   const int grid = 512;
   hipLaunchKernelGGL(r3d_edge_stats1_kernel, dim3(grid), dim3(256), 0, st, PQ, idx, N, K, (long)B * N, ws);
-  hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(128 / 4), dim3(256), 0, st, ws, grid, 128, sums_out);
+  hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(128 / 64), dim3(1024), 0, st, ws, grid, 128, sums_out, 128, nullptr);
   R3D_LAUNCH_CHECK("r3d_edge_stats1");
   return R3D_OK;
 }
@@ -484,7 +505,7 @@ extern "C" int r3d_edgeconv_train_fwd(const float* PQ, const int32_t* idx, const
     R3D_REQUIRE(sums_out, "r3d_edgeconv_train_fwd: mode 1 needs sums_out");
     hipLaunchKernelGGL(r3d_edgeconv_train_fwd_kernel<1>, dim3(grid), dim3(64 * waves), lds, st, PQ, idx, s1, t1, W2, s2, t2,
                        out, ldo, N, K, (long)B * N, argmax_out, zmax_out, ws);
-    hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(128 / 4), dim3(256), 0, st, ws, grid, 128, sums_out);
+    hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(128 / 64), dim3(1024), 0, st, ws, grid, 128, sums_out, 128, nullptr);
   } else {
     R3D_REQUIRE(out && s2 && t2 && ldo >= 64, "r3d_edgeconv_train_fwd: mode 0 needs out, s2, t2");
     hipLaunchKernelGGL(r3d_edgeconv_train_fwd_kernel<0>, dim3(grid), dim3(64 * waves), lds, st, PQ, idx, s1, t1, W2, s2, t2,
@@ -537,7 +558,7 @@ extern "C" int r3d_edgeconv_train_fwd_minmax(const float* PQ, const int32_t* idx
   int grid = 0;
   rc = fwd2_launch(K, (long)B * N / E2_PTS, st, PQ, idx, s1, t1, W2, N, (long)B * N, argmax, zmax, zmin, argmin, ws, &grid);
   if (rc) return rc;
-  hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(128 / 4), dim3(256), 0, st, ws, grid, 128, sums_out);
+  hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(128 / 64), dim3(1024), 0, st, ws, grid, 128, sums_out, 128, nullptr);
   R3D_LAUNCH_CHECK("r3d_edgeconv_train_fwd_minmax");
   return R3D_OK;
 }
@@ -620,13 +641,18 @@ extern "C" int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float
                    (long)B * N, DY1, ws, &grid);
   if (rc) return rc;
   // partial layout: dW2 (4096) | sum dy1 (64) | sum dy1*ehat1 (64)
-  float* red = ws + (long)grid * ET_PART;  // ET_PART floats of headroom are part of r3d_edgeconv_train_ws_words
-  hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(r3d_cdiv(ET_PART, 4)), dim3(256), 0, st, ws, grid, ET_PART, red);
-  r3d_copy_words(dW2, red, 4096, st);
-  r3d_copy_words(bn1_sums, red + 4096, 128, st);
+  hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(r3d_cdiv(ET_PART, 64)), dim3(1024), 0, st, ws, grid, ET_PART, dW2, 4096,
+                     bn1_sums);
   r3d_zero_words(dPQ, (long)B * N * 128, st);
-  hipLaunchKernelGGL(r3d_edgeconv_bwd2_kernel, dim3(1024), dim3(256), 0, st, PQ, idx, s1, mean1, invstd1, bn1_sums, DY1, N,
-                     K, (long)B * N, dPQ);
+#define E2_CASE(RT)                                                                                                    \
+  case RT:                                                                                                             \
+    hipLaunchKernelGGL(r3d_edgeconv_bwd2_kernel<RT>, dim3(1024), dim3(256), 0, st, PQ, idx, s1, mean1, invstd1, bn1_sums, DY1, \
+                       N, (long)B * N, dPQ);                                                                           \
+    break
+  switch (K / 4) {
+    E2_CASE(1); E2_CASE(2); E2_CASE(3); E2_CASE(4); E2_CASE(5); E2_CASE(6); E2_CASE(7); E2_CASE(8);
+  }
+#undef E2_CASE
   R3D_LAUNCH_CHECK("r3d_edgeconv_bwd");
   return R3D_OK;
 }
