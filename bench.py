@@ -189,6 +189,7 @@ def main():
         lp_flags.append(head_flags())
 
     invalid = []  # reasons why a timed leg does not count (every episode must have a converged, exact head)
+    lp_budget_info = {}
 
     def timed(step_fn, steps, warmup, graphs=None):
         for i in range(warmup):
@@ -211,11 +212,13 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = t.item()
         if graphs is not None:
+            lp_budget_info[step_fn.__name__] = {"captured": graphs.lp_budget, "enabled_at_end": graphs.active_budget}
+            enabled = graphs.active_budget
             bad, it_sum, it_max = graphs.check()
             if bad:  # recorded, not fatal: an abort on one rank would leave the others in the next barrier
                 invalid.append("%s: %d episode(s) with unconverged label propagation / FPS time-out (CG max %d of budget %d), "
                                "%d with 201-NN survivor overflow" % (step_fn.__name__, graphs.last_unconverged, it_max,
-                                                                     graphs.lp_budget, graphs.last_knn_overflow))
+                                                                     enabled, graphs.last_knn_overflow))
             return el, (it_sum / (steps * E), it_max)
         lp = torch.stack(lp_flags).cpu()
         if int(lp[:, 2].max()) != 0:
@@ -244,7 +247,7 @@ def main():
         step_fn = eval_step_eager
     if train and G:
         n_ev = max(args.steps // 2, 1)
-        el_ev, _ = timed(eval_step, n_ev, 2, eval_graphs)
+        el_ev, _ = timed(eval_step, n_ev, 3, eval_graphs)
         extra["eval_forward_episodes_per_sec"] = n_ev * E * world / el_ev
         model.train()
 
@@ -382,6 +385,7 @@ def main():
         "roofline": roof, "rooflines": rooflines, "cpu_baseline": cpu,
         "entry_point_ms_per_step": breakdown,
         "lp_cg_iterations": {"mean": cg_mean, "max": cg_max},
+        "lp_cg_launch_budget": lp_budget_info,  # CG iterations captured per graph / kept enabled (episode_graph.py)
     }
     out.update(extra)
     if not out["valid"]:

@@ -108,6 +108,12 @@ int r3d_label_propagate(const float* nodes, long ldn, int D, const int32_t* nbr,
                         const int32_t* n_dev, int n_cap, float sigma, float alpha, int max_iter, float tol,
                         float* Z, int32_t* ws, int32_t* stats_out, void* stream);
 
+/* Captured episodes: enable the CG kernel nodes of iterations < budget in an instantiated hipGraph holding
+ * r3d_label_propagate / r3d_label_propagate_bwd launches, disable the rest (no dispatch for them).  graph: the
+ * hipGraph_t the hipGraphExec_t graph_exec was instantiated from.  n_cg (optional, host): CG nodes found.
+ * No reference counterpart (the reference inverts the dense matrix, models/mpti.py:758-776). */
+int r3d_graph_set_lp_budget(void* graph, void* graph_exec, int budget, int* n_cg);
+
 /* ---- query logits + cross entropy (models/mpti.py:558-559, 778-781) ------------------ */
 int r3d_query_logits_ce(const float* Z, const int32_t* n_proto_dev, int n_q, int N, int n_classes,
                         const int64_t* labels /*opt (n_q,N)*/, float* logits /*(n_q,n_classes,N)*/,

@@ -706,3 +706,45 @@ extern "C" int r3d_query_logits_ce(const float* Z, const int32_t* n_proto_dev, i
   R3D_LAUNCH_CHECK("r3d_query_logits_ce");
   return R3D_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Captured episodes (hipGraph): the CG loop of r3d_label_propagate / _bwd is frozen into the graph with its full
+// launch budget; iterations after convergence are launches that return at once, yet each still costs ~2.5 us of
+// queue time (141 of 200 pairs on average at workload S).  This call enables the CG kernel nodes of iterations
+// < budget in the instantiated graph and disables the others (a disabled node is an empty node: no dispatch), so
+// the owner can track the iteration counts it observes without re-capturing.  `graph` is the captured hipGraph_t
+// the executable graph was instantiated from.  Returns the number of CG nodes found through *n_cg (optional).
+// A solve that needs more than the enabled iterations reports "not converged" through stats_out as before.
+// ---------------------------------------------------------------------------
+extern "C" int r3d_graph_set_lp_budget(void* graph, void* graph_exec, int budget, int* n_cg) {
+  R3D_REQUIRE(graph && graph_exec && budget > 0, "r3d_graph_set_lp_budget: bad arguments");
+  hipGraph_t g = (hipGraph_t)graph;
+  hipGraphExec_t ge = (hipGraphExec_t)graph_exec;
+  size_t n = 0;
+  R3D_REQUIRE(hipGraphGetNodes(g, nullptr, &n) == hipSuccess, "r3d_graph_set_lp_budget: hipGraphGetNodes failed");
+  hipGraphNode_t* nodes = (hipGraphNode_t*)malloc(sizeof(hipGraphNode_t) * (n ? n : 1));
+  R3D_REQUIRE(nodes, "r3d_graph_set_lp_budget: out of memory");
+  int found = 0, rc = R3D_OK;
+  if (hipGraphGetNodes(g, nodes, &n) != hipSuccess) rc = R3D_ERR_LAUNCH;
+  for (size_t i = 0; rc == R3D_OK && i < n; ++i) {
+    hipGraphNodeType ty;
+    if (hipGraphNodeGetType(nodes[i], &ty) != hipSuccess) { rc = R3D_ERR_LAUNCH; break; }
+    if (ty != hipGraphNodeTypeKernel) continue;
+    hipKernelNodeParams kp;
+    if (hipGraphKernelNodeGetParams(nodes[i], &kp) != hipSuccess) { rc = R3D_ERR_LAUNCH; break; }
+    int it;
+    if (kp.func == (void*)r3d_cg_spmv_kernel) it = *(const int*)kp.kernelParams[6];
+    else if (kp.func == (void*)r3d_cg_update_kernel) it = *(const int*)kp.kernelParams[2];
+    else continue;
+    ++found;
+    if (hipGraphNodeSetEnabled(ge, nodes[i], it < budget ? 1u : 0u) != hipSuccess) { rc = R3D_ERR_LAUNCH; break; }
+  }
+  free(nodes);
+  if (rc != R3D_OK) {
+    r3d_set_error("r3d_graph_set_lp_budget: HIP graph call failed: %s", hipGetErrorString(hipGetLastError()));
+    return rc;
+  }
+  if (n_cg) *n_cg = found;
+  return R3D_OK;
+}
+

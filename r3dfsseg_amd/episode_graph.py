@@ -21,12 +21,19 @@ Frozen-sequence consequences, all checked or documented:
   * the attention-dropout seed advances in device memory (slot.seed_dev), not in a Python counter;
   * BatchNorm running statistics are updated by slot 0 only (shared buffers, concurrent slots would race);
     the batch statistics used for normalisation are per episode either way.
+
+The CG launch budget is adaptive without re-capturing: launches after convergence return at once but still cost
+~2.5 us of queue time each, so ``run()`` reads -- one step late, through a pinned buffer, never blocking -- the largest
+iteration count seen and keeps only the CG kernel nodes of the first ``2 * max + 8`` iterations enabled
+(``r3d_graph_set_lp_budget``: a disabled node is an empty node).  A replay that needs more reports "not converged"
+through ``check()`` as before, and the budget returns to the captured maximum.
 """
+import ctypes
 import os
 
 import torch
 
-from . import ops, train_ops
+from . import _lib, ops, train_ops
 from .mpti import EpisodeSlot
 
 
@@ -49,7 +56,13 @@ class EpisodeGraphs:
             assert self.grad_rows.shape[0] == n_slots and self.grad_rows.shape[1] >= n
         if lp_budget is None:  # CG iterations frozen into the graph; launches after convergence are no-ops (~3 us each)
             lp_budget = min(model.lp_max_iter, 200 if train else 128)
-        self.lp_budget = lp_budget
+        self.lp_budget = lp_budget          # CG iterations captured into every graph
+        self.active_budget = lp_budget      # ... of which this many are enabled
+        self.adaptive_budget = os.environ.get("R3D_FIXED_LP_BUDGET") is None
+        # per slot: [not converged / FPS time-out, 201-NN overflow, CG iterations (sum), CG iterations (max)]
+        self.counters = torch.zeros(n_slots, 4, device=dev, dtype=torch.int32)
+        self._probes = []                   # (event, pinned copy of the counters) of the steps still in flight
+        self._probe_pool = [torch.zeros(n_slots, 4, dtype=torch.int32).pin_memory() for _ in range(3)]
         self.slots = []
         self.ev_start = torch.cuda.Event()
         saved_slot = model._slot
@@ -98,10 +111,7 @@ class EpisodeGraphs:
         sl.done = torch.cuda.Event()
         sl.inputs = [t.to(dev).clone() for t in example]
         sl.loss_sum = torch.zeros((), device=dev)
-        sl.bad = torch.zeros((), device=dev, dtype=torch.int32)
-        sl.knn_overflow = torch.zeros((), device=dev, dtype=torch.int32)
-        sl.cg_iters = torch.zeros((), device=dev, dtype=torch.int32)
-        sl.cg_max = torch.zeros((), device=dev, dtype=torch.int32)
+        sl.bad, sl.knn_overflow, sl.cg_iters, sl.cg_max = (self.counters[s, i] for i in range(4))
         st = EpisodeSlot(s)
         st.fixed_budget = self.lp_budget
         st.update_running = (s == 0)
@@ -128,13 +138,44 @@ class EpisodeGraphs:
                 self._run_once(sl)
         cur.wait_stream(sl.stream)
         torch.cuda.synchronize()
-        sl.graph = torch.cuda.CUDAGraph()
+        sl.graph = torch.cuda.CUDAGraph(keep_graph=True)  # the hipGraph_t stays: its nodes are enabled / disabled later
         # thread-local capture mode: only this thread launches into the capture (no autograd engine threads in the
         # explicit episode), while other threads -- e.g. the RCCL watchdog of torch.distributed polling its events --
         # must stay free to call the HIP runtime
         with torch.cuda.graph(sl.graph, capture_error_mode="thread_local"):
             self._run_once(sl)
+        sl.graph.instantiate()
         return sl
+
+    # ------------------------------------------------------------------ CG launch budget
+    def set_lp_budget(self, budget):
+        """Enable the CG kernel nodes of the first `budget` iterations in every slot's graph, disable the rest."""
+        budget = max(1, min(int(budget), self.lp_budget))
+        if budget == self.active_budget:
+            return
+        lib = _lib.load()
+        for sl in self.slots:
+            sl.stream.synchronize()  # never edit an executable graph that is in flight
+            n_cg = ctypes.c_int(0)
+            _lib.check(lib.r3d_graph_set_lp_budget(ctypes.c_void_p(sl.graph.raw_cuda_graph()),
+                                                   ctypes.c_void_p(sl.graph.raw_cuda_graph_exec()), budget, ctypes.byref(n_cg)))
+            assert n_cg.value > 0, "no CG nodes found in the captured episode"
+        self.active_budget = budget
+
+    def _adapt_budget(self):
+        """At most two steps run ahead of the GPU: wait for the step before the previous one and read the counters it
+        left in pinned memory (no device synchronisation, the previous step keeps the GPU busy meanwhile)."""
+        while len(self._probes) >= 2:
+            ev, c = self._probes.pop(0)
+            ev.synchronize()
+            bad, mx = int(c[:, 0].sum()), int(c[:, 3].max())
+            self._probe_pool.append(c)
+            if not self.adaptive_budget:
+                continue
+            if bad > 0:      # a replay did not converge: back to everything that was captured
+                self.set_lp_budget(self.lp_budget)
+            elif mx > 0:
+                self.set_lp_budget(max(32, 8 * ((2 * mx + 8 + 7) // 8)))
 
     # ------------------------------------------------------------------ replay
     def reset(self):
@@ -160,6 +201,7 @@ class EpisodeGraphs:
         stream.  logits_out: optional (len(episodes), n_q, n_classes, N) buffer receiving every episode's query
         logits.  Returns the device scalar sum of the episodes' losses."""
         main = torch.cuda.current_stream()
+        self._adapt_budget()
         self.reset()
         self._refresh_folds()
         self.ev_start.record(main)
@@ -182,16 +224,20 @@ class EpisodeGraphs:
         total = self.slots[0].loss_sum
         for sl in self.slots[1:min(G, len(episodes))]:
             total = total + sl.loss_sum
+        c = self._probe_pool.pop()
+        c.copy_(self.counters, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self._probes.append((ev, c))
         return total
 
     def check(self):
         """Host check (synchronises): (number of replays whose label propagation did not converge or whose
         201-NN survivor buffer overflowed since the last check, mean CG iterations, max CG iterations)."""
-        self.last_unconverged = int(sum(int(sl.bad.item()) for sl in self.slots))
-        self.last_knn_overflow = int(sum(int(sl.knn_overflow.item()) for sl in self.slots))
-        bad = self.last_unconverged + self.last_knn_overflow
-        it = [int(sl.cg_iters.item()) for sl in self.slots]
-        mx = max(int(sl.cg_max.item()) for sl in self.slots)
-        for sl in self.slots:
-            sl.bad.zero_(); sl.knn_overflow.zero_(); sl.cg_iters.zero_(); sl.cg_max.zero_()
-        return bad, sum(it), mx
+        c = self.counters.cpu()
+        self.counters.zero_()
+        self.last_unconverged = int(c[:, 0].sum())
+        self.last_knn_overflow = int(c[:, 1].sum())
+        if self.last_unconverged:
+            self.set_lp_budget(self.lp_budget)
+        return self.last_unconverged + self.last_knn_overflow, int(c[:, 2].sum()), int(c[:, 3].max())

@@ -65,6 +65,45 @@ def test_eval_graphs_match_eager():
     np.testing.assert_allclose(out[0].cpu().numpy(), want.cpu().numpy(), atol=2e-5, rtol=1e-5)
 
 
+def test_cg_budget_by_disabling_graph_nodes():
+    """The captured CG loop can be shortened without re-capturing (r3d_graph_set_lp_budget): same logits while
+    the enabled iterations cover the solve, a reported miss when they do not, and full recovery afterwards."""
+    from r3dfsseg_amd.episode_graph import EpisodeGraphs
+    cfg = S.make_cfg(n_way=2, k_shot=2, pc_npts=512)
+    m = _model(cfg, False)
+    eps = [ep[:4] for ep in _episodes(cfg, 4)]
+    g = EpisodeGraphs(m, eps[0], n_slots=2, train=False, lp_budget=120)
+    g.adaptive_budget = False
+    ref = torch.empty(len(eps), 2, 3, 512, device="cuda")
+    g.run(eps, logits_out=ref)
+    torch.cuda.synchronize()
+    bad, _, mx = g.check()
+    assert bad == 0 and 0 < mx < 100
+    out = torch.empty_like(ref)
+    g.set_lp_budget(mx + 2)          # convergence is detected by the launch after the last productive one
+    assert g.active_budget == mx + 2
+    g.run(eps, logits_out=out)
+    torch.cuda.synchronize()
+    assert g.check()[0] == 0
+    assert torch.equal(out, ref)
+    g.set_lp_budget(3)               # far too few: every replay must say so
+    g.run(eps, logits_out=out)
+    torch.cuda.synchronize()
+    bad, _, _ = g.check()
+    assert bad == len(eps) and g.last_unconverged == len(eps)
+    assert g.active_budget == 120    # check() restores everything that was captured
+    g.run(eps, logits_out=out)
+    torch.cuda.synchronize()
+    assert g.check()[0] == 0 and torch.equal(out, ref)
+    # adaptive mode: the lagged probe shrinks the budget to 2 * max + 8 (rounded up to 8, at least 32)
+    g.adaptive_budget = True
+    for _ in range(4):
+        g.run(eps, logits_out=out)
+    torch.cuda.synchronize()
+    assert g.active_budget == max(32, 8 * ((2 * mx + 8 + 7) // 8)) and g.active_budget < 120
+    assert g.check()[0] == 0 and torch.equal(out, ref)
+
+
 def test_train_graphs_accumulate_the_eager_gradient():
     from r3dfsseg_amd.dist import FlatGradBucket
     from r3dfsseg_amd.episode_graph import EpisodeGraphs
