@@ -547,8 +547,11 @@ __global__ __launch_bounds__(256) void r3d_knn_small_kernel(
 //       and is recomputed by the exact insertion kernel launched right behind (it returns at once elsewhere).
 template <int KB_WAVES, int KB_CAP, int KB_TOP, int KCH /* k-pairs per channel chunk: 32 (64 channels) or 8 (16) */,
           int KB_SAMPLE /* pass A visits every KB_SAMPLE-th sub-tile of a wave: tau from a sample is still a lower bound */,
-          bool FULLC /* C is a multiple of the chunk width: no channel clamping / masking in the fragment loads */>
-__global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_append_kernel(
+          bool FULLC /* C is a multiple of the chunk width: no channel clamping / masking in the fragment loads */,
+          int SMODE /* score form (R3D_SCORE_*), a compile-time constant: the score arithmetic is VALU work that
+                       competes with the MFMAs for issue slots, 8 instructions per element with both forms computed */>
+__global__ __launch_bounds__(64 * KB_WAVES) __attribute__((amdgpu_waves_per_eu(KB_WAVES == 4 && (FULLC || KCH < 32) ? 3 : 2)))
+void r3d_knn_append_kernel(
     const float* __restrict__ xT, long ldT, int N, int C, int k, int mode, const int* __restrict__ n_dev,
     const float* __restrict__ nrm, int* __restrict__ idx_out, float* __restrict__ score_out,
     int* __restrict__ status, int* __restrict__ tile_flags) {
@@ -632,14 +635,19 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_append_kernel(
     const float nj = r3d_keep(nb[min(cand, n - 1)], valid);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      // both score forms, selected without a branch (a uniform `if (mode)` inside the unrolled loop became 32
-      // branches per sub-tile)
-      const float inner = -2.f * acc[r];
-      const float v_dg = ((-nj) - inner) - nq[r];
-      const float dis = (nq[r] + nj) - 2.f * acc[r];
-      const float v_l2 = -fmaxf(dis, 0.f);
-      const float v = mode == R3D_SCORE_DGCNN ? v_dg : v_l2;
-      sc[r] = valid ? v : -INFINITY;
+      float v;
+      if (SMODE == R3D_SCORE_DGCNN) {
+        const float inner = -2.f * acc[r];
+        v = ((-nj) - inner) - nq[r];
+      } else {
+        const float dis = (nq[r] + nj) - 2.f * acc[r];
+        v = -fmaxf(dis, 0.f);
+      }
+      sc[r] = v;
+    }
+    if (32 * st + 32 > n) {  // uniform: only the last sub-tile has candidates beyond n
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = valid ? sc[r] : -INFINITY;
     }
   };
 
@@ -753,27 +761,51 @@ __global__ __launch_bounds__(64 * KB_WAVES) void r3d_knn_append_kernel(
     if (tile_flags) tile_flags[(long)b * gridDim.x + blockIdx.x] = 1;
   }
   __syncthreads();
+  KSTAMP(14);
 
   // ------------------------------------------------------------------ rank the survivors
   for (int qq = 0; qq < 32 / KB_WAVES; ++qq) {
     const int q = (32 / KB_WAVES) * w + qq;
     const int row = q0 + q;
     if (row >= n) break;
-    const int M = min(cnt_s[q], KB_CAP);
+    const int M = __builtin_amdgcn_readfirstlane(min(cnt_s[q], KB_CAP));
     float mv[KB_CAP / 64];
     int mi[KB_CAP / 64], rank[KB_CAP / 64];
+    // one 64-bit key per survivor, larger = better: order-preserving score bits above the complemented index
+    // (equal scores: the lower index wins, as entry_better)
+    unsigned khi[KB_CAP / 64], klo[KB_CAP / 64];
+    unsigned long long key[KB_CAP / 64];
 #pragma unroll
     for (int i = 0; i < KB_CAP / 64; ++i) {
       const int e = 64 * i + lane;
       mv[i] = e < M ? bufv[q * KB_CAP + e] : -INFINITY;
       mi[i] = e < M ? bufi[q * KB_CAP + e] : 0x7fffffff;
+      khi[i] = f2key(mv[i] + 0.0f);  // -0 -> +0: equal scores must have equal keys
+      klo[i] = 0x7fffffffu - (unsigned)mi[i];
+      key[i] = ((unsigned long long)khi[i] << 32) | klo[i];
       rank[i] = 0;
     }
-    for (int t = 0; t < M; ++t) {
-      const float ov = bufv[q * KB_CAP + t];
-      const int oi = bufi[q * KB_CAP + t];
+    // every survivor against every survivor: the opponent's key comes out of the registers the entries sit in
+    // (two v_readlane with a uniform lane index), one 64-bit compare and one add per own entry
+    if (M <= 64) {  // uniform; the usual case of the k <= 32 configuration: one register of entries, half the compares
+#pragma unroll 4
+      for (int t = 0; t < M; ++t) {
+        const unsigned long long ok = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)khi[0], t) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane((int)klo[0], t);
+        rank[0] += ok > key[0] ? 1 : 0;
+      }
+    } else {
 #pragma unroll
-      for (int i = 0; i < KB_CAP / 64; ++i) rank[i] += entry_better(ov, oi, mv[i], mi[i]) ? 1 : 0;
+      for (int c = 0; c < KB_CAP / 64; ++c) {
+        const int cnt = min(max(M - 64 * c, 0), 64);  // uniform
+#pragma unroll 4
+        for (int t = 0; t < cnt; ++t) {
+          const unsigned long long ok = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)khi[c], t) << 32) |
+                                        (unsigned)__builtin_amdgcn_readlane((int)klo[c], t);
+#pragma unroll
+          for (int i = 0; i < KB_CAP / 64; ++i) rank[i] += ok > key[i] ? 1 : 0;
+        }
+      }
     }
 #pragma unroll
     for (int i = 0; i < KB_CAP / 64; ++i) {
@@ -811,20 +843,30 @@ static size_t knn_lds_bytes(int C) {
 }
 
 // launch one instance of the append-and-rank kernel (raising its dynamic-LDS limit once per instance)
-template <int WAVES, int CAP, int TOP, int KCH, int SAMPLE, bool FULLC>
-static int knn_append_launch(dim3 grid, size_t lds, hipStream_t st, const float* xT, long ldT, int N, int C, int k, int mode,
-                             const int* n_valid_dev, const float* nrm, int* idx_out, float* score_out, int* status,
-                             int* tile_flags) {
+template <int WAVES, int CAP, int TOP, int KCH, int SAMPLE, bool FULLC, int SMODE>
+static int knn_append_launch_mode(dim3 grid, size_t lds, hipStream_t st, const float* xT, long ldT, int N, int C, int k,
+                                  const int* n_valid_dev, const float* nrm, int* idx_out, float* score_out, int* status,
+                                  int* tile_flags) {
   static size_t attr = 0;
   if (lds > attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)r3d_knn_append_kernel<WAVES, CAP, TOP, KCH, SAMPLE, FULLC>,
+    hipError_t e = hipFuncSetAttribute((const void*)r3d_knn_append_kernel<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, SMODE>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     R3D_REQUIRE(e == hipSuccess, "r3d_knn_topk: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
     attr = lds;
   }
-  hipLaunchKernelGGL((r3d_knn_append_kernel<WAVES, CAP, TOP, KCH, SAMPLE, FULLC>), grid, dim3(64 * WAVES), lds, st, xT, ldT, N, C,
-                     k, mode, n_valid_dev, nrm, idx_out, score_out, status, tile_flags);
+  hipLaunchKernelGGL((r3d_knn_append_kernel<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, SMODE>), grid, dim3(64 * WAVES), lds, st, xT, ldT,
+                     N, C, k, SMODE, n_valid_dev, nrm, idx_out, score_out, status, tile_flags);
   return R3D_OK;
+}
+template <int WAVES, int CAP, int TOP, int KCH, int SAMPLE, bool FULLC>
+static int knn_append_launch(dim3 grid, size_t lds, hipStream_t st, const float* xT, long ldT, int N, int C, int k, int mode,
+                             const int* n_valid_dev, const float* nrm, int* idx_out, float* score_out, int* status,
+                             int* tile_flags) {
+  return mode == R3D_SCORE_DGCNN
+             ? knn_append_launch_mode<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, R3D_SCORE_DGCNN>(grid, lds, st, xT, ldT, N, C, k, n_valid_dev,
+                                                                                            nrm, idx_out, score_out, status, tile_flags)
+             : knn_append_launch_mode<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, R3D_SCORE_L2>(grid, lds, st, xT, ldT, N, C, k, n_valid_dev, nrm,
+                                                                                         idx_out, score_out, status, tile_flags);
 }
 
 extern "C" int r3d_sqnorm(const float* x, long ldx, long rows, int C, float* out, void* stream) {
