@@ -190,16 +190,32 @@ __global__ void r3d_attention_combine_kernel(const float* __restrict__ part, int
 // clouds) with most CUs idle while every workgroup walks all N keys; the streamed axis is cut into `split` ranges
 // (blockIdx.z) so that ~512 workgroups exist, and the partial results are merged by a small kernel in a fixed
 // order (deterministic).  ws == NULL keeps the unsplit launch.
-static int attention_split(int B, int N) {
-  const int wgs = B * r3d_cdiv(N, 128), ntiles = r3d_cdiv(N, 32);
-  int split = r3d_cdiv(512, wgs);
-  if (split > 16) split = 16;
-  if (split > ntiles) split = ntiles;
-  return split < 1 ? 1 : split;
+// The split is chosen per kernel against the workgroups the chip holds at once (`slots`): a grid slightly above a
+// multiple of the slots pays a whole extra round of workgroups -- 640 workgroups on 512 slots ran at 62 %.  Cost model:
+// rounds x (key tiles per workgroup + 2 tiles' worth of fixed work) + a merge term.
+static int attention_split(int B, int N, int slots) {
+  const int T = B * r3d_cdiv(N, 128), ntiles = r3d_cdiv(N, 32);
+  int best = 1;
+  float best_cost = 1e30f;
+  for (int s = 1; s <= 16 && s <= ntiles; ++s) {
+    const int tps = r3d_cdiv(ntiles, s), nz = r3d_cdiv(ntiles, tps);
+    if (nz != s) continue;  // same launch as a smaller s
+    const int rounds = r3d_cdiv(T * nz, slots);
+    const float cost = (float)rounds * (float)(tps + 2) + 0.25f * (float)nz;
+    if (cost < best_cost) { best_cost = cost; best = s; }
+  }
+  return best;
 }
+enum { ATT_FWD = 0, ATT_BWD_KV = 1, ATT_BWD_Q = 2 };
+static int attention_slots(int which);  // defined below the kernels
 extern "C" long r3d_attention_ws_words(int B, int N) {
   // forward: split * M * 66; backward: M (row dots) + split * M * 128 (dK | dV partials, reused for dQ)
-  return (long)B * N * (1 + 128L * attention_split(B, N)) + 64;
+  int smax = 1;
+  for (int w = 0; w < 3; ++w) {
+    const int sp = attention_split(B, N, attention_slots(w));
+    smax = sp > smax ? sp : smax;
+  }
+  return (long)B * N * (1 + 128L * smax) + 64;
 }
 
 static int attention_launch(const float* qkv, long ld, int B, int N, float* out, long ldo, float* lse_out, float p_drop,
@@ -209,7 +225,7 @@ static int attention_launch(const float* qkv, long ld, int B, int N, float* out,
               "r3d_attention_fwd: bad shape B=%d N=%d ld=%ld ldo=%ld", B, N, ld, ldo);
   R3D_REQUIRE(((uintptr_t)qkv & 15) == 0, "r3d_attention_fwd: qkv must be 16-byte aligned");
   R3D_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "r3d_attention_fwd: dropout probability %f out of range", p_drop);
-  const int split = ws ? attention_split(B, N) : 1;
+  const int split = ws ? attention_split(B, N, attention_slots(ATT_FWD)) : 1;
   const int ntiles = r3d_cdiv(N, 32);
   const int tps = r3d_cdiv(ntiles, split);
   const int nz = r3d_cdiv(ntiles, tps);  // no empty split
@@ -502,20 +518,48 @@ extern "C" int r3d_attention_bwd(const float* qkv, long ld, int B, int N, const 
   const long M = (long)B * N;
   hipLaunchKernelGGL(r3d_attention_rowdot_kernel, dim3(r3d_cdiv(M, 4)), dim3(256), 0, st, dO, lddo, O, ldo, M, ws);
   const int ntiles = r3d_cdiv(N, 32);
-  const int tps = r3d_cdiv(ntiles, attention_split(B, N));
-  const int nz = r3d_cdiv(ntiles, tps);
-  float* part = nz > 1 ? ws + M : nullptr;
-  dim3 grid(r3d_cdiv(N, 128), B, nz);
-  hipLaunchKernelGGL(r3d_attention_bwd_kv_kernel, grid, dim3(256), 0, st, qkv, ld, N, dO, lddo, lse, ws, dqkv, ldd, p_drop,
-                     seed, seed_dev, tps, part);
-  if (part)
-    hipLaunchKernelGGL(r3d_attention_sum_kernel, dim3(r3d_cdiv(M * 128, 256)), dim3(256), 0, st, part, nz, M, 128, 1.f, dqkv,
-                       ldd, 64);
-  hipLaunchKernelGGL(r3d_attention_bwd_q_kernel, grid, dim3(256), 0, st, qkv, ld, N, dO, lddo, lse, ws, dqkv, ldd, p_drop,
-                     seed, seed_dev, q_scale, tps, part);
-  if (part)
-    hipLaunchKernelGGL(r3d_attention_sum_kernel, dim3(r3d_cdiv(M * 64, 256)), dim3(256), 0, st, part, nz, M, 64, q_scale, dqkv,
-                       ldd, 0);
+  {
+    const int tps = r3d_cdiv(ntiles, attention_split(B, N, attention_slots(ATT_BWD_KV)));
+    const int nz = r3d_cdiv(ntiles, tps);
+    float* part = nz > 1 ? ws + M : nullptr;
+    hipLaunchKernelGGL(r3d_attention_bwd_kv_kernel, dim3(r3d_cdiv(N, 128), B, nz), dim3(256), 0, st, qkv, ld, N, dO, lddo, lse, ws,
+                       dqkv, ldd, p_drop, seed, seed_dev, tps, part);
+    if (part)
+      hipLaunchKernelGGL(r3d_attention_sum_kernel, dim3(r3d_cdiv(M * 128, 256)), dim3(256), 0, st, part, nz, M, 128, 1.f, dqkv,
+                         ldd, 64);
+  }
+  {
+    const int tps = r3d_cdiv(ntiles, attention_split(B, N, attention_slots(ATT_BWD_Q)));
+    const int nz = r3d_cdiv(ntiles, tps);
+    float* part = nz > 1 ? ws + M : nullptr;
+    hipLaunchKernelGGL(r3d_attention_bwd_q_kernel, dim3(r3d_cdiv(N, 128), B, nz), dim3(256), 0, st, qkv, ld, N, dO, lddo, lse, ws,
+                       dqkv, ldd, p_drop, seed, seed_dev, q_scale, tps, part);
+    if (part)
+      hipLaunchKernelGGL(r3d_attention_sum_kernel, dim3(r3d_cdiv(M * 64, 256)), dim3(256), 0, st, part, nz, M, 64, q_scale, dqkv,
+                         ldd, 0);
+  }
   R3D_LAUNCH_CHECK("r3d_attention_bwd");
   return R3D_OK;
+}
+
+
+// workgroups (256 threads) of each attention kernel the chip holds at once; the defaults stand in when there is no
+// device to ask (host-only sizing calls)
+static int attention_slots(int which) {
+  static int cache[3] = {0, 0, 0};
+  if (cache[which]) return cache[which];
+  const int fallback[3] = {512, 256, 512};
+  int per_cu = 0, dev = 0;
+  hipDeviceProp_t prop;
+  hipError_t e = hipErrorUnknown;
+  if (which == ATT_FWD) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, r3d_attention_fwd_kernel, 256, 0);
+  else if (which == ATT_BWD_KV) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, r3d_attention_bwd_kv_kernel, 256, 0);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, r3d_attention_bwd_q_kernel, 256, 0);
+  if (e == hipSuccess && per_cu > 0 && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+    cache[which] = per_cu * prop.multiProcessorCount;
+  else {
+    (void)hipGetLastError();
+    cache[which] = fallback[which];
+  }
+  return cache[which];
 }

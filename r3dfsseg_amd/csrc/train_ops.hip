@@ -170,9 +170,11 @@ __global__ void r3d_bn_bwd_apply_kernel(const float* __restrict__ Z, long ldz, c
 // kernel adds in ascending chunk order (deterministic, no float atomics).
 #define TN_ROWS_MAX 1024
 static int tn_rows(long M, int Ca, int Cb) {
-  // enough workgroups to fill the chip even for 64 x 64 outputs, chunks of at least 128 rows
+  // enough workgroups to fill the chip even for 64 x 64 outputs, chunks of at least 128 rows; never a few more than
+  // the 1024 the chip holds at once (4 per CU): 24 tiles x 43 chunks = 1032 workgroups ran as two rounds
   const long tiles = (long)((Ca + 63) / 64) * ((Cb + 63) / 64);
-  long chunks = (1024 + tiles - 1) / tiles;
+  long chunks = 1024 / tiles;
+  if (chunks < 1) chunks = 1;
   long rows = (M + chunks - 1) / chunks;
   rows = ((rows + 31) / 32) * 32;
   if (rows < 128) rows = 128;
