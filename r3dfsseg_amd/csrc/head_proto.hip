@@ -423,11 +423,15 @@ __global__ __launch_bounds__(HP_MAXK) void r3d_fps_finalize_kernel(SegGeom g, in
 // ---------------------------------------------------------------------------
 // 4. nearest-seed assignment (mpti.py:618-622): dist = sqrt(chain(((x - s) + 1e-6)^2))
 // ---------------------------------------------------------------------------
+// One workgroup = 256 points x ONE tile of 16 seeds (blockIdx.y): the seed axis is spread over the grid (160
+// workgroups of one wave per SIMD took 170 us at S) and the tiles meet in a 64-bit minimum per point: distance bits
+// above the seed position, so that the smallest distance wins and, among equal distances, the first seed -- what
+// the ascending scan with `<` gave.  Distances are non-negative: their bit patterns order like the values.
 #define AS_TILE 16
 __global__ __launch_bounds__(HP_BLOCK) void r3d_assign_kernel(const float* __restrict__ featC, long pitch, int D,
                                                               SegGeom g, const int* __restrict__ desc,
                                                               const int* __restrict__ seeds,
-                                                              int* __restrict__ assign) {
+                                                              unsigned long long* __restrict__ best_packed) {
   __shared__ float sf[256 * AS_TILE];  // [c][AS_TILE], D <= 256
   int blk0;
   const int seg = g.seg_of_block(blockIdx.x, &blk0);
@@ -436,55 +440,57 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_assign_kernel(const float* __res
   const int bis = blockIdx.x - blk0;
   if ((long)bis * HP_BLOCK >= count) return;
   const int m = desc[HD_SEG_M + seg];
+  const int s0 = blockIdx.y * AS_TILE;
+  if (s0 >= m) return;
   const int pos = bis * HP_BLOCK + tid;
   const bool ok = pos < count;
   const float* fp = featC + g.off(seg) + min(pos, count - 1);
-  float best = INFINITY;
-  int besti = 0;
-  for (int s0 = 0; s0 < m; s0 += AS_TILE) {
-    __syncthreads();
-    for (int e = tid; e < D * AS_TILE; e += HP_BLOCK) {
-      const int c = e / AS_TILE, s = e - c * AS_TILE;
-      const int sp = seeds[seg * HP_MAXK + min(s0 + s, m - 1)];
-      sf[c * AS_TILE + s] = r3d_keep(featC[(long)c * pitch + g.off(seg) + sp], s0 + s < m);
-    }
-    __syncthreads();
-    if (ok) {
-      float acc[AS_TILE];
+  for (int e = tid; e < D * AS_TILE; e += HP_BLOCK) {
+    const int c = e / AS_TILE, s = e - c * AS_TILE;
+    const int sp = seeds[seg * HP_MAXK + min(s0 + s, m - 1)];
+    sf[c * AS_TILE + s] = r3d_keep(featC[(long)c * pitch + g.off(seg) + sp], s0 + s < m);
+  }
+  __syncthreads();
+  if (!ok) return;
+  float acc[AS_TILE];
 #pragma unroll
-      for (int s = 0; s < AS_TILE; ++s) acc[s] = 0.f;
-      int c = 0;
-      for (; c + 8 <= D; c += 8) {  // 8 channel loads in flight; chains stay channel-ascending
-        float xv[8];
+  for (int s = 0; s < AS_TILE; ++s) acc[s] = 0.f;
+  int c = 0;
+  for (; c + 8 <= D; c += 8) {  // 8 channel loads in flight; chains stay channel-ascending
+    float xv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) xv[u] = fp[(long)(c + u) * pitch];
+    for (int u = 0; u < 8; ++u) xv[u] = fp[(long)(c + u) * pitch];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-#pragma unroll
-          for (int s = 0; s < AS_TILE; ++s) {
-            const float df = (xv[u] - sf[(c + u) * AS_TILE + s]) + 1e-6f;
-            acc[s] = __builtin_fmaf(df, df, acc[s]);
-          }
-        }
-      }
-      for (; c < D; ++c) {
-        const float xv = fp[(long)c * pitch];
-#pragma unroll
-        for (int s = 0; s < AS_TILE; ++s) {
-          const float df = (xv - sf[c * AS_TILE + s]) + 1e-6f;
-          acc[s] = __builtin_fmaf(df, df, acc[s]);
-        }
-      }
+    for (int u = 0; u < 8; ++u) {
 #pragma unroll
       for (int s = 0; s < AS_TILE; ++s) {
-        if (s0 + s < m) {
-          const float d = sqrtf(acc[s]);
-          if (d < best) { best = d; besti = s0 + s; }
-        }
+        const float df = (xv[u] - sf[(c + u) * AS_TILE + s]) + 1e-6f;
+        acc[s] = __builtin_fmaf(df, df, acc[s]);
       }
     }
   }
-  if (ok) assign[g.off(seg) + pos] = besti;
+  for (; c < D; ++c) {
+    const float xv = fp[(long)c * pitch];
+#pragma unroll
+    for (int s = 0; s < AS_TILE; ++s) {
+      const float df = (xv - sf[c * AS_TILE + s]) + 1e-6f;
+      acc[s] = __builtin_fmaf(df, df, acc[s]);
+    }
+  }
+  float best = INFINITY;
+  int besti = 0;
+#pragma unroll
+  for (int s = 0; s < AS_TILE; ++s) {
+    if (s0 + s < m) {
+      const float d = sqrtf(acc[s]);
+      if (d < best) { best = d; besti = s0 + s; }
+    }
+  }
+  atomicMin(&best_packed[g.off(seg) + pos], ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)besti);
+}
+__global__ void r3d_assign_unpack_kernel(const unsigned long long* __restrict__ best_packed, long n, int* __restrict__ assign) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) assign[i] = (int)(unsigned)(best_packed[i] & 0xffffffffull);
 }
 
 // ---------------------------------------------------------------------------
@@ -615,7 +621,8 @@ extern "C" long r3d_head_proto_ws_words(int n_way, int k_shot, int N) {
   const long max_chunks = (g.cap(0) + CM_CHUNK - 1) / CM_CHUNK;
   return cap * 3 + 4L * g.total_blocks() + 2L * HP_MAXSEG * HP_MAXK + 64 +
          (long)g.nseg() * HP_MAXK * max_chunks * 257 + 256L * (cap + 64) +  // ... + featC (D <= 256 rows)
-         2L * HP_MAXK * g.total_blocks() + 8;                               // ... + one-launch FPS exchange words
+         2L * HP_MAXK * g.total_blocks() + 8 +                              // ... + one-launch FPS exchange words
+         2L * cap + 2;                                                      // ... + 64-bit (distance, seed) minimum per point
 }
 
 // Builds prototypes into node rows [0, n_proto) and appends the query rows.
@@ -653,6 +660,7 @@ extern "C" int r3d_head_prototypes(const int32_t* support_y, const int32_t* shot
   long xoff = (featC + 256L * (cap + 64)) - (float*)ws;  // exchange words of the one-launch FPS, 8-byte aligned
   xoff += xoff & 1;
   unsigned long long* xch = (unsigned long long*)(ws + xoff);
+  unsigned long long* best_packed = xch + (long)HP_MAXK * g.total_blocks() + 1;  // behind the exchange words
   hipLaunchKernelGGL(r3d_head_compact_kernel, dim3(g.nseg()), dim3(1024), 0, st, support_y, shot_keep, g,
                      comp, desc);
   hipLaunchKernelGGL(r3d_head_gather_kernel, dim3(g.total_blocks()), dim3(HP_BLOCK), 0, st, feat, ldf, D, g, comp,
@@ -682,8 +690,11 @@ extern "C" int r3d_head_prototypes(const int32_t* support_y, const int32_t* shot
   }
   hipLaunchKernelGGL(r3d_fps_finalize_kernel, dim3(1), dim3(HP_MAXK), 0, st, g, k, n_query_pts, sel, seeds,
                      desc);
-  hipLaunchKernelGGL(r3d_assign_kernel, dim3(g.total_blocks()), dim3(HP_BLOCK), 0, st, featC, pitch, D, g, desc,
-                     seeds, assign);
+  hipLaunchKernelGGL(r3d_fill_words_kernel, dim3(r3d_cdiv(2 * cap, 256)), dim3(256), 0, st, (unsigned*)best_packed, 0xffffffffu,
+                     2 * cap);
+  hipLaunchKernelGGL(r3d_assign_kernel, dim3(g.total_blocks(), r3d_cdiv(k, AS_TILE)), dim3(HP_BLOCK), 0, st, featC, pitch, D, g,
+                     desc, seeds, best_packed);
+  hipLaunchKernelGGL(r3d_assign_unpack_kernel, dim3(r3d_cdiv(cap, 256)), dim3(256), 0, st, best_packed, cap, assign);
   hipLaunchKernelGGL(r3d_cluster_partial_kernel, dim3(k, max_chunks, g.nseg()), dim3(HP_BLOCK), 0, st, feat, ldf, D,
                      g, comp, desc, assign, max_chunks, part, part_cnt);
   hipLaunchKernelGGL(r3d_cluster_reduce_kernel, dim3(k, g.nseg()), dim3(HP_BLOCK), 0, st, D, desc, max_chunks, part,
