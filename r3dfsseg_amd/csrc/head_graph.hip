@@ -128,46 +128,66 @@ __global__ __launch_bounds__(256) void r3d_graph_cols_kernel(const unsigned* __r
   }
 }
 
-// 3c. gaussian weights + row sums D.  One wave per row i, ONE LANE PER ENTRY: each lane walks
-//     the 192 channels of its own neighbour row (float4 loads, L2 resident) against x_i held
-//     in LDS (broadcast reads), so there is no cross-lane reduction per entry and the
-//     squared distance is the channel-ascending chain of oracle/r3d_oracle.c:orc_pair_dist.
+// 3c. gaussian weights + row sums D.  One WORKGROUP per row i, its four waves take every fourth group of eight
+//     entries, EIGHT LANES PER ENTRY: lane 8e + p reads float4 number p, p + 8, ... of neighbour e's row (a wave load
+//     touches 8 rows x one 128-B line), the eight partial sums of an entry meet in a three-step butterfly.  A wave's
+//     work is a chain of (column index -> neighbour rows) round trips, ~3 us each with the 3.4 MB node matrix
+//     spilling out of a 4 MB L2: one wave per row walked 34 of them (250 us at S), a quarter of a row leaves 9 and
+//     four times as many waves to overlap.  Weights are not index-deciding: the summation order differs from
+//     oracle/r3d_oracle.c:orc_pair_dist by rounding only.
 __global__ __launch_bounds__(256) void r3d_graph_weights_kernel(
     const float* __restrict__ nodes, long ldn, int D, const unsigned* __restrict__ outb, int words,
     const int* __restrict__ n_dev, int n_cap, const int* __restrict__ row_ptr, const int* __restrict__ col,
     float sigma, float* __restrict__ val, float* __restrict__ dinv, float* __restrict__ wdir /* [nnz][2] */) {
-  __shared__ __attribute__((aligned(16))) float xs[4][256];
+  __shared__ __attribute__((aligned(16))) float xs[256];
+  __shared__ float wsum[4];
   const int n = min(*n_dev, n_cap);
   const int w = threadIdx.x >> 6;
-  const int i = blockIdx.x * 4 + w;
+  const int i = blockIdx.x;
   const int lane = threadIdx.x & 63;
-  if (i >= n) return;
+  if (i >= n) return;  // uniform over the workgroup
   const float* xi = nodes + (long)i * ldn;
-  for (int c = lane; c < 256; c += 64) xs[w][c] = c < D ? xi[c] : 0.f;
-  __builtin_amdgcn_wave_barrier();
+  xs[threadIdx.x] = (int)threadIdx.x < D ? xi[threadIdx.x] : 0.f;
+  __syncthreads();
   const int beg = row_ptr[i], end = row_ptr[i + 1];
   const int D4 = D >> 2;
+  const int part = lane & 7, slot = lane >> 3;
   float dsum = 0.f;
-  for (int e0 = beg; e0 < end; e0 += 64) {
-    const int e = e0 + lane;
+  for (int e0 = beg + 8 * w; e0 < end; e0 += 32) {
+    const int e = e0 + slot;
     const bool ok = e < end;
     const int j = col[min(e, end - 1)];
     const float* xj = nodes + (long)j * ldn;
-    float a = 0.f, b = 0.f;  // a: ||x_i - x_j + eps||^2, b: ||x_j - x_i + eps||^2
-    for (int c4 = 0; c4 < D4; ++c4) {
-      const float4 y = *reinterpret_cast<const float4*>(xj + 4 * c4);
-      const float4 x = *reinterpret_cast<const float4*>(&xs[w][4 * c4]);
+    float a = 0.f, b = 0.f;  // a: ||x_i - x_j + eps||^2, b: ||x_j - x_i + eps||^2 (partial: this lane's channels)
+    auto step = [&](const float4 y, int c4) {
+      const float4 x = *reinterpret_cast<const float4*>(&xs[4 * c4]);
       float d1, d2;
       d1 = (x.x - y.x) + 1e-6f; d2 = (y.x - x.x) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b);
       d1 = (x.y - y.y) + 1e-6f; d2 = (y.y - x.y) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b);
       d1 = (x.z - y.z) + 1e-6f; d2 = (y.z - x.z) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b);
       d1 = (x.w - y.w) + 1e-6f; d2 = (y.w - x.w) + 1e-6f; a = __builtin_fmaf(d1, d1, a); b = __builtin_fmaf(d2, d2, b);
+    };
+    int c4 = part;
+    for (; c4 + 40 < D4; c4 += 48) {  // six float4 per lane in flight (D = 192: exactly one trip)
+      float4 y[6];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) y[u] = *reinterpret_cast<const float4*>(xj + 4 * (c4 + 8 * u));
+#pragma unroll
+      for (int u = 0; u < 6; ++u) step(y[u], c4 + 8 * u);
     }
-    for (int c = 4 * D4; c < D; ++c) {
-      const float y = xj[c], x = xs[w][c];
-      const float d1 = (x - y) + 1e-6f, d2 = (y - x) + 1e-6f;
-      a = __builtin_fmaf(d1, d1, a);
-      b = __builtin_fmaf(d2, d2, b);
+    for (; c4 < D4; c4 += 8) step(*reinterpret_cast<const float4*>(xj + 4 * c4), c4);
+    if (part == 0) {
+      for (int c = 4 * D4; c < D; ++c) {
+        const float y = xj[c], x = xs[c];
+        const float d1 = (x - y) + 1e-6f, d2 = (y - x) + 1e-6f;
+        a = __builtin_fmaf(d1, d1, a);
+        b = __builtin_fmaf(d2, d2, b);
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      a += __shfl_xor(a, o);
+      b += __shfl_xor(b, o);
     }
     const bool out_ij = (outb[(long)i * words + (j >> 5)] >> (j & 31)) & 1u;
     const bool out_ji = (outb[(long)j * words + (i >> 5)] >> (i & 31)) & 1u;
@@ -175,14 +195,17 @@ __global__ __launch_bounds__(256) void r3d_graph_weights_kernel(
     if (out_ij) { const float d = sqrtf(a) / sigma; wij = expf(-0.5f * (d * d)); }
     if (out_ji) { const float d = sqrtf(b) / sigma; wji = expf(-0.5f * (d * d)); }
     const float wgt = wij + wji;
-    if (ok) {
+    if (ok && part == 0) {
       val[e] = wgt;
       *reinterpret_cast<float2*>(wdir + 2L * e) = make_float2(wij, wji);
       dsum += wgt;
     }
   }
   dsum = r3d_wave_sum(dsum);
-  if (lane == 0) dinv[i] = sqrtf(1.0f / (dsum + 2.220446049250313e-16f));  // mpti.py:768-770
+  if (lane == 0) wsum[w] = dsum;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    dinv[i] = sqrtf(1.0f / ((((wsum[0] + wsum[1]) + wsum[2]) + wsum[3]) + 2.220446049250313e-16f));  // mpti.py:768-770
 }
 
 // 4. S_ij = (dinv_i * A_ij) * dinv_j   (mpti.py:771-772: two diagonal matmuls)
@@ -301,21 +324,23 @@ __global__ __launch_bounds__(256) void r3d_cg_spmv_kernel(
     float4 s = f4_zero();
     {
       const int rb = row_ptr[i], re = row_ptr[i + 1];
-      for (int e0 = rb + lane; e0 < re; e0 += 256) {  // 4 entries per lane in flight
-        int jv[4];
-        float av[4];
+      // 6 entries per lane in flight: a row of the symmetrised 200-NN graph (~270 entries at S) is ONE trip of the
+      // dependent chain column index -> gather (with 4 per lane the last 14 entries cost a second full round trip)
+      for (int e0 = rb + lane; e0 < re; e0 += 384) {
+        int jv[6];
+        float av[6];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 6; ++u) {
           const int e = e0 + 64 * u;
           const int ec = min(e, re - 1);
           jv[u] = col[ec];
           av[u] = r3d_keep(val[ec], e < re);
         }
-        float4 rj[4], pj[4];
+        float4 rj[6], pj[6];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { rj[u] = r[jv[u]]; pj[u] = p_old[jv[u]]; }
+        for (int u = 0; u < 6; ++u) { rj[u] = r[jv[u]]; pj[u] = p_old[jv[u]]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 6; ++u) {
           s.x += av[u] * (rj[u].x + beta.x * pj[u].x);
           s.y += av[u] * (rj[u].y + beta.y * pj[u].y);
           s.z += av[u] * (rj[u].z + beta.z * pj[u].z);
@@ -531,7 +556,7 @@ extern "C" int r3d_label_propagate(const float* nodes, long ldn, int D, const in
   hipLaunchKernelGGL(r3d_scan_kernel, dim3(1), dim3(1024), 0, st, L.row_len, n_cap, L.row_ptr);
   hipLaunchKernelGGL(r3d_graph_cols_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, L.sym, (int)words, n_dev,
                      n_cap, L.row_ptr, L.col);
-  hipLaunchKernelGGL(r3d_graph_weights_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, nodes, ldn, D, L.outb,
+  hipLaunchKernelGGL(r3d_graph_weights_kernel, dim3(n_cap), dim3(256), 0, st, nodes, ldn, D, L.outb,
                      (int)words, n_dev, n_cap, L.row_ptr, L.col, sigma, L.val, L.dinv, L.wdir);
   hipLaunchKernelGGL(r3d_graph_normalize_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, L.row_ptr, L.col, L.dinv,
                      n_dev, n_cap, L.val);
@@ -581,21 +606,24 @@ __global__ __launch_bounds__(256) void r3d_lp_bwd_dx_kernel(
     const int* __restrict__ row_ptr, const int* __restrict__ col, const float* __restrict__ dinv,
     const int* __restrict__ n_dev, int n_cap, float sigma, float alpha, const float4* __restrict__ lam,
     const float4* __restrict__ Z, const float* __restrict__ dD, float* __restrict__ dnodes, long ldd) {
+  // one WORKGROUP per row, its four waves take every fourth chunk of 64 entries (a wave's work is a chain of
+  // column-index -> neighbour-row round trips; one wave per row walked five chunks: 185 us at S)
+  __shared__ float acc_s[4][256];
+  __shared__ float uv_s[4][2];
   const int n = min(*n_dev, n_cap);
   const int w = threadIdx.x >> 6;
-  const int i = blockIdx.x * 4 + w;
+  const int i = blockIdx.x;
   const int lane = threadIdx.x & 63;
-  if (i >= n) return;
+  if (i >= n) return;  // uniform over the workgroup
   const float* xi = nodes + (long)i * ldn;
   const float4 li = lam[i], zi = Z[i];
   const float di = dinv[i], ddi = dD[i];
   const int beg = row_ptr[i], end = row_ptr[i + 1];
   const float inv_s2 = 1.f / (sigma * sigma);
-  const bool k0 = lane < D, k1 = lane + 64 < D, k2 = lane + 128 < D, k3 = lane + 192 < D;
   const int c0 = min(lane, D - 1), c1 = min(lane + 64, D - 1), c2 = min(lane + 128, D - 1), c3 = min(lane + 192, D - 1);
   float U = 0.f, V = 0.f;                        // sum (c_ij + c_ji), sum (c_ij - c_ji)
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // sum_j u_j x_j[c], channels lane, lane+64, ...
-  for (int e0 = beg; e0 < end; e0 += 64) {
+  for (int e0 = beg + 64 * w; e0 < end; e0 += 256) {
     const int e = e0 + lane;
     const bool ok = e < end;
     const int ec = min(e, end - 1);
@@ -610,17 +638,17 @@ __global__ __launch_bounds__(256) void r3d_lp_bwd_dx_kernel(
     V += cij - cji;
     const int cnt = min(64, end - e0);
     int t = 0;
-    for (; t + 4 <= cnt; t += 4) {  // 4 neighbour rows (up to 16 loads) in flight
-      float x0[4], x1[4], x2[4], x3[4], ut[4];
+    for (; t + 8 <= cnt; t += 8) {  // 8 neighbour rows (up to 32 loads) in flight
+      float x0[8], x1[8], x2[8], x3[8], ut[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 8; ++q) {
         ut[q] = r3d_readlane_f(u, t + q);
         const float* xr = nodes + (long)__builtin_amdgcn_readlane(j, t + q) * ldn;
         x0[q] = xr[c0]; x1[q] = xr[c1]; x2[q] = xr[c2];
         x3[q] = D > 192 ? xr[c3] : 0.f;
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 8; ++q) {
         a0 = __builtin_fmaf(ut[q], x0[q], a0); a1 = __builtin_fmaf(ut[q], x1[q], a1);
         a2 = __builtin_fmaf(ut[q], x2[q], a2); a3 = __builtin_fmaf(ut[q], x3[q], a3);
       }
@@ -634,11 +662,16 @@ __global__ __launch_bounds__(256) void r3d_lp_bwd_dx_kernel(
   }
   U = r3d_wave_sum(U);
   V = r3d_wave_sum(V);
-  float* dr = dnodes + (long)i * ldd;
-  if (k0) dr[lane] = xi[c0] * U - a0 + 1e-6f * V;
-  if (k1) dr[lane + 64] = xi[c1] * U - a1 + 1e-6f * V;
-  if (k2) dr[lane + 128] = xi[c2] * U - a2 + 1e-6f * V;
-  if (k3) dr[lane + 192] = xi[c3] * U - a3 + 1e-6f * V;
+  acc_s[w][lane] = a0; acc_s[w][64 + lane] = a1; acc_s[w][128 + lane] = a2; acc_s[w][192 + lane] = a3;
+  if (lane == 0) { uv_s[w][0] = U; uv_s[w][1] = V; }
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (c < D) {
+    const float At = ((acc_s[0][c] + acc_s[1][c]) + acc_s[2][c]) + acc_s[3][c];
+    const float Ut = ((uv_s[0][0] + uv_s[1][0]) + uv_s[2][0]) + uv_s[3][0];
+    const float Vt = ((uv_s[0][1] + uv_s[1][1]) + uv_s[2][1]) + uv_s[3][1];
+    dnodes[(long)i * ldd + c] = xi[c] * Ut - At + 1e-6f * Vt;
+  }
 }
 
 // dL/dZ of the mean cross entropy over the query rows (mpti.py:778-781), scaled by *gscale
@@ -679,7 +712,7 @@ extern "C" int r3d_label_propagate_bwd(const float* nodes, long ldn, int D, int 
   float* dD = (float*)L.q;  // the CG vectors are free again after the solve
   hipLaunchKernelGGL(r3d_lp_bwd_dd_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, L.row_ptr, L.col, L.val, L.dinv, n_dev,
                      n_cap, alpha, (const float4*)lam, (const float4*)Z, dD);
-  hipLaunchKernelGGL(r3d_lp_bwd_dx_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, nodes, ldn, D, L.wdir,
+  hipLaunchKernelGGL(r3d_lp_bwd_dx_kernel, dim3(n_cap), dim3(256), 0, st, nodes, ldn, D, L.wdir,
                      L.row_ptr, L.col, L.dinv, n_dev, n_cap, sigma, alpha, (const float4*)lam, (const float4*)Z, dD, dnodes,
                      ldd);
   R3D_LAUNCH_CHECK("r3d_label_propagate_bwd");
