@@ -22,12 +22,12 @@
 __global__ __launch_bounds__(256) void r3d_colpartial_kernel(
     const float* __restrict__ X, long ldx, const float* __restrict__ DY, long lddy, long M, int C, int mode,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ invstd, int act, float* __restrict__ part /* [chunks][2][C] */) {
+    const float* __restrict__ invstd, int act, int rows_per_chunk, float* __restrict__ part /* [chunks][2][C] */) {
   __shared__ float sa[4][64], sb[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
-  const long r0 = (long)blockIdx.y * TS_ROWS;
-  const long r1 = min(M, r0 + TS_ROWS);
+  const long r0 = (long)blockIdx.y * rows_per_chunk;
+  const long r1 = min(M, r0 + rows_per_chunk);
   float a = 0.f, b = 0.f;
   if (c < C) {
     float sc = 1.f, sh = 0.f, mu = 0.f, is = 1.f;
@@ -282,7 +282,22 @@ __global__ void r3d_add_cols_kernel(const float* __restrict__ src, long lds_, fl
 // ===========================================================================
 // C ABI
 // ===========================================================================
-extern "C" long r3d_colstats_ws_words(long M, int C) { return ((M + TS_ROWS - 1) / TS_ROWS) * 2L * C + 16; }
+// rows per partial: ~1024 workgroups whatever the column count (512 rows per partial left 40 workgroups for a 64-column
+// matrix, each walking 16 dependent round trips), at least 64 rows, a multiple of the 32 rows of one step
+static int ts_rows(long M, int C) {
+  const long groups = (C + 63) / 64;
+  long chunks = 1024 / groups;
+  if (chunks > M / 64) chunks = M / 64;
+  if (chunks < 1) chunks = 1;
+  long rows = (M + chunks - 1) / chunks;
+  rows = ((rows + 31) / 32) * 32;
+  if (rows > TS_ROWS) rows = TS_ROWS;
+  return (int)rows;
+}
+extern "C" long r3d_colstats_ws_words(long M, int C) {
+  const int rows = ts_rows(M, C);
+  return ((M + rows - 1) / rows) * 2L * C + 16;
+}
 
 // sums_out [2][C]: mode 0 (sum x, sum x^2); mode 1 (sum du, sum du*zhat) -- see kernel comment
 extern "C" int r3d_colstats(const float* X, long ldx, const float* DY, long lddy, long M, int C, int mode,
@@ -290,10 +305,11 @@ extern "C" int r3d_colstats(const float* X, long ldx, const float* DY, long lddy
                             float* sums_out, float* ws, void* stream) {
   R3D_REQUIRE(X && sums_out && ws && M > 0 && C > 0 && C <= TS_MAXC, "r3d_colstats: bad arguments");
   R3D_REQUIRE(mode == 0 || (DY && scale && shift && mean && invstd), "r3d_colstats: mode 1 needs dy and the BN vectors");
-  const int chunks = r3d_cdiv(M, TS_ROWS);
+  const int rows = ts_rows(M, C);
+  const int chunks = r3d_cdiv(M, rows);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(r3d_colpartial_kernel, dim3(r3d_cdiv(C, 64), chunks), dim3(256), 0, st, X, ldx, DY, lddy, M, C, mode,
-                     scale, shift, mean, invstd, act, ws);
+                     scale, shift, mean, invstd, act, rows, ws);
   hipLaunchKernelGGL(r3d_colreduce_kernel, dim3(r3d_cdiv(C, 64)), dim3(256), 0, st, ws, chunks, C, sums_out);
   R3D_LAUNCH_CHECK("r3d_colstats");
   return R3D_OK;
