@@ -21,9 +21,10 @@
 static __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : 0.2f * v; }
 
 // ---- BN1 statistics over edges: partial[block][2][64] ------------------------------------------
+template <int RT>
 __global__ __launch_bounds__(256) void r3d_edge_stats1_kernel(const float* __restrict__ PQ, const int* __restrict__ idx,
-                                                              int N, int K, long total_points,
-                                                              float* __restrict__ part) {
+                                                              int N, long total_points, float* __restrict__ part) {
+  constexpr int K = 4 * RT;
   __shared__ float sa[4][64], sb[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float a = 0.f, b = 0.f;
@@ -31,16 +32,14 @@ __global__ __launch_bounds__(256) void r3d_edge_stats1_kernel(const float* __res
     const long cloud0 = (pt / N) * N;
     const float q = PQ[pt * 128 + 64 + lane];
     const int my_idx = idx[pt * K + min(lane, K - 1)];
-    for (int t = 0; t < K; t += 4) {  // K % 4 == 0: four neighbour rows in flight (was one: a chain of L2 round trips)
-      float pv[4];
+    float pv[K];  // all K neighbour rows in flight (four at a time was a chain of K/4 L2 round trips per point)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) pv[u] = PQ[(cloud0 + __builtin_amdgcn_readlane(my_idx, t + u)) * 128 + lane];
+    for (int t = 0; t < K; ++t) pv[t] = PQ[(cloud0 + __builtin_amdgcn_readlane(my_idx, t)) * 128 + lane];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float e = pv[u] + q;
-        a += e;
-        b += e * e;
-      }
+    for (int t = 0; t < K; ++t) {
+      const float e = pv[t] + q;
+      a += e;
+      b += e * e;
     }
   }
   sa[w][lane] = a;
@@ -479,8 +478,13 @@ extern "C" int r3d_edge_stats1(const float* PQ, const int32_t* idx, int B, int N
   int rc = et_check("r3d_edge_stats1", B, N, K);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  const int grid = 512;
-  hipLaunchKernelGGL(r3d_edge_stats1_kernel, dim3(grid), dim3(256), 0, st, PQ, idx, N, K, (long)B * N, ws);
+  const int grid = 1024;
+#define E2_CASE(RT) \
+  case RT: hipLaunchKernelGGL(r3d_edge_stats1_kernel<RT>, dim3(grid), dim3(256), 0, st, PQ, idx, N, (long)B * N, ws); break
+  switch (K / 4) {
+    E2_CASE(1); E2_CASE(2); E2_CASE(3); E2_CASE(4); E2_CASE(5); E2_CASE(6); E2_CASE(7); E2_CASE(8);
+  }
+#undef E2_CASE
   hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(128 / 64), dim3(1024), 0, st, ws, grid, 128, sums_out, 128, nullptr);
   R3D_LAUNCH_CHECK("r3d_edge_stats1");
   return R3D_OK;
