@@ -98,9 +98,9 @@ def main():
     ap.add_argument("--episodes-per-rank", type=int, default=32,
                     help="episodes of one step on every rank (BASELINE configs[4]: 256-episode batch / 8 GPUs)")
     ap.add_argument("--slots", type=int, default=None,
-                    help="episodes in flight per GPU (hipGraphs on HIP streams); 0 = eager; default 6 (train) / 4 (eval), "
-                         "the measured optima on MI355X")
-    ap.add_argument("--eval-slots", type=int, default=4, help="slots of the eval-forward leg of train mode")
+                    help="episodes in flight per GPU (hipGraphs on HIP streams); 0 = eager; default 6, "
+                         "the measured optimum on MI355X for both modes")
+    ap.add_argument("--eval-slots", type=int, default=6, help="slots of the eval-forward leg of train mode")
     ap.add_argument("--lp-budget", type=int, default=None, help="CG launches frozen into each episode graph")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -135,7 +135,7 @@ def main():
     model.to(dev)
 
     if args.slots is None:
-        args.slots = 6 if args.mode == "train" else 4
+        args.slots = 6
     E, G = args.episodes_per_rank, args.slots
     n_pool = max(8, min(E, 32))  # distinct episodes per rank, resident in HBM before timing starts
     pool = []
