@@ -288,7 +288,9 @@ __global__ __launch_bounds__(256) void r3d_cg_init_kernel(const float4* __restri
 }
 
 // A: p_new = r + beta p_old ; q = (I - alpha S) p_new ; partial <p_new, q>
-__global__ __launch_bounds__(256) void r3d_cg_spmv_kernel(
+// 5 waves per SIMD: the 4396 one-row waves of workload S must all be resident at once (108 registers -> 4 per SIMD ->
+// two rounds of waves)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void r3d_cg_spmv_kernel(
     const int* __restrict__ row_ptr, const int* __restrict__ col, const float* __restrict__ val,
     const int* __restrict__ n_dev, int n_cap, float alpha_lp, int it, int nblk_rr, float tol2, int rows_per_block,
     const float4* __restrict__ r, const float4* __restrict__ p_old, float4* __restrict__ p_new,
