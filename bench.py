@@ -247,8 +247,9 @@ def main():
         step_fn = eval_step_eager
     if train and G:
         n_ev = max(args.steps // 2, 1)
-        el_ev, _ = timed(eval_step, n_ev, 3, eval_graphs)
+        el_ev, cg_ev = timed(eval_step, n_ev, 3, eval_graphs)
         extra["eval_forward_episodes_per_sec"] = n_ev * E * world / el_ev
+        extra["eval_forward_lp_cg_iterations"] = {"mean": cg_ev[0], "max": cg_ev[1]}
         model.train()
 
     # roofline leg: single-episode EAGER steps; every entry point's library calls are launched again 8 times back

@@ -29,7 +29,7 @@ static __device__ __forceinline__ bool attn_keep(unsigned seed, unsigned row, un
   return x >= thresh;
 }
 
-__global__ __launch_bounds__(256) void r3d_attention_fwd_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void r3d_attention_fwd_kernel(
     const float* __restrict__ qkv, long ld, int N, float* __restrict__ out, long ldo,
     float* __restrict__ lse_out, float p_drop, unsigned seed, const unsigned* __restrict__ seed_dev,
     int tiles_per_split, float* __restrict__ part /* split > 1: [split][M][66] = unnormalised o | m | l */) {
@@ -272,7 +272,7 @@ __global__ void r3d_attention_rowdot_kernel(const float* __restrict__ dO, long l
   if (lane == 0) Dv[row] = v;
 }
 
-__global__ __launch_bounds__(256) void r3d_attention_bwd_kv_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r3d_attention_bwd_kv_kernel(
     const float* __restrict__ qkv, long ld, int N, const float* __restrict__ dO, long lddo, const float* __restrict__ lse,
     const float* __restrict__ Dv, float* __restrict__ dqkv, long ldd, float p_drop, unsigned seed,
     const unsigned* __restrict__ seed_dev, int tiles_per_split, float* __restrict__ part /* [split][M][128] or NULL */) {
