@@ -927,24 +927,27 @@ extern "C" int r3d_knn_topk(const float* x, long ldx, const float* x_cm, int B, 
       // append-and-rank (mid configuration); tiles whose survivor buffer overflowed are redone by the exact
       // sorted-insertion kernel in the same stream -- no host round trip, never a wrong result
       r3d_zero_words(tile_flags, (long)B * g2.x, st);
-      const size_t lds = knn_append_lds_bytes(C, KM_WAVES, KM_CAP, KM_TOP, C <= 16 ? 8 : 32);
+      // fewer row tiles than CUs (the 2 query clouds of a training episode: 128 tiles): 8 waves per tile instead of 4,
+      // each wave's chain of sub-tiles is half as long
+      const bool few = (long)g2.x * B <= 256;
+      const size_t lds = knn_append_lds_bytes(C, few ? 8 : KM_WAVES, KM_CAP, KM_TOP, C <= 16 ? 8 : 32);
       int rc;
+#define KM_LAUNCH(WAVES, KCH, FULLC)                                                                                       \
+  knn_append_launch<WAVES, KM_CAP, KM_TOP, KCH, KM_SAMPLE, FULLC>(g2, lds, st, xT, ldT, N, C, k, mode, n_valid_dev, norm_ws, \
+                                                                  idx_out, score_out, nullptr, tile_flags)
       if (C <= 16) {
-        rc = knn_append_launch<KM_WAVES, KM_CAP, KM_TOP, 8, KM_SAMPLE, false>(g2, lds, st, xT, ldT, N, C, k, mode, n_valid_dev,
-                                                                              norm_ws, idx_out, score_out, nullptr, tile_flags);
+        rc = few ? KM_LAUNCH(8, 8, false) : KM_LAUNCH(KM_WAVES, 8, false);
         if (rc) return rc;
         hipLaunchKernelGGL(r3d_knn_small_kernel<8>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, norm_ws,
                            idx_out, score_out, (const int*)tile_flags);
       } else {
-        rc = C % 64 == 0
-                 ? knn_append_launch<KM_WAVES, KM_CAP, KM_TOP, 32, KM_SAMPLE, true>(g2, lds, st, xT, ldT, N, C, k, mode, n_valid_dev,
-                                                                                    norm_ws, idx_out, score_out, nullptr, tile_flags)
-                 : knn_append_launch<KM_WAVES, KM_CAP, KM_TOP, 32, KM_SAMPLE, false>(g2, lds, st, xT, ldT, N, C, k, mode, n_valid_dev,
-                                                                                     norm_ws, idx_out, score_out, nullptr, tile_flags);
+        if (C % 64 == 0) rc = few ? KM_LAUNCH(8, 32, true) : KM_LAUNCH(KM_WAVES, 32, true);
+        else rc = few ? KM_LAUNCH(8, 32, false) : KM_LAUNCH(KM_WAVES, 32, false);
         if (rc) return rc;
         hipLaunchKernelGGL(r3d_knn_small_kernel<32>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, norm_ws,
                            idx_out, score_out, (const int*)tile_flags);
       }
+#undef KM_LAUNCH
     }
     R3D_LAUNCH_CHECK("r3d_knn_topk(small)");
     return R3D_OK;
