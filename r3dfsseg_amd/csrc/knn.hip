@@ -278,7 +278,7 @@ __global__ void r3d_sqnorm_cm_kernel(const float* __restrict__ xT, long ldT, int
 
 #ifdef KNN_STAMPS
 __device__ unsigned long long g_knn_dbg[16];
-#define KSTAMP(i) do { if (blockIdx.x == 7 && blockIdx.y == 3 && threadIdx.x == 0) g_knn_dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define KSTAMP(i) do { if (blockIdx.x == 7 && blockIdx.y == (gridDim.y > 3 ? 3 : 0) && threadIdx.x == 0) g_knn_dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define KSTAMP(i)
 #endif
