@@ -234,7 +234,8 @@ __global__ void r3d_graph_normalize_kernel(const int* __restrict__ row_ptr, cons
 #define HG_MAX_ITER 1022
 struct CgState {            // device memory
   float rr_hist[2][HG_NC];  // rr of the last two iterations
-  float bb[HG_NC];          // ||b||^2
+  float bb[HG_NC];          // ||b||^2 (of the deflated right-hand side)
+  float defl[HG_NC];        // <u,b> / (<u,u> (1 - alpha)): multiple of u = D^1/2 1 added back to the solution
   int done;                 // statistics only: set once every column converged
   int iters;                // statistics only: iterations actually performed
   // stop[it] != 0: iteration `it` must not run.  A launch only READS stop[it] and only
@@ -269,22 +270,73 @@ static __device__ __forceinline__ float4 reduce_partials(const float4* part, int
   return block_sum4(a, sm);
 }
 
-__global__ __launch_bounds__(256) void r3d_cg_init_kernel(const float4* __restrict__ Y, const int* __restrict__ n_dev,
-                                                          int n_cap, float4* __restrict__ x, float4* __restrict__ r,
+// Deflation of the one eigenvector that is known in closed form: S u = u for u = D^1/2 1 (u_i = 1 / dinv_i), so
+// (I - alpha S) u = (1 - alpha) u is the SMALLEST eigenvalue of the system (0.01 at alpha = 0.99) -- the mode CG
+// otherwise spends its first iterations discovering.  The right-hand side is split b = b' + u <u,b>/<u,u>; CG solves
+// for b' (orthogonal to u, and every Krylov vector stays so up to rounding), the other part is u <u,b>/(<u,u>(1-alpha)).
+// Measured at S: 25 -> 20 iterations, same residual.  Exact for disconnected graphs too (u is still an eigenvector).
+__global__ __launch_bounds__(256) void r3d_cg_defl_dots_kernel(const float4* __restrict__ Y, const float* __restrict__ dinv,
+                                                               const int* __restrict__ n_dev, int n_cap,
+                                                               float4* __restrict__ part /* [2][HG_MAX_PART/2] */) {
+  __shared__ float4 sm[4];
+  const int n = min(*n_dev, n_cap);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float4 uy = f4_zero(), uu = f4_zero();
+  if (i < n) {
+    const float u = 1.f / dinv[i];
+    const float4 b = Y[i];
+    uy = make_float4(u * b.x, u * b.y, u * b.z, u * b.w);
+    uu.x = u * u;
+  }
+  uy = block_sum4(uy, sm);
+  uu = block_sum4(uu, sm);
+  if (threadIdx.x == 0) { part[blockIdx.x] = uy; part[HG_MAX_PART / 2 + blockIdx.x] = uu; }
+}
+
+__global__ __launch_bounds__(256) void r3d_cg_init_kernel(const float4* __restrict__ Y, const float* __restrict__ dinv,
+                                                          const int* __restrict__ n_dev, int n_cap, float alpha_lp,
+                                                          const float4* __restrict__ part_defl, int nblk,
+                                                          float4* __restrict__ x, float4* __restrict__ r,
                                                           float4* __restrict__ p, float4* __restrict__ part_rr,
                                                           CgState* __restrict__ st) {
   __shared__ float4 sm[4];
   const int n = min(*n_dev, n_cap);
   const int i = blockIdx.x * 256 + threadIdx.x;
+  // <u,b> and <u,u>: every block reduces the same partials in the same order
+  const float4 uy = reduce_partials(part_defl, nblk, sm);
+  const float4 uu4 = reduce_partials(part_defl + HG_MAX_PART / 2, nblk, sm);
+  const float inv_uu = uu4.x > 0.f ? 1.f / uu4.x : 0.f;
+  const float4 c = make_float4(uy.x * inv_uu, uy.y * inv_uu, uy.z * inv_uu, uy.w * inv_uu);
   float4 b = f4_zero();
-  if (i < n) b = Y[i];
+  if (i < n) {
+    const float u = 1.f / dinv[i];
+    const float4 y = Y[i];
+    b = make_float4(y.x - u * c.x, y.y - u * c.y, y.z - u * c.z, y.w - u * c.w);
+  }
   if (i < n_cap) { x[i] = f4_zero(); r[i] = b; p[i] = f4_zero(); }
   float4 sq = make_float4(b.x * b.x, b.y * b.y, b.z * b.z, b.w * b.w);
   sq = block_sum4(sq, sm);
   if (threadIdx.x == 0) part_rr[blockIdx.x] = sq;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { st->done = 0; st->iters = 0; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->done = 0;
+    st->iters = 0;
+    const float k = 1.f / (1.f - alpha_lp);
+    st->defl[0] = c.x * k; st->defl[1] = c.y * k; st->defl[2] = c.z * k; st->defl[3] = c.w * k;
+  }
   if (blockIdx.x == 0)
     for (int q = threadIdx.x; q < HG_MAX_ITER + 2; q += 256) st->stop[q] = 0;
+}
+
+// x += u * defl: the closed-form component along the deflated eigenvector
+__global__ void r3d_cg_defl_add_kernel(float4* __restrict__ x, const float* __restrict__ dinv, const int* __restrict__ n_dev,
+                                       int n_cap, const CgState* __restrict__ st) {
+  const int n = min(*n_dev, n_cap);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float u = 1.f / dinv[i];
+  float4 v = x[i];
+  v.x += u * st->defl[0]; v.y += u * st->defl[1]; v.z += u * st->defl[2]; v.w += u * st->defl[3];
+  x[i] = v;
 }
 
 // A: p_new = r + beta p_old ; q = (I - alpha S) p_new ; partial <p_new, q>
@@ -521,8 +573,10 @@ static int lp_solve(const LpWs& L, const float* RHS, const int32_t* n_dev, int n
   const int nblk_s = r3d_cdiv(n_cap, rpb);
   R3D_REQUIRE(nblk_s <= HG_MAX_PART, "r3d_label_propagate: n_cap too large");
   float4* x = (float4*)X;
-  hipLaunchKernelGGL(r3d_cg_init_kernel, dim3(nblk_v), dim3(256), 0, st, (const float4*)RHS, n_dev, n_cap, x, L.r, L.p0,
-                     L.part_rr, L.cg);
+  R3D_REQUIRE(nblk_v <= HG_MAX_PART / 2, "r3d_label_propagate: n_cap too large");
+  hipLaunchKernelGGL(r3d_cg_defl_dots_kernel, dim3(nblk_v), dim3(256), 0, st, (const float4*)RHS, L.dinv, n_dev, n_cap, L.part_pq);
+  hipLaunchKernelGGL(r3d_cg_init_kernel, dim3(nblk_v), dim3(256), 0, st, (const float4*)RHS, L.dinv, n_dev, n_cap, alpha,
+                     L.part_pq, nblk_v, x, L.r, L.p0, L.part_rr, L.cg);
   const float tol2 = tol * tol;
   for (int it = 0; it < max_iter; ++it) {
     float4* pold = (it & 1) ? L.p1 : L.p0;
@@ -532,6 +586,7 @@ static int lp_solve(const LpWs& L, const float* RHS, const int32_t* n_dev, int n
     hipLaunchKernelGGL(r3d_cg_update_kernel, dim3(nblk_v), dim3(256), 0, st, n_dev, n_cap, it, nblk_s, tol2, pnew, L.q,
                        x, L.r, L.part_pq, L.part_rr, L.cg);
   }
+  hipLaunchKernelGGL(r3d_cg_defl_add_kernel, dim3(nblk_v), dim3(256), 0, st, x, L.dinv, n_dev, n_cap, L.cg);
   if (stats_out) r3d_copy_words(stats_out, &L.cg->done, 2, st);
   return R3D_OK;
 }
