@@ -37,6 +37,8 @@ def test_abi_argument_validation_without_gpu():
     rc = lib.r3d_edgeconv_fwd(ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8),
                               ctypes.c_void_p(8), ctypes.c_void_p(8), 64, 1, 102, 20, None, None)
     assert rc != 0 and b"multiple" in lib.r3d_last_error_string()
+    rc = lib.r3d_graph_set_lp_budget(None, None, 16, None)
+    assert rc != 0 and b"r3d_graph_set_lp_budget" in lib.r3d_last_error_string()
 
 
 def test_state_dict_names_match_reference_contract():

@@ -139,7 +139,8 @@ def test_pointwise_conv_strided_views(ops):
 
 
 # ------------------------------------------------------------------ a2+a3 EdgeConv (dgcnn.py:26-61,117-118)
-@pytest.mark.parametrize("B,C,N,K", [(2, 9, 512, 20), (1, 64, 1024, 20), (1, 64, 256, 8), (1, 64, 256, 12)])
+@pytest.mark.parametrize("B,C,N,K", [(2, 9, 512, 20), (1, 64, 1024, 20), (1, 64, 256, 4), (1, 64, 256, 8), (1, 64, 256, 12),
+                                      (1, 64, 256, 16), (2, 64, 132, 24), (1, 64, 256, 28), (1, 64, 256, 32)])
 def test_edgeconv_vs_oracle(ops, B, C, N, K):
     from r3dfsseg_amd.dgcnn import DGCNN
     cfg = S.make_cfg()
