@@ -54,8 +54,8 @@ class EpisodeGraphs:
             n = sum(p.numel() for p in self.params)
             self.grad_rows = grad_rows if grad_rows is not None else torch.zeros(n_slots, n, device=dev)
             assert self.grad_rows.shape[0] == n_slots and self.grad_rows.shape[1] >= n
-        if lp_budget is None:  # CG iterations frozen into the graph; launches after convergence are no-ops (~3 us each)
-            lp_budget = min(model.lp_max_iter, 200 if train else 128)
+        if lp_budget is None:  # CG iterations frozen into the graph; the ones beyond the adaptive budget are disabled nodes
+            lp_budget = min(model.lp_max_iter, 200)
         self.lp_budget = lp_budget          # CG iterations captured into every graph
         self.active_budget = lp_budget      # ... of which this many are enabled
         self.adaptive_budget = os.environ.get("R3D_FIXED_LP_BUDGET") is None
