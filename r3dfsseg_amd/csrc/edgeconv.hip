@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void r3d_edgeconv_kernel(
     const long pt0 = u * E2_PTS;        // first point of the unit (global row)
     const long cloud0 = (pt0 / N) * N;  // first row of its cloud
     {
-      const int my_idx = idx[(pt0 + w) * K + min(lane, K - 1)];
+      const int my_idx = min(max(idx[(pt0 + w) * K + min(lane, K - 1)], 0), N - 1);  // never gather outside the cloud, whatever the list holds
       const float q = PQ[(pt0 + w) * 128 + 64 + lane];
       float pv[K];
 #pragma unroll

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void r3d_edge_stats1_kernel(const float* __res
   for (long pt = (long)blockIdx.x * 4 + w; pt < total_points; pt += (long)gridDim.x * 4) {
     const long cloud0 = (pt / N) * N;
     const float q = PQ[pt * 128 + 64 + lane];
-    const int my_idx = idx[pt * K + min(lane, K - 1)];
+    const int my_idx = min(max(idx[pt * K + min(lane, K - 1)], 0), N - 1);  // never gather outside the cloud, whatever the list holds
     float pv[K];  // all K neighbour rows in flight (four at a time was a chain of K/4 L2 round trips per point)
 #pragma unroll
     for (int t = 0; t < K; ++t) pv[t] = PQ[(cloud0 + __builtin_amdgcn_readlane(my_idx, t)) * 128 + lane];
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(512) void r3d_edgeconv_train_fwd_kernel(
     const long pt0 = u * ET_PTS;
     const long cloud0 = (pt0 / N) * N;
     {
-      const int my_idx = idx[pt0 * K + 32 * w + (lane & 31)];
+      const int my_idx = min(max(idx[pt0 * K + 32 * w + (lane & 31)], 0), N - 1);  // never gather outside the cloud, whatever the list holds
       float* hrow = H + (32 * w) * ET_LD;
       // all 32 neighbour rows in flight at once (L2-latency bound gather); the point's own Q row per edge is an
       // L1 hit and is loaded alongside
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT <= 5 ? 3
     }
     float eh[K];  // ehat1 of the K edges of point w (this wave's rows), channel = lane
     {
-      const int my_idx = idx[(pt0 + w) * K + min(lane, K - 1)];
+      const int my_idx = min(max(idx[(pt0 + w) * K + min(lane, K - 1)], 0), N - 1);  // never gather outside the cloud, whatever the list holds
       const float q = PQ[(pt0 + w) * 128 + 64 + lane];
       float pv[K];
 #pragma unroll
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void r3d_edgeconv_train_fwd2_kernel(
     const long pt0 = u * E2_PTS;
     const long cloud0 = (pt0 / N) * N;
     {
-      const int my_idx = idx[(pt0 + w) * K + min(lane, K - 1)];
+      const int my_idx = min(max(idx[(pt0 + w) * K + min(lane, K - 1)], 0), N - 1);  // never gather outside the cloud, whatever the list holds
       const float q = PQ[(pt0 + w) * 128 + 64 + lane];
       float pv[K];
 #pragma unroll
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void r3d_edgeconv_bwd2_kernel(
   for (long pt = (long)blockIdx.x * 4 + w; pt < total_points; pt += (long)gridDim.x * 4) {
     const long cloud0 = (pt / N) * N;
     const float q = PQ[pt * 128 + 64 + lane];
-    const int my_idx = idx[pt * K + min(lane, K - 1)];
+    const int my_idx = min(max(idx[pt * K + min(lane, K - 1)], 0), N - 1);  // never gather outside the cloud, whatever the list holds
     // all K neighbour rows and all K dy1 rows of the point in flight at once (four at a time was a chain of K/4
     // memory round trips per point)
     float pv[K], dv[K];
