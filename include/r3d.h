@@ -65,7 +65,8 @@ int r3d_pointwise_conv(const float* X, long ldx, const float* W /*(Co,K)*/, long
 /* ---- fused EdgeConv: gather + 2-layer edge MLP + max over K --------------------------
  * models/dgcnn.py:26-61,117-118.  PQ (B*N,128) = [s1*Wa x | s1*(Wb-Wa) x + t1] per point
  * (from r3d_pointwise_conv), idx (B,N,K) local neighbour ids, W2 (64,64), s2/t2 (64) folded BN2.
- * out (B*N, ldo) 64 columns; argmax_out optional (B*N,64) winning neighbour slot. */
+ * out (B*N, ldo) 64 columns; argmax_out optional (B*N,64) winning neighbour slot.
+ * Shapes: N a multiple of 4, K in {4, 8, ..., 32}; neighbour ids outside [0, N) are clamped, never dereferenced. */
 int r3d_edgeconv_fwd(const float* PQ, const int32_t* idx, const float* W2, const float* s2, const float* t2,
                      float* out, long ldo, int B, int N, int K, int32_t* argmax_out, void* stream);
 
