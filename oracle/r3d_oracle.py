@@ -137,17 +137,24 @@ def conv_block(sd, prefix, x, n_layers, dims, train=False, new_stats=None):
 # a5  DGCNN.forward (models/dgcnn.py:113-127)
 # --------------------------------------------------------------------------
 def dgcnn_forward(sd, x, k=20, n_edgeconv=3, prefix="encoder", train=False,
-                  new_stats=None, return_idx=False, idx_override=None):
+                  new_stats=None, return_idx=False, idx_override=None, argmax_override=None):
     """idx_override: optional per-layer (B,N,k) neighbour lists used instead of
     :func:`knn` (lets the float pipeline be checked against the reference on the
-    reference's own GEMM-ordered neighbour choice)."""
+    reference's own GEMM-ordered neighbour choice).  argmax_override: optional
+    per-layer (B,64,N) int64 winning neighbour slot of the max over K
+    (dgcnn.py:118): two edges whose activations agree to the last bits may swap
+    winners between implementations, which moves a gradient from one edge to
+    the other; gradient parity tests pin the winner."""
     outs, idxs = [], []
     for i in range(n_edgeconv):
         idx = knn(x, k) if idx_override is None else idx_override[i]
         idxs.append(idx)
         e = get_edge_feature(x, K=k, idx=idx)
         e = conv_block(sd, "%s.edge_convs.%d" % (prefix, i), e, 2, 2, train, new_stats)
-        x = e.max(dim=-1)[0]
+        if argmax_override is None:
+            x = e.max(dim=-1)[0]
+        else:
+            x = e.gather(-1, argmax_override[i].unsqueeze(-1)).squeeze(-1)
         outs.append(x)
     out = torch.cat(outs, dim=1)
     out = conv_block(sd, prefix + ".conv", out, 2, 1, train, new_stats)
@@ -188,8 +195,9 @@ def self_attention(sd, x, prefix="att_learner", drop_mask=None):
 # --------------------------------------------------------------------------
 # a8  getFeatures (models/mpti.py:579-595)
 # --------------------------------------------------------------------------
-def get_features(sd, x, cfg, train=False, new_stats=None, drop_mask=None, idx_override=None):
-    l1, l2 = dgcnn_forward(sd, x, k=cfg["dgcnn_k"], train=train, new_stats=new_stats, idx_override=idx_override)
+def get_features(sd, x, cfg, train=False, new_stats=None, drop_mask=None, idx_override=None, argmax_override=None):
+    l1, l2 = dgcnn_forward(sd, x, k=cfg["dgcnn_k"], train=train, new_stats=new_stats, idx_override=idx_override,
+                           argmax_override=argmax_override)
     l3 = base_learner(sd, l2, train=train, new_stats=new_stats)
     if cfg.get("use_attention", True):
         att = self_attention(sd, l2, drop_mask=drop_mask)
@@ -450,14 +458,25 @@ DEFAULT_CFG = dict(n_way=2, k_shot=5, pc_in_dim=9, pc_npts=2048, use_attention=T
 
 def mpti_forward(sd, cfg, support_x, support_y, query_x, query_y, gt_support_y=None,
                  gt_query_y=None, train=False, eval=False, support_flag=None,
-                 new_stats=None, drop_masks=(None, None), return_aux=False):
+                 new_stats=None, drop_masks=(None, None), return_aux=False, idx_override=(None, None),
+                 argmax_override=(None, None)):
+    """idx_override / argmax_override: (support pass, query pass) per-layer lists for :func:`dgcnn_forward`."""
+    n_way, k_shot, N = cfg["n_way"], cfg["k_shot"], cfg["pc_npts"]
+    sx = support_x.reshape(n_way * k_shot, cfg["pc_in_dim"], N)
+    sfeat = get_features(sd, sx, cfg, train, new_stats, drop_masks[0], idx_override[0], argmax_override[0])
+    qfeat = get_features(sd, query_x, cfg, train, new_stats, drop_masks[1], idx_override[1], argmax_override[1])
+    return mpti_head(sd, cfg, sfeat, qfeat, support_x, support_y, query_y, gt_support_y, gt_query_y, train, eval,
+                     support_flag, return_aux)
+
+
+def mpti_head(sd, cfg, sfeat, qfeat, support_x, support_y, query_y, gt_support_y=None, gt_query_y=None,
+              train=False, eval=False, support_flag=None, return_aux=False):
+    """Everything of MPTI_SelfAtten.forward behind the two getFeatures calls (models/mpti.py:438-577).
+    sfeat (n_way*k_shot, d, N), qfeat (n_q, d, N) channel-major as getFeatures returns them."""
     n_way, k_shot, N = cfg["n_way"], cfg["k_shot"], cfg["pc_npts"]
     n_classes = n_way + 1
-    sx = support_x.reshape(n_way * k_shot, cfg["pc_in_dim"], N)
-    sfeat = get_features(sd, sx, cfg, train, new_stats, drop_masks[0])
     d = sfeat.shape[1]
     sfeat = sfeat.view(n_way, k_shot, d, N)
-    qfeat = get_features(sd, query_x, cfg, train, new_stats, drop_masks[1])
     qfeat = qfeat.transpose(1, 2).reshape(-1, d)
 
     pl, clean_flag = None, None
@@ -484,14 +503,14 @@ def mpti_forward(sd, cfg, support_x, support_y, query_x, query_y, gt_support_y=N
     Y = torch.zeros(n_nodes, n_classes)
     Y[:n_proto] = plab
     node_feat = torch.cat((protos, qfeat), 0)
-    A = affinity(node_feat, cfg["k_connect"], cfg["sigma"])
+    A, nbr, _ = affinity(node_feat, cfg["k_connect"], cfg["sigma"], return_knn=True)
     Z = label_propagate(A, Y)
     qpred = Z[n_proto:].view(-1, query_y.shape[1], n_classes).transpose(1, 2)
     loss = F.cross_entropy(qpred, query_y)
     aux = dict(support_feat=sfeat, query_feat=qfeat, prototypes=protos, proto_labels=plab,
                n_proto=n_proto, A=A, Z=Z, fg_assign=fg_assign, fg_num=fg_num,
                bg_assign=bg_assign, bg_num=bg_num, pl_support_y=pl, clean_flag=clean_flag,
-               node_feat=node_feat)
+               node_feat=node_feat, nbr=nbr)
     if train:
         # debug metrics, mpti.py:515-568
         lp_avg, orig_avg, begin = 0.0, 0.0, 0

@@ -92,6 +92,7 @@ class DGCNN(nn.Module):
         in_dim = sum(w[-1] for w in edgeconv_widths)
         self.conv = conv1d(in_dim, mlp_widths)
         self._folded = None
+        self.trace = None  # a list while a parity test records the neighbour lists of a pass
 
     def _fold(self):
         """Fold eval-mode BN into GEMM epilogues (cached until parameters change)."""
@@ -133,6 +134,8 @@ class DGCNN(nn.Module):
         for l in range(self.n_edgeconv):
             Wpq, sc, sh, W2, s2, t2 = f["ec"][l]
             idx = ops.knn(inp, B, N, self.k, x_cm=x_cm if l == 0 else None)
+            if self.trace is not None:
+                self.trace.append(idx)
             PQ = ops.pointwise_conv(inp, Wpq, sc, sh, ops.ACT_NONE)
             out = cat[:, 64 * l:64 * (l + 1)]
             ops.edgeconv(PQ, idx, W2, s2, t2, out, B, N)

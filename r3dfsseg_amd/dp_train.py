@@ -26,26 +26,50 @@ class DPTrainer:
 
     def step(self, episodes, logger=None):
         """episodes: list of train-layout data lists (loader.py:1666-1671) local to this rank.
-        Returns the mean (lp_loss + 0.1 contrast) over the local episodes as a device tensor."""
+        Returns the mean (lp_loss + 0.1 contrast) over the local episodes as a device tensor.
+
+        Fails closed: the optimiser never steps on a gradient from an episode whose CG solves (forward or adjoint) ran
+        out of launch budget, whose 201-NN survivor buffer overflowed or whose one-launch FPS timed out.  The status
+        words are read after the local episodes and BEFORE the all-reduce (one host wait per step, ~0.3 % of a
+        32-episode step); a miss makes this rank redo its episodes of the step on the conservative schedule (full
+        budget, exact kernels) and raises if that fails too.  Ranks decide locally: a rank's contribution to the
+        all-reduce is always an exact gradient, so no agreement between ranks is needed."""
         self.model.train()
+        self.redone = False
         if self.graphs is not None:
             total = self.graphs.run(episodes)
-            torch.sum(self.rows, 0, out=self.bucket.store)
-            self.bucket.all_reduce_mean(len(episodes))
-            self.learner.optimizer.step()
-            self.learner.lr_scheduler.step()
-            return total / max(len(episodes), 1)
+            bad, overflow, _, _ = self.graphs.step_status()
+            if bad or overflow:
+                total = self._eager_pass(episodes, logger, conservative=True)
+                self.redone = True
+            else:
+                torch.sum(self.rows, 0, out=self.bucket.store)
+        else:
+            total = self._eager_pass(episodes, logger, conservative=False)
+        self.bucket.all_reduce_mean(len(episodes))
+        self.learner.optimizer.step()
+        self.learner.lr_scheduler.step()
+        return total / max(len(episodes), 1)
+
+    def _eager_pass(self, episodes, logger, conservative):
+        """Forward + backward of every episode into the bucket (parameter .grad tensors are views into it)."""
         self.bucket.zero_()
         total = None
         for data in episodes:
             (support_x, support_y, query_x, query_y, support_c, query_c, gt_support_y, gt_query_y, bg_pcd_x, bg_pcd_y,
              support_flag) = data
-            out = self.model(support_x, support_y, query_x, query_y, gt_support_y=gt_support_y, gt_query_y=gt_query_y,
-                             train=True, logger=logger, support_flag=support_flag)
-            loss = out[1] + 0.1 * out[2]  # mpti_learner.py:66
-            loss.backward()               # accumulates into the bucket views
+            for lp_iters in ((self.model.lp_max_iter,) if conservative else (None, self.model.lp_max_iter)):
+                keep = self.bucket.store.clone() if lp_iters is None else None
+                out = self.model(support_x, support_y, query_x, query_y, gt_support_y=gt_support_y,
+                                 gt_query_y=gt_query_y, train=True, logger=logger, support_flag=support_flag,
+                                 lp_iters=lp_iters)
+                loss = out[1] + 0.1 * out[2]  # mpti_learner.py:66
+                loss.backward()               # accumulates into the bucket views
+                if self.model.lp_converged(backward=True):
+                    break
+                if keep is not None:          # drop the inexact gradient again, then the conservative schedule
+                    self.bucket.store.copy_(keep)
+            else:
+                raise RuntimeError("label propagation did not converge in %d CG iterations" % self.model.lp_max_iter)
             total = loss.detach() if total is None else total + loss.detach()
-        self.bucket.all_reduce_mean(len(episodes))
-        self.learner.optimizer.step()
-        self.learner.lr_scheduler.step()
-        return total / max(len(episodes), 1)
+        return total

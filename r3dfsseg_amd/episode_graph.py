@@ -17,7 +17,8 @@ per-episode results are the same as the eager path of this package (tests/test_g
 
 Frozen-sequence consequences, all checked or documented:
   * the CG launch budget is fixed at capture (iterations after convergence are no-op launches); every replay
-    adds its "did not converge / survivor buffer overflowed" flags into ``slot.bad`` and ``check()`` reads them;
+    adds its "did not converge / survivor buffer overflowed" flags into per-step device counters: ``step_status()``
+    (one host wait, used by the trainer before every optimiser step) and ``check()`` read them;
   * the attention-dropout seed advances in device memory (slot.seed_dev), not in a Python counter;
   * BatchNorm running statistics are updated by slot 0 only (shared buffers, concurrent slots would race);
     the batch statistics used for normalisation are per episode either way.
@@ -59,10 +60,12 @@ class EpisodeGraphs:
         self.lp_budget = lp_budget          # CG iterations captured into every graph
         self.active_budget = lp_budget      # ... of which this many are enabled
         self.adaptive_budget = os.environ.get("R3D_FIXED_LP_BUDGET") is None
-        # per slot: [not converged / FPS time-out, 201-NN overflow, CG iterations (sum), CG iterations (max)]
+        # per slot, per run(): [not converged / FPS time-out, 201-NN overflow, CG iterations (sum), CG iterations (max)]
         self.counters = torch.zeros(n_slots, 4, device=dev, dtype=torch.int32)
-        self._probes = []                   # (event, pinned copy of the counters) of the steps still in flight
-        self._probe_pool = [torch.zeros(n_slots, 4, dtype=torch.int32).pin_memory() for _ in range(3)]
+        self._probes = []                   # (event, pinned copy of the counters) of the runs not yet accounted for
+        self._probe_pool = [torch.zeros(n_slots, 4, dtype=torch.int32).pin_memory() for _ in range(4)]
+        self._since_check = [0, 0, 0, 0]    # host totals since the last check(): bad, overflow, iterations, max
+        self._mx_decay = 0                  # slowly decaying maximum of the iteration counts (budget adaptation)
         self.slots = []
         self.ev_start = torch.cuda.Event()
         saved_slot = model._slot
@@ -80,6 +83,7 @@ class EpisodeGraphs:
             for k, v in model.named_buffers():
                 v.copy_(buffers[k])
         self.reset()
+        self.counters.zero_()  # the warm-up and capture passes are not episodes of any step
         torch.cuda.synchronize()
 
     # ------------------------------------------------------------------ capture
@@ -162,20 +166,37 @@ class EpisodeGraphs:
             assert n_cg.value > 0, "no CG nodes found in the captured episode"
         self.active_budget = budget
 
+    def _account(self, c):
+        """One finished run()'s counters (host copy): totals for check(), launch budget for the next runs."""
+        bad, ovf, its, mx = int(c[:, 0].sum()), int(c[:, 1].sum()), int(c[:, 2].sum()), int(c[:, 3].max())
+        t = self._since_check
+        t[0] += bad; t[1] += ovf; t[2] += its; t[3] = max(t[3], mx)
+        self._probe_pool.append(c)
+        if bad > 0:          # a replay did not converge: back to everything that was captured
+            self._mx_decay = max(self._mx_decay, mx)
+            self.set_lp_budget(self.lp_budget)
+        elif self.adaptive_budget and mx > 0:  # the budget follows a slowly decaying maximum, so it can shrink again
+            self._mx_decay = max(mx, self._mx_decay - max(1, self._mx_decay // 16))
+            self.set_lp_budget(max(32, 8 * ((2 * self._mx_decay + 8 + 7) // 8)))
+        return bad, ovf, its, mx
+
     def _adapt_budget(self):
-        """At most two steps run ahead of the GPU: wait for the step before the previous one and read the counters it
-        left in pinned memory (no device synchronisation, the previous step keeps the GPU busy meanwhile)."""
+        """At most two runs stay ahead of the GPU: wait for the run before the previous one and read the counters it
+        left in pinned memory (no device synchronisation, the previous run keeps the GPU busy meanwhile)."""
         while len(self._probes) >= 2:
             ev, c = self._probes.pop(0)
             ev.synchronize()
-            bad, mx = int(c[:, 0].sum()), int(c[:, 3].max())
-            self._probe_pool.append(c)
-            if not self.adaptive_budget:
-                continue
-            if bad > 0:      # a replay did not converge: back to everything that was captured
-                self.set_lp_budget(self.lp_budget)
-            elif mx > 0:
-                self.set_lp_budget(max(32, 8 * ((2 * mx + 8 + 7) // 8)))
+            self._account(c)
+
+    def step_status(self):
+        """Host wait for the LATEST run(): (replays that did not converge or timed out, 201-NN overflows, sum and max
+        of the CG iteration counts) of that run alone.  The trainer calls this before it steps the optimiser."""
+        out = (0, 0, 0, 0)
+        while self._probes:
+            ev, c = self._probes.pop(0)
+            ev.synchronize()
+            out = self._account(c)
+        return out
 
     # ------------------------------------------------------------------ replay
     def reset(self):
@@ -203,6 +224,7 @@ class EpisodeGraphs:
         main = torch.cuda.current_stream()
         self._adapt_budget()
         self.reset()
+        self.counters.zero_()  # on the main stream, which every slot stream waits for: counters are per run
         self._refresh_folds()
         self.ev_start.record(main)
         G = self.n_slots
@@ -233,11 +255,9 @@ class EpisodeGraphs:
 
     def check(self):
         """Host check (synchronises): (number of replays whose label propagation did not converge or whose
-        201-NN survivor buffer overflowed since the last check, mean CG iterations, max CG iterations)."""
-        c = self.counters.cpu()
-        self.counters.zero_()
-        self.last_unconverged = int(c[:, 0].sum())
-        self.last_knn_overflow = int(c[:, 1].sum())
-        if self.last_unconverged:
-            self.set_lp_budget(self.lp_budget)
-        return self.last_unconverged + self.last_knn_overflow, int(c[:, 2].sum()), int(c[:, 3].max())
+        201-NN survivor buffer overflowed since the last check, sum of the CG iterations, max CG iterations)."""
+        self.step_status()
+        bad, ovf, its, mx = self._since_check
+        self._since_check = [0, 0, 0, 0]
+        self.last_unconverged, self.last_knn_overflow = bad, ovf
+        return bad + ovf, its, mx

@@ -16,11 +16,15 @@ class HeadLPFn(torch.autograd.Function):
         hb = model._head_buffers(n_q, sfeat.device)
         sfeatT = ops.pm_to_cm(sfeat, S, N)
         sy = support_y.reshape(S, N).to(torch.int32).contiguous()
+        if model._lp_force:  # the conservative re-run (see MPTILearner_V3.train): one FPS launch per round as well
+            hb.fps_one_launch = False
         ops.head_prototypes(hb, sy, None, sfeat, sfeatT, qfeat)
         nbr = ops.knn(hb.nodes, 1, hb.n_cap, hb.kp1, mode=ops.SCORE_L2, n_valid=hb.desc[ops.HD_N_NODES:],
-                      status=hb.knn_status)
-        # same launch-budget policy as eval (mpti.py: _lp_next_budget); the training loop's own host sync
-        # (loss.item(), mpti_train_noise.py:107) is where lp_converged() can be checked
+                      status=None if model._lp_force else hb.knn_status)
+        if model._lp_force:
+            hb.knn_status.zero_()
+        # same launch-budget policy as eval (mpti.py: _lp_next_budget); MPTILearner_V3.train / DPTrainer.step check
+        # lp_converged(backward=True) before the optimiser step and redo the episode on this conservative schedule
         ctx.budget = model._lp_next_budget()
         ops.label_propagate(hb, nbr, model.sigma, 0.99, ctx.budget, model.lp_tol)
         model._lp_post(hb)
@@ -73,6 +77,10 @@ def mpti_train_forward(model, support_x, support_y, query_x, query_y, gt_support
     # two getFeatures calls, each with its own BatchNorm batch statistics (mpti.py:434,436)
     sfeat = T.get_features_train(model, sx, seed)
     qfeat = T.get_features_train(model, query_x, seed + 1)
+    if model._trace is not None:  # parity tests read the features and, after backward(), their gradients
+        sfeat.retain_grad()
+        qfeat.retain_grad()
+        model._trace.update(sfeat=sfeat, qfeat=qfeat)
     contrast_loss = contrast.per_way_contrast_loss(model, sfeat, support_y, support_flag)
     lp_loss = HeadLPFn.apply(sfeat, qfeat, model, support_y, query_y)
     logits = model._train_logits
@@ -92,6 +100,7 @@ def explicit_train_episode(model, episode, grad_sink, loss_weight=0.1):
     (support_x, support_y, query_x, query_y, _sc, _qc, gt_support_y, gt_query_y, _bx, _by, support_flag) = episode
     S, N = model.n_way * model.k_shot, model.n_points
     with torch.no_grad():
+        model._lp_force = False  # a frozen launch sequence always runs on the slot's fixed budget
         slot = model._slot
         if slot.seed_dev is not None:
             slot.seed_dev.add_(2)

@@ -65,13 +65,22 @@ class MPTI_SelfAtten(nn.Module):
         # call lp_converged() and re-run with the full lp_max_iter in the rare miss.
         self._lp_budget = min(32, self.lp_max_iter)
         self._lp_probe = None
+        self._lp_force = False  # True: the conservative schedule (full CG budget, exact 201-NN kernel, FPS per round)
+        # parity tests set this to a dict; forward() then leaves its index decisions and intermediate tensors in it
+        # (neighbour lists per encoder pass and layer, max-pool winners, features, shot flags, 201-NN lists)
+        self._trace = None
 
     # ------------------------------------------------------------------ features (mpti.py:579-595)
     def getFeatures_pm(self, x):
         """x (B, C_in, N) -> point-major features (B*N, feat_dim): [level1 | att | base]."""
         B, _, N = x.shape
         x = x.contiguous().float()
+        self.encoder.trace = [] if self._trace is not None else None
         cat, level2 = self.encoder.forward_pm(ops.cm_to_pm(x), B, N, x_cm=x)
+        if self._trace is not None:
+            self._trace.setdefault("idx", []).append(self.encoder.trace)
+            self._trace.setdefault("cat", []).append(cat)
+            self.encoder.trace = None
         d1 = 64
         feat = torch.empty(B * N, self.feat_dim, device=x.device, dtype=torch.float32)
         ops.copy_cols(cat[:, :d1], feat[:, :d1])
@@ -104,6 +113,8 @@ class MPTI_SelfAtten(nn.Module):
         return slot.heads[key]
 
     def _lp_next_budget(self):
+        if self._lp_force:
+            return self.lp_max_iter
         if self._slot.fixed_budget is not None:
             return min(self.lp_max_iter, self._slot.fixed_budget)
         if self._lp_probe is not None:
@@ -127,23 +138,35 @@ class MPTI_SelfAtten(nn.Module):
             ev.record()
             self._lp_probe = (host, ev)
 
-    def lp_converged(self):
+    def lp_converged(self, backward=False):
         """Host check (synchronises): did the last forward's label propagation converge AND did the
-        201-NN append kernel stay inside its survivor buffer?  False -> call forward again with
-        lp_iters=self.lp_max_iter (which also selects the always-exact insertion kNN kernel)."""
+        201-NN append kernel stay inside its survivor buffer AND did the one-launch FPS finish?  False -> call
+        forward again with lp_iters=self.lp_max_iter (which also selects the always-exact insertion kNN kernel).
+        backward=True: the adjoint solve of the last backward pass must have converged as well."""
         hb = self._head[1]
-        return (bool(hb.stats[0].item()) and int(hb.knn_status.item()) == 0
-                and int(hb.desc[ops.HD_FPS_TIMEOUT].item()) == 0)
+        words = [hb.stats[:1], hb.knn_status, hb.desc[ops.HD_FPS_TIMEOUT:ops.HD_FPS_TIMEOUT + 1]]
+        if backward:
+            words.append(hb.stats_bwd[:1])
+        w = torch.cat(words).tolist()  # one device-to-host copy
+        return w[0] != 0 and w[1] == 0 and w[2] == 0 and (not backward or w[3] != 0)
 
     # ------------------------------------------------------------------ forward (mpti.py:414-577)
     def forward(self, support_x, support_y, query_x, query_y, gt_support_y=None, gt_query_y=None, train=False,
                 logger=None, step=None, path=None, sampled_classes=None, bg_pcd_x=None, bg_pcd_y=None,
                 support_c=None, support_flag=None, pcd_1024=None, label_1024=None, pcd_cutout=None,
                 label_cutout=None, eval=False, lp_iters=None):
-        if train or self.training:
+        self._lp_force = bool(lp_iters)
+        if train:  # the reference keys the 7-tuple / contrastive path on this argument alone (mpti.py:465,573)
+            if not self.training:
+                raise NotImplementedError("train=True needs model.train(): the training kernels use batch-statistics "
+                                          "BatchNorm and attention dropout (models/mpti_learner.py:58-63)")
             from . import train_ops
             return train_ops.mpti_train_forward(self, support_x, support_y, query_x, query_y, gt_support_y,
                                                 gt_query_y, logger, support_flag)
+        if self.training:
+            raise NotImplementedError("train=False on a model in .train() mode (batch-statistics BatchNorm in an "
+                                      "inference forward) is not built; call model.eval() first as "
+                                      "models/mpti_learner.py:93 does")
         S = self.n_way * self.k_shot
         N = self.n_points
         n_q = query_x.shape[0]
@@ -153,9 +176,11 @@ class MPTI_SelfAtten(nn.Module):
         sfeat, qfeat = feat[:S * N], feat[S * N:]
         sfeatT = ops.pm_to_cm(sfeat, S, N)
         shot_keep = None
-        if eval:  # clean-shot detection (mpti.py:440-442), eval only
-            from . import clean_detect
-            shot_keep = clean_detect.shot_keep_flags(self, sfeat, sfeatT, support_x, support_y)
+        if eval:
+            # clean-shot detection (mpti.py:87-223, 316-371, called at :440-442), eval only: 0 = the shot's foreground
+            # points are ignored when the class prototypes are built (the reference's pl_support_y, which is
+            # constant within a shot)
+            shot_keep = ops.clean_shot_detect(sfeat, support_x, support_y, self.n_way, self.k_shot, N)
         hb = self._head_buffers(n_q, feat.device)
         if lp_iters:  # the conservative re-run: one FPS launch per round as well
             hb.fps_one_launch = False
@@ -170,4 +195,6 @@ class MPTI_SelfAtten(nn.Module):
         labels = query_y.to(torch.int64).contiguous() if query_y is not None else None
         logits, loss, _ = ops.query_logits_ce(hb, n_q, self.n_classes, labels)
         self.num_prototypes_dev = hb.desc[ops.HD_N_PROTO]
+        if self._trace is not None:
+            self._trace.update(sfeat=sfeat, qfeat=qfeat, shot_keep=shot_keep, nbr=nbr)
         return logits, loss

@@ -126,15 +126,37 @@ def _box_mask(rs, pts, lo=0.10, hi=0.40):
     return m
 
 
-def make_episode(cfg, seed=0, noise_ratio=0.0, dup_frac=0.0, train=False):
+SPLIT_CLASSES = (1, 2, 5, 6, 7, 9)  # six class ids of one cross-validation split, as dataloaders/s3dis.py:30
+
+
+def make_noise_episode(cfg, seed=0, noise_ratio=0.4, noise_mode="ood", train=False, sampled_classes=None):
+    """An episode built by the reference's noise rules (episode_sampler.NoiseEpisodeSampler, loader.py:648-890) on
+    synthetic blocks: noise_mode 'ood' draws the noisy shots from classes OUTSIDE the episode, 'sym' from the
+    episode's other classes, 'partial' flips a wrong object into the mask (BASELINE.json configs[2] is 'ood' at
+    noise_ratio 0.4).  Same return value as make_episode; support_flag holds absolute class ids."""
+    from . import episode_sampler as ES
+    src = ES.SyntheticBlocks(SPLIT_CLASSES, scans_per_class=4 * cfg["k_shot"] + 8,
+                             points_per_block=max(3000, cfg["pc_npts"] * 3 // 2), seed=seed)
+    smp = ES.NoiseEpisodeSampler(src, SPLIT_CLASSES, n_way=cfg["n_way"], k_shot=cfg["k_shot"],
+                                 n_queries=cfg.get("n_queries", 1), num_point=cfg["pc_npts"],
+                                 mode="train" if train else "test", noise_ratio=[noise_ratio] if train else noise_ratio,
+                                 noise_type=noise_mode, seed=seed)
+    arrays, sc = smp.episode(sampled_classes)
+    return (ES.collate_train if train else ES.collate_test)(arrays)
+
+
+def make_episode(cfg, seed=0, noise_ratio=0.0, dup_frac=0.0, train=False, noise_mode=None):
     """One episode as the reference collate would hand it to a learner
     (channel-major tensors).  Returns (data_list, sampled_classes).
+    noise_mode ('ood' | 'sym' | 'partial'): route to make_noise_episode (the reference's own noise rules).
 
     test layout (loader.py:1680-1682): [support_x, support_y, query_x, query_y,
     support_clusters, query_clusters, gt_support_y]; train layout
     (loader.py:1666-1671) appends gt_query_y, bg_pcd_x, bg_pcd_y, support_flag.
     A noisy shot keeps its (wrong-object) foreground mask in support_y while
     gt_support_y is zeroed for that shot (loader.py:673, 'ood' noise)."""
+    if noise_mode is not None:
+        return make_noise_episode(cfg, seed, noise_ratio, noise_mode, train)
     rs = np.random.RandomState(seed)
     n_way, k_shot, N = cfg["n_way"], cfg["k_shot"], cfg["pc_npts"]
     n_q = n_way * cfg.get("n_queries", 1)

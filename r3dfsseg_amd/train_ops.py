@@ -237,6 +237,9 @@ class EncoderTrainFn(torch.autograd.Function):
                                                    ctypes.c_uint(seed & 0xffffffff), _p(model._slot.seed_dev), _p(aws), _st()))
         ctx.model, ctx.dims, ctx.seed_dev = model, (B, N, seed, p_drop), model._slot.seed_dev
         model._dbg_idx = [sv[1] for sv in ec_saved]  # neighbour lists of this pass (parity tests inject them into the oracle)
+        if getattr(model, "_trace", None) is not None:
+            model._trace.setdefault("idx", []).append([sv[1] for sv in ec_saved])
+            model._trace.setdefault("argmax", []).append([sv[7] for sv in ec_saved])
         ctx.saved = (ec_saved, mlp_saved, base_saved, cat, level2, Wqkv, qkv, lse, feat)
         return feat
 

@@ -43,5 +43,7 @@ col = ws[o:o + nnz_cap]; o += nnz_cap
 val = ws[o:o + nnz_cap].view(np.float32); o += nnz_cap
 nnz = int(row_ptr[n])
 np.savez_compressed(out, n=n, row_ptr=row_ptr[:n + 1].copy(), col=col[:nnz].copy(), val=val[:nnz].copy(),
-                    Y=hb.Y.cpu().numpy()[:n], Z=hb.Z.cpu().numpy()[:n], stats=hb.stats.cpu().numpy())
+                    Y=hb.Y.cpu().numpy()[:n], Z=hb.Z.cpu().numpy()[:n], stats=hb.stats.cpu().numpy(),
+                    nodes=hb.nodes.cpu().numpy()[:n].astype(np.float16), n_proto=int(hb.desc[ops.HD_N_PROTO].item()),
+                    query_y=pool[3][3].cpu().numpy())
 print("dumped n", n, "nnz", nnz, "stats (converged, iterations)", hb.stats.cpu().numpy())

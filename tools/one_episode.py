@@ -1,5 +1,5 @@
-"""Two eager episodes (one warm-up, one measured) of the S workload: a small launch count for PMC passes.
-usage: one_episode.py [train|eval]"""
+"""Two eager episodes (one warm-up, one measured) of workload S or C: a small launch count for PMC passes.
+usage: one_episode.py [train|eval] [S|C]"""
 import os, sys
 from types import SimpleNamespace
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,7 +7,7 @@ import torch
 from r3dfsseg_amd import synthetic as S
 from r3dfsseg_amd.mpti import MPTI_SelfAtten
 mode = sys.argv[1] if len(sys.argv) > 1 else "eval"
-cfg = S.workload_cfg("S")
+cfg = S.workload_cfg(sys.argv[2] if len(sys.argv) > 2 else "S")
 m = MPTI_SelfAtten(SimpleNamespace(**cfg)); m.load_state_dict(S.make_state_dict(cfg, 123)); m.cuda().train(mode == "train")
 data, _ = S.make_episode(cfg, seed=1000, noise_ratio=0.2, train=True)
 ep = [t.cuda() for t in data]
