@@ -101,15 +101,21 @@ int r3d_head_prototypes(const int32_t* support_y /*(n_way*k_shot,N)*/, const int
 
 /* ---- affinity + label propagation (models/mpti.py:717-776) ---------------------------
  * nbr (n_cap, kp1) from r3d_knn_topk mode 1 (column 0 is dropped as in mpti.py:736).
- * Z = (I - alpha D^-1/2 A D^-1/2)^-1 Y by CG (all columns at once), A the symmetrised gaussian
- * kNN affinity with zero diagonal.  Y, Z (n_cap, 4) fp32, 16-byte aligned.  stats_out optional
- * device int32[2] = {converged, iterations}. */
+ * Z = (I - alpha D^-1/2 A D^-1/2)^-1 Y (all columns at once), A the symmetrised gaussian kNN affinity with zero
+ * diagonal, solved by two-level conjugate gradients: coarse space = D^1/2 x indicators of 64 aggregates (nodes
+ * grouped around an even subsample of the first *n_proto_dev rows, the prototypes), A-DEF2 preconditioner.
+ * nodes rows are read as float4 (ldn % 4 == 0, 16-byte aligned); Y, Z (n_cap, 4) fp32, 16-byte aligned; n_cap <= 32768.
+ * ws: r3d_lp_ws_words(n_cap, kp1) int32 words, 16-byte aligned; it keeps the graph, the coarse space and the
+ * directed weights for r3d_label_propagate_bwd.  stats_out optional device int32[2] = {converged, iterations}.
+ * r3d_lp_ws_offsets: int32-word offsets inside ws of {row_ptr, col (uint16 entries), val, dinv, aggregate ids,
+ * solver state} for tests and tools that read the system back. */
 long r3d_lp_ws_words(int n_cap, int kp1);
+int r3d_lp_ws_offsets(int n_cap, int kp1, long* out6);
 int r3d_label_propagate(const float* nodes, long ldn, int D, const int32_t* nbr, int kp1, const float* Y,
-                        const int32_t* n_dev, int n_cap, float sigma, float alpha, int max_iter, float tol,
-                        float* Z, int32_t* ws, int32_t* stats_out, void* stream);
+                        const int32_t* n_dev, const int32_t* n_proto_dev, int n_cap, float sigma, float alpha,
+                        int max_iter, float tol, float* Z, int32_t* ws, int32_t* stats_out, void* stream);
 
-/* Captured episodes: enable the CG kernel nodes of iterations < budget in an instantiated hipGraph holding
+/* Captured episodes: enable the CG kernel nodes (three per iteration) of iterations < budget in an instantiated hipGraph holding
  * r3d_label_propagate / r3d_label_propagate_bwd launches, disable the rest (no dispatch for them).  graph: the
  * hipGraph_t the hipGraphExec_t graph_exec was instantiated from.  n_cg (optional, host): CG nodes found.
  * No reference counterpart (the reference inverts the dense matrix, models/mpti.py:758-776). */

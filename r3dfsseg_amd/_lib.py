@@ -41,7 +41,8 @@ _SIGS = {
     "r3d_head_prototypes": (c_i, [c_f, c_f, c_f, c_l, c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_l,
                                   c_f, c_f, c_f, c_f, c_f, c_i, c_f]),
     "r3d_lp_ws_words": (c_l, [c_i, c_i]),
-    "r3d_label_propagate": (c_i, [c_f, c_l, c_i, c_f, c_i, c_f, c_f, c_i, c_fl, c_fl, c_i, c_fl, c_f, c_f,
+    "r3d_lp_ws_offsets": (c_i, [c_i, c_i, ctypes.POINTER(c_l)]),
+    "r3d_label_propagate": (c_i, [c_f, c_l, c_i, c_f, c_i, c_f, c_f, c_f, c_i, c_fl, c_fl, c_i, c_fl, c_f, c_f,
                                   c_f, c_f]),
     "r3d_graph_set_lp_budget": (c_i, [c_f, c_f, c_i, ctypes.POINTER(c_i)]),
     "r3d_pointwise_conv_acc": (c_i, [c_f, c_l, c_f, c_l, c_i, c_i, c_f, c_f, c_i, c_f, c_l, c_f]),

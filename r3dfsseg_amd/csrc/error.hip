@@ -13,4 +13,4 @@ void r3d_set_error(const char* fmt, ...) {
 
 extern "C" const char* r3d_last_error_string(void) { return g_err; }
 
-extern "C" int r3d_abi_version(void) { return 1; }
+extern "C" int r3d_abi_version(void) { return 2; }

@@ -19,6 +19,7 @@
 #include "common.h"
 
 #define HG_NC 4                 // label columns carried (n_way + 1 <= 4), float4 per node
+typedef unsigned short hg_col_t; // CSR column ids: n_cap <= 32768 (checked at the entry points), half the bytes of int
 #define HG_ROWS_PER_BLOCK_MIN 4 // CG SpMV: rows per 256-thread block (1 per wave; more when n_cap / 4 > HG_MAX_PART)
 #define HG_MAX_PART 2048        // max CG blocks
 
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(1024) void r3d_scan_kernel(const int* __restrict__ 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void r3d_graph_cols_kernel(const unsigned* __restrict__ sym, int words,
                                                              const int* __restrict__ n_dev, int n_cap,
-                                                             const int* __restrict__ row_ptr, int* __restrict__ col) {
+                                                             const int* __restrict__ row_ptr, hg_col_t* __restrict__ col) {
   const int n = min(*n_dev, n_cap);
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void r3d_graph_cols_kernel(const unsigned* __r
     while (bits) {
       const int b = __ffs((int)bits) - 1;
       bits &= bits - 1;
-      col[wpos++] = wd * 32 + b;
+      col[wpos++] = (hg_col_t)(wd * 32 + b);
     }
   }
 }
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void r3d_graph_cols_kernel(const unsigned* __r
 //     oracle/r3d_oracle.c:orc_pair_dist by rounding only.
 __global__ __launch_bounds__(256) void r3d_graph_weights_kernel(
     const float* __restrict__ nodes, long ldn, int D, const unsigned* __restrict__ outb, int words,
-    const int* __restrict__ n_dev, int n_cap, const int* __restrict__ row_ptr, const int* __restrict__ col,
+    const int* __restrict__ n_dev, int n_cap, const int* __restrict__ row_ptr, const hg_col_t* __restrict__ col,
     float sigma, float* __restrict__ val, float* __restrict__ dinv, float* __restrict__ wdir /* [nnz][2] */) {
   __shared__ __attribute__((aligned(16))) float xs[256];
   __shared__ float wsum[4];
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void r3d_graph_weights_kernel(
 }
 
 // 4. S_ij = (dinv_i * A_ij) * dinv_j   (mpti.py:771-772: two diagonal matmuls)
-__global__ void r3d_graph_normalize_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col,
+__global__ void r3d_graph_normalize_kernel(const int* __restrict__ row_ptr, const hg_col_t* __restrict__ col,
                                            const float* __restrict__ dinv, const int* __restrict__ n_dev,
                                            int n_cap, float* __restrict__ val) {
   const int n = min(*n_dev, n_cap);
@@ -221,26 +222,44 @@ __global__ void r3d_graph_normalize_kernel(const int* __restrict__ row_ptr, cons
 }
 
 // ---------------------------------------------------------------------------
-// 5. conjugate gradients on M = I - alpha S, HG_NC right-hand sides at once.
-//    Two launches per iteration; scalar reductions are done redundantly by every block
-//    from per-block partials written by the previous launch (no grid barrier, no host
-//    sync, deterministic summation order).
+// 5. Two-level conjugate gradients on M = I - alpha S, HG_NC right-hand sides at once.
+//
+//    Spectrum: [1 - alpha, 1 + alpha] = [0.01, 1.99].  The slow modes are known from measurement (dumped systems,
+//    profiles/r02_experiments.md): D^1/2 1 (eigenvalue of S exactly 1), then ONE MODE PER FEATURE CLUSTER once the
+//    encoder has trained (0.9999, 0.9996 at workload S after 150 steps), then smooth modes inside the clusters
+//    (0.98, 0.97, 0.96 ...).  Plain CG needs 48-67 iterations on such a system, 20-25 at initialisation.
+//    Coarse space: W = D^1/2 [indicator of HG_M = 64 aggregates]; aggregate = nearest of 64 SEEDS in feature space,
+//    the seeds being an even subsample of the prototypes (they are FPS-spread cluster means, so they cover the
+//    feature clusters; the graph is the kNN graph of that same space).  span(W) contains D^1/2 1 exactly and the
+//    cluster modes up to their boundary error.  The coarse operator E = W^T M W (64 x 64) is inverted once per
+//    episode in fp64 and shared by the forward and the adjoint solve.
+//    Preconditioner: A-DEF2 (Tang, Nabben, Vuik, Erlangga 2009), z = r + W E^-1 (W^T r - (M W)^T r), start vector
+//    x0 = W E^-1 W^T b.  Unlike plain deflation it does not rely on r staying orthogonal to W, which fp32 does not
+//    keep (measured: deflated CG stagnates / diverges on the trained system once W^T r has drifted to 1e-6 |b|).
+//    Measured on the dumped systems (fp32, tol 1e-6): 20 -> 12 iterations at initialisation, 48 -> 15 (forward) and
+//    49 -> 13 (adjoint) after 150 training steps.
+//    q = M p by recurrence, q_new = M r + (M W) mu + beta q: the SpMV gathers ONE float4 per entry (r), not two.
+//
+//    Three launches per iteration, no grid barrier, no host sync, fixed summation orders:
+//      R (1 workgroup)    reduce the per-workgroup partials, mu = E^-1 (t - t2), rz, beta, convergence
+//      S (1 row per wave) p = r + u mu[agg] + beta p ; q = M r + (M W) mu + beta q ; partial <p,q>
+//      U (128 rows / wg)  alpha = rz / <p,q> ; x += alpha p ; r -= alpha q ; partial rr, W^T r, (M W)^T r
 //    Why not one persistent kernel with a grid barrier: measured on MI355X (tools/probe/grid_barrier.hip) a
 //    device-wide barrier whose workgroups exchange data needs agent-scope release/acquire fences, i.e. an L2
-//    write-back + invalidate per workgroup, and costs 3 us at 32 workgroups, 7 us at 128 and 13 us at 256
-//    (43 us with a fence in every wave); a persistent CG with two such barriers per iteration ran 3x SLOWER
-//    (100 us / iteration) than these two launches (17 us / iteration back to back).
+//    write-back + invalidate per workgroup, and costs 3 us at 32 workgroups, 7 us at 128 and 13 us at 256.
 // ---------------------------------------------------------------------------
 #define HG_MAX_ITER 1022
+#define HG_M 64                 // aggregates = coarse dimensions (one per lane)
+#define HG_UROWS 128            // rows per workgroup of the vector kernels (U, init)
+#define HG_PART (4 + 2 * HG_M * HG_NC)  // floats of one workgroup's partial: rr[4], t[HG_M][4], t2[HG_M][4]
+static_assert(HG_M == 64 && HG_M * HG_NC == 256, "the CG kernels map (aggregate, column) onto 256 threads, aggregate = lane");
 struct CgState {            // device memory
-  float rr_hist[2][HG_NC];  // rr of the last two iterations
-  float bb[HG_NC];          // ||b||^2 (of the deflated right-hand side)
-  float defl[HG_NC];        // <u,b> / (<u,u> (1 - alpha)): multiple of u = D^1/2 1 added back to the solution
-  int done;                 // statistics only: set once every column converged
-  int iters;                // statistics only: iterations actually performed
-  // stop[it] != 0: iteration `it` must not run.  A launch only READS stop[it] and only
-  // WRITES stop[it + 1], so no flag is read and written inside one launch.
-  int stop[HG_MAX_ITER + 2];
+  int done;                 // set by R once every column has converged; S / U / later R launches return at once
+  int iters;                // iterations performed when `done` was set (or so far)
+  float bb[HG_NC];          // ||b||^2
+  float rz[HG_NC];          // <r, z> of the current iteration
+  float beta[HG_NC];
+  float mu[HG_M * HG_NC];   // E^-1 (W^T r - (MW)^T r) of the current iteration; c0 = E^-1 W^T b before the first
 };
 
 static __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -270,154 +289,382 @@ static __device__ __forceinline__ float4 reduce_partials(const float4* part, int
   return block_sum4(a, sm);
 }
 
-// Deflation of the one eigenvector that is known in closed form: S u = u for u = D^1/2 1 (u_i = 1 / dinv_i), so
-// (I - alpha S) u = (1 - alpha) u is the SMALLEST eigenvalue of the system (0.01 at alpha = 0.99) -- the mode CG
-// otherwise spends its first iterations discovering.  The right-hand side is split b = b' + u <u,b>/<u,u>; CG solves
-// for b' (orthogonal to u, and every Krylov vector stays so up to rounding), the other part is u <u,b>/(<u,u>(1-alpha)).
-// Measured at S: 25 -> 20 iterations, same residual.  Exact for disconnected graphs too (u is still an eigenvector).
-__global__ __launch_bounds__(256) void r3d_cg_defl_dots_kernel(const float4* __restrict__ Y, const float* __restrict__ dinv,
-                                                               const int* __restrict__ n_dev, int n_cap,
-                                                               float4* __restrict__ part /* [2][HG_MAX_PART/2] */) {
-  __shared__ float4 sm[4];
+static __device__ __forceinline__ float f4_get(const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+
+// ---- 5a. aggregates: node -> nearest of HG_M seed prototypes (squared L2 in feature space, ties to the lower seed).
+// One wave per node, LANE = SEED: the seeds sit in LDS with an odd row pitch (conflict-free column reads), the node's
+// row is read through LDS as a broadcast.  Not index-deciding for the result (any partition gives a valid coarse
+// space), so the summation order is free.
+#define HG_SEED_PITCH 257
+__global__ __launch_bounds__(256) void r3d_cg_aggregate_kernel(const float* __restrict__ nodes, long ldn, int D,
+                                                               const int* __restrict__ n_dev, const int* __restrict__ n_proto_dev,
+                                                               int n_cap, int rows_per_wave, int* __restrict__ agg) {
+  extern __shared__ float smem[];           // seeds [HG_M][pitch] + 4 node rows [D]
+  const int pitch = D | 1;
+  float* seeds = smem;
+  float* xrow = smem + HG_M * pitch + (threadIdx.x >> 6) * D;
   const int n = min(*n_dev, n_cap);
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  float4 uy = f4_zero(), uu = f4_zero();
-  if (i < n) {
-    const float u = 1.f / dinv[i];
-    const float4 b = Y[i];
-    uy = make_float4(u * b.x, u * b.y, u * b.z, u * b.w);
-    uu.x = u * u;
+  const int n_proto = max(1, min(*n_proto_dev, n));
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int e = threadIdx.x; e < HG_M * D; e += 256) {
+    const int sd = e / D, c = e - sd * D;
+    const int src = (int)(((long)sd * (n_proto - 1)) / (HG_M - 1));
+    seeds[sd * pitch + c] = nodes[(long)src * ldn + c];
   }
-  uy = block_sum4(uy, sm);
-  uu = block_sum4(uu, sm);
-  if (threadIdx.x == 0) { part[blockIdx.x] = uy; part[HG_MAX_PART / 2 + blockIdx.x] = uu; }
+  __syncthreads();
+  const int row0 = (blockIdx.x * 4 + w) * rows_per_wave;
+  for (int k = 0; k < rows_per_wave; ++k) {
+    const int i = row0 + k;
+    if (i >= n) break;  // uniform over the wave
+    for (int c = lane; c < D; c += 64) xrow[c] = nodes[(long)i * ldn + c];
+    // a wave executes in lockstep: its own LDS writes are visible to its own later reads (no workgroup barrier)
+    __builtin_amdgcn_wave_barrier();
+    float d2 = 0.f;
+    const float* sp = seeds + lane * pitch;
+#pragma unroll 8
+    for (int c = 0; c < D; ++c) {
+      const float df = xrow[c] - sp[c];
+      d2 = __builtin_fmaf(df, df, d2);
+    }
+    // arg-min over the lanes on 64-bit keys (distance bits are order preserving for non-negative floats)
+    unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long other = __shfl_xor(key, o);
+      key = other < key ? other : key;
+    }
+    if (lane == 0) agg[i] = (int)(key & 63u);
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
-__global__ __launch_bounds__(256) void r3d_cg_init_kernel(const float4* __restrict__ Y, const float* __restrict__ dinv,
-                                                          const int* __restrict__ n_dev, int n_cap, float alpha_lp,
-                                                          const float4* __restrict__ part_defl, int nblk,
-                                                          float4* __restrict__ x, float4* __restrict__ r,
-                                                          float4* __restrict__ p, float4* __restrict__ part_rr,
-                                                          CgState* __restrict__ st) {
-  __shared__ float4 sm[4];
-  const int n = min(*n_dev, n_cap);
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  // <u,b> and <u,u>: every block reduces the same partials in the same order
-  const float4 uy = reduce_partials(part_defl, nblk, sm);
-  const float4 uu4 = reduce_partials(part_defl + HG_MAX_PART / 2, nblk, sm);
-  const float inv_uu = uu4.x > 0.f ? 1.f / uu4.x : 0.f;
-  const float4 c = make_float4(uy.x * inv_uu, uy.y * inv_uu, uy.z * inv_uu, uy.w * inv_uu);
-  float4 b = f4_zero();
-  if (i < n) {
-    const float u = 1.f / dinv[i];
-    const float4 y = Y[i];
-    b = make_float4(y.x - u * c.x, y.y - u * c.y, y.z - u * c.z, y.w - u * c.w);
-  }
-  if (i < n_cap) { x[i] = f4_zero(); r[i] = b; p[i] = f4_zero(); }
-  float4 sq = make_float4(b.x * b.x, b.y * b.y, b.z * b.z, b.w * b.w);
-  sq = block_sum4(sq, sm);
-  if (threadIdx.x == 0) part_rr[blockIdx.x] = sq;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    st->done = 0;
-    st->iters = 0;
-    const float k = 1.f / (1.f - alpha_lp);
-    st->defl[0] = c.x * k; st->defl[1] = c.y * k; st->defl[2] = c.z * k; st->defl[3] = c.w * k;
-  }
-  if (blockIdx.x == 0)
-    for (int q = threadIdx.x; q < HG_MAX_ITER + 2; q += 256) st->stop[q] = 0;
-}
-
-// x += u * defl: the closed-form component along the deflated eigenvector
-__global__ void r3d_cg_defl_add_kernel(float4* __restrict__ x, const float* __restrict__ dinv, const int* __restrict__ n_dev,
-                                       int n_cap, const CgState* __restrict__ st) {
-  const int n = min(*n_dev, n_cap);
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float u = 1.f / dinv[i];
-  float4 v = x[i];
-  v.x += u * st->defl[0]; v.y += u * st->defl[1]; v.z += u * st->defl[2]; v.w += u * st->defl[3];
-  x[i] = v;
-}
-
-// A: p_new = r + beta p_old ; q = (I - alpha S) p_new ; partial <p_new, q>
-// 5 waves per SIMD: the 4396 one-row waves of workload S must all be resident at once (108 registers -> 4 per SIMD ->
-// two rounds of waves)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void r3d_cg_spmv_kernel(
-    const int* __restrict__ row_ptr, const int* __restrict__ col, const float* __restrict__ val,
-    const int* __restrict__ n_dev, int n_cap, float alpha_lp, int it, int nblk_rr, float tol2, int rows_per_block,
-    const float4* __restrict__ r, const float4* __restrict__ p_old, float4* __restrict__ p_new,
-    float4* __restrict__ q, const float4* __restrict__ part_rr, float4* __restrict__ part_pq,
-    CgState* __restrict__ st) {
-  __shared__ float4 sm[4];
-  __shared__ float4 wsum[4];
-  if (st->stop[it]) return;
+// ---- 5b. MW = W - alpha S W, row by row.  (S W)[i][a] = sum over the row's entries of S_ij u_j [agg_j == a]: the
+// wave writes (agg_j, S_ij u_j) pairs of a chunk of entries to LDS, then lane a walks the chunk and adds the pairs of
+// its aggregate in entry order (deterministic; all lanes read the same LDS word = a broadcast).
+__global__ __launch_bounds__(256) void r3d_cg_mw_kernel(const int* __restrict__ row_ptr, const hg_col_t* __restrict__ col,
+                                                        const float* __restrict__ val, const float* __restrict__ dinv,
+                                                        const int* __restrict__ agg, const int* __restrict__ n_dev, int n_cap,
+                                                        float alpha_lp, int rows_per_wave, float* __restrict__ MW) {
+  __shared__ float2 pairs[4][256];
   const int n = min(*n_dev, n_cap);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const float4 rr = reduce_partials(part_rr, nblk_rr, sm);
-  float4 beta = f4_zero();
-  if (it == 0) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { st->bb[0] = rr.x; st->bb[1] = rr.y; st->bb[2] = rr.z; st->bb[3] = rr.w; }
-  } else {
-    const float* ro = st->rr_hist[(it - 1) & 1];
-    beta.x = ro[0] > 0.f ? rr.x / ro[0] : 0.f;
-    beta.y = ro[1] > 0.f ? rr.y / ro[1] : 0.f;
-    beta.z = ro[2] > 0.f ? rr.z / ro[2] : 0.f;
-    beta.w = ro[3] > 0.f ? rr.w / ro[3] : 0.f;
+  const int row0 = (blockIdx.x * 4 + w) * rows_per_wave;
+  for (int k = 0; k < rows_per_wave; ++k) {
+    const int i = row0 + k;
+    if (i >= n_cap) break;
+    float acc = 0.f;
+    if (i < n) {
+      const int rb = row_ptr[i], re = row_ptr[i + 1];
+      for (int e0 = rb; e0 < re; e0 += 256) {
+        const int cnt = min(256, re - e0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = lane + 64 * u;
+          if (t < cnt) {
+            const int j = col[e0 + t];
+            pairs[w][t] = make_float2(__int_as_float(agg[j]), val[e0 + t] / dinv[j]);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int t = 0; t < cnt; ++t) {
+          const float2 pr = pairs[w][t];
+          acc += __float_as_int(pr.x) == lane ? pr.y : 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      acc = (agg[i] == lane ? 1.f / dinv[i] : 0.f) - alpha_lp * acc;
+    }
+    MW[(long)i * HG_M + lane] = acc;  // rows >= n are zero
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    float* rn = st->rr_hist[it & 1];
-    rn[0] = rr.x; rn[1] = rr.y; rn[2] = rr.z; rn[3] = rr.w;
+}
+
+// ---- 5c. E = W^T (M W): per workgroup of HG_UROWS rows a partial HG_M x HG_M matrix (lane = column b, one LDS
+// accumulator matrix per wave, row = aggregate of the node), then the single workgroup below adds the partials in
+// fixed order, symmetrises, and inverts in fp64 (Gauss-Jordan without pivoting: E is SPD; an EMPTY aggregate --
+// duplicate seeds, or fewer prototypes than seeds -- has a zero row and column and gets a unit diagonal, its
+// coefficient is then always zero).
+__global__ __launch_bounds__(128) void r3d_cg_epart_kernel(const float* __restrict__ MW, const float* __restrict__ dinv,
+                                                           const int* __restrict__ agg, const int* __restrict__ n_dev, int n_cap,
+                                                           float* __restrict__ Epart /* [blocks][HG_M][HG_M] */) {
+  __shared__ float Ew[2][HG_M][HG_M];  // 32 KB, two waves
+  const int n = min(*n_dev, n_cap);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int a = 0; a < HG_M; ++a) Ew[w][a][lane] = 0.f;
+  const int row0 = blockIdx.x * HG_UROWS;
+  for (int k = w; k < HG_UROWS; k += 2) {
+    const int i = row0 + k;
+    if (i >= n) break;
+    const int a = agg[i];
+    Ew[w][a][lane] += MW[(long)i * HG_M + lane] / dinv[i];
   }
+  __syncthreads();
+  float* out = Epart + (long)blockIdx.x * HG_M * HG_M;
+  for (int e = threadIdx.x; e < HG_M * HG_M; e += 128) {
+    const int a = e >> 6, b = e & 63;
+    out[e] = Ew[0][a][b] + Ew[1][a][b];
+  }
+}
+
+__global__ __launch_bounds__(1024) void r3d_cg_einv_kernel(const float* __restrict__ Epart, int nblk, double* __restrict__ Einv) {
+  __shared__ double A[HG_M][HG_M + 1];
+  __shared__ double B[HG_M][HG_M + 1];
+  __shared__ double colk[HG_M];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < HG_M * HG_M; e += 1024) {
+    double s = 0.0;
+    for (int q = 0; q < nblk; ++q) s += (double)Epart[(long)q * HG_M * HG_M + e];
+    A[e >> 6][e & 63] = s;
+  }
+  __syncthreads();
+  for (int e = tid; e < HG_M * HG_M; e += 1024) {
+    const int a = e >> 6, b = e & 63;
+    double v = 0.5 * (A[a][b] + A[b][a]);
+    B[a][b] = v;
+  }
+  __syncthreads();
+  for (int e = tid; e < HG_M * HG_M; e += 1024) {
+    const int a = e >> 6, b = e & 63;
+    double v = B[a][b];
+    if (a == b && !(v > 0.0)) v = 1.0;  // empty aggregate
+    A[a][b] = v;
+    B[a][b] = a == b ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  // Gauss-Jordan on [A | B]: thread (row = tid >> 4, 4-column group = tid & 15) x 2 matrices
+  const int row = tid >> 4, cg = (tid & 15) * 4;
+  for (int k = 0; k < HG_M; ++k) {
+    if (tid < HG_M) colk[tid] = A[tid][k];
+    __syncthreads();
+    const double piv = 1.0 / colk[k];
+    const double f = row == k ? 0.0 : colk[row] * piv;
+    double ak[4], bk[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { ak[c] = A[k][cg + c]; bk[c] = B[k][cg + c]; }
+    __syncthreads();
+    if (row == k) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { A[k][cg + c] = ak[c] * piv; B[k][cg + c] = bk[c] * piv; }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { A[row][cg + c] -= f * ak[c]; B[row][cg + c] -= f * bk[c]; }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < HG_M * HG_M; e += 1024) {
+    const int a = e >> 6, b = e & 63;
+    Einv[e] = 0.5 * (B[a][b] + B[b][a]);
+  }
+}
+
+// ---- 5d. per-workgroup partials of a residual block: rr, t = W^T r, t2 = (M W)^T r.
+// rs / us / ag: this workgroup's HG_UROWS rows of r, u = D^1/2, aggregate (LDS).  Thread (a = tid & 63, c = tid >> 6)
+// owns t[a][c] and t2[a][c] and walks the rows in order (deterministic); M W rows are read as coalesced 256-B lines.
+static __device__ __forceinline__ void cg_block_partials(const float4* rs, const float* us, const int* ag, int row0, int n,
+                                                         const float* __restrict__ MW, bool with_t2, float* __restrict__ part,
+                                                         float4* sm) {
+  const int a = threadIdx.x & 63, c = threadIdx.x >> 6;
+  float t = 0.f, t2 = 0.f;
+  const float* rsf = reinterpret_cast<const float*>(rs);
+  const int rows = min(HG_UROWS, n - row0);
+  const float* mw = MW + (long)row0 * HG_M + a;
+  int k = 0;
+  for (; k + 8 <= rows; k += 8) {
+    float m[8];
+    if (with_t2) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) m[u] = mw[(long)(k + u) * HG_M];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float rv = rsf[4 * (k + u) + c];
+      t += ag[k + u] == a ? us[k + u] * rv : 0.f;
+      if (with_t2) t2 = __builtin_fmaf(m[u], rv, t2);
+    }
+  }
+  for (; k < rows; ++k) {
+    const float rv = rsf[4 * k + c];
+    t += ag[k] == a ? us[k] * rv : 0.f;
+    if (with_t2) t2 = __builtin_fmaf(mw[(long)k * HG_M], rv, t2);
+  }
+  float4 sq = f4_zero();
+  if ((int)threadIdx.x < rows) {
+    const float4 v = rs[threadIdx.x];
+    sq = make_float4(v.x * v.x, v.y * v.y, v.z * v.z, v.w * v.w);
+  }
+  sq = block_sum4(sq, sm);
+  if (threadIdx.x == 0) *reinterpret_cast<float4*>(part) = sq;
+  part[4 + a * HG_NC + c] = t;
+  part[4 + HG_M * HG_NC + a * HG_NC + c] = t2;
+}
+
+// mode 0: partials of b itself (rr = ||b||^2, t = W^T b).  mode 1: x0 = W c0, r0 = b - (M W) c0, p = q = 0, partials
+// of r0.  c0 = cg->mu.
+__global__ __launch_bounds__(256) void r3d_cg_init_kernel(const float4* __restrict__ B, const float* __restrict__ dinv,
+                                                          const int* __restrict__ agg, const float* __restrict__ MW,
+                                                          const int* __restrict__ n_dev, int n_cap, int mode,
+                                                          float4* __restrict__ x, float4* __restrict__ r,
+                                                          float4* __restrict__ p, float4* __restrict__ q,
+                                                          float* __restrict__ part, const CgState* __restrict__ cg) {
+  __shared__ float4 sm[4];
+  __shared__ float4 rs[HG_UROWS];
+  __shared__ float us[HG_UROWS];
+  __shared__ int ag[HG_UROWS];
+  __shared__ float mu_s[HG_M * HG_NC];
+  const int n = min(*n_dev, n_cap);
+  const int row0 = blockIdx.x * HG_UROWS;
+  if (mode == 1) mu_s[threadIdx.x] = cg->mu[threadIdx.x];
+  __syncthreads();
+  if ((int)threadIdx.x < HG_UROWS) {
+    const int i = row0 + threadIdx.x;
+    float4 rv = f4_zero();
+    float u = 0.f;
+    int a = 0;
+    if (i < n) {
+      u = 1.f / dinv[i];
+      a = agg[i];
+      rv = B[i];
+      if (mode == 1) {
+        const float* mw = MW + (long)i * HG_M;
+        float4 s = f4_zero();
+        for (int b = 0; b < HG_M; ++b) {
+          const float m = mw[b];
+          s.x = __builtin_fmaf(m, mu_s[b * HG_NC + 0], s.x); s.y = __builtin_fmaf(m, mu_s[b * HG_NC + 1], s.y);
+          s.z = __builtin_fmaf(m, mu_s[b * HG_NC + 2], s.z); s.w = __builtin_fmaf(m, mu_s[b * HG_NC + 3], s.w);
+        }
+        rv = make_float4(rv.x - s.x, rv.y - s.y, rv.z - s.z, rv.w - s.w);
+        x[i] = make_float4(u * mu_s[a * HG_NC + 0], u * mu_s[a * HG_NC + 1], u * mu_s[a * HG_NC + 2], u * mu_s[a * HG_NC + 3]);
+        r[i] = rv;
+      }
+    }
+    if (mode == 1 && i < n_cap) {
+      p[i] = f4_zero(); q[i] = f4_zero();
+      if (i >= n) { x[i] = f4_zero(); r[i] = f4_zero(); }
+    }
+    rs[threadIdx.x] = rv; us[threadIdx.x] = u; ag[threadIdx.x] = a;
+  }
+  __syncthreads();
+  cg_block_partials(rs, us, ag, row0, n, MW, mode == 1, part + (long)blockIdx.x * HG_PART, sm);
+}
+
+// R: the single-workgroup step between U and S.  phase 0: c0 = E^-1 W^T b, bb (before the init kernel);
+// phase 1: mu, rz, beta, convergence test of iteration `it` (it == max_iter: test only).
+__global__ __launch_bounds__(256) void r3d_cg_reduce_kernel(const float* __restrict__ part, int nblk, const double* __restrict__ Einv,
+                                                            int phase, int it, float tol2, CgState* __restrict__ cg) {
+  __shared__ double d_s[HG_M * HG_NC];
+  __shared__ float t_s[HG_M * HG_NC];
+  __shared__ float rr_s[HG_NC];
+  __shared__ float rz_s[HG_NC];
+  if (phase == 1 && cg->done) return;
+  const int a = threadIdx.x & 63, c = threadIdx.x >> 6;
+  float t = 0.f, t2 = 0.f;
+  for (int b = 0; b < nblk; ++b) {
+    t += part[(long)b * HG_PART + 4 + a * HG_NC + c];
+    t2 += part[(long)b * HG_PART + 4 + HG_M * HG_NC + a * HG_NC + c];
+  }
+  if (threadIdx.x < HG_NC) {
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(long)b * HG_PART + threadIdx.x];
+    rr_s[threadIdx.x] = s;
+  }
+  d_s[a * HG_NC + c] = phase == 0 ? (double)t : (double)t - (double)t2;
+  t_s[a * HG_NC + c] = t;
+  __syncthreads();
+  if (phase == 1) {
+    const float* bb = cg->bb;
+    const bool conv = rr_s[0] <= tol2 * bb[0] && rr_s[1] <= tol2 * bb[1] && rr_s[2] <= tol2 * bb[2] && rr_s[3] <= tol2 * bb[3];
+    if (conv) {  // uniform over the workgroup
+      if (threadIdx.x == 0) { cg->done = 1; cg->iters = it; }
+      return;
+    }
+  }
+  double m = 0.0;
+  for (int b = 0; b < HG_M; ++b) m += Einv[b * HG_M + a] * d_s[b * HG_NC + c];  // E^-1 is symmetric: coalesced over a
+  const float mu = (float)m;
+  float tm = t_s[a * HG_NC + c] * mu;
+  tm = r3d_wave_sum(tm);  // one wave = one column c
+  cg->mu[a * HG_NC + c] = mu;
+  if (a == 0) {
+    if (phase == 0) {
+      cg->bb[c] = rr_s[c];
+    } else {
+      const float rz = rr_s[c] + tm;
+      const float rz_old = cg->rz[c];
+      cg->beta[c] = (it > 0 && rz_old > 0.f) ? rz / rz_old : 0.f;
+      cg->rz[c] = rz;
+    }
+  }
+  if (threadIdx.x == 0) {
+    if (phase == 0) { cg->done = 0; cg->iters = 0; }
+    else cg->iters = it;
+  }
+}
+
+// S: p = r + u mu[agg] + beta p ; q = (r - alpha S r) + (M W) mu + beta q ; partial <p, q>.
+// One matrix row per wave taken in ONE trip of the chain column index -> gather (6 entries per lane in flight).
+__global__ __launch_bounds__(256) void r3d_cg_spmv_kernel(
+    const int* __restrict__ row_ptr, const hg_col_t* __restrict__ col, const float* __restrict__ val,
+    const float* __restrict__ dinv, const int* __restrict__ agg, const float* __restrict__ MW,
+    const int* __restrict__ n_dev, int n_cap, float alpha_lp, int it, int rows_per_block,
+    const float4* __restrict__ r, float4* __restrict__ p, float4* __restrict__ q,
+    float4* __restrict__ part_pq, const CgState* __restrict__ cg) {
+  __shared__ float4 mu_s[HG_M];
+  __shared__ float4 wsum[4];
+  if (cg->done) return;
+  const int n = min(*n_dev, n_cap);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x < HG_M) mu_s[threadIdx.x] = reinterpret_cast<const float4*>(cg->mu)[threadIdx.x];
+  const float4 beta = *reinterpret_cast<const float4*>(cg->beta);
+  __syncthreads();
+  const float4 mul = mu_s[lane];
   float4 acc_pq = f4_zero();
-  // few rows per wave: the SpMV is a chain of dependent loads per row (col -> gather), so its time is
-  // rows-per-wave x that latency: 1 row per wave at n = 4.4k (was 8) took the CG iteration from 21 to 16 us
   const int row0 = blockIdx.x * rows_per_block + w * (rows_per_block / 4);
   for (int rr_i = 0; rr_i < rows_per_block / 4; ++rr_i) {
     const int i = row0 + rr_i;
     if (i >= n) break;
     float4 s = f4_zero();
-    {
-      const int rb = row_ptr[i], re = row_ptr[i + 1];
-      // 6 entries per lane in flight: a row of the symmetrised 200-NN graph (~270 entries at S) is ONE trip of the
-      // dependent chain column index -> gather (with 4 per lane the last 14 entries cost a second full round trip)
-      for (int e0 = rb + lane; e0 < re; e0 += 384) {
-        int jv[6];
-        float av[6];
+    const int rb = row_ptr[i], re = row_ptr[i + 1];
+    const float mw = MW[(long)i * HG_M + lane];
+    for (int e0 = rb + lane; e0 < re; e0 += 384) {
+      int jv[6];
+      float av[6];
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-          const int e = e0 + 64 * u;
-          const int ec = min(e, re - 1);
-          jv[u] = col[ec];
-          av[u] = r3d_keep(val[ec], e < re);
-        }
-        float4 rj[6], pj[6];
+      for (int u = 0; u < 6; ++u) {
+        const int e = e0 + 64 * u;
+        const int ec = min(e, re - 1);
+        jv[u] = col[ec];
+        av[u] = r3d_keep(val[ec], e < re);
+      }
+      float4 rj[6];
 #pragma unroll
-        for (int u = 0; u < 6; ++u) { rj[u] = r[jv[u]]; pj[u] = p_old[jv[u]]; }
+      for (int u = 0; u < 6; ++u) rj[u] = r[jv[u]];
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-          s.x += av[u] * (rj[u].x + beta.x * pj[u].x);
-          s.y += av[u] * (rj[u].y + beta.y * pj[u].y);
-          s.z += av[u] * (rj[u].z + beta.z * pj[u].z);
-          s.w += av[u] * (rj[u].w + beta.w * pj[u].w);
-        }
+      for (int u = 0; u < 6; ++u) {
+        s.x = __builtin_fmaf(av[u], rj[u].x, s.x); s.y = __builtin_fmaf(av[u], rj[u].y, s.y);
+        s.z = __builtin_fmaf(av[u], rj[u].z, s.z); s.w = __builtin_fmaf(av[u], rj[u].w, s.w);
       }
     }
+    // (M W) mu rides the same butterfly: per lane -alpha s + MW[i][lane] mu[lane]
+    s.x = __builtin_fmaf(mw, mul.x, -alpha_lp * s.x); s.y = __builtin_fmaf(mw, mul.y, -alpha_lp * s.y);
+    s.z = __builtin_fmaf(mw, mul.z, -alpha_lp * s.z); s.w = __builtin_fmaf(mw, mul.w, -alpha_lp * s.w);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       s.x += __shfl_xor(s.x, o); s.y += __shfl_xor(s.y, o);
       s.z += __shfl_xor(s.z, o); s.w += __shfl_xor(s.w, o);
     }
     if (lane == 0) {
-      const float4 ri = r[i], pi = p_old[i];
-      float4 pn = make_float4(ri.x + beta.x * pi.x, ri.y + beta.y * pi.y, ri.z + beta.z * pi.z, ri.w + beta.w * pi.w);
-      float4 qi = make_float4(pn.x - alpha_lp * s.x, pn.y - alpha_lp * s.y, pn.z - alpha_lp * s.z, pn.w - alpha_lp * s.w);
-      p_new[i] = pn;
-      q[i] = qi;
-      acc_pq.x += pn.x * qi.x; acc_pq.y += pn.y * qi.y; acc_pq.z += pn.z * qi.z; acc_pq.w += pn.w * qi.w;
+      const float4 ri = r[i], pi = p[i], qi = q[i];
+      const float u = 1.f / dinv[i];
+      const float4 m = mu_s[agg[i]];
+      const float4 pn = make_float4((ri.x + u * m.x) + beta.x * pi.x, (ri.y + u * m.y) + beta.y * pi.y,
+                                    (ri.z + u * m.z) + beta.z * pi.z, (ri.w + u * m.w) + beta.w * pi.w);
+      const float4 qn = make_float4((ri.x + s.x) + beta.x * qi.x, (ri.y + s.y) + beta.y * qi.y,
+                                    (ri.z + s.z) + beta.z * qi.z, (ri.w + s.w) + beta.w * qi.w);
+      p[i] = pn;
+      q[i] = qn;
+      acc_pq.x += pn.x * qn.x; acc_pq.y += pn.y * qn.y; acc_pq.z += pn.z * qn.z; acc_pq.w += pn.w * qn.w;
     }
   }
   // fixed-order combine of the four waves' lane-0 partials
-  __syncthreads();
   if (lane == 0) wsum[w] = acc_pq;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -427,46 +674,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void r
   }
 }
 
-// B: alpha = rr / <p,q> ; x += alpha p ; r -= alpha q ; partial rr ; convergence flag
+// U: alpha = rz / <p,q> ; x += alpha p ; r -= alpha q ; partials of the new residual
 __global__ __launch_bounds__(256) void r3d_cg_update_kernel(
-    const int* __restrict__ n_dev, int n_cap, int it, int nblk_pq, float tol2, const float4* __restrict__ p,
-    const float4* __restrict__ q, float4* __restrict__ x, float4* __restrict__ r,
-    const float4* __restrict__ part_pq, float4* __restrict__ part_rr, CgState* __restrict__ st) {
+    const int* __restrict__ n_dev, int n_cap, int it, int nblk_pq, const float* __restrict__ dinv, const int* __restrict__ agg,
+    const float* __restrict__ MW, const float4* __restrict__ p, const float4* __restrict__ q, float4* __restrict__ x,
+    float4* __restrict__ r, const float4* __restrict__ part_pq, float* __restrict__ part, const CgState* __restrict__ cg) {
   __shared__ float4 sm[4];
-  if (st->stop[it]) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->stop[it + 1] = 1;
-    return;
-  }
+  __shared__ float4 rs[HG_UROWS];
+  __shared__ float us[HG_UROWS];
+  __shared__ int ag[HG_UROWS];
+  if (cg->done) return;
   const int n = min(*n_dev, n_cap);
   const float4 pq = reduce_partials(part_pq, nblk_pq, sm);
-  const float* rn = st->rr_hist[it & 1];
-  const float* bb = st->bb;
-  // converged already before this step? (all columns)  -> freeze the solution
-  const bool conv = rn[0] <= tol2 * bb[0] && rn[1] <= tol2 * bb[1] && rn[2] <= tol2 * bb[2] && rn[3] <= tol2 * bb[3];
-  if (conv) {
-    // every block takes this branch together (same inputs, same arithmetic); the flag is
-    // only read by LATER launches
-    if (blockIdx.x == 0 && threadIdx.x == 0) { st->done = 1; st->stop[it + 1] = 1; }
-    return;
-  }
+  const float* rz = cg->rz;
   float4 al;
-  al.x = pq.x > 0.f ? rn[0] / pq.x : 0.f;
-  al.y = pq.y > 0.f ? rn[1] / pq.y : 0.f;
-  al.z = pq.z > 0.f ? rn[2] / pq.z : 0.f;
-  al.w = pq.w > 0.f ? rn[3] / pq.w : 0.f;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  float4 sq = f4_zero();
-  if (i < n) {
-    const float4 pi = p[i], qi = q[i];
-    float4 xi = x[i], ri = r[i];
-    xi.x += al.x * pi.x; xi.y += al.y * pi.y; xi.z += al.z * pi.z; xi.w += al.w * pi.w;
-    ri.x -= al.x * qi.x; ri.y -= al.y * qi.y; ri.z -= al.z * qi.z; ri.w -= al.w * qi.w;
-    x[i] = xi; r[i] = ri;
-    sq = make_float4(ri.x * ri.x, ri.y * ri.y, ri.z * ri.z, ri.w * ri.w);
+  al.x = pq.x > 0.f ? rz[0] / pq.x : 0.f;
+  al.y = pq.y > 0.f ? rz[1] / pq.y : 0.f;
+  al.z = pq.z > 0.f ? rz[2] / pq.z : 0.f;
+  al.w = pq.w > 0.f ? rz[3] / pq.w : 0.f;
+  const int row0 = blockIdx.x * HG_UROWS;
+  if ((int)threadIdx.x < HG_UROWS) {
+    const int i = row0 + threadIdx.x;
+    float4 ri = f4_zero();
+    float u = 0.f;
+    int a = 0;
+    if (i < n) {
+      const float4 pi = p[i], qi = q[i];
+      float4 xi = x[i];
+      ri = r[i];
+      xi.x += al.x * pi.x; xi.y += al.y * pi.y; xi.z += al.z * pi.z; xi.w += al.w * pi.w;
+      ri.x -= al.x * qi.x; ri.y -= al.y * qi.y; ri.z -= al.z * qi.z; ri.w -= al.w * qi.w;
+      x[i] = xi; r[i] = ri;
+      u = 1.f / dinv[i];
+      a = agg[i];
+    }
+    rs[threadIdx.x] = ri; us[threadIdx.x] = u; ag[threadIdx.x] = a;
   }
-  sq = block_sum4(sq, sm);
-  if (threadIdx.x == 0) part_rr[blockIdx.x] = sq;
-  if (blockIdx.x == 0 && threadIdx.x == 0) st->iters = it + 1;
+  __syncthreads();
+  cg_block_partials(rs, us, ag, row0, n, MW, true, part + (long)blockIdx.x * HG_PART, sm);
 }
 
 // ---------------------------------------------------------------------------
@@ -511,91 +756,117 @@ __global__ __launch_bounds__(1024) void r3d_logits_ce_kernel(const float4* __res
 // ===========================================================================
 // C ABI
 // ===========================================================================
-// scratch words for r3d_label_propagate: bitmaps, CSR, CG vectors
-extern "C" long r3d_lp_ws_words(int n_cap, int kp1) {
-  const long words = (n_cap + 31) / 32;
-  const long nnz_cap = 2L * n_cap * (kp1 - 1);
-  long t = 0;
-  t += 2 * n_cap * words;          // outb, sym
-  t += n_cap + 8;                  // row_len
-  t += n_cap + 8;                  // row_ptr
-  t += nnz_cap * 2;                // col, val
-  t += nnz_cap * 2;                // wdir: directed gaussian weights (w_ij, w_ji) per entry, kept for the backward
-  t += n_cap;                      // dinv
-  t += 5L * n_cap * HG_NC;         // x(out is separate) r, p0, p1, q  (+1 spare)
-  t += 2L * HG_MAX_PART * HG_NC;   // partials
-  t += sizeof(CgState) / 4 + 8;    // CgState
-  return t + 64;
-}
-
-// nodes (n_cap, ldn), nbr (n_cap, kp1) from r3d_knn_topk (mode L2), Y (n_cap, 4) one-hot
-// rows for prototypes / zeros for queries.  Z (n_cap, 4) out.  n_dev: device int = n.
-// stats_out (optional, device, 2 ints): {converged flag, iterations}.
+// scratch words for r3d_label_propagate: bitmaps, CSR, coarse space, CG vectors
 struct LpWs {
   unsigned *outb, *sym;
-  int *row_len, *row_ptr, *col;
-  float *val, *dinv, *wdir;
-  float4 *r, *p0, *p1, *q, *part_rr, *part_pq;
+  int *row_len, *row_ptr, *agg;
+  hg_col_t* col;
+  float *val, *dinv, *wdir, *MW, *Epart, *part;
+  double* Einv;
+  float4 *r, *p, *q, *part_pq;
   CgState* cg;
-  long words;
+  long words, total;
 };
+
+static inline long hg_vblocks(int n_cap) { return r3d_cdiv(n_cap, HG_UROWS); }
 
 static LpWs lp_carve(int32_t* ws, int n_cap, int kp1) {
   LpWs L;
   L.words = (n_cap + 31) / 32;
   const long nnz_cap = 2L * n_cap * (kp1 - 1);
   int32_t* wp = ws;
+  auto align4 = [&]() { wp += (4 - ((wp - ws) & 3)) & 3; };  // 16-byte alignment (ws itself must be 16-B aligned)
   L.outb = (unsigned*)wp; wp += n_cap * L.words;
   L.sym = (unsigned*)wp; wp += n_cap * L.words;
   L.row_len = wp; wp += n_cap + 8;
   L.row_ptr = wp; wp += n_cap + 8;
-  L.col = wp; wp += nnz_cap;
+  L.col = (hg_col_t*)wp; wp += (nnz_cap + 1) / 2;
   L.val = (float*)wp; wp += nnz_cap;
   L.wdir = (float*)wp; wp += 2 * nnz_cap;
   L.dinv = (float*)wp; wp += n_cap;
-  wp += (4 - ((wp - ws) & 3)) & 3;  // float4 alignment (ws itself must be 16-B aligned)
+  L.agg = wp; wp += n_cap;
+  align4();
+  L.MW = (float*)wp; wp += (long)n_cap * HG_M;
+  L.Epart = (float*)wp; wp += hg_vblocks(n_cap) * HG_M * HG_M;
+  align4();
+  L.Einv = (double*)wp; wp += 2L * HG_M * HG_M;
+  L.part = (float*)wp; wp += hg_vblocks(n_cap) * HG_PART;
+  align4();
   L.r = (float4*)wp; wp += 4L * n_cap;
-  L.p0 = (float4*)wp; wp += 4L * n_cap;
-  L.p1 = (float4*)wp; wp += 4L * n_cap;
+  L.p = (float4*)wp; wp += 4L * n_cap;
   L.q = (float4*)wp; wp += 4L * n_cap;
-  L.part_rr = (float4*)wp; wp += 4L * HG_MAX_PART;
   L.part_pq = (float4*)wp; wp += 4L * HG_MAX_PART;
-  L.cg = (CgState*)wp;
+  L.cg = (CgState*)wp; wp += (sizeof(CgState) + 3) / 4;
+  L.total = (wp - ws) + 64;
   return L;
 }
 
-// CG on the already built graph: X = (I - alpha S)^-1 RHS
+extern "C" long r3d_lp_ws_words(int n_cap, int kp1) { return lp_carve(nullptr, n_cap, kp1).total; }
+
+// word offsets (int32 units from ws) of what tests / tools read back: row_ptr, col (uint16 entries!), val, dinv, agg, CgState
+extern "C" int r3d_lp_ws_offsets(int n_cap, int kp1, long* out6) {
+  R3D_REQUIRE(out6 && n_cap > 0 && kp1 >= 2, "r3d_lp_ws_offsets: bad arguments");
+  const LpWs L = lp_carve(nullptr, n_cap, kp1);
+  const int32_t* base = nullptr;
+  out6[0] = (const int32_t*)L.row_ptr - base; out6[1] = (const int32_t*)L.col - base; out6[2] = (const int32_t*)L.val - base;
+  out6[3] = (const int32_t*)L.dinv - base; out6[4] = (const int32_t*)L.agg - base; out6[5] = (const int32_t*)L.cg - base;
+  return R3D_OK;
+}
+
+// coarse space of the graph r3d_label_propagate built: aggregates, M W, E^-1 (shared by forward and adjoint solve)
+static int lp_coarse_space(const LpWs& L, const float* nodes, long ldn, int D, const int32_t* n_dev, const int32_t* n_proto_dev,
+                           int n_cap, float alpha, hipStream_t st) {
+  const int agg_rpw = 4;  // 16 nodes per workgroup: the 64 seed rows are staged once per workgroup
+  const size_t agg_lds = ((size_t)HG_M * (D | 1) + 4 * D) * sizeof(float);
+  static bool lds_opt_in = false;
+  if (!lds_opt_in) {  // 69 KB of dynamic LDS at D = 256 (64 KB is the default ceiling)
+    hipFuncSetAttribute((const void*)r3d_cg_aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    lds_opt_in = true;
+  }
+  hipLaunchKernelGGL(r3d_cg_aggregate_kernel, dim3(r3d_cdiv(n_cap, 4 * agg_rpw)), dim3(256), agg_lds, st, nodes, ldn, D, n_dev,
+                     n_proto_dev, n_cap, agg_rpw, L.agg);
+  hipLaunchKernelGGL(r3d_cg_mw_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, L.row_ptr, L.col, L.val, L.dinv, L.agg, n_dev,
+                     n_cap, alpha, 1, L.MW);
+  const int nblk_v = (int)hg_vblocks(n_cap);
+  hipLaunchKernelGGL(r3d_cg_epart_kernel, dim3(nblk_v), dim3(128), 0, st, L.MW, L.dinv, L.agg, n_dev, n_cap, L.Epart);
+  hipLaunchKernelGGL(r3d_cg_einv_kernel, dim3(1), dim3(1024), 0, st, L.Epart, nblk_v, L.Einv);
+  return R3D_OK;
+}
+
+// two-level CG on the already built graph and coarse space: X = (I - alpha S)^-1 RHS
 static int lp_solve(const LpWs& L, const float* RHS, const int32_t* n_dev, int n_cap, float alpha, int max_iter, float tol,
                     float* X, int32_t* stats_out, hipStream_t st) {
-  const int nblk_v = r3d_cdiv(n_cap, 256);
+  const int nblk_v = (int)hg_vblocks(n_cap);
   int rpb = HG_ROWS_PER_BLOCK_MIN;
   while (r3d_cdiv(n_cap, rpb) > HG_MAX_PART) rpb += 4;
   const int nblk_s = r3d_cdiv(n_cap, rpb);
   R3D_REQUIRE(nblk_s <= HG_MAX_PART, "r3d_label_propagate: n_cap too large");
   float4* x = (float4*)X;
-  R3D_REQUIRE(nblk_v <= HG_MAX_PART / 2, "r3d_label_propagate: n_cap too large");
-  hipLaunchKernelGGL(r3d_cg_defl_dots_kernel, dim3(nblk_v), dim3(256), 0, st, (const float4*)RHS, L.dinv, n_dev, n_cap, L.part_pq);
-  hipLaunchKernelGGL(r3d_cg_init_kernel, dim3(nblk_v), dim3(256), 0, st, (const float4*)RHS, L.dinv, n_dev, n_cap, alpha,
-                     L.part_pq, nblk_v, x, L.r, L.p0, L.part_rr, L.cg);
   const float tol2 = tol * tol;
-  for (int it = 0; it < max_iter; ++it) {
-    float4* pold = (it & 1) ? L.p1 : L.p0;
-    float4* pnew = (it & 1) ? L.p0 : L.p1;
-    hipLaunchKernelGGL(r3d_cg_spmv_kernel, dim3(nblk_s), dim3(256), 0, st, L.row_ptr, L.col, L.val, n_dev, n_cap, alpha,
-                       it, nblk_v, tol2, rpb, L.r, pold, pnew, L.q, L.part_rr, L.part_pq, L.cg);
-    hipLaunchKernelGGL(r3d_cg_update_kernel, dim3(nblk_v), dim3(256), 0, st, n_dev, n_cap, it, nblk_s, tol2, pnew, L.q,
-                       x, L.r, L.part_pq, L.part_rr, L.cg);
+  hipLaunchKernelGGL(r3d_cg_init_kernel, dim3(nblk_v), dim3(256), 0, st, (const float4*)RHS, L.dinv, L.agg, L.MW, n_dev, n_cap, 0,
+                     x, L.r, L.p, L.q, L.part, L.cg);
+  hipLaunchKernelGGL(r3d_cg_reduce_kernel, dim3(1), dim3(256), 0, st, L.part, nblk_v, L.Einv, 0, 0, tol2, L.cg);
+  hipLaunchKernelGGL(r3d_cg_init_kernel, dim3(nblk_v), dim3(256), 0, st, (const float4*)RHS, L.dinv, L.agg, L.MW, n_dev, n_cap, 1,
+                     x, L.r, L.p, L.q, L.part, L.cg);
+  for (int it = 0; it <= max_iter; ++it) {
+    hipLaunchKernelGGL(r3d_cg_reduce_kernel, dim3(1), dim3(256), 0, st, L.part, nblk_v, L.Einv, 1, it, tol2, L.cg);
+    if (it == max_iter) break;  // the last launch only tests the residual the last update left
+    hipLaunchKernelGGL(r3d_cg_spmv_kernel, dim3(nblk_s), dim3(256), 0, st, L.row_ptr, L.col, L.val, L.dinv, L.agg, L.MW, n_dev,
+                       n_cap, alpha, it, rpb, L.r, L.p, L.q, L.part_pq, L.cg);
+    hipLaunchKernelGGL(r3d_cg_update_kernel, dim3(nblk_v), dim3(256), 0, st, n_dev, n_cap, it, nblk_s, L.dinv, L.agg, L.MW, L.p,
+                       L.q, x, L.r, L.part_pq, L.part, L.cg);
   }
-  hipLaunchKernelGGL(r3d_cg_defl_add_kernel, dim3(nblk_v), dim3(256), 0, st, x, L.dinv, n_dev, n_cap, L.cg);
   if (stats_out) r3d_copy_words(stats_out, &L.cg->done, 2, st);
   return R3D_OK;
 }
 
 extern "C" int r3d_label_propagate(const float* nodes, long ldn, int D, const int32_t* nbr, int kp1,
-                                   const float* Y, const int32_t* n_dev, int n_cap, float sigma,
+                                   const float* Y, const int32_t* n_dev, const int32_t* n_proto_dev, int n_cap, float sigma,
                                    float alpha, int max_iter, float tol, float* Z, int32_t* ws,
                                    int32_t* stats_out, void* stream) {
-  R3D_REQUIRE(nodes && nbr && Y && n_dev && Z && ws, "r3d_label_propagate: null pointer");
+  R3D_REQUIRE(nodes && nbr && Y && n_dev && n_proto_dev && Z && ws, "r3d_label_propagate: null pointer");
+  R3D_REQUIRE((ldn & 3) == 0 && ((uintptr_t)nodes & 15) == 0,
+              "r3d_label_propagate: node rows are read as float4: ldn must be a multiple of 4 and nodes 16-byte aligned");
   R3D_REQUIRE(n_cap > 0 && n_cap <= 32768 && D > 0 && D <= 256 && kp1 >= 2,
               "r3d_label_propagate: unsupported n_cap=%d D=%d kp1=%d", n_cap, D, kp1);
   R3D_REQUIRE(max_iter > 0 && max_iter <= HG_MAX_ITER && sigma > 0.f, "r3d_label_propagate: bad solver parameters");
@@ -617,7 +888,9 @@ extern "C" int r3d_label_propagate(const float* nodes, long ldn, int D, const in
                      (int)words, n_dev, n_cap, L.row_ptr, L.col, sigma, L.val, L.dinv, L.wdir);
   hipLaunchKernelGGL(r3d_graph_normalize_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, L.row_ptr, L.col, L.dinv,
                      n_dev, n_cap, L.val);
-  int rc = lp_solve(L, Y, n_dev, n_cap, alpha, max_iter, tol, Z, stats_out, st);
+  int rc = lp_coarse_space(L, nodes, ldn, D, n_dev, n_proto_dev, n_cap, alpha, st);
+  if (rc) return rc;
+  rc = lp_solve(L, Y, n_dev, n_cap, alpha, max_iter, tol, Z, stats_out, st);
   if (rc) return rc;
   R3D_LAUNCH_CHECK("r3d_label_propagate");
   return R3D_OK;
@@ -633,7 +906,7 @@ extern "C" int r3d_label_propagate(const float* nodes, long ldn, int D, const in
 static __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
 // pass 1: dD_i = -1/2 dinv_i^3 * sum_j (dS_ij + dS_ji) A_ij dinv_j      (A_ij dinv_j = S_ij / dinv_i)
-__global__ __launch_bounds__(256) void r3d_lp_bwd_dd_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col,
+__global__ __launch_bounds__(256) void r3d_lp_bwd_dd_kernel(const int* __restrict__ row_ptr, const hg_col_t* __restrict__ col,
                                                             const float* __restrict__ val, const float* __restrict__ dinv,
                                                             const int* __restrict__ n_dev, int n_cap, float alpha,
                                                             const float4* __restrict__ lam, const float4* __restrict__ Z,
@@ -660,7 +933,7 @@ __global__ __launch_bounds__(256) void r3d_lp_bwd_dd_kernel(const int* __restric
 //   walks the entries and every lane accumulates its channels of the weighted neighbour sum (coalesced rows).
 __global__ __launch_bounds__(256) void r3d_lp_bwd_dx_kernel(
     const float* __restrict__ nodes, long ldn, int D, const float* __restrict__ wdir,
-    const int* __restrict__ row_ptr, const int* __restrict__ col, const float* __restrict__ dinv,
+    const int* __restrict__ row_ptr, const hg_col_t* __restrict__ col, const float* __restrict__ dinv,
     const int* __restrict__ n_dev, int n_cap, float sigma, float alpha, const float4* __restrict__ lam,
     const float4* __restrict__ Z, const float* __restrict__ dD, float* __restrict__ dnodes, long ldd) {
   // one WORKGROUP per row, its four waves take every fourth chunk of 64 entries (a wave's work is a chain of
@@ -760,6 +1033,9 @@ extern "C" int r3d_label_propagate_bwd(const float* nodes, long ldn, int D, int 
                                        const int32_t* n_dev, int n_cap, float sigma, float alpha, int max_iter, float tol,
                                        float* lam, float* dnodes, long ldd, int32_t* ws, int32_t* stats_out, void* stream) {
   R3D_REQUIRE(nodes && Z && G && n_dev && lam && dnodes && ws, "r3d_label_propagate_bwd: null pointer");
+  R3D_REQUIRE((ldn & 3) == 0 && ((uintptr_t)nodes & 15) == 0 && ((uintptr_t)ws & 15) == 0 && ((uintptr_t)Z & 15) == 0 &&
+                  ((uintptr_t)G & 15) == 0 && ((uintptr_t)lam & 15) == 0,
+              "r3d_label_propagate_bwd: ldn must be a multiple of 4; nodes, ws, Z, G, lam 16-byte aligned");
   R3D_REQUIRE(n_cap > 0 && n_cap <= 32768 && D > 0 && D <= 256 && max_iter > 0 && max_iter <= HG_MAX_ITER,
               "r3d_label_propagate_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
@@ -822,12 +1098,16 @@ extern "C" int r3d_graph_set_lp_budget(void* graph, void* graph_exec, int budget
     if (ty != hipGraphNodeTypeKernel) continue;
     hipKernelNodeParams kp;
     if (hipGraphKernelNodeGetParams(nodes[i], &kp) != hipSuccess) { rc = R3D_ERR_LAUNCH; break; }
-    int it;
-    if (kp.func == (void*)r3d_cg_spmv_kernel) it = *(const int*)kp.kernelParams[6];
-    else if (kp.func == (void*)r3d_cg_update_kernel) it = *(const int*)kp.kernelParams[2];
-    else continue;
+    int it, on;
+    if (kp.func == (void*)r3d_cg_spmv_kernel) { it = *(const int*)kp.kernelParams[9]; on = it < budget; }
+    else if (kp.func == (void*)r3d_cg_update_kernel) { it = *(const int*)kp.kernelParams[2]; on = it < budget; }
+    else if (kp.func == (void*)r3d_cg_reduce_kernel) {
+      if (*(const int*)kp.kernelParams[3] == 0) continue;  // phase 0 belongs to the start-up of a solve
+      it = *(const int*)kp.kernelParams[4];
+      on = it <= budget;  // R(budget) tests the residual the last enabled update left
+    } else continue;
     ++found;
-    if (hipGraphNodeSetEnabled(ge, nodes[i], it < budget ? 1u : 0u) != hipSuccess) { rc = R3D_ERR_LAUNCH; break; }
+    if (hipGraphNodeSetEnabled(ge, nodes[i], on ? 1u : 0u) != hipSuccess) { rc = R3D_ERR_LAUNCH; break; }
   }
   free(nodes);
   if (rc != R3D_OK) {

@@ -224,6 +224,19 @@ class HeadBuffers:
         off = (ctypes.c_long * 6)()
         lib.r3d_head_proto_ws_offsets(n_way, k_shot, N, off)
         self.ws_off = list(off)
+        lib.r3d_lp_ws_offsets(self.n_cap, self.kp1, off)
+        self.lp_off = dict(zip(("row_ptr", "col", "val", "dinv", "agg", "cg"), off))
+
+    def csr(self):
+        """(n, row_ptr (n+1) int64, col (nnz) int64, val (nnz) fp32) of the normalised graph S the last
+        r3d_label_propagate left in the workspace (synchronises; tests, tools and bench.py's byte counts)."""
+        n = int(self.desc[HD_N_NODES].item())
+        o = self.lp_off
+        row_ptr = self.lp_ws[o["row_ptr"]:o["row_ptr"] + n + 1].to(torch.int64)
+        nnz = int(row_ptr[-1].item())
+        col = self.lp_ws[o["col"]:o["col"] + (nnz + 1) // 2].view(torch.int16)[:nnz].to(torch.int64) & 0xffff
+        val = self.lp_ws[o["val"]:o["val"] + nnz].view(torch.float32)
+        return n, row_ptr, col, val
 
 
 def head_prototypes(hb, support_y, shot_keep, sfeat_pm, sfeatT, qfeat_pm):
@@ -243,8 +256,9 @@ def label_propagate(hb, nbr, sigma, alpha=0.99, max_iter=200, tol=1e-6):
     assert nbr.shape == (1, hb.n_cap, hb.kp1) or nbr.shape == (hb.n_cap, hb.kp1)
     with _timed("label_propagate"):
         _lib.check(_lib.load().r3d_label_propagate(
-            _p(hb.nodes), hb.nodes.stride(0), hb.D, _p(nbr), hb.kp1, _p(hb.Y), _p(hb.desc[HD_N_NODES:]), hb.n_cap,
-            float(sigma), float(alpha), int(max_iter), float(tol), _p(hb.Z), _p(hb.lp_ws), _p(hb.stats), _st()))
+            _p(hb.nodes), hb.nodes.stride(0), hb.D, _p(nbr), hb.kp1, _p(hb.Y), _p(hb.desc[HD_N_NODES:]),
+            _p(hb.desc[HD_N_PROTO:]), hb.n_cap, float(sigma), float(alpha), int(max_iter), float(tol), _p(hb.Z),
+            _p(hb.lp_ws), _p(hb.stats), _st()))
     return hb.Z
 
 

@@ -21,18 +21,9 @@ def _model(cfg):
 
 def _lp_residual(model):
     """|| Y - (I - alpha S) Z ||_F / || Y ||_F per label column, S rebuilt from the CSR the solver left in its workspace."""
-    from r3dfsseg_amd import ops
     hb = model._head[1]
-    n = int(hb.desc[ops.HD_N_NODES].item())
-    words = (hb.n_cap + 31) // 32
-    nnz_cap = 2 * hb.n_cap * (hb.kp1 - 1)
-    o_rowptr = 2 * hb.n_cap * words + hb.n_cap + 8
-    o_col = o_rowptr + hb.n_cap + 8
-    o_val = o_col + nnz_cap
-    row_ptr = hb.lp_ws[o_rowptr:o_rowptr + n + 1].to(torch.int64)
+    n, row_ptr, col, val = hb.csr()
     nnz = int(row_ptr[-1].item())
-    col = hb.lp_ws[o_col:o_col + nnz].to(torch.int64)
-    val = hb.lp_ws[o_val:o_val + nnz].view(torch.float32)
     Sm = torch.sparse_csr_tensor(row_ptr, col, val.double(), size=(n, n))
     Z, Y = hb.Z[:n].double(), hb.Y[:n].double()
     r = Y - (Z - 0.99 * (Sm @ Z))

@@ -127,6 +127,56 @@ def test_label_propagation_vs_closed_form(ops, n_proto, n_q_pts, cap_extra):
     print("CG iterations:", iters, "max|Z|:", scale, "err:", err)
 
 
+@pytest.mark.parametrize("sep,n_proto", [(6.0, 300), (10.0, 300), (6.0, 20)])
+def test_label_propagation_on_clustered_features(ops, sep, n_proto):
+    """The trained regime: well separated feature clusters make the graph nearly disconnected, S gets one eigenvalue
+    ~1 per cluster and plain CG needs 50-70 iterations (measured on systems dumped after 150 training steps).  The
+    two-level solver must reach the same closed-form answer in a fraction of that, also when there are fewer
+    prototypes than coarse seeds (empty aggregates) and when a right-hand side column is all zero."""
+    n_q_pts = 2048
+    n = n_proto + n_q_pts
+    x, Y = _graph_nodes(n_proto, n_q_pts, 9, scale=0.06)
+    rs = np.random.RandomState(10)
+    lab = rs.randint(0, 3, n)
+    x = x + torch.from_numpy(np.eye(3, 192, dtype=np.float32)[lab] * (sep * 0.06))  # push the clusters apart
+    Y = torch.zeros(n, 4)
+    Y[torch.arange(n_proto), torch.from_numpy(lab[:n_proto])] = 1
+    hb = ops.HeadBuffers(2, 1, n_q_pts // 2, n_q_pts, (n_proto + 2) // 3, 200, 192, "cuda")
+    assert hb.n_cap >= n
+    hb.nodes[:n] = x.cuda()
+    hb.Y.zero_()
+    hb.Y[:n] = Y.cuda()
+    hb.desc[ops.HD_N_PROTO] = n_proto
+    hb.desc[ops.HD_N_NODES] = n
+    nbr = ops.knn(hb.nodes, 1, hb.n_cap, 201, mode=ops.SCORE_L2, n_valid=hb.desc[ops.HD_N_NODES:], status=None)
+    Z = ops.label_propagate(hb, nbr, 1.0, 0.99, 300, 1e-6)
+    torch.cuda.synchronize()
+    conv, iters = hb.stats.cpu().tolist()
+    A = O.affinity(x, 200, 1.0)
+    Z64 = O.label_propagate(A, Y[:, :3], dtype=torch.float64)
+    scale = Z64.abs().max().item()
+    err = (Z[:n, :3].cpu().double() - Z64).abs().max().item()
+    # what plain CG would need on this system (float64, same tolerance)
+    D = A.double().sum(1)
+    Sm = A.double() / torch.sqrt(D[:, None] * D[None, :])
+    M = torch.eye(n, dtype=torch.float64) - 0.99 * Sm
+    b = Y[:, :3].double()
+    xx, r = torch.zeros_like(b), b.clone()
+    p, rr, plain = r.clone(), (r * r).sum(0), 0
+    while (rr > 1e-12 * (b * b).sum(0)).any() and plain < 500:
+        q = M @ p
+        al = rr / (p * q).sum(0)
+        xx += al * p; r -= al * q
+        rn = (r * r).sum(0)
+        p = r + (rn / rr) * p
+        rr = rn; plain += 1
+    print("sep %.0f n_proto %d: two-level CG %d iterations (plain CG %d), max|Z| %.1f err %.2e" % (sep, n_proto, iters, plain, scale, err))
+    assert conv == 1 and err <= TOL * max(1.0, scale), (conv, iters, err, scale)
+    assert (Z[:n, 3] == 0).all()                       # an all-zero right-hand side column stays zero
+    if n_proto >= 64:
+        assert iters <= max(12, plain // 2), (iters, plain)
+
+
 def test_logits_and_cross_entropy(ops):
     n_q, N = 2, 512
     hb = ops.HeadBuffers(2, 1, N, n_q * N, 100, 200, 192, "cuda")

@@ -182,18 +182,19 @@ def test_config2_full_size_training_episode_gradients():
     for i, (a, b) in enumerate(zip(out[3:], ref[3:])):  # the four debug metrics of mpti.py:515-568
         assert abs(float(a) - float(b)) <= 2e-3, (i, float(a), float(b))
 
-    # ---- encoder segment: oracle autograd driven by the HIP feature gradients
-    sde = {k_: (v.clone().requires_grad_() if v.dtype.is_floating_point and "running" not in k_ else v.clone())
-           for k_, v in sd.items()}
-    ns = {}
-    grads = {}
+    # ---- encoder segment: oracle autograd driven by the HIP feature gradients.  The oracle runs this segment in
+    # float64: a gradient here is a sum over 20 480 points (409 600 edges) behind BatchNorm's cancellations, where an
+    # fp32 CPU summation is itself only good to ~1e-3 -- the comparison needs a reference that is better than both.
+    sde = {k_: (v.double().requires_grad_() if v.dtype.is_floating_point and "running" not in k_
+                else (v.double() if v.dtype.is_floating_point else v.clone())) for k_, v in sd.items()}
     for p, (x, dfeat) in enumerate(((sx.reshape(Sn, 9, N), dsf), (qx, dqf))):
         idx, am = lists(p)
-        f = O.get_features(sde, x, cfg, train=True, new_stats=ns, idx_override=idx, argmax_override=am)
+        f = O.get_features(sde, x.double(), cfg, train=True, new_stats={}, idx_override=idx, argmax_override=am)
         f_pm = f.transpose(1, 2).reshape(x.shape[0] * N, -1)
-        got = (sfeat if p == 0 else qfeat).detach().cpu()
+        got = (sfeat if p == 0 else qfeat).detach().cpu().double()
         assert _close(got, f_pm.detach()) <= TOL, ("features of pass %d" % p, _close(got, f_pm.detach()))
-        f_pm.backward(dfeat)
+        f_pm.backward(dfeat.double())
+        del f, f_pm
     worst = []
     for name, prm in m.named_parameters():
         if name.startswith("proj."):
@@ -204,9 +205,9 @@ def test_config2_full_size_training_episode_gradients():
             # a conv bias in front of batch-statistics BatchNorm has an exactly zero gradient (round-off noise only)
             assert prm.grad.abs().max().item() < 1e-3 and gref.abs().max().item() < 1e-3
             continue
-        worst.append((rel(prm.grad.cpu(), gref), name))
+        worst.append((rel(prm.grad.cpu().double(), gref), name))
     worst.sort()
-    print("full-size encoder gradient errors (worst 5):", worst[-5:])
+    print("full-size encoder gradient errors against the float64 oracle (worst 5):", worst[-5:])
     assert worst[-1][0] <= 1e-3, worst[-5:]
 
 

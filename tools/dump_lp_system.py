@@ -32,15 +32,8 @@ with torch.no_grad():
     model(*pool[3][:4], lp_iters=model.lp_max_iter)
 torch.cuda.synchronize()
 hb = model._head[1]
-n = int(hb.desc[ops.HD_N_NODES].item()); n_cap, kp1 = hb.n_cap, hb.kp1
-words = (n_cap + 31) // 32
-ws = hb.lp_ws.cpu().numpy()
-o = 2 * n_cap * words
-row_len = ws[o:o + n_cap + 8]; o += n_cap + 8
-row_ptr = ws[o:o + n_cap + 8]; o += n_cap + 8
-nnz_cap = 2 * n_cap * (kp1 - 1)
-col = ws[o:o + nnz_cap]; o += nnz_cap
-val = ws[o:o + nnz_cap].view(np.float32); o += nnz_cap
+n, row_ptr, col, val = hb.csr()
+row_ptr, col, val = row_ptr.cpu().numpy(), col.cpu().numpy().astype(np.int32), val.cpu().numpy()
 nnz = int(row_ptr[n])
 np.savez_compressed(out, n=n, row_ptr=row_ptr[:n + 1].copy(), col=col[:nnz].copy(), val=val[:nnz].copy(),
                     Y=hb.Y.cpu().numpy()[:n], Z=hb.Z.cpu().numpy()[:n], stats=hb.stats.cpu().numpy(),
