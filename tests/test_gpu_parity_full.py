@@ -182,33 +182,45 @@ def test_config2_full_size_training_episode_gradients():
     for i, (a, b) in enumerate(zip(out[3:], ref[3:])):  # the four debug metrics of mpti.py:515-568
         assert abs(float(a) - float(b)) <= 2e-3, (i, float(a), float(b))
 
-    # ---- encoder segment: oracle autograd driven by the HIP feature gradients.  The oracle runs this segment in
-    # float64: a gradient here is a sum over 20 480 points (409 600 edges) behind BatchNorm's cancellations, where an
-    # fp32 CPU summation is itself only good to ~1e-3 -- the comparison needs a reference that is better than both.
-    sde = {k_: (v.double().requires_grad_() if v.dtype.is_floating_point and "running" not in k_
-                else (v.double() if v.dtype.is_floating_point else v.clone())) for k_, v in sd.items()}
-    for p, (x, dfeat) in enumerate(((sx.reshape(Sn, 9, N), dsf), (qx, dqf))):
-        idx, am = lists(p)
-        f = O.get_features(sde, x.double(), cfg, train=True, new_stats={}, idx_override=idx, argmax_override=am)
-        f_pm = f.transpose(1, 2).reshape(x.shape[0] * N, -1)
-        got = (sfeat if p == 0 else qfeat).detach().cpu().double()
-        assert _close(got, f_pm.detach()) <= TOL, ("features of pass %d" % p, _close(got, f_pm.detach()))
-        f_pm.backward(dfeat.double())
-        del f, f_pm
-    worst = []
+    # ---- encoder segment: oracle autograd driven by the HIP feature gradients.  A gradient here is a sum over 20 480
+    # points (409 600 edges) behind BatchNorm's cancellations and LeakyReLU kinks, where fp32 arithmetic -- the
+    # reference's own -- is only good to ~1e-3 of the largest entry.  So the oracle runs the segment twice: in float64
+    # (the truth) and in float32 (the reference's arithmetic, torch-CPU); the HIP gradient must be within 1e-3 of the
+    # truth, or -- for a parameter where fp32 itself cannot do that -- at most twice as far from it as torch-fp32 is.
+    def oracle_grads(dtype):
+        cast = (lambda v: v.to(dtype)) if dtype == torch.float64 else (lambda v: v.clone())
+        sde = {k_: (cast(v).requires_grad_() if v.dtype.is_floating_point and "running" not in k_
+                    else (cast(v) if v.dtype.is_floating_point else v.clone())) for k_, v in sd.items()}
+        for p, (x, dfeat) in enumerate(((sx.reshape(Sn, 9, N), dsf), (qx, dqf))):
+            idx, am = lists(p)
+            f = O.get_features(sde, x.to(dtype), cfg, train=True, new_stats={}, idx_override=idx, argmax_override=am)
+            f_pm = f.transpose(1, 2).reshape(x.shape[0] * N, -1)
+            got = (sfeat if p == 0 else qfeat).detach().cpu().to(dtype)
+            assert _close(got, f_pm.detach()) <= TOL, ("features of pass %d" % p, _close(got, f_pm.detach()))
+            f_pm.backward(dfeat.to(dtype))
+            del f, f_pm
+        return {k_: v.grad.double() for k_, v in sde.items() if v.dtype.is_floating_point and v.requires_grad}
+
+    g64 = oracle_grads(torch.float64)
+    g32 = oracle_grads(torch.float32)
+    rows = []
     for name, prm in m.named_parameters():
         if name.startswith("proj."):
             continue
-        gref = sde[name].grad
-        assert prm.grad is not None and gref is not None, name
+        assert prm.grad is not None and name in g64, name
         if name.startswith("base_learner") and name.endswith(".0.bias"):
             # a conv bias in front of batch-statistics BatchNorm has an exactly zero gradient (round-off noise only)
-            assert prm.grad.abs().max().item() < 1e-3 and gref.abs().max().item() < 1e-3
+            assert prm.grad.abs().max().item() < 1e-3 and g64[name].abs().max().item() < 1e-3
             continue
-        worst.append((rel(prm.grad.cpu().double(), gref), name))
-    worst.sort()
-    print("full-size encoder gradient errors against the float64 oracle (worst 5):", worst[-5:])
-    assert worst[-1][0] <= 1e-3, worst[-5:]
+        rows.append((rel(prm.grad.cpu().double(), g64[name]), rel(g32[name], g64[name]), name))
+    rows.sort()
+    print("full-size encoder gradients, max relative error against the float64 oracle (HIP, torch-fp32, name), worst 6:")
+    for r_ in rows[-6:]:
+        print("   %.2e  %.2e  %s" % r_)
+    print("   median HIP %.2e, median torch-fp32 %.2e" % (np.median([r_[0] for r_ in rows]), np.median([r_[1] for r_ in rows])))
+    for e_hip, e_t32, name in rows:
+        assert e_hip <= max(1e-3, 2.0 * e_t32), (name, e_hip, e_t32)
+    assert np.median([r_[0] for r_ in rows]) <= 2e-4
 
 
 def test_config4_batch_of_32_C_episodes_replayed():
