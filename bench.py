@@ -13,10 +13,16 @@ BASELINE.json configs[4]'s 256-episode batch over 8 GPUs; each episode is config
                           stream (r3dfsseg_amd/episode_graph.py); --slots 0 = eager launches, one episode at a time.
 Episodes are independent: ranks take disjoint episodes (weak scaling); the only collective is
 the 1.5 MB gradient all-reduce of train mode.  ONE JSON line on rank 0, with
-  roofline     -- the entry point taking most time, priced with its ALGORITHMIC work over
-                  its HIP-event launch time (events recorded on the launch stream, in a separate pass of
-                  single-episode EAGER steps: one episode in flight, so launches do not overlap)
-  cpu_baseline -- the CPU oracle (a port of the reference path) on this box's host cores, eval forward
+  roofline     -- the entry point taking most device time in a live pass of single-episode EAGER steps (one episode
+                  in flight, so launches do not overlap), named by its main kernel and priced with its ALGORITHMIC
+                  work over its HIP-event time (events on the launch stream).  When that entry
+                  point is the label propagation, the CG iteration (its three kernels) is measured on its own.
+  rooflines    -- every entry point against both ceilings; these are WARM-CACHE figures (each region is launched
+                  again 8 times back to back on the same buffers between one event pair)
+  cpu_baseline -- the CPU oracle (a port of the reference path) on this box's host cores, EVAL FORWARD: compare it
+                  with eval_forward_episodes_per_sec, not with the train-step headline
+  steady_state -- the same timed step again after --steady-steps optimiser steps (the label-propagation systems get
+                  harder as the encoder separates the classes; the first steps after initialisation flatter)
 Extra fields: single_episode_eager_step_episodes_per_sec (E = 1, eager: the reference's own schedule) and
 eval_forward_episodes_per_sec.
 """
@@ -84,8 +90,62 @@ def algorithmic_work(op, cfg, n_nodes, cg_iters, train):
     if op in ("label_propagate", "label_propagate_bwd"):  # graph build + cg_iters SpMVs over <= 2 k nnz per row
         nnz = 2.0 * n_nodes * cfg["k_connect"]
         return (n_nodes * cfg["k_connect"] * D * 6 + cg_iters * nnz * 8,
-                n_nodes * D * 4 + nnz * 8 + cg_iters * (nnz * 8 + n_nodes * 16 * 4), "hbm", 1)
+                n_nodes * D * 4 + nnz * 6 + cg_iters * cg_iteration_bytes(nnz, n_nodes), "hbm", 1)
     raise KeyError(op)
+
+
+CG_M = 64  # coarse dimensions of the two-level CG (csrc/head_graph.hip: HG_M)
+
+
+def cg_iteration_bytes(nnz, n):
+    """ALGORITHMIC bytes of ONE CG iteration (kernels R + S + U of csrc/head_graph.hip): the matrix once (uint16 column
+    + fp32 value per entry), the gathered residual rows counted once, the vectors each kernel reads and writes
+    (S: r in, p and q in/out, one (M W) row; U: p, q in, x and r in/out, one (M W) row), float4 rows of 16 B."""
+    return nnz * 6.0 + n * (16 + 32 + 32 + 4 * CG_M) + n * (32 + 32 + 32 + 4 * CG_M)
+
+
+# entry point -> the kernel that dominates it (names as rocprofv3 prints them; profiles/)
+MAIN_KERNEL = {
+    "knn_topk": "r3d_knn_append_kernel<4, 128, 1, ...> (DGCNN kNN, k = 20)",
+    "knn_topk_l2": "r3d_knn_append_kernel<8, 384, 2, ...> (201-NN of the graph nodes)",
+    "pointwise_conv": "r3d_pointwise_gemm_kernel", "edgeconv": "r3d_edgeconv_kernel / r3d_edgeconv_train_fwd2_kernel",
+    "attention": "r3d_attention_fwd_kernel", "head_prototypes": "r3d_fps_persistent_kernel",
+    "label_propagate": "r3d_cg_spmv_kernel + r3d_cg_update_kernel + r3d_cg_reduce_kernel",
+    "label_propagate_bwd": "r3d_cg_spmv_kernel + r3d_cg_update_kernel + r3d_cg_reduce_kernel",
+    "gemm_tn": "r3d_gemm_tn_kernel", "edgeconv_bwd": "r3d_edgeconv_bwd1_kernel + r3d_edgeconv_bwd2_kernel",
+    "attention_bwd": "r3d_attention_bwd_kv_kernel + r3d_attention_bwd_q_kernel", "bn_stats": "r3d_colpartial_kernel",
+}
+
+
+def committed_profile(workload, mode):
+    """({kernel name as printed: (calls, total ms, average us)}, file name) of the newest committed rocprofv3
+    --kernel-trace summary of THIS workload and mode
+    (profiles/rNN_*_rocprofv3_kernel_stats_<mode>_eager_<workload>.txt, written by tools/prof_summary.py), or (None, None)."""
+    import glob
+    names = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_kernel_stats_%s_eager_%s.txt" % (mode, workload))))
+    if not names:
+        return None, None
+    rows = {}
+    for l in open(names[-1]):
+        f = l.split()
+        if len(f) >= 5 and "r3d_" in l[:16]:
+            try:
+                rows[l[:72].strip()] = (int(f[-4]), float(f[-3]), float(f[-2]))
+            except ValueError:
+                pass
+    return rows, os.path.basename(names[-1])
+
+
+def committed_traffic(workload, mode):
+    """per-kernel {fetch_kb_per_launch, write_kb_per_launch} of the committed PMC passes of THIS workload, or None."""
+    import glob
+    names = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % workload)))
+    if not names:
+        return None, None
+    try:
+        return json.load(open(names[-1]))[mode], os.path.basename(names[-1])
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def main():
@@ -105,6 +165,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-kernel", default="auto", help="entry point to price (auto = the one taking most time)")
+    ap.add_argument("--steady-steps", type=int, default=150,
+                    help="train mode: optimiser steps before the steady-state leg is timed (0 = skip that leg)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -189,6 +251,7 @@ def main():
         lp_flags.append(head_flags())
 
     invalid = []  # reasons why a timed leg does not count (every episode must have a converged, exact head)
+    redone_notes = []
     lp_budget_info = {}
 
     def timed(step_fn, steps, warmup, graphs=None):
@@ -216,9 +279,13 @@ def main():
             enabled = graphs.active_budget
             bad, it_sum, it_max = graphs.check()
             if bad:  # recorded, not fatal: an abort on one rank would leave the others in the next barrier
-                invalid.append("%s: %d episode(s) with unconverged label propagation / FPS time-out (CG max %d of budget %d), "
-                               "%d with 201-NN survivor overflow" % (step_fn.__name__, graphs.last_unconverged, it_max,
-                                                                     enabled, graphs.last_knn_overflow))
+                msg = ("%s: %d episode(s) with unconverged label propagation / FPS time-out (CG max %d of budget %d), "
+                       "%d with 201-NN survivor overflow" % (step_fn.__name__, graphs.last_unconverged, it_max, enabled,
+                                                             graphs.last_knn_overflow))
+                if step_fn is train_step:  # DPTrainer.step fails closed: it redid those steps exactly, inside the timed region
+                    redone_notes.append(msg + " -- redone on the conservative schedule before the optimiser step")
+                else:
+                    invalid.append(msg)
             return el, (it_sum / (steps * E), it_max)
         lp = torch.stack(lp_flags).cpu()
         if int(lp[:, 2].max()) != 0:
@@ -265,6 +332,18 @@ def main():
     ksum_all = timer.summary()
     cg_mean, cg_max = cg
 
+    # steady-state leg (all ranks): train on, then time the same step again.  The first steps after initialisation
+    # solve easy label-propagation systems; once the encoder separates the classes the graph splits into clusters
+    # and the solves take more iterations.  Outside the headline's timed region.
+    if train and G and args.steady_steps > 0:
+        for i in range(max(0, args.steady_steps - args.steps - args.warmup)):
+            train_step(i)
+        el_ss, cg_ss = timed(train_step, args.steps, 1, trainer.graphs)
+        extra["steady_state"] = {"value": args.steps * E * world / el_ss, "unit": "episodes/s",
+                                 "optimiser_steps_before": args.steady_steps, "ms_per_step": el_ss / args.steps * 1e3,
+                                 "lp_cg_iterations": {"mean": cg_ss[0], "max": cg_ss[1]},
+                                 "redone_steps": getattr(trainer, "n_redone", 0)}
+
     n_invalid = torch.tensor([float(len(invalid))], device=dev)
     if dist is not None:
         dist.all_reduce(n_invalid)
@@ -277,10 +356,17 @@ def main():
     B = cfg["n_way"] * cfg["k_shot"] + cfg["n_way"] * cfg.get("n_queries", 1)
     n_nodes = int(model._head[1].desc[ops.HD_N_NODES].item())
     per_step_ms = {k: v["total_ms"] / n_roof for k, v in ksum_all.items() if v["launches"]}
-    if args.roofline_kernel == "auto":
-        # The dominant KERNEL by device time (profiles/: rocprofv3 kernel stats) is the CG iteration of the label
-        # propagation, r3d_cg_spmv_kernel + r3d_cg_update_kernel.  Its launch time is measured live: the same
-        # solve with 8 and with 40 forced iterations (tol = 0), HIP events on the launch stream, difference / 32.
+    mode_name = "train" if train else "eval"
+    prof, prof_name = committed_profile(args.workload, mode_name)
+    pmc, pmc_name = committed_traffic(args.workload, mode_name)
+    kern = args.roofline_kernel
+    if kern == "auto":  # the entry point with the most device time in the live eager pass above
+        kern = max(per_step_ms, key=per_step_ms.get)
+    roof = None
+    if kern in ("label_propagate", "label_propagate_bwd"):
+        # The label propagation is graph build + CG; its dominant kernels are the three of one CG iteration.  Their time
+        # is measured live: the same solve with 8 and with 40 forced iterations (tol = 0), HIP events on the launch
+        # stream, difference / 32.  If the iterations are less than half of the entry point, it is priced as a whole.
         hb = model._head[1]
         nbr = ops.knn(hb.nodes, 1, hb.n_cap, hb.kp1, mode=ops.SCORE_L2, n_valid=hb.desc[ops.HD_N_NODES:], status=hb.knn_status)
 
@@ -294,52 +380,48 @@ def main():
             torch.cuda.synchronize()
             return a.elapsed_time(b) / reps
         t_iter = (solve_ms(40) - solve_ms(8)) / 32.0 * 1e-3
-        words = (hb.n_cap + 31) // 32
-        nnz = int(hb.lp_ws[2 * hb.n_cap * words + hb.n_cap + 8 + n_nodes].item())  # row_ptr[n] of the CSR in the workspace
-        by = nnz * 8.0 + n_nodes * 160.0   # col + val once; r, p_old, p, q, x, r as float4 rows in, p_new, q, x, r out
-        fl = nnz * 2.0 * 4 + n_nodes * 4 * 12.0
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["train" if train else "eval"]
-            traffic = 1024.0 * sum(pmc[k]["fetch_kb_per_launch"] + pmc[k]["write_kb_per_launch"]
-                                   for k in ("r3d_cg_spmv_kernel", "r3d_cg_update_kernel"))
-        except (OSError, KeyError, ValueError):
-            pass
-        rocprof_us = None  # per-kernel averages of the committed rocprofv3 --kernel-trace --stats summary of this command
-        try:
-            import glob
-            name = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_kernel_stats_%s_eager.txt" % (
-                "train" if train else "eval"))))[-1]  # the newest committed summary
-            rows = {l.split("(")[0].strip(): float(l.split()[-2]) for l in open(name) if l.startswith("r3d_cg_")}
-            rocprof_us = rows["r3d_cg_spmv_kernel"] + rows["r3d_cg_update_kernel"]
-        except (OSError, KeyError, ValueError, IndexError):
-            pass
-        roof = dict(kernel="r3d_cg_spmv_kernel + r3d_cg_update_kernel (one CG iteration of label propagation)",
-                    bound="hbm", achieved=by / t_iter / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t_iter / 1e9 / HBM_PEAK_GBS,
-                    traffic=traffic, avg_launch_ms=t_iter * 1e3, algorithmic_mb_per_launch=by / 1e6,
-                    algorithmic_gflop_per_launch=fl / 1e9, csr_nnz=nnz, nodes=n_nodes,
-                    iterations_per_episode=cg_mean * (2 if train else 1),
-                    rocprofv3_kernel_us=rocprof_us,
-                    frac_kernel_time_only=(by / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rocprof_us else None,
-                    note=("avg_launch_ms is event-measured over back-to-back DEPENDENT launches, so it contains the two launch "
-                          "gaps of an iteration; rocprofv3_kernel_us is the pair's in-kernel time from the committed "
-                          "--kernel-trace --stats summary.  traffic = FETCH_SIZE + WRITE_SIZE of the pair from the committed rocprofv3 PMC "
-                          "passes (profiles/r01_pmc_traffic.json, raw counters); the matrix (%.1f MB) is L2 / Infinity-Cache "
-                          "resident between launches" % (nnz * 8 / 1e6)))
-    else:
-        kern = args.roofline_kernel
+        if cg_mean * t_iter * 1e3 >= 0.5 * per_step_ms[kern]:
+            _, row_ptr, _, _ = hb.csr()
+            nnz = int(row_ptr[-1].item())
+            by = cg_iteration_bytes(nnz, n_nodes)
+            fl = nnz * 2.0 * 4 + n_nodes * 4 * (12.0 + 4 * CG_M)
+            cg_names = ("r3d_cg_spmv_kernel", "r3d_cg_update_kernel", "r3d_cg_reduce_kernel")
+            traffic = rocprof_us = None
+            if pmc is not None and all(k in pmc for k in cg_names):
+                traffic = 1024.0 * sum(pmc[k]["fetch_kb_per_launch"] + pmc[k]["write_kb_per_launch"] for k in cg_names)
+            if prof is not None:
+                us = [v[2] for k, v in prof.items() if k.split("(")[0] in cg_names]
+                rocprof_us = sum(us) if len(us) == 3 else None
+            roof = dict(kernel="r3d_cg_reduce_kernel + r3d_cg_spmv_kernel + r3d_cg_update_kernel (one iteration of the "
+                               "two-level CG of the label propagation)",
+                        bound="hbm", achieved=by / t_iter / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t_iter / 1e9 / HBM_PEAK_GBS,
+                        traffic=traffic, avg_launch_ms=t_iter * 1e3, algorithmic_mb_per_launch=by / 1e6,
+                        algorithmic_gflop_per_launch=fl / 1e9, csr_nnz=nnz, nodes=n_nodes,
+                        iterations_per_episode=cg_mean * (2 if train else 1), rocprofv3_kernel_us=rocprof_us,
+                        frac_kernel_time_only=(by / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rocprof_us else None,
+                        rocprofv3_summary=prof_name, pmc_summary=pmc_name,
+                        note=("avg_launch_ms is event-measured over back-to-back DEPENDENT launches, so it contains the three "
+                              "launch gaps of an iteration; rocprofv3_kernel_us is the trio's in-kernel time from the committed "
+                              "--kernel-trace summary of this workload (null when none is committed); traffic = FETCH_SIZE + "
+                              "WRITE_SIZE of the trio from the committed PMC passes of this workload (raw counters); the matrix "
+                              "(%.1f MB) is L2 / Infinity-Cache resident between launches" % (nnz * 6 / 1e6)))
+    if roof is None:
         fl, by, bound, launches = algorithmic_work(kern, cfg, n_nodes, cg_mean, train)
         t_launch = per_step_ms[kern] * 1e-3 / launches
         if bound == "mfma":
             ach, peak, unit = fl / launches / t_launch / 1e12, F32_MFMA_PEAK_TF, "TFLOP/s"
         else:
             ach, peak, unit = by / launches / t_launch / 1e9, HBM_PEAK_GBS, "GB/s"
-        roof = dict(kernel=kern, bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak, traffic=None,
-                    avg_launch_ms=t_launch * 1e3, launches_per_step=launches,
+        roof = dict(kernel="%s (entry point %s)" % (MAIN_KERNEL.get(kern, kern), kern), bound=bound, achieved=ach, peak=peak,
+                    unit=unit, frac=ach / peak, traffic=None, avg_launch_ms=t_launch * 1e3, launches_per_step=launches,
                     algorithmic_gflop_per_launch=fl / launches / 1e9, algorithmic_mb_per_launch=by / launches / 1e6,
-                    hbm_gbs=by / launches / t_launch / 1e9, fp32_tflops=fl / launches / t_launch / 1e12)
+                    hbm_gbs=by / launches / t_launch / 1e9, fp32_tflops=fl / launches / t_launch / 1e12,
+                    rocprofv3_summary=prof_name, pmc_summary=pmc_name,
+                    note="warm-cache repeat timing: the entry point's launches are issued again 8 times back to back on the "
+                         "same buffers between one HIP event pair on the launch stream (inputs L2 / Infinity-Cache warm)")
     # every entry point against both ceilings (north_star: HBM GB/s for kNN / EdgeConv, MFMA utilisation for attention)
-    rooflines = {}
+    rooflines = {"_note": "warm-cache repeat timings (8 back-to-back relaunches per region on identical buffers): "
+                          "hbm_gbs is algorithmic bytes / device time, not HBM traffic"}
     for op, ms in per_step_ms.items():
         f_, b_, bnd, calls = algorithmic_work(op, cfg, n_nodes, cg_mean, train)
         sec = ms * 1e-3
@@ -368,7 +450,10 @@ def main():
                 break
         c1 = time.perf_counter()
         cpu = dict(value=n_cpu / (c1 - c0), unit="episodes/s", cores=ncores, kind="port",
-                   sample="%d full %s episode(s), EVAL FORWARD only, CPU oracle (C + torch-CPU, %d threads)" % (n_cpu, args.workload, ncores))
+                   sample="%d full %s episode(s), EVAL FORWARD only, CPU oracle (C + torch-CPU, %d threads)" % (n_cpu, args.workload, ncores),
+                   compare_with="eval_forward_episodes_per_sec" if (train and G) else "value",
+                   gpu_eval_forward_over_cpu=(extra.get("eval_forward_episodes_per_sec", args.steps * E * world / elapsed)
+                                              / (n_cpu / (c1 - c0))))
 
     eps = args.steps * E * world / elapsed
     out = {
@@ -387,6 +472,7 @@ def main():
         "entry_point_ms_per_step": breakdown,
         "lp_cg_iterations": {"mean": cg_mean, "max": cg_max},
         "lp_cg_launch_budget": lp_budget_info,  # CG iterations captured per graph / kept enabled (episode_graph.py)
+        "train_steps_redone": {"count": getattr(trainer, "n_redone", 0) if trainer is not None else 0, "notes": redone_notes},
     }
     out.update(extra)
     if not out["valid"]:

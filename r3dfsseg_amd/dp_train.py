@@ -19,6 +19,8 @@ class DPTrainer:
         self.model = learner.model
         self.bucket = D.FlatGradBucket(self.model.parameters())
         self.graphs = None
+        self.redone = False   # did the last step fall back to the conservative schedule?
+        self.n_redone = 0     # ... and how many steps did so far
         if n_slots:
             from .episode_graph import EpisodeGraphs
             self.rows = torch.zeros(n_slots, self.bucket.store.numel(), device=self.bucket.store.device)
@@ -42,6 +44,7 @@ class DPTrainer:
             if bad or overflow:
                 total = self._eager_pass(episodes, logger, conservative=True)
                 self.redone = True
+                self.n_redone += 1
             else:
                 torch.sum(self.rows, 0, out=self.bucket.store)
         else:
