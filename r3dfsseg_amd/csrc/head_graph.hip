@@ -240,22 +240,28 @@ __global__ void r3d_graph_normalize_kernel(const int* __restrict__ row_ptr, cons
 //    49 -> 13 (adjoint) after 150 training steps.
 //    q = M p by recurrence, q_new = M r + (M W) mu + beta q: the SpMV gathers ONE float4 per entry (r), not two.
 //
-//    Three launches per iteration, no grid barrier, no host sync, fixed summation orders:
-//      R (1 workgroup)    reduce the per-workgroup partials, mu = E^-1 (t - t2), rz, beta, convergence
+//    Two launches per iteration, no grid barrier, no host sync, fixed summation orders:
 //      S (1 row per wave) p = r + u mu[agg] + beta p ; q = M r + (M W) mu + beta q ; partial <p,q>
-//      U (128 rows / wg)  alpha = rz / <p,q> ; x += alpha p ; r -= alpha q ; partial rr, W^T r, (M W)^T r
+//      U (256 rows / wg)  alpha = rz / <p,q> ; x += alpha p ; r -= alpha q ; partial rr, W^T r, (M W)^T r ;
+//                         the workgroup that delivers its partials LAST (ticket counter) reduces them: mu = E^-1 (t - t2),
+//                         rz, beta, convergence test -- the step that was a one-workgroup launch of its own (R) at first:
+//                         every launch on this dependent chain costs ~3 us of dispatch plus a ~2 us memory hop between
+//                         XCDs (measured: R 7.5 us, U 7.5 us, S 6.4 us per iteration as three launches)
 //    Why not one persistent kernel with a grid barrier: measured on MI355X (tools/probe/grid_barrier.hip) a
 //    device-wide barrier whose workgroups exchange data needs agent-scope release/acquire fences, i.e. an L2
 //    write-back + invalidate per workgroup, and costs 3 us at 32 workgroups, 7 us at 128 and 13 us at 256.
 // ---------------------------------------------------------------------------
 #define HG_MAX_ITER 1022
 #define HG_M 64                 // aggregates = coarse dimensions (one per lane)
-#define HG_UROWS 128            // rows per workgroup of the vector kernels (U, init)
+#define HG_UROWS 256            // rows per workgroup of the vector kernels (U, init): one per thread
+#define HG_EBLOCKS 16           // workgroups (= partial matrices) of the E = W^T M W accumulation, two waves each
 #define HG_PART (4 + 2 * HG_M * HG_NC)  // floats of one workgroup's partial: rr[4], t[HG_M][4], t2[HG_M][4]
 static_assert(HG_M == 64 && HG_M * HG_NC == 256, "the CG kernels map (aggregate, column) onto 256 threads, aggregate = lane");
 struct CgState {            // device memory
-  int done;                 // set by R once every column has converged; S / U / later R launches return at once
+  int done;                 // set once every column has converged; later S / U launches return at once
   int iters;                // iterations performed when `done` was set (or so far)
+  unsigned ticket;          // workgroups of the vector kernels that have delivered their partials (zeroed per solve)
+  int pad_;
   float bb[HG_NC];          // ||b||^2
   float rz[HG_NC];          // <r, z> of the current iteration
   float beta[HG_NC];
@@ -282,9 +288,17 @@ static __device__ __forceinline__ float4 block_sum4(float4 v, float4* sm /*[4]*/
 
 static __device__ __forceinline__ float4 reduce_partials(const float4* part, int nblk, float4* sm) {
   float4 a = f4_zero();
-  for (int q = threadIdx.x; q < nblk; q += blockDim.x) {
-    const float4 p = part[q];
-    a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+  for (int q0 = threadIdx.x; q0 < nblk; q0 += 8 * 256) {  // 8 loads in flight per trip (blockDim.x == 256), fixed add order
+    float4 p[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = q0 + 256 * u;
+      const bool ok = q < nblk;
+      p[u] = part[min(q, nblk - 1)];
+      p[u].x = r3d_keep(p[u].x, ok); p[u].y = r3d_keep(p[u].y, ok); p[u].z = r3d_keep(p[u].z, ok); p[u].w = r3d_keep(p[u].w, ok);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a.x += p[u].x; a.y += p[u].y; a.z += p[u].z; a.w += p[u].w; }
   }
   return block_sum4(a, sm);
 }
@@ -306,10 +320,26 @@ __global__ __launch_bounds__(256) void r3d_cg_aggregate_kernel(const float* __re
   const int n = min(*n_dev, n_cap);
   const int n_proto = max(1, min(*n_proto_dev, n));
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int e = threadIdx.x; e < HG_M * D; e += 256) {
-    const int sd = e / D, c = e - sd * D;
-    const int src = (int)(((long)sd * (n_proto - 1)) / (HG_M - 1));
-    seeds[sd * pitch + c] = nodes[(long)src * ldn + c];
+  // seed rows -> LDS: 16 seeds per pass, thread = (seed, 16-float4 stripe): up to 4 independent float4 loads per thread
+  // per pass are in flight together (a one-load-per-trip loop is a chain of 48 memory round trips: measured 30 us)
+  {
+    const int D4 = D >> 2;  // D % 4 == 0 (checked by the entry point through ldn / float4 rows)
+    for (int s0 = 0; s0 < HG_M; s0 += 16) {
+      const int sd = s0 + (threadIdx.x >> 4), l16 = threadIdx.x & 15;
+      const int src = (int)(((long)sd * (n_proto - 1)) / (HG_M - 1));
+      const float4* row = reinterpret_cast<const float4*>(nodes + (long)src * ldn);
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = row[min(l16 + 16 * u, D4 - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c4 = l16 + 16 * u;
+        if (c4 < D4) {
+          float* dst = seeds + sd * pitch + 4 * c4;
+          dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
+        }
+      }
+    }
   }
   __syncthreads();
   const int row0 = (blockIdx.x * 4 + w) * rows_per_wave;
@@ -321,10 +351,15 @@ __global__ __launch_bounds__(256) void r3d_cg_aggregate_kernel(const float* __re
     __builtin_amdgcn_wave_barrier();
     float d2 = 0.f;
     const float* sp = seeds + lane * pitch;
-#pragma unroll 8
-    for (int c = 0; c < D; ++c) {
-      const float df = xrow[c] - sp[c];
-      d2 = __builtin_fmaf(df, df, d2);
+    for (int c0 = 0; c0 < D; c0 += 16) {  // 16 + 16 LDS reads in flight, then the fma chain
+      float xs_[16], ss_[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) { xs_[c] = xrow[min(c0 + c, D - 1)]; ss_[c] = sp[min(c0 + c, D - 1)]; }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const float df = c0 + c < D ? xs_[c] - ss_[c] : 0.f;
+        d2 = __builtin_fmaf(df, df, d2);
+      }
     }
     // arg-min over the lanes on 64-bit keys (distance bits are order preserving for non-negative floats)
     unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)lane;
@@ -366,9 +401,12 @@ __global__ __launch_bounds__(256) void r3d_cg_mw_kernel(const int* __restrict__ 
           }
         }
         __builtin_amdgcn_wave_barrier();
-        for (int t = 0; t < cnt; ++t) {
-          const float2 pr = pairs[w][t];
-          acc += __float_as_int(pr.x) == lane ? pr.y : 0.f;
+        for (int t0 = 0; t0 < cnt; t0 += 16) {  // 16 broadcast reads in flight; entries beyond cnt are stale pairs: masked
+          float2 pr[16];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) pr[t] = pairs[w][t0 + t];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) acc += (__float_as_int(pr[t].x) == lane && t0 + t < cnt) ? pr[t].y : 0.f;
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -385,17 +423,24 @@ __global__ __launch_bounds__(256) void r3d_cg_mw_kernel(const int* __restrict__ 
 // coefficient is then always zero).
 __global__ __launch_bounds__(128) void r3d_cg_epart_kernel(const float* __restrict__ MW, const float* __restrict__ dinv,
                                                            const int* __restrict__ agg, const int* __restrict__ n_dev, int n_cap,
-                                                           float* __restrict__ Epart /* [blocks][HG_M][HG_M] */) {
-  __shared__ float Ew[2][HG_M][HG_M];  // 32 KB, two waves
+                                                           float* __restrict__ Epart /* [HG_EBLOCKS][HG_M][HG_M] */) {
+  __shared__ float Ew[2][HG_M][HG_M];  // one accumulator matrix per wave (lane = column: conflict free), 32 KB
   const int n = min(*n_dev, n_cap);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int a = 0; a < HG_M; ++a) Ew[w][a][lane] = 0.f;
-  const int row0 = blockIdx.x * HG_UROWS;
-  for (int k = w; k < HG_UROWS; k += 2) {
-    const int i = row0 + k;
-    if (i >= n) break;
-    const int a = agg[i];
-    Ew[w][a][lane] += MW[(long)i * HG_M + lane] / dinv[i];
+  // rows are dealt to the 2 * HG_EBLOCKS waves in a fixed pattern; 8 rows of loads in flight per trip
+  const int stride = 2 * HG_EBLOCKS;
+  for (int i0 = blockIdx.x * 2 + w; i0 < n; i0 += 8 * stride) {
+    float m[8], u[8];
+    int a[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int i = min(i0 + t * stride, n - 1);
+      m[t] = MW[(long)i * HG_M + lane]; u[t] = 1.f / dinv[i]; a[t] = agg[i];
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      if (i0 + t * stride < n) Ew[w][a[t]][lane] += m[t] * u[t];
   }
   __syncthreads();
   float* out = Epart + (long)blockIdx.x * HG_M * HG_M;
@@ -405,96 +450,208 @@ __global__ __launch_bounds__(128) void r3d_cg_epart_kernel(const float* __restri
   }
 }
 
-__global__ __launch_bounds__(1024) void r3d_cg_einv_kernel(const float* __restrict__ Epart, int nblk, double* __restrict__ Einv) {
-  __shared__ double A[HG_M][HG_M + 1];
-  __shared__ double B[HG_M][HG_M + 1];
-  __shared__ double colk[HG_M];
+// E^-1 in fp64 by Gauss-Jordan elimination on [E | I].  Thread (row = tid >> 4, column group = 4 * (tid & 15)) keeps its
+// 4 + 4 entries in registers for the whole elimination; per step the owners of pivot row k and of column k publish
+// them through double-buffered LDS, so a step costs ONE workgroup barrier.
+__global__ __launch_bounds__(1024) void r3d_cg_einv_kernel(const float* __restrict__ Epart, double* __restrict__ Einv) {
+  __shared__ double S0[HG_M][HG_M + 1];
+  __shared__ double prow[2][2 * HG_M];  // pivot row of [A | B], already scaled by 1 / pivot
+  __shared__ double pcol[2][HG_M];      // column k of A
   const int tid = threadIdx.x;
-  for (int e = tid; e < HG_M * HG_M; e += 1024) {
-    double s = 0.0;
-    for (int q = 0; q < nblk; ++q) s += (double)Epart[(long)q * HG_M * HG_M + e];
-    A[e >> 6][e & 63] = s;
-  }
-  __syncthreads();
-  for (int e = tid; e < HG_M * HG_M; e += 1024) {
-    const int a = e >> 6, b = e & 63;
-    double v = 0.5 * (A[a][b] + A[b][a]);
-    B[a][b] = v;
-  }
-  __syncthreads();
-  for (int e = tid; e < HG_M * HG_M; e += 1024) {
-    const int a = e >> 6, b = e & 63;
-    double v = B[a][b];
-    if (a == b && !(v > 0.0)) v = 1.0;  // empty aggregate
-    A[a][b] = v;
-    B[a][b] = a == b ? 1.0 : 0.0;
-  }
-  __syncthreads();
-  // Gauss-Jordan on [A | B]: thread (row = tid >> 4, 4-column group = tid & 15) x 2 matrices
   const int row = tid >> 4, cg = (tid & 15) * 4;
-  for (int k = 0; k < HG_M; ++k) {
-    if (tid < HG_M) colk[tid] = A[tid][k];
-    __syncthreads();
-    const double piv = 1.0 / colk[k];
-    const double f = row == k ? 0.0 : colk[row] * piv;
-    double ak[4], bk[4];
+  // sum of the partial matrices (fixed order), symmetrised through LDS
+  double a[4], b[4];
+  {
+    float v[HG_EBLOCKS][4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { ak[c] = A[k][cg + c]; bk[c] = B[k][cg + c]; }
-    __syncthreads();
+    for (int q = 0; q < HG_EBLOCKS; ++q) {
+      const float4 t = *reinterpret_cast<const float4*>(Epart + (long)q * HG_M * HG_M + row * HG_M + cg);
+      v[q][0] = t.x; v[q][1] = t.y; v[q][2] = t.z; v[q][3] = t.w;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double s = 0.0;
+#pragma unroll
+      for (int q = 0; q < HG_EBLOCKS; ++q) s += (double)v[q][c];
+      S0[row][cg + c] = s;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double v = 0.5 * (S0[row][cg + c] + S0[cg + c][row]);
+    if (row == cg + c && !(v > 0.0)) v = 1.0;  // empty aggregate: zero row and column, unit diagonal
+    a[c] = v;
+    b[c] = row == cg + c ? 1.0 : 0.0;
+  }
+  // owners of pivot row k (16 threads of one wave) and of column k (the threads whose column group holds k) publish
+  auto publish = [&](int k, int buf) {
+    const int kc = k & 3;
+    const double sel = kc == 0 ? a[0] : kc == 1 ? a[1] : kc == 2 ? a[2] : a[3];
+    if (row == k) {
+      const double piv = 1.0 / __shfl(sel, (k * 16 + (k >> 2)) & 63, 64);  // A[k][k] sits in the row's thread of group k / 4
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { prow[buf][cg + c] = a[c] * piv; prow[buf][HG_M + cg + c] = b[c] * piv; }
+    }
+    if (cg == (k & ~3)) pcol[buf][row] = sel;
+  };
+  publish(0, 0);
+  __syncthreads();
+  for (int k = 0; k < HG_M; ++k) {
+    const int buf = k & 1;
+    double pa[4], pb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { pa[c] = prow[buf][cg + c]; pb[c] = prow[buf][HG_M + cg + c]; }
     if (row == k) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) { A[k][cg + c] = ak[c] * piv; B[k][cg + c] = bk[c] * piv; }
+      for (int c = 0; c < 4; ++c) { a[c] = pa[c]; b[c] = pb[c]; }
     } else {
+      const double f = pcol[buf][row];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) { A[row][cg + c] -= f * ak[c]; B[row][cg + c] -= f * bk[c]; }
+      for (int c = 0; c < 4; ++c) { a[c] -= f * pa[c]; b[c] -= f * pb[c]; }
     }
+    if (k + 1 < HG_M) publish(k + 1, buf ^ 1);
     __syncthreads();
   }
-  for (int e = tid; e < HG_M * HG_M; e += 1024) {
-    const int a = e >> 6, b = e & 63;
-    Einv[e] = 0.5 * (B[a][b] + B[b][a]);
-  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 4; ++c) S0[row][cg + c] = b[c];
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 4; ++c) Einv[row * HG_M + cg + c] = 0.5 * (S0[row][cg + c] + S0[cg + c][row]);
 }
 
 // ---- 5d. per-workgroup partials of a residual block: rr, t = W^T r, t2 = (M W)^T r.
-// rs / us / ag: this workgroup's HG_UROWS rows of r, u = D^1/2, aggregate (LDS).  Thread (a = tid & 63, c = tid >> 6)
-// owns t[a][c] and t2[a][c] and walks the rows in order (deterministic); M W rows are read as coalesced 256-B lines.
+// rs / us / ag: this workgroup's HG_UROWS = 256 rows of r, u = D^1/2, aggregate (LDS).  Wave w owns rows 64 w .. 64 w + 63,
+// lane a owns aggregate a for all four columns; the wave's 64 values of column a of M W sit in REGISTERS, loaded by the
+// caller before anything else in the kernel (64 independent loads in flight: one memory round trip instead of a walk
+// -- a kernel of 18 workgroups on a dependent chain is pure latency: measured 8-15 us per launch for per-row / LDS-tile
+// walks against ~3 us).  The four waves' partials meet in LDS and are added in wave order (deterministic).
+static __device__ __forceinline__ void cg_load_mw_column(const float* __restrict__ MW, int row0, int n_cap, float (&m)[64]) {
+  const int a = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // rows < n_cap exist and rows in [n, n_cap) are zero (r3d_cg_mw_kernel); beyond n_cap the index is clamped
+#pragma unroll
+  for (int k = 0; k < 64; ++k) m[k] = MW[(long)min(row0 + 64 * w + k, n_cap - 1) * HG_M + a];
+}
+
 static __device__ __forceinline__ void cg_block_partials(const float4* rs, const float* us, const int* ag, int row0, int n,
-                                                         const float* __restrict__ MW, bool with_t2, float* __restrict__ part,
-                                                         float4* sm) {
-  const int a = threadIdx.x & 63, c = threadIdx.x >> 6;
-  float t = 0.f, t2 = 0.f;
-  const float* rsf = reinterpret_cast<const float*>(rs);
-  const int rows = min(HG_UROWS, n - row0);
-  const float* mw = MW + (long)row0 * HG_M + a;
-  int k = 0;
-  for (; k + 8 <= rows; k += 8) {
-    float m[8];
+                                                         const float (&m)[64], bool with_t2, float* __restrict__ part,
+                                                         float4* sm, float4* wpart /* [2][4][HG_M] */) {
+  const int a = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float4 t = f4_zero(), t2 = f4_zero();
+  // rows >= n carry r = 0 and u = 0 in LDS (the callers zero them), so no row guard is needed
+#pragma unroll 16
+  for (int k = 0; k < 64; ++k) {
+    const float4 rv = rs[64 * w + k];
+    const float uw = ag[64 * w + k] == a ? us[64 * w + k] : 0.f;
+    t.x = __builtin_fmaf(uw, rv.x, t.x); t.y = __builtin_fmaf(uw, rv.y, t.y);
+    t.z = __builtin_fmaf(uw, rv.z, t.z); t.w = __builtin_fmaf(uw, rv.w, t.w);
     if (with_t2) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) m[u] = mw[(long)(k + u) * HG_M];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const float rv = rsf[4 * (k + u) + c];
-      t += ag[k + u] == a ? us[k + u] * rv : 0.f;
-      if (with_t2) t2 = __builtin_fmaf(m[u], rv, t2);
+      t2.x = __builtin_fmaf(m[k], rv.x, t2.x); t2.y = __builtin_fmaf(m[k], rv.y, t2.y);
+      t2.z = __builtin_fmaf(m[k], rv.z, t2.z); t2.w = __builtin_fmaf(m[k], rv.w, t2.w);
     }
   }
-  for (; k < rows; ++k) {
-    const float rv = rsf[4 * k + c];
-    t += ag[k] == a ? us[k] * rv : 0.f;
-    if (with_t2) t2 = __builtin_fmaf(mw[(long)k * HG_M], rv, t2);
-  }
+  wpart[w * HG_M + a] = t;
+  wpart[4 * HG_M + w * HG_M + a] = t2;
   float4 sq = f4_zero();
-  if ((int)threadIdx.x < rows) {
+  if ((int)threadIdx.x < n - row0) {
     const float4 v = rs[threadIdx.x];
     sq = make_float4(v.x * v.x, v.y * v.y, v.z * v.z, v.w * v.w);
   }
-  sq = block_sum4(sq, sm);
+  sq = block_sum4(sq, sm);  // its barriers also publish wpart
   if (threadIdx.x == 0) *reinterpret_cast<float4*>(part) = sq;
-  part[4 + a * HG_NC + c] = t;
-  part[4 + HG_M * HG_NC + a * HG_NC + c] = t2;
+  {
+    const int c = w;  // thread (a, c = w) adds the four waves' partials of entry [a][c]
+    float st = 0.f, st2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      st += f4_get(wpart[q * HG_M + a], c);
+      st2 += f4_get(wpart[4 * HG_M + q * HG_M + a], c);
+    }
+    part[4 + a * HG_NC + c] = st;
+    part[4 + HG_M * HG_NC + a * HG_NC + c] = st2;
+  }
+}
+
+// The reduction step between U and S, run by the workgroup that delivered its partials last.
+// phase 0: c0 = E^-1 W^T b, bb (partials of b itself); phase 1: mu, rz, beta, convergence test before iteration `it`.
+// ev: column a = tid & 63 of E^-1 in registers (loaded by the caller at kernel start).
+static __device__ __forceinline__ void cg_reduce_step(const float* __restrict__ part, int nblk, const double (&ev)[HG_M],
+                                                      int phase, int it, float tol2, CgState* __restrict__ cg, double* d_s,
+                                                      float* t_s, float* rr_s) {
+  const int a = threadIdx.x & 63, c = threadIdx.x >> 6;
+  const float rz_old = cg->rz[c];
+  const float bbv = cg->bb[threadIdx.x & 3];
+  float t = 0.f, t2 = 0.f, rrp = 0.f;
+  const float* pa = part + 4 + a * HG_NC + c;
+  for (int b0 = 0; b0 < nblk; b0 += 16) {  // 16 workgroups' partials in flight per trip; the add order stays fixed
+    float tv[16], t2v[16], rv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const long b = min(b0 + u, nblk - 1);
+      const bool ok = b0 + u < nblk;
+      tv[u] = r3d_keep(pa[b * HG_PART], ok);
+      t2v[u] = r3d_keep(pa[b * HG_PART + HG_M * HG_NC], ok);
+      rv[u] = r3d_keep(part[b * HG_PART + (threadIdx.x & 3)], ok);
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { t += tv[u]; t2 += t2v[u]; rrp += rv[u]; }
+  }
+  if (threadIdx.x < HG_NC) rr_s[threadIdx.x] = rrp;
+  d_s[a * HG_NC + c] = phase == 0 ? (double)t : (double)t - (double)t2;
+  t_s[a * HG_NC + c] = t;
+  __syncthreads();
+  if (phase == 1) {
+    const bool conv = rr_s[0] <= tol2 * __shfl(bbv, 0) && rr_s[1] <= tol2 * __shfl(bbv, 1) &&
+                      rr_s[2] <= tol2 * __shfl(bbv, 2) && rr_s[3] <= tol2 * __shfl(bbv, 3);
+    if (conv) {  // uniform over the workgroup
+      if (threadIdx.x == 0) { cg->done = 1; cg->iters = it; }
+      return;
+    }
+  }
+  double mm = 0.0;
+#pragma unroll
+  for (int b = 0; b < HG_M; ++b) mm += ev[b] * d_s[b * HG_NC + c];
+  const float mu = (float)mm;
+  float tm = t_s[a * HG_NC + c] * mu;
+  tm = r3d_wave_sum(tm);  // one wave = one column c
+  cg->mu[a * HG_NC + c] = mu;
+  if (a == 0) {
+    if (phase == 0) {
+      cg->bb[c] = rr_s[c];
+    } else {
+      const float rz = rr_s[c] + tm;
+      cg->beta[c] = (it > 0 && rz_old > 0.f) ? rz / rz_old : 0.f;
+      cg->rz[c] = rz;
+    }
+  }
+  if (threadIdx.x == 0) {
+    if (phase == 0) { cg->done = 0; cg->iters = 0; }
+    else cg->iters = it;
+  }
+}
+
+// Was this workgroup the last of its launch to deliver its partials?  Release / acquire at agent scope in thread 0 only
+// (the workgroup barrier in front has completed every thread's stores to the L2; the fence writes the L2 back and, on
+// the winner, invalidates it -- the XCDs' L2 caches are not coherent with each other).  Every launch that reaches this
+// point adds exactly `nblk` tickets, so "last" is ticket % nblk == nblk - 1 without resetting the counter in between.
+static __device__ __forceinline__ bool cg_delivered_last(CgState* __restrict__ cg, int nblk, int* flag) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned t = atomicAdd(&cg->ticket, 1u);
+    const int last = (t + 1u) % (unsigned)nblk == 0u;
+    if (last) __threadfence();
+    *flag = last;
+  }
+  __syncthreads();
+  return *flag != 0;
+}
+
+static __device__ __forceinline__ void cg_load_einv_column(const double* __restrict__ Einv, double (&ev)[HG_M]) {
+  const int a = threadIdx.x & 63;  // E^-1 is symmetric: column a read as row-strided, coalesced over the lanes
+#pragma unroll
+  for (int b = 0; b < HG_M; ++b) ev[b] = Einv[b * HG_M + a];
 }
 
 // mode 0: partials of b itself (rr = ||b||^2, t = W^T b).  mode 1: x0 = W c0, r0 = b - (M W) c0, p = q = 0, partials
@@ -504,17 +661,27 @@ __global__ __launch_bounds__(256) void r3d_cg_init_kernel(const float4* __restri
                                                           const int* __restrict__ n_dev, int n_cap, int mode,
                                                           float4* __restrict__ x, float4* __restrict__ r,
                                                           float4* __restrict__ p, float4* __restrict__ q,
-                                                          float* __restrict__ part, const CgState* __restrict__ cg) {
+                                                          float* __restrict__ part, const double* __restrict__ Einv, float tol2,
+                                                          CgState* __restrict__ cg) {
   __shared__ float4 sm[4];
   __shared__ float4 rs[HG_UROWS];
   __shared__ float us[HG_UROWS];
   __shared__ int ag[HG_UROWS];
   __shared__ float mu_s[HG_M * HG_NC];
-  const int n = min(*n_dev, n_cap);
+  __shared__ float4 wpart[2 * 4 * HG_M];
+  __shared__ double d_s[HG_M * HG_NC];
+  __shared__ float t_s[HG_M * HG_NC];
+  __shared__ float rr_s[HG_NC];
+  __shared__ int last_s;
   const int row0 = blockIdx.x * HG_UROWS;
+  float m[64];
+  double ev[HG_M];
+  cg_load_einv_column(Einv, ev);
+  if (mode == 1) cg_load_mw_column(MW, row0, n_cap, m);
+  const int n = min(*n_dev, n_cap);
   if (mode == 1) mu_s[threadIdx.x] = cg->mu[threadIdx.x];
   __syncthreads();
-  if ((int)threadIdx.x < HG_UROWS) {
+  {
     const int i = row0 + threadIdx.x;
     float4 rv = f4_zero();
     float u = 0.f;
@@ -524,12 +691,20 @@ __global__ __launch_bounds__(256) void r3d_cg_init_kernel(const float4* __restri
       a = agg[i];
       rv = B[i];
       if (mode == 1) {
-        const float* mw = MW + (long)i * HG_M;
+        const float4* mw4 = reinterpret_cast<const float4*>(MW + (long)i * HG_M);
         float4 s = f4_zero();
-        for (int b = 0; b < HG_M; ++b) {
-          const float m = mw[b];
-          s.x = __builtin_fmaf(m, mu_s[b * HG_NC + 0], s.x); s.y = __builtin_fmaf(m, mu_s[b * HG_NC + 1], s.y);
-          s.z = __builtin_fmaf(m, mu_s[b * HG_NC + 2], s.z); s.w = __builtin_fmaf(m, mu_s[b * HG_NC + 3], s.w);
+        float4 mv[HG_M / 4];
+#pragma unroll
+        for (int b4 = 0; b4 < HG_M / 4; ++b4) mv[b4] = mw4[b4];  // the whole row in flight
+#pragma unroll
+        for (int b4 = 0; b4 < HG_M / 4; ++b4) {
+          const float mm[4] = {mv[b4].x, mv[b4].y, mv[b4].z, mv[b4].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int b = 4 * b4 + e;
+            s.x = __builtin_fmaf(mm[e], mu_s[b * HG_NC + 0], s.x); s.y = __builtin_fmaf(mm[e], mu_s[b * HG_NC + 1], s.y);
+            s.z = __builtin_fmaf(mm[e], mu_s[b * HG_NC + 2], s.z); s.w = __builtin_fmaf(mm[e], mu_s[b * HG_NC + 3], s.w);
+          }
         }
         rv = make_float4(rv.x - s.x, rv.y - s.y, rv.z - s.z, rv.w - s.w);
         x[i] = make_float4(u * mu_s[a * HG_NC + 0], u * mu_s[a * HG_NC + 1], u * mu_s[a * HG_NC + 2], u * mu_s[a * HG_NC + 3]);
@@ -543,60 +718,8 @@ __global__ __launch_bounds__(256) void r3d_cg_init_kernel(const float4* __restri
     rs[threadIdx.x] = rv; us[threadIdx.x] = u; ag[threadIdx.x] = a;
   }
   __syncthreads();
-  cg_block_partials(rs, us, ag, row0, n, MW, mode == 1, part + (long)blockIdx.x * HG_PART, sm);
-}
-
-// R: the single-workgroup step between U and S.  phase 0: c0 = E^-1 W^T b, bb (before the init kernel);
-// phase 1: mu, rz, beta, convergence test of iteration `it` (it == max_iter: test only).
-__global__ __launch_bounds__(256) void r3d_cg_reduce_kernel(const float* __restrict__ part, int nblk, const double* __restrict__ Einv,
-                                                            int phase, int it, float tol2, CgState* __restrict__ cg) {
-  __shared__ double d_s[HG_M * HG_NC];
-  __shared__ float t_s[HG_M * HG_NC];
-  __shared__ float rr_s[HG_NC];
-  __shared__ float rz_s[HG_NC];
-  if (phase == 1 && cg->done) return;
-  const int a = threadIdx.x & 63, c = threadIdx.x >> 6;
-  float t = 0.f, t2 = 0.f;
-  for (int b = 0; b < nblk; ++b) {
-    t += part[(long)b * HG_PART + 4 + a * HG_NC + c];
-    t2 += part[(long)b * HG_PART + 4 + HG_M * HG_NC + a * HG_NC + c];
-  }
-  if (threadIdx.x < HG_NC) {
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(long)b * HG_PART + threadIdx.x];
-    rr_s[threadIdx.x] = s;
-  }
-  d_s[a * HG_NC + c] = phase == 0 ? (double)t : (double)t - (double)t2;
-  t_s[a * HG_NC + c] = t;
-  __syncthreads();
-  if (phase == 1) {
-    const float* bb = cg->bb;
-    const bool conv = rr_s[0] <= tol2 * bb[0] && rr_s[1] <= tol2 * bb[1] && rr_s[2] <= tol2 * bb[2] && rr_s[3] <= tol2 * bb[3];
-    if (conv) {  // uniform over the workgroup
-      if (threadIdx.x == 0) { cg->done = 1; cg->iters = it; }
-      return;
-    }
-  }
-  double m = 0.0;
-  for (int b = 0; b < HG_M; ++b) m += Einv[b * HG_M + a] * d_s[b * HG_NC + c];  // E^-1 is symmetric: coalesced over a
-  const float mu = (float)m;
-  float tm = t_s[a * HG_NC + c] * mu;
-  tm = r3d_wave_sum(tm);  // one wave = one column c
-  cg->mu[a * HG_NC + c] = mu;
-  if (a == 0) {
-    if (phase == 0) {
-      cg->bb[c] = rr_s[c];
-    } else {
-      const float rz = rr_s[c] + tm;
-      const float rz_old = cg->rz[c];
-      cg->beta[c] = (it > 0 && rz_old > 0.f) ? rz / rz_old : 0.f;
-      cg->rz[c] = rz;
-    }
-  }
-  if (threadIdx.x == 0) {
-    if (phase == 0) { cg->done = 0; cg->iters = 0; }
-    else cg->iters = it;
-  }
+  cg_block_partials(rs, us, ag, row0, n, m, mode == 1, part + (long)blockIdx.x * HG_PART, sm, wpart);
+  if (cg_delivered_last(cg, gridDim.x, &last_s)) cg_reduce_step(part, gridDim.x, ev, mode, 0, tol2, cg, d_s, t_s, rr_s);
 }
 
 // S: p = r + u mu[agg] + beta p ; q = (r - alpha S r) + (M W) mu + beta q ; partial <p, q>.
@@ -674,44 +797,59 @@ __global__ __launch_bounds__(256) void r3d_cg_spmv_kernel(
   }
 }
 
-// U: alpha = rz / <p,q> ; x += alpha p ; r -= alpha q ; partials of the new residual
+// U: alpha = rz / <p,q> ; x += alpha p ; r -= alpha q ; partials of the new residual.
+// 18 workgroups at workload S: pure latency, so every load that does not depend on alpha is issued first.
 __global__ __launch_bounds__(256) void r3d_cg_update_kernel(
     const int* __restrict__ n_dev, int n_cap, int it, int nblk_pq, const float* __restrict__ dinv, const int* __restrict__ agg,
     const float* __restrict__ MW, const float4* __restrict__ p, const float4* __restrict__ q, float4* __restrict__ x,
-    float4* __restrict__ r, const float4* __restrict__ part_pq, float* __restrict__ part, const CgState* __restrict__ cg) {
+    float4* __restrict__ r, const float4* __restrict__ part_pq, float* __restrict__ part, const double* __restrict__ Einv,
+    float tol2, CgState* __restrict__ cg) {
   __shared__ float4 sm[4];
   __shared__ float4 rs[HG_UROWS];
   __shared__ float us[HG_UROWS];
   __shared__ int ag[HG_UROWS];
-  if (cg->done) return;
+  __shared__ float4 wpart[2 * 4 * HG_M];
+  __shared__ double d_s[HG_M * HG_NC];
+  __shared__ float t_s[HG_M * HG_NC];
+  __shared__ float rr_s[HG_NC];
+  __shared__ int last_s;
+  const int row0 = blockIdx.x * HG_UROWS;
+  const int i = row0 + threadIdx.x;
+  const int ic = min(i, n_cap - 1);
+  float m[64];
+  double ev[HG_M];
+  cg_load_mw_column(MW, row0, n_cap, m);
+  cg_load_einv_column(Einv, ev);
+  const float4 pi = p[ic], qi = q[ic];
+  float4 xi = x[ic], ri = r[ic];
+  const float dv = dinv[ic];
+  const int av = agg[ic];
+  const int done = cg->done;
+  const float4 rz = *reinterpret_cast<const float4*>(cg->rz);
   const int n = min(*n_dev, n_cap);
   const float4 pq = reduce_partials(part_pq, nblk_pq, sm);
-  const float* rz = cg->rz;
+  if (done) return;  // uniform
   float4 al;
-  al.x = pq.x > 0.f ? rz[0] / pq.x : 0.f;
-  al.y = pq.y > 0.f ? rz[1] / pq.y : 0.f;
-  al.z = pq.z > 0.f ? rz[2] / pq.z : 0.f;
-  al.w = pq.w > 0.f ? rz[3] / pq.w : 0.f;
-  const int row0 = blockIdx.x * HG_UROWS;
-  if ((int)threadIdx.x < HG_UROWS) {
-    const int i = row0 + threadIdx.x;
-    float4 ri = f4_zero();
-    float u = 0.f;
-    int a = 0;
-    if (i < n) {
-      const float4 pi = p[i], qi = q[i];
-      float4 xi = x[i];
-      ri = r[i];
-      xi.x += al.x * pi.x; xi.y += al.y * pi.y; xi.z += al.z * pi.z; xi.w += al.w * pi.w;
-      ri.x -= al.x * qi.x; ri.y -= al.y * qi.y; ri.z -= al.z * qi.z; ri.w -= al.w * qi.w;
-      x[i] = xi; r[i] = ri;
-      u = 1.f / dinv[i];
-      a = agg[i];
-    }
-    rs[threadIdx.x] = ri; us[threadIdx.x] = u; ag[threadIdx.x] = a;
+  al.x = pq.x > 0.f ? rz.x / pq.x : 0.f;
+  al.y = pq.y > 0.f ? rz.y / pq.y : 0.f;
+  al.z = pq.z > 0.f ? rz.z / pq.z : 0.f;
+  al.w = pq.w > 0.f ? rz.w / pq.w : 0.f;
+  float u = 0.f;
+  int a = 0;
+  if (i < n) {
+    xi.x += al.x * pi.x; xi.y += al.y * pi.y; xi.z += al.z * pi.z; xi.w += al.w * pi.w;
+    ri.x -= al.x * qi.x; ri.y -= al.y * qi.y; ri.z -= al.z * qi.z; ri.w -= al.w * qi.w;
+    x[i] = xi; r[i] = ri;
+    u = 1.f / dv;
+    a = av;
+  } else {
+    ri = f4_zero();
   }
+  rs[threadIdx.x] = ri; us[threadIdx.x] = u; ag[threadIdx.x] = a;
   __syncthreads();
-  cg_block_partials(rs, us, ag, row0, n, MW, true, part + (long)blockIdx.x * HG_PART, sm);
+  cg_block_partials(rs, us, ag, row0, n, m, true, part + (long)blockIdx.x * HG_PART, sm, wpart);
+  // the convergence test / coefficients of iteration it + 1
+  if (cg_delivered_last(cg, gridDim.x, &last_s)) cg_reduce_step(part, gridDim.x, ev, 1, it + 1, tol2, cg, d_s, t_s, rr_s);
 }
 
 // ---------------------------------------------------------------------------
@@ -787,7 +925,7 @@ static LpWs lp_carve(int32_t* ws, int n_cap, int kp1) {
   L.agg = wp; wp += n_cap;
   align4();
   L.MW = (float*)wp; wp += (long)n_cap * HG_M;
-  L.Epart = (float*)wp; wp += hg_vblocks(n_cap) * HG_M * HG_M;
+  L.Epart = (float*)wp; wp += (long)HG_EBLOCKS * HG_M * HG_M;
   align4();
   L.Einv = (double*)wp; wp += 2L * HG_M * HG_M;
   L.part = (float*)wp; wp += hg_vblocks(n_cap) * HG_PART;
@@ -828,8 +966,8 @@ static int lp_coarse_space(const LpWs& L, const float* nodes, long ldn, int D, c
   hipLaunchKernelGGL(r3d_cg_mw_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, L.row_ptr, L.col, L.val, L.dinv, L.agg, n_dev,
                      n_cap, alpha, 1, L.MW);
   const int nblk_v = (int)hg_vblocks(n_cap);
-  hipLaunchKernelGGL(r3d_cg_epart_kernel, dim3(nblk_v), dim3(128), 0, st, L.MW, L.dinv, L.agg, n_dev, n_cap, L.Epart);
-  hipLaunchKernelGGL(r3d_cg_einv_kernel, dim3(1), dim3(1024), 0, st, L.Epart, nblk_v, L.Einv);
+  hipLaunchKernelGGL(r3d_cg_epart_kernel, dim3(HG_EBLOCKS), dim3(128), 0, st, L.MW, L.dinv, L.agg, n_dev, n_cap, L.Epart);
+  hipLaunchKernelGGL(r3d_cg_einv_kernel, dim3(1), dim3(1024), 0, st, L.Epart, L.Einv);
   return R3D_OK;
 }
 
@@ -843,18 +981,16 @@ static int lp_solve(const LpWs& L, const float* RHS, const int32_t* n_dev, int n
   R3D_REQUIRE(nblk_s <= HG_MAX_PART, "r3d_label_propagate: n_cap too large");
   float4* x = (float4*)X;
   const float tol2 = tol * tol;
-  hipLaunchKernelGGL(r3d_cg_init_kernel, dim3(nblk_v), dim3(256), 0, st, (const float4*)RHS, L.dinv, L.agg, L.MW, n_dev, n_cap, 0,
-                     x, L.r, L.p, L.q, L.part, L.cg);
-  hipLaunchKernelGGL(r3d_cg_reduce_kernel, dim3(1), dim3(256), 0, st, L.part, nblk_v, L.Einv, 0, 0, tol2, L.cg);
-  hipLaunchKernelGGL(r3d_cg_init_kernel, dim3(nblk_v), dim3(256), 0, st, (const float4*)RHS, L.dinv, L.agg, L.MW, n_dev, n_cap, 1,
-                     x, L.r, L.p, L.q, L.part, L.cg);
-  for (int it = 0; it <= max_iter; ++it) {
-    hipLaunchKernelGGL(r3d_cg_reduce_kernel, dim3(1), dim3(256), 0, st, L.part, nblk_v, L.Einv, 1, it, tol2, L.cg);
-    if (it == max_iter) break;  // the last launch only tests the residual the last update left
+  r3d_zero_words(&L.cg->ticket, 1, st);
+  // partials of b -> (last workgroup) c0 = E^-1 W^T b ; x0 = W c0, r0 = b - (M W) c0 -> (last workgroup) mu, rz of iteration 0
+  for (int mode = 0; mode < 2; ++mode)
+    hipLaunchKernelGGL(r3d_cg_init_kernel, dim3(nblk_v), dim3(256), 0, st, (const float4*)RHS, L.dinv, L.agg, L.MW, n_dev, n_cap,
+                       mode, x, L.r, L.p, L.q, L.part, L.Einv, tol2, L.cg);
+  for (int it = 0; it < max_iter; ++it) {
     hipLaunchKernelGGL(r3d_cg_spmv_kernel, dim3(nblk_s), dim3(256), 0, st, L.row_ptr, L.col, L.val, L.dinv, L.agg, L.MW, n_dev,
                        n_cap, alpha, it, rpb, L.r, L.p, L.q, L.part_pq, L.cg);
     hipLaunchKernelGGL(r3d_cg_update_kernel, dim3(nblk_v), dim3(256), 0, st, n_dev, n_cap, it, nblk_s, L.dinv, L.agg, L.MW, L.p,
-                       L.q, x, L.r, L.part_pq, L.part, L.cg);
+                       L.q, x, L.r, L.part_pq, L.part, L.Einv, tol2, L.cg);
   }
   if (stats_out) r3d_copy_words(stats_out, &L.cg->done, 2, st);
   return R3D_OK;
@@ -867,7 +1003,7 @@ extern "C" int r3d_label_propagate(const float* nodes, long ldn, int D, const in
   R3D_REQUIRE(nodes && nbr && Y && n_dev && n_proto_dev && Z && ws, "r3d_label_propagate: null pointer");
   R3D_REQUIRE((ldn & 3) == 0 && ((uintptr_t)nodes & 15) == 0,
               "r3d_label_propagate: node rows are read as float4: ldn must be a multiple of 4 and nodes 16-byte aligned");
-  R3D_REQUIRE(n_cap > 0 && n_cap <= 32768 && D > 0 && D <= 256 && kp1 >= 2,
+  R3D_REQUIRE(n_cap > 0 && n_cap <= 32768 && D > 0 && D <= 256 && (D & 3) == 0 && kp1 >= 2,
               "r3d_label_propagate: unsupported n_cap=%d D=%d kp1=%d", n_cap, D, kp1);
   R3D_REQUIRE(max_iter > 0 && max_iter <= HG_MAX_ITER && sigma > 0.f, "r3d_label_propagate: bad solver parameters");
   R3D_REQUIRE(((uintptr_t)ws & 15) == 0 && ((uintptr_t)Y & 15) == 0 && ((uintptr_t)Z & 15) == 0,
@@ -1101,11 +1237,7 @@ extern "C" int r3d_graph_set_lp_budget(void* graph, void* graph_exec, int budget
     int it, on;
     if (kp.func == (void*)r3d_cg_spmv_kernel) { it = *(const int*)kp.kernelParams[9]; on = it < budget; }
     else if (kp.func == (void*)r3d_cg_update_kernel) { it = *(const int*)kp.kernelParams[2]; on = it < budget; }
-    else if (kp.func == (void*)r3d_cg_reduce_kernel) {
-      if (*(const int*)kp.kernelParams[3] == 0) continue;  // phase 0 belongs to the start-up of a solve
-      it = *(const int*)kp.kernelParams[4];
-      on = it <= budget;  // R(budget) tests the residual the last enabled update left
-    } else continue;
+    else continue;
     ++found;
     if (hipGraphNodeSetEnabled(ge, nodes[i], on ? 1u : 0u) != hipSuccess) { rc = R3D_ERR_LAUNCH; break; }
   }

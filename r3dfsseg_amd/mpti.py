@@ -122,7 +122,7 @@ class MPTI_SelfAtten(nn.Module):
             if ev.query():
                 conv, iters = int(host[0]), int(host[1])
                 if conv:
-                    self._lp_budget = min(self.lp_max_iter, max(12, iters + iters // 2 + 4))
+                    self._lp_budget = min(self.lp_max_iter, max(12, iters + iters // 3 + 4))
                 else:
                     self._lp_budget = min(self.lp_max_iter, self._lp_budget * 2)
                 self._lp_probe = None
