@@ -341,14 +341,21 @@ __global__ __launch_bounds__(256) void r3d_cg_aggregate_kernel(const float* __re
       }
     }
   }
-  __syncthreads();
   const int row0 = (blockIdx.x * 4 + w) * rows_per_wave;
+  // the wave's node rows are requested together, in front of the seed staging barrier's wait (rows_per_wave <= 4, D <= 256)
+  float xr[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      xr[k][u] = nodes[(long)min(row0 + min(k, rows_per_wave - 1), n - 1) * ldn + min(lane + 64 * u, D - 1)];
+  __syncthreads();
   for (int k = 0; k < rows_per_wave; ++k) {
     const int i = row0 + k;
     if (i >= n) break;  // uniform over the wave
-    for (int c = lane; c < D; c += 64) xrow[c] = nodes[(long)i * ldn + c];
-    // a wave executes in lockstep: its own LDS writes are visible to its own later reads (no workgroup barrier)
-    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (lane + 64 * u < D) xrow[lane + 64 * u] = k == 0 ? xr[0][u] : k == 1 ? xr[1][u] : k == 2 ? xr[2][u] : xr[3][u];
     float d2 = 0.f;
     const float* sp = seeds + lane * pitch;
     for (int c0 = 0; c0 < D; c0 += 16) {  // 16 + 16 LDS reads in flight, then the fma chain
@@ -667,12 +674,14 @@ __global__ __launch_bounds__(256) void r3d_cg_init_kernel(const float4* __restri
   __shared__ float4 rs[HG_UROWS];
   __shared__ float us[HG_UROWS];
   __shared__ int ag[HG_UROWS];
-  __shared__ float mu_s[HG_M * HG_NC];
+  __shared__ __attribute__((aligned(16))) float mu_s[HG_M * HG_NC];
   __shared__ float4 wpart[2 * 4 * HG_M];
   __shared__ double d_s[HG_M * HG_NC];
   __shared__ float t_s[HG_M * HG_NC];
   __shared__ float rr_s[HG_NC];
   __shared__ int last_s;
+  __shared__ float tile_s[4 * 32 * 65];
+  __shared__ float4 dot_s[HG_UROWS];
   const int row0 = blockIdx.x * HG_UROWS;
   float m[64];
   double ev[HG_M];
@@ -680,6 +689,34 @@ __global__ __launch_bounds__(256) void r3d_cg_init_kernel(const float4* __restri
   if (mode == 1) cg_load_mw_column(MW, row0, n_cap, m);
   const int n = min(*n_dev, n_cap);
   if (mode == 1) mu_s[threadIdx.x] = cg->mu[threadIdx.x];
+  __syncthreads();
+  if (mode == 1) {
+    // dot_s[row] = (M W)[row] . c0: the wave's 64 rows x 64 columns sit in registers with the COLUMN on the lane; two
+    // half tiles of 32 rows go through LDS (pitch 65: conflict free both ways), lane l then owns row l & 31 over the
+    // column half l >> 5, and one shuffle joins the halves.  (A thread-per-row walk over global memory reads 64 cache
+    // lines per load instruction: measured 27 us per launch.)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float* tl = tile_s + w * (32 * 65);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int k = 0; k < 32; ++k) tl[k * 65 + lane] = m[32 * h + k];
+      __builtin_amdgcn_wave_barrier();
+      const int rk = lane & 31, a0 = 32 * (lane >> 5);
+      float4 acc = f4_zero();
+#pragma unroll 8
+      for (int a = 0; a < 32; ++a) {
+        const float mv = tl[rk * 65 + a0 + a];
+        const float4 cv = *reinterpret_cast<const float4*>(&mu_s[(a0 + a) * HG_NC]);
+        acc.x = __builtin_fmaf(mv, cv.x, acc.x); acc.y = __builtin_fmaf(mv, cv.y, acc.y);
+        acc.z = __builtin_fmaf(mv, cv.z, acc.z); acc.w = __builtin_fmaf(mv, cv.w, acc.w);
+      }
+      acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32);
+      acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
+      if (lane < 32) dot_s[64 * w + 32 * h + lane] = acc;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
   __syncthreads();
   {
     const int i = row0 + threadIdx.x;
@@ -691,21 +728,7 @@ __global__ __launch_bounds__(256) void r3d_cg_init_kernel(const float4* __restri
       a = agg[i];
       rv = B[i];
       if (mode == 1) {
-        const float4* mw4 = reinterpret_cast<const float4*>(MW + (long)i * HG_M);
-        float4 s = f4_zero();
-        float4 mv[HG_M / 4];
-#pragma unroll
-        for (int b4 = 0; b4 < HG_M / 4; ++b4) mv[b4] = mw4[b4];  // the whole row in flight
-#pragma unroll
-        for (int b4 = 0; b4 < HG_M / 4; ++b4) {
-          const float mm[4] = {mv[b4].x, mv[b4].y, mv[b4].z, mv[b4].w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int b = 4 * b4 + e;
-            s.x = __builtin_fmaf(mm[e], mu_s[b * HG_NC + 0], s.x); s.y = __builtin_fmaf(mm[e], mu_s[b * HG_NC + 1], s.y);
-            s.z = __builtin_fmaf(mm[e], mu_s[b * HG_NC + 2], s.z); s.w = __builtin_fmaf(mm[e], mu_s[b * HG_NC + 3], s.w);
-          }
-        }
+        const float4 s = dot_s[threadIdx.x];  // (M W)[i] . c0, computed by the wave below
         rv = make_float4(rv.x - s.x, rv.y - s.y, rv.z - s.z, rv.w - s.w);
         x[i] = make_float4(u * mu_s[a * HG_NC + 0], u * mu_s[a * HG_NC + 1], u * mu_s[a * HG_NC + 2], u * mu_s[a * HG_NC + 3]);
         r[i] = rv;

@@ -199,7 +199,7 @@ def test_config2_full_size_training_episode_gradients():
             assert _close(got, f_pm.detach()) <= TOL, ("features of pass %d" % p, _close(got, f_pm.detach()))
             f_pm.backward(dfeat.to(dtype))
             del f, f_pm
-        return {k_: v.grad.double() for k_, v in sde.items() if v.dtype.is_floating_point and v.requires_grad}
+        return {k_: v.grad.double() for k_, v in sde.items() if v.dtype.is_floating_point and v.requires_grad and v.grad is not None}
 
     g64 = oracle_grads(torch.float64)
     g32 = oracle_grads(torch.float32)
