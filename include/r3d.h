@@ -173,11 +173,16 @@ int r3d_edgeconv_train_fwd_minmax(const float* PQ, const int32_t* idx, const flo
 int r3d_edge_select(float* zmax /*in: max, out: selected z*/, const float* zmin, int32_t* argmax /*in/out*/,
                     const int32_t* argmin, const float* s2, const float* t2, long M, float* out, long ldo,
                     void* stream);
+/* reverse neighbour list (for every point the edges that name it, ascending): rev_ws = r3d_edge_reverse_ws_words int32
+ * words.  The backward gathers along it instead of scattering with float atomics: deterministic gradients. */
+long r3d_edge_reverse_ws_words(int B, int N, int K);
+int r3d_edge_reverse(const int32_t* idx, int B, int N, int K, int32_t* rev_ws, void* stream);
 int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float* s1, const float* t1, const float* mean1,
                      const float* invstd1, const float* W2, const float* s2, const float* t2, const float* mean2,
                      const float* invstd2, const float* bn2_sums, const float* dout, long lddo, const int32_t* argmax,
-                     int B, int N, int K, float* DY1 /*(B*N*K,64) scratch*/, float* dW2, float* bn1_sums, float* dPQ,
-                     float* ws, void* stream);
+                     int B, int N, int K, float* DY1 /*(B*N*K,64) scratch*/, float* BE /*(B*N,128) scratch*/,
+                     const int32_t* rev_ws /* r3d_edge_reverse of the same idx */, float* dW2, float* bn1_sums,
+                     float* dPQ, float* ws, void* stream);
 
 /* attention with dropout on the weights (attention.py:45) and flash-style backward */
 /* effective dropout seed = seed + *seed_dev (seed_dev may be NULL); a captured hipGraph bumps *seed_dev per replay */

@@ -62,7 +62,9 @@ _SIGS = {
     "r3d_edgeconv_train_ws_words": (c_l, []),
     "r3d_edge_stats1": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f]),
     "r3d_edgeconv_train_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_l, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f]),
-    "r3d_edgeconv_bwd": (c_i, [c_f] * 13 + [c_l, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "r3d_edge_reverse_ws_words": (c_l, [c_i, c_i, c_i]),
+    "r3d_edge_reverse": (c_i, [c_f, c_i, c_i, c_i, c_f, c_f]),
+    "r3d_edgeconv_bwd": (c_i, [c_f] * 13 + [c_l, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "r3d_attention_fwd_train": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_fl, c_u, c_f, c_f, c_f]),
     "r3d_attention_bwd": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_l, c_f, c_fl, c_u, c_f, c_fl, c_f, c_l, c_f, c_f]),
     "r3d_ce_grad": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),

@@ -10,8 +10,14 @@
 // dz2 DENSE over edges, so the backward re-runs the edge GEMM:
 //   B1 (matrix core): recompute h1, z2; dz2 = s2 (dy2 - m1 - zhat2 m2); dW2 += dz2^T h1;
 //       dh1 = dz2 W2; dy1 = dh1 lrelu'(u1) -> stored per edge; partial sums of dy1, dy1 ehat1
-//   B2 (gather/scatter): de1 = s1 (dy1 - n1 - ehat1 n2); dQ[i] = sum_t de1; dP[j] += de1 (float atomics
-//       on whole 256-B rows, the shape the memory-side atomic units run at full rate).
+//       also per point: B[i] = sum_t dy1(i,t), EH[i] = sum_t ehat1(i,t)
+//   R  (once per layer): the REVERSE neighbour list -- for every target j the edges (i,t) with idx[i][t] == j, in
+//       ascending edge order -- by a counting sort per (cloud, target range) in LDS
+//   B2 (gather only): de1 = s1 (dy1 - n1 - ehat1 n2), so
+//       dQ[i] = s1 (B[i] - K n1 - n2 EH[i])
+//       dP[j] = s1 (sum_in dy1 - c_j n1 - n2 is1 (c_j (P[j] - mu1) + sum_in Q[i]))   over the c_j incoming edges of j
+//       one wave per point, plain stores, fixed summation order: deterministic.  (The first version scattered de1 with
+//       float atomics on 256-B rows: 3/4 of that kernel's time, and the one non-deterministic sum of the training step.)
 #include "edge_tile.h"
 
 #define ET_PTS 8
@@ -208,7 +214,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT <= 5 ? 3
     const float* __restrict__ s2, const float* __restrict__ t2, const float* __restrict__ mean2,
     const float* __restrict__ invstd2, const float* __restrict__ bn2_sums /* [2][64]: sum dy2, sum dy2 zhat2 */,
     const float* __restrict__ dout, long lddo, const int* __restrict__ argmax, int N, long total_points,
-    float* __restrict__ DY1 /* (total_points*K, 64) */, float* __restrict__ part) {
+    float* __restrict__ DY1 /* (total_points*K, 64) */, float* __restrict__ BE /* (total_points, 128): sum_t dy1 | sum_t ehat1 */,
+    float* __restrict__ part) {
   constexpr int K = 4 * RT, R = 16 * RT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* H = smem;                        // [R][E2_LD] h1
@@ -307,13 +314,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT <= 5 ? 3
     {
       float* drow = DY1 + ((pt0 + w) * K) * 64 + lane;
       const float* grow = G + (K * w) * E2_LD + lane;
+      float bs = 0.f, es = 0.f;
 #pragma unroll
       for (int t = 0; t < K; ++t) {
         const float v = grow[t * E2_LD];
         drow[t * 64] = v;
-        sdy += v;
+        bs += v;
+        es += eh[t];
         sdye += v * eh[t];
       }
+      sdy += bs;
+      BE[(pt0 + w) * 128 + lane] = bs;
+      BE[(pt0 + w) * 128 + 64 + lane] = es;
     }
     // the next unit writes H / dsm / asm_ (last read before the third barrier) before its first barrier and G after it
   }
@@ -409,38 +421,156 @@ __global__ __launch_bounds__(256) void r3d_edgeconv_train_fwd2_kernel(
   }
 }
 
-// ---- backward pass B2: de1 -> dQ (sum over K), dP (scatter-add) ------------------------------------
+// ---- reverse neighbour list -----------------------------------------------------------------------
+// rev_ptr[cloud * N + j] .. rev_ptr[cloud * N + j + 1]: positions in `rev` of the GLOBAL edge ids e = point * K + t whose
+// neighbour is point j of that cloud, ascending in e.  One workgroup per (cloud, range of RV_RANGE targets): it reads
+// the cloud's lists twice (count, fill), keeps its entries in LDS, and writes every target's segment out in rank
+// order (rank = number of smaller edge ids of the segment: an out-of-place sort from LDS to global memory, so the LDS
+// atomics that placed the entries in arbitrary order leave no trace).  If the range's entries exceed the LDS buffer it is
+// processed in sub-ranges; a single target with more entries than the buffer (impossible for lists of distinct
+// neighbours, possible for the garbage lists a non-finite feature cascade can leave) is written by an ordered
+// compaction over the edges instead.  Neighbour ids are clamped to the cloud like everywhere else.
+#define RV_RANGE 512
+#define RV_CAP 12288
+__global__ __launch_bounds__(1024) void r3d_edge_reverse_kernel(const int* __restrict__ idx, int N, int K, int n_clouds,
+                                                                int* __restrict__ rev_ptr, int* __restrict__ rev) {
+  __shared__ int cnt[RV_RANGE];
+  __shared__ int off[RV_RANGE + 1];
+  __shared__ int cur[RV_RANGE];
+  __shared__ int buf[RV_CAP];
+  __shared__ int wsum[16];
+  __shared__ int below_s, a_s, b_s;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int cloud = blockIdx.y;
+  const int r0 = blockIdx.x * RV_RANGE, nr = min(RV_RANGE, N - r0);
+  const long E = (long)N * K, gbase = (long)cloud * E;
+  const int* lst = idx + gbase;
+  if (tid < RV_RANGE) cnt[tid] = 0;
+  if (tid == 0) below_s = 0;
+  __syncthreads();
+  int my_below = 0;
+  for (long e = tid; e < E; e += 1024) {
+    const int j = min(max(lst[e], 0), N - 1) - r0;
+    if (j < 0) ++my_below;
+    else if (j < nr) atomicAdd(&cnt[j], 1);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) my_below += __shfl_xor(my_below, o);
+  if (lane == 0) atomicAdd(&below_s, my_below);  // integer adds: order free
+  __syncthreads();
+  // exclusive scan of cnt[0 .. RV_RANGE) (8 waves of 64)
+  if (tid < RV_RANGE) {
+    const int v = tid < nr ? cnt[tid] : 0;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
+    cur[tid] = x - v;  // exclusive inside the wave
+  }
+  __syncthreads();
+  if (tid < RV_RANGE) {
+    int wb = 0;
+    for (int q = 0; q < w; ++q) wb += wsum[q];
+    off[tid] = cur[tid] + wb;
+  }
+  if (tid == 0) {
+    int t = 0;
+    for (int q = 0; q < RV_RANGE / 64; ++q) t += wsum[q];
+    off[RV_RANGE] = t;
+  }
+  __syncthreads();
+  const long seg0 = gbase + below_s;  // position in rev of the first entry of target r0
+  if (tid < nr) rev_ptr[(long)cloud * N + r0 + tid] = (int)(seg0 + off[tid]);
+  if (cloud == n_clouds - 1 && r0 + nr == N && tid == 0) rev_ptr[(long)n_clouds * N] = (int)((long)n_clouds * E);
+  // sub-ranges [a, b) of targets whose entries fit the LDS buffer
+  int a = 0;
+  while (a < nr) {
+    if (tid == 0) {
+      int b = a;
+      while (b < nr && off[b + 1] - off[a] <= RV_CAP) ++b;
+      a_s = a; b_s = b;
+    }
+    __syncthreads();
+    const int b = b_s;
+    if (b == a) {
+      // one target with more entries than the buffer: ordered compaction over the cloud's edges
+      long outp = seg0 + off[a];
+      for (long e0 = 0; e0 < E; e0 += 1024) {
+        const long e = e0 + tid;
+        const bool hit = e < E && min(max(lst[min(e, E - 1)], 0), N - 1) - r0 == a;
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) wsum[w] = __popcll(m);
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int q = 0; q < 16; ++q) { before += q < w ? wsum[q] : 0; total += wsum[q]; }
+        if (hit) rev[outp + before + __popcll(m & ((1ull << lane) - 1ull))] = (int)(gbase + e);
+        outp += total;
+        __syncthreads();
+      }
+      a += 1;
+      continue;
+    }
+    if (tid < RV_RANGE) cur[tid] = (tid >= a && tid < b) ? off[tid] - off[a] : 0;
+    __syncthreads();
+    for (long e = tid; e < E; e += 1024) {
+      const int j = min(max(lst[e], 0), N - 1) - r0;
+      if (j >= a && j < b) buf[atomicAdd(&cur[j], 1)] = (int)e;  // arbitrary order inside a segment: ranked below
+    }
+    __syncthreads();
+    for (int j = a + w; j < b; j += 16) {
+      const int s0 = off[j] - off[a], c = cnt[j];
+      const long out0 = seg0 + off[j];
+      for (int m0 = 0; m0 < c; m0 += 64) {
+        const int mine = m0 + lane < c ? buf[s0 + m0 + lane] : 0x7fffffff;
+        int rank = 0;
+        for (int t = 0; t < c; ++t) rank += buf[s0 + t] < mine ? 1 : 0;  // broadcast reads
+        if (m0 + lane < c) rev[out0 + rank] = (int)(gbase + mine);
+      }
+    }
+    __syncthreads();
+    a = b;
+  }
+}
+
+// ---- backward pass B2: dQ from the point sums of B1, dP by a gather over the incoming edges -----------------------
 template <int RT>
 __global__ __launch_bounds__(256) void r3d_edgeconv_bwd2_kernel(
-    const float* __restrict__ PQ, const int* __restrict__ idx, const float* __restrict__ s1, const float* __restrict__ mean1,
+    const float* __restrict__ PQ, const float* __restrict__ s1, const float* __restrict__ mean1,
     const float* __restrict__ invstd1, const float* __restrict__ bn1_sums /* [2][64] */, const float* __restrict__ DY1,
-    int N, long total_points, float* __restrict__ dPQ /* (M,128), zero-initialised */) {
+    const float* __restrict__ BE, const int* __restrict__ rev_ptr, const int* __restrict__ rev, long total_points,
+    float* __restrict__ dPQ /* (M,128), every entry written */) {
   constexpr int K = 4 * RT;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const double E = (double)total_points * K;
   const float sc1 = s1[lane], mu1 = mean1[lane], is1 = invstd1[lane];
   const float n1 = (float)((double)bn1_sums[lane] / E), n2 = (float)((double)bn1_sums[64 + lane] / E);
   for (long pt = (long)blockIdx.x * 4 + w; pt < total_points; pt += (long)gridDim.x * 4) {
-    const long cloud0 = (pt / N) * N;
-    const float q = PQ[pt * 128 + 64 + lane];
-    const int my_idx = min(max(idx[pt * K + min(lane, K - 1)], 0), N - 1);  // never gather outside the cloud, whatever the list holds
-    // all K neighbour rows and all K dy1 rows of the point in flight at once (four at a time was a chain of K/4
-    // memory round trips per point)
-    float pv[K], dv[K];
+    const int rb = rev_ptr[pt], re = rev_ptr[pt + 1];
+    const float pj = PQ[pt * 128 + lane];
+    const float bs = BE[pt * 128 + lane], es = BE[pt * 128 + 64 + lane];
+    float asum = 0.f, gsum = 0.f;
+    for (int e0 = rb; e0 < re; e0 += 16) {  // 16 incoming edges = 32 rows in flight per trip; adds in list order
+      const int my_e = rev[min(e0 + min(lane, 15), re - 1)];
+      float dv[16], qv[16];
 #pragma unroll
-    for (int t = 0; t < K; ++t) {
-      pv[t] = PQ[(cloud0 + __builtin_amdgcn_readlane(my_idx, t)) * 128 + lane];
-      dv[t] = DY1[(pt * K + t) * 64 + lane];
-    }
-    float dq = 0.f;
+      for (int t = 0; t < 16; ++t) {
+        const int e = __builtin_amdgcn_readlane(my_e, t);
+        dv[t] = DY1[(long)e * 64 + lane];
+        qv[t] = PQ[(long)(e / K) * 128 + 64 + lane];
+      }
 #pragma unroll
-    for (int t = 0; t < K; ++t) {
-      const float e1 = pv[t] + q;
-      const float de = sc1 * (dv[t] - n1 - ((e1 - mu1) * is1) * n2);
-      dq += de;
-      atomicAdd(&dPQ[(cloud0 + __builtin_amdgcn_readlane(my_idx, t)) * 128 + lane], de);
+      for (int t = 0; t < 16; ++t) {
+        const bool ok = e0 + t < re;
+        asum += r3d_keep(dv[t], ok);
+        gsum += r3d_keep(qv[t], ok);
+      }
     }
-    atomicAdd(&dPQ[pt * 128 + 64 + lane], dq);
+    const float cj = (float)(re - rb);
+    dPQ[pt * 128 + lane] = sc1 * (asum - cj * n1 - n2 * (is1 * (cj * (pj - mu1) + gsum)));
+    dPQ[pt * 128 + 64 + lane] = sc1 * (bs - (float)K * n1 - n2 * es);
   }
 }
 
@@ -596,7 +726,7 @@ template <int RT>
 static int bwd1_launch_rt(long units, hipStream_t st, const float* PQ, const int32_t* idx, const float* s1, const float* t1,
                           const float* mean1, const float* invstd1, const float* W2, const float* s2, const float* t2,
                           const float* mean2, const float* invstd2, const float* bn2_sums, const float* dout, long lddo,
-                          const int32_t* argmax, int N, long total_points, float* DY1, float* ws, int* grid_out) {
+                          const int32_t* argmax, int N, long total_points, float* DY1, float* BE, float* ws, int* grid_out) {
   const size_t lds = sizeof(float) * ((size_t)2 * 16 * RT * E2_LD + 2 * E2_PTS * 64);
   static int resident = 0;  // workgroups the chip holds at once (persistent loop over the units)
   if (!resident) {
@@ -605,18 +735,18 @@ static int bwd1_launch_rt(long units, hipStream_t st, const float* PQ, const int
   }
   const int grid = (int)(units < resident ? units : resident);
   hipLaunchKernelGGL(r3d_edgeconv_bwd1_kernel<RT>, dim3(grid), dim3(256), lds, st, PQ, idx, s1, t1, mean1, invstd1, W2, s2, t2,
-                     mean2, invstd2, bn2_sums, dout, lddo, argmax, N, total_points, DY1, ws);
+                     mean2, invstd2, bn2_sums, dout, lddo, argmax, N, total_points, DY1, BE, ws);
   *grid_out = grid;
   return R3D_OK;
 }
 static int bwd1_launch(int K, long units, hipStream_t st, const float* PQ, const int32_t* idx, const float* s1, const float* t1,
                        const float* mean1, const float* invstd1, const float* W2, const float* s2, const float* t2,
                        const float* mean2, const float* invstd2, const float* bn2_sums, const float* dout, long lddo,
-                       const int32_t* argmax, int N, long total_points, float* DY1, float* ws, int* grid_out) {
+                       const int32_t* argmax, int N, long total_points, float* DY1, float* BE, float* ws, int* grid_out) {
 #define E2_CASE(RT)                                                                                                       \
   case RT:                                                                                                                \
     return bwd1_launch_rt<RT>(units, st, PQ, idx, s1, t1, mean1, invstd1, W2, s2, t2, mean2, invstd2, bn2_sums, dout, lddo, \
-                              argmax, N, total_points, DY1, ws, grid_out)
+                              argmax, N, total_points, DY1, BE, ws, grid_out)
   switch (K / 4) {
     E2_CASE(1); E2_CASE(2); E2_CASE(3); E2_CASE(4); E2_CASE(5); E2_CASE(6); E2_CASE(7); E2_CASE(8);
   }
@@ -625,16 +755,29 @@ static int bwd1_launch(int K, long units, hipStream_t st, const float* PQ, const
   return R3D_ERR_ARG;
 }
 
+// Reverse neighbour list of a layer's kNN lists (used by r3d_edgeconv_bwd): rev_ws = B*N + 1 offsets followed by B*N*K
+// edge ids.  Deterministic; no reference counterpart (autograd's scatter-add does this implicitly, dgcnn.py:38).
+extern "C" long r3d_edge_reverse_ws_words(int B, int N, int K) { return (long)B * N + 1 + (long)B * N * K + 16; }
+extern "C" int r3d_edge_reverse(const int32_t* idx, int B, int N, int K, int32_t* rev_ws, void* stream) {
+  R3D_REQUIRE(idx && rev_ws, "r3d_edge_reverse: null pointer");
+  R3D_REQUIRE(B > 0 && N > 0 && K > 0 && (long)B * N * K < 0x7fffffffL, "r3d_edge_reverse: bad shape B=%d N=%d K=%d", B, N, K);
+  hipLaunchKernelGGL(r3d_edge_reverse_kernel, dim3(r3d_cdiv(N, RV_RANGE), B), dim3(1024), 0, (hipStream_t)stream, idx, N, K, B,
+                     rev_ws, rev_ws + (long)B * N + 1);
+  R3D_LAUNCH_CHECK("r3d_edge_reverse");
+  return R3D_OK;
+}
+
 // Backward.  bn2_sums [2][64] = (sum dy2, sum dy2*zhat2) (from the point-level winners, computed by the
 // caller with r3d_colstats mode 1 on zmax).  Outputs: dW2 (64,64), bn1_sums [2][64] (sum dy1, sum dy1*ehat1),
-// dPQ (B*N,128) (zero-initialised by this call).  DY1 scratch: B*N*K*64 floats.
+// dPQ (B*N,128) (every entry written).  Scratch: DY1 B*N*K*64 floats, BE B*N*128 floats; rev_ws from r3d_edge_reverse
+// on the same idx.
 extern "C" int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float* s1, const float* t1, const float* mean1,
                                 const float* invstd1, const float* W2, const float* s2, const float* t2,
                                 const float* mean2, const float* invstd2, const float* bn2_sums, const float* dout,
-                                long lddo, const int32_t* argmax, int B, int N, int K, float* DY1, float* dW2,
-                                float* bn1_sums, float* dPQ, float* ws, void* stream) {
+                                long lddo, const int32_t* argmax, int B, int N, int K, float* DY1, float* BE,
+                                const int32_t* rev_ws, float* dW2, float* bn1_sums, float* dPQ, float* ws, void* stream) {
   R3D_REQUIRE(PQ && idx && s1 && t1 && mean1 && invstd1 && W2 && s2 && t2 && mean2 && invstd2 && bn2_sums && dout &&
-                  argmax && DY1 && dW2 && bn1_sums && dPQ && ws,
+                  argmax && DY1 && BE && rev_ws && dW2 && bn1_sums && dPQ && ws,
               "r3d_edgeconv_bwd: null pointer");
   int rc = et_check("r3d_edgeconv_bwd", B, N, K);
   if (rc) return rc;
@@ -642,16 +785,17 @@ extern "C" int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float
   hipStream_t st = (hipStream_t)stream;
   int grid = 0;
   rc = bwd1_launch(K, units, st, PQ, idx, s1, t1, mean1, invstd1, W2, s2, t2, mean2, invstd2, bn2_sums, dout, lddo, argmax, N,
-                   (long)B * N, DY1, ws, &grid);
+                   (long)B * N, DY1, BE, ws, &grid);
   if (rc) return rc;
   // partial layout: dW2 (4096) | sum dy1 (64) | sum dy1*ehat1 (64)
   hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(r3d_cdiv(ET_PART, 64)), dim3(1024), 0, st, ws, grid, ET_PART, dW2, 4096,
                      bn1_sums);
-  r3d_zero_words(dPQ, (long)B * N * 128, st);
+  const int32_t* rev_ptr = rev_ws;
+  const int32_t* rev = rev_ws + (long)B * N + 1;
 #define E2_CASE(RT)                                                                                                    \
   case RT:                                                                                                             \
-    hipLaunchKernelGGL(r3d_edgeconv_bwd2_kernel<RT>, dim3(1024), dim3(256), 0, st, PQ, idx, s1, mean1, invstd1, bn1_sums, DY1, \
-                       N, (long)B * N, dPQ);                                                                           \
+    hipLaunchKernelGGL(r3d_edgeconv_bwd2_kernel<RT>, dim3(1024), dim3(256), 0, st, PQ, s1, mean1, invstd1, bn1_sums, DY1, BE, \
+                       rev_ptr, rev, (long)B * N, dPQ);                                                                \
     break
   switch (K / 4) {
     E2_CASE(1); E2_CASE(2); E2_CASE(3); E2_CASE(4); E2_CASE(5); E2_CASE(6); E2_CASE(7); E2_CASE(8);

@@ -638,17 +638,26 @@ static __device__ __forceinline__ void cg_reduce_step(const float* __restrict__ 
   }
 }
 
-// Was this workgroup the last of its launch to deliver its partials?  Release / acquire at agent scope in thread 0 only
-// (the workgroup barrier in front has completed every thread's stores to the L2; the fence writes the L2 back and, on
-// the winner, invalidates it -- the XCDs' L2 caches are not coherent with each other).  Every launch that reaches this
-// point adds exactly `nblk` tickets, so "last" is ticket % nblk == nblk - 1 without resetting the counter in between.
+// Was this workgroup the last of its launch to deliver its partials?  The in-launch hand-off recipe of the CDNA guide
+// (cdna_hip_programming.md, Guideline 16, counter form): plain stores -> EVERY storing wave drains its stores
+// (s_waitcnt vmcnt(0)) -> workgroup barrier -> lane 0: ONE agent-scope release, its own drain (ROCm 7.2 can drop the
+// fence's wait), then the relaxed agent-scope ticket add; the workgroup that draws the last ticket: lane 0 ONE
+// agent-scope acquire + drain -> workgroup barrier -> every wave reads the partials with plain loads.  (The XCDs' L2
+// caches are not coherent with each other; `__threadfence()` here -- release AND acquire in every workgroup -- is the
+// measured-slower form.)  Every launch that reaches this point adds exactly `nblk` tickets, so "last" is
+// ticket % nblk == nblk - 1 without resetting the counter between the launches of a solve.
 static __device__ __forceinline__ bool cg_delivered_last(CgState* __restrict__ cg, int nblk, int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __threadfence();
-    const unsigned t = atomicAdd(&cg->ticket, 1u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(&cg->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = (t + 1u) % (unsigned)nblk == 0u;
-    if (last) __threadfence();
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     *flag = last;
   }
   __syncthreads();

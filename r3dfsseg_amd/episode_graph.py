@@ -25,7 +25,7 @@ Frozen-sequence consequences, all checked or documented:
 
 The CG launch budget is adaptive without re-capturing: launches after convergence return at once but still cost
 ~2.5 us of queue time each, so ``run()`` reads -- one step late, through a pinned buffer, never blocking -- the largest
-iteration count seen and keeps only the CG kernel nodes of the first ``2 * max + 8`` iterations enabled
+iteration count seen and keeps only the CG kernel nodes of the first ``1.5 * max + 8`` iterations enabled
 (``r3d_graph_set_lp_budget``: a disabled node is an empty node).  A replay that needs more reports "not converged"
 through ``check()`` as before, and the budget returns to the captured maximum.
 """
@@ -166,6 +166,12 @@ class EpisodeGraphs:
             assert n_cg.value > 0, "no CG nodes found in the captured episode"
         self.active_budget = budget
 
+    @staticmethod
+    def budget_for(mx):
+        """Enabled CG iterations for an observed maximum of `mx`: half as many again plus 8, rounded up to 8, at least 24
+        (convergence is detected inside the last productive launch, so nothing extra is needed for the test itself)."""
+        return max(24, 8 * ((mx + mx // 2 + 8 + 7) // 8))
+
     def _account(self, c):
         """One finished run()'s counters (host copy): totals for check(), launch budget for the next runs."""
         bad, ovf, its, mx = int(c[:, 0].sum()), int(c[:, 1].sum()), int(c[:, 2].sum()), int(c[:, 3].max())
@@ -177,7 +183,7 @@ class EpisodeGraphs:
             self.set_lp_budget(self.lp_budget)
         elif self.adaptive_budget and mx > 0:  # the budget follows a slowly decaying maximum, so it can shrink again
             self._mx_decay = max(mx, self._mx_decay - max(1, self._mx_decay // 16))
-            self.set_lp_budget(max(32, 8 * ((2 * self._mx_decay + 8 + 7) // 8)))
+            self.set_lp_budget(self.budget_for(self._mx_decay))
         return bad, ovf, its, mx
 
     def _adapt_budget(self):

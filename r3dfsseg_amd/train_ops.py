@@ -178,13 +178,17 @@ def edgeconv_train_bwd(saved, dout, B, N, dx_acc):
     K = idx.shape[-1]
     M = B * N
     bn2_sums = colstats(zmax, 64, mode=1, DY=dout, bn=bn2, act=ops.ACT_LRELU)
-    DY1 = _f(M * K * 64, dev)
+    DY1, BE = _f(M * K * 64, dev), _f(M * 128, dev)
     dW2, bn1_sums, dPQ = _f(64 * 64, dev), _f(128, dev), _f(M * 128, dev).view(M, 128)
     ws = _f(lib.r3d_edgeconv_train_ws_words(), dev)
+    rev = torch.empty(lib.r3d_edge_reverse_ws_words(B, N, K), device=dev, dtype=torch.int32)
     with _timed("edgeconv_bwd"):
+        # the reverse neighbour list: the input gradient is a gather over incoming edges (deterministic, no float atomics)
+        _lib.check(lib.r3d_edge_reverse(_p(idx), B, N, K, _p(rev), _st()))
         _lib.check(lib.r3d_edgeconv_bwd(_p(PQ), _p(idx), _p(bn1[0]), _p(bn1[1]), _p(bn1[2]), _p(bn1[3]), _p(W2), _p(bn2[0]),
                                         _p(bn2[1]), _p(bn2[2]), _p(bn2[3]), _p(bn2_sums), _p(dout), dout.stride(0),
-                                        _p(argmax), B, N, K, _p(DY1), _p(dW2), _p(bn1_sums), _p(dPQ), _p(ws), _st()))
+                                        _p(argmax), B, N, K, _p(DY1), _p(BE), _p(rev), _p(dW2), _p(bn1_sums), _p(dPQ),
+                                        _p(ws), _st()))
     dWpq = gemm_tn(dPQ, inp)  # (128, C): rows 0..63 = dP^T x, rows 64..127 = dQ^T x
     dW1 = torch.cat((dWpq[:64] - dWpq[64:], dWpq[64:]), 1).reshape(64, 2 * C, 1, 1)
     if dx_acc is not None:

@@ -95,12 +95,12 @@ def test_cg_budget_by_disabling_graph_nodes():
     g.run(eps, logits_out=out)
     torch.cuda.synchronize()
     assert g.check()[0] == 0 and torch.equal(out, ref)
-    # adaptive mode: the lagged probe shrinks the budget to 2 * max + 8 (rounded up to 8, at least 32)
+    # adaptive mode: the lagged probe shrinks the budget to 1.5 * max + 8 (rounded up to 8, at least 24)
     g.adaptive_budget = True
     for _ in range(4):
         g.run(eps, logits_out=out)
     torch.cuda.synchronize()
-    assert g.active_budget == max(32, 8 * ((2 * mx + 8 + 7) // 8)) and g.active_budget < 120
+    assert g.active_budget == g.budget_for(mx) and g.active_budget < 120
     assert g.check()[0] == 0 and torch.equal(out, ref)
 
 
