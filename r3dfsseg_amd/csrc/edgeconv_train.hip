@@ -449,10 +449,18 @@ __global__ __launch_bounds__(1024) void r3d_edge_reverse_kernel(const int* __res
   if (tid == 0) below_s = 0;
   __syncthreads();
   int my_below = 0;
-  for (long e = tid; e < E; e += 1024) {
-    const int j = min(max(lst[e], 0), N - 1) - r0;
-    if (j < 0) ++my_below;
-    else if (j < nr) atomicAdd(&cnt[j], 1);
+  for (long e0 = tid; e0 < E; e0 += 8 * 1024) {  // 8 list entries in flight per thread and trip
+    int jv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) jv[u] = lst[min(e0 + 1024 * u, E - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = min(max(jv[u], 0), N - 1) - r0;
+      if (e0 + 1024 * u < E) {
+        if (j < 0) ++my_below;
+        else if (j < nr) atomicAdd(&cnt[j], 1);
+      }
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) my_below += __shfl_xor(my_below, o);
@@ -515,9 +523,16 @@ __global__ __launch_bounds__(1024) void r3d_edge_reverse_kernel(const int* __res
     }
     if (tid < RV_RANGE) cur[tid] = (tid >= a && tid < b) ? off[tid] - off[a] : 0;
     __syncthreads();
-    for (long e = tid; e < E; e += 1024) {
-      const int j = min(max(lst[e], 0), N - 1) - r0;
-      if (j >= a && j < b) buf[atomicAdd(&cur[j], 1)] = (int)e;  // arbitrary order inside a segment: ranked below
+    for (long e0 = tid; e0 < E; e0 += 8 * 1024) {
+      int jv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) jv[u] = lst[min(e0 + 1024 * u, E - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = min(max(jv[u], 0), N - 1) - r0;
+        if (e0 + 1024 * u < E && j >= a && j < b)
+          buf[atomicAdd(&cur[j], 1)] = (int)(e0 + 1024 * u);  // arbitrary order inside a segment: ranked below
+      }
     }
     __syncthreads();
     for (int j = a + w; j < b; j += 16) {
@@ -526,7 +541,13 @@ __global__ __launch_bounds__(1024) void r3d_edge_reverse_kernel(const int* __res
       for (int m0 = 0; m0 < c; m0 += 64) {
         const int mine = m0 + lane < c ? buf[s0 + m0 + lane] : 0x7fffffff;
         int rank = 0;
-        for (int t = 0; t < c; ++t) rank += buf[s0 + t] < mine ? 1 : 0;  // broadcast reads
+        for (int t0 = 0; t0 < c; t0 += 16) {  // 16 broadcast reads in flight (entries beyond c: clamped, masked)
+          int ov[16];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) ov[t] = buf[s0 + min(t0 + t, c - 1)];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) rank += (t0 + t < c && ov[t] < mine) ? 1 : 0;
+        }
         if (m0 + lane < c) rev[out0 + rank] = (int)(gbase + mine);
       }
     }

@@ -534,6 +534,10 @@ __global__ __launch_bounds__(1024) void r3d_cg_einv_kernel(const float* __restri
 // caller before anything else in the kernel (64 independent loads in flight: one memory round trip instead of a walk
 // -- a kernel of 18 workgroups on a dependent chain is pure latency: measured 8-15 us per launch for per-row / LDS-tile
 // walks against ~3 us).  The four waves' partials meet in LDS and are added in wave order (deterministic).
+static __device__ __forceinline__ void cg_store_sc1(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 static __device__ __forceinline__ void cg_load_mw_column(const float* __restrict__ MW, int row0, int n_cap, float (&m)[64]) {
   const int a = threadIdx.x & 63, w = threadIdx.x >> 6;
   // rows < n_cap exist and rows in [n, n_cap) are zero (r3d_cg_mw_kernel); beyond n_cap the index is clamped
@@ -566,7 +570,9 @@ static __device__ __forceinline__ void cg_block_partials(const float4* rs, const
     sq = make_float4(v.x * v.x, v.y * v.y, v.z * v.z, v.w * v.w);
   }
   sq = block_sum4(sq, sm);  // its barriers also publish wpart
-  if (threadIdx.x == 0) *reinterpret_cast<float4*>(part) = sq;
+  // the partials are handed to another workgroup INSIDE this launch (cg_delivered_last): write-through (sc1) stores,
+  // which need no release fence in front of the ticket
+  if (threadIdx.x < 4) cg_store_sc1(part + threadIdx.x, f4_get(sq, threadIdx.x));
   {
     const int c = w;  // thread (a, c = w) adds the four waves' partials of entry [a][c]
     float st = 0.f, st2 = 0.f;
@@ -575,8 +581,8 @@ static __device__ __forceinline__ void cg_block_partials(const float4* rs, const
       st += f4_get(wpart[q * HG_M + a], c);
       st2 += f4_get(wpart[4 * HG_M + q * HG_M + a], c);
     }
-    part[4 + a * HG_NC + c] = st;
-    part[4 + HG_M * HG_NC + a * HG_NC + c] = st2;
+    cg_store_sc1(part + 4 + a * HG_NC + c, st);
+    cg_store_sc1(part + 4 + HG_M * HG_NC + a * HG_NC + c, st2);
   }
 }
 
@@ -639,19 +645,17 @@ static __device__ __forceinline__ void cg_reduce_step(const float* __restrict__ 
 }
 
 // Was this workgroup the last of its launch to deliver its partials?  The in-launch hand-off recipe of the CDNA guide
-// (cdna_hip_programming.md, Guideline 16, counter form): plain stores -> EVERY storing wave drains its stores
-// (s_waitcnt vmcnt(0)) -> workgroup barrier -> lane 0: ONE agent-scope release, its own drain (ROCm 7.2 can drop the
-// fence's wait), then the relaxed agent-scope ticket add; the workgroup that draws the last ticket: lane 0 ONE
-// agent-scope acquire + drain -> workgroup barrier -> every wave reads the partials with plain loads.  (The XCDs' L2
-// caches are not coherent with each other; `__threadfence()` here -- release AND acquire in every workgroup -- is the
-// measured-slower form.)  Every launch that reaches this point adds exactly `nblk` tickets, so "last" is
-// ticket % nblk == nblk - 1 without resetting the counter between the launches of a solve.
+// (cdna_hip_programming.md, Guideline 16 / split-K combine, counter form with write-through payload): sc1 stores of the
+// partials (cg_block_partials) -> EVERY storing wave drains its stores (s_waitcnt vmcnt(0)) -> workgroup barrier -> lane
+// 0: relaxed agent-scope ticket add (no release fence: nothing dirty to write back); the workgroup that draws the last
+// ticket: lane 0 ONE agent-scope acquire + drain -> workgroup barrier -> every wave reads the partials with plain loads.
+// (The XCDs' L2 caches are not coherent with each other; `__threadfence()` in every workgroup is the measured-slower
+// form.)  Every launch that reaches this point adds exactly `nblk` tickets, so "last" is ticket % nblk == nblk - 1
+// without resetting the counter between the launches of a solve.
 static __device__ __forceinline__ bool cg_delivered_last(CgState* __restrict__ cg, int nblk, int* flag) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned t = __hip_atomic_fetch_add(&cg->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = (t + 1u) % (unsigned)nblk == 0u;
     if (last) {

@@ -190,7 +190,7 @@ def test_config2_full_size_training_episode_gradients():
     # expected per layer pass (the same category as max-pool winner flips, which this test pins by injection).  So the
     # oracle runs the segment twice, in float64 (the truth) and in float32 (torch-CPU, the reference's own arithmetic),
     # and the bar is: every parameter within 1e-3 in the relative L2 norm (robust to single flips); in the max norm
-    # within 1e-3, or no further from the truth than 2 x torch-fp32, or at most 5e-3 on at most 4 entries of the tensor.
+    # within 1e-3, or no further from the truth than 2 x torch-fp32, or at most 5e-3 on at most 0.1 % of the entries.
     def oracle_grads(dtype):
         cast = (lambda v: v.to(dtype)) if dtype == torch.float64 else (lambda v: v.clone())
         sde = {k_: (cast(v).requires_grad_() if v.dtype.is_floating_point and "running" not in k_
@@ -220,17 +220,18 @@ def test_config2_full_size_training_episode_gradients():
         scale = gt.abs().max().item()
         l2 = ((gh - gt).norm() / gt.norm()).item()
         n_out = int(((gh - gt).abs() > 1e-3 * scale).sum())
-        rows.append((rel(gh, gt), rel(g32[name], gt), l2, n_out, name))
+        rows.append((rel(gh, gt), rel(g32[name], gt), l2, n_out, gt.numel(), name))
     rows.sort()
     print("full-size encoder gradients against the float64 oracle: max-rel HIP, max-rel torch-fp32, rel-L2 HIP, entries "
           "beyond 1e-3, name (worst 6 of %d):" % len(rows))
     for r_ in rows[-6:]:
-        print("   %.2e  %.2e  %.2e  %3d  %s" % r_)
+        print("   %.2e  %.2e  %.2e  %3d of %6d  %s" % r_)
     print("   median max-rel HIP %.2e, torch-fp32 %.2e; parameters with max-rel <= 1e-3: %d of %d" % (
         np.median([r_[0] for r_ in rows]), np.median([r_[1] for r_ in rows]), sum(r_[0] <= 1e-3 for r_ in rows), len(rows)))
-    for e_hip, e_t32, l2, n_out, name in rows:
+    for e_hip, e_t32, l2, n_out, numel, name in rows:
         assert l2 <= 1e-3, (name, l2)
-        assert e_hip <= 1e-3 or e_hip <= 2.0 * e_t32 or (e_hip <= 5e-3 and n_out <= 4), (name, e_hip, e_t32, n_out)
+        assert e_hip <= 1e-3 or e_hip <= 2.0 * e_t32 or (e_hip <= 5e-3 and n_out <= max(4, numel // 1000)), (
+            name, e_hip, e_t32, n_out, numel)
     assert np.median([r_[0] for r_ in rows]) <= 1e-3
 
 
