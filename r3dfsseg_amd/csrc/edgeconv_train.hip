@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void r3d_edgeconv_train_fwd2_kernel(
 // processed in sub-ranges; a single target with more entries than the buffer (impossible for lists of distinct
 // neighbours, possible for the garbage lists a non-finite feature cascade can leave) is written by an ordered
 // compaction over the edges instead.  Neighbour ids are clamped to the cloud like everywhere else.
-#define RV_RANGE 512
+#define RV_RANGE 256
 #define RV_CAP 12288
 __global__ __launch_bounds__(1024) void r3d_edge_reverse_kernel(const int* __restrict__ idx, int N, int K, int n_clouds,
                                                                 int* __restrict__ rev_ptr, int* __restrict__ rev) {
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(1024) void r3d_edge_reverse_kernel(const int* __res
   __shared__ int cur[RV_RANGE];
   __shared__ int buf[RV_CAP];
   __shared__ int wsum[16];
-  __shared__ int below_s, a_s, b_s;
+  __shared__ int below_s, b_s;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int cloud = blockIdx.y;
   const int r0 = blockIdx.x * RV_RANGE, nr = min(RV_RANGE, N - r0);
@@ -497,9 +497,16 @@ __global__ __launch_bounds__(1024) void r3d_edge_reverse_kernel(const int* __res
   int a = 0;
   while (a < nr) {
     if (tid == 0) {
-      int b = a;
-      while (b < nr && off[b + 1] - off[a] <= RV_CAP) ++b;
-      a_s = a; b_s = b;
+      int b = nr;  // the usual case: everything that is left fits
+      if (off[nr] - off[a] > RV_CAP) {
+        int lo = a, hi = nr;  // largest b with off[b] - off[a] <= RV_CAP (off is non-decreasing)
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (off[mid] - off[a] <= RV_CAP) lo = mid; else hi = mid - 1;
+        }
+        b = lo;
+      }
+      b_s = b;
     }
     __syncthreads();
     const int b = b_s;
