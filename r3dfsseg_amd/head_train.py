@@ -50,7 +50,7 @@ class HeadLPFn(torch.autograd.Function):
         with _timed("label_propagate_bwd"):
           _lib.check(lib.r3d_label_propagate_bwd(_p(hb.nodes), hb.nodes.stride(0), D, hb.kp1, _p(hb.Z), _p(G),
                                                _p(hb.desc[ops.HD_N_NODES:]), hb.n_cap, float(model.sigma), 0.99,
-                                               int(min(model.lp_max_iter, ctx.budget + max(8, ctx.budget // 2))), float(model.lp_tol), _p(lam),
+                                               int(min(model.lp_max_iter, ctx.budget + max(4, ctx.budget // 4))), float(model.lp_tol), _p(lam),
                                                _p(dnodes), D,
                                                _p(hb.lp_ws), _p(hb.stats_bwd), _st()))
         dsfeat = torch.zeros(ctx.shapes[0], device=dev, dtype=torch.float32)
