@@ -364,7 +364,7 @@ def main():
         kern = max(per_step_ms, key=per_step_ms.get)
     roof = None
     if kern in ("label_propagate", "label_propagate_bwd"):
-        # The label propagation is graph build + CG; its dominant kernels are the three of one CG iteration.  Their time
+        # The label propagation is graph build + CG; its dominant kernels are the two of one CG iteration.  Their time
         # is measured live: the same solve with 8 and with 40 forced iterations (tol = 0), HIP events on the launch
         # stream, difference / 32.
         hb = model._head[1]
@@ -380,33 +380,32 @@ def main():
             torch.cuda.synchronize()
             return a.elapsed_time(b) / reps
         t_iter = (solve_ms(40) - solve_ms(8)) / 32.0 * 1e-3
-        if True:
-            _, row_ptr, _, _ = hb.csr()
-            nnz = int(row_ptr[-1].item())
-            by = cg_iteration_bytes(nnz, n_nodes)
-            fl = nnz * 2.0 * 4 + n_nodes * 4 * (12.0 + 4 * CG_M)
-            cg_names = ("r3d_cg_spmv_kernel", "r3d_cg_update_kernel")
-            traffic = rocprof_us = None
-            if pmc is not None and all(k in pmc for k in cg_names):
-                traffic = 1024.0 * sum(pmc[k]["fetch_kb_per_launch"] + pmc[k]["write_kb_per_launch"] for k in cg_names)
-            if prof is not None:
-                us = [v[2] for k, v in prof.items() if k.split("(")[0] in cg_names]
-                rocprof_us = sum(us) if len(us) == 2 else None
-            roof = dict(kernel="r3d_cg_spmv_kernel + r3d_cg_update_kernel (one iteration of the two-level CG of the label "
-                               "propagation; entry point %s)" % kern,
-                        bound="hbm", achieved=by / t_iter / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t_iter / 1e9 / HBM_PEAK_GBS,
-                        traffic=traffic, avg_launch_ms=t_iter * 1e3, algorithmic_mb_per_launch=by / 1e6,
-                        algorithmic_gflop_per_launch=fl / 1e9, csr_nnz=nnz, nodes=n_nodes,
-                        iterations_per_episode=cg_mean * (2 if train else 1), rocprofv3_kernel_us=rocprof_us,
-                        frac_kernel_time_only=(by / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rocprof_us else None,
-                        rocprofv3_summary=prof_name, pmc_summary=pmc_name,
-                        lp_solve_ms_per_episode=cg_mean * (2 if train else 1) * t_iter * 1e3,
-                        note=("avg_launch_ms is event-measured over back-to-back DEPENDENT launches, so it contains the two "
-                              "launch gaps of an iteration; rocprofv3_kernel_us is the pair's in-kernel time from the committed "
-                              "--kernel-trace summary of this workload (null when none is committed; that average includes the "
-                              "launches past convergence, which return at once); traffic = FETCH_SIZE + "
-                              "WRITE_SIZE of the pair from the committed PMC passes of this workload (raw counters); the matrix "
-                              "(%.1f MB) is L2 / Infinity-Cache resident between launches" % (nnz * 6 / 1e6)))
+        _, row_ptr, _, _ = hb.csr()
+        nnz = int(row_ptr[-1].item())
+        by = cg_iteration_bytes(nnz, n_nodes)
+        fl = nnz * 2.0 * 4 + n_nodes * 4 * (12.0 + 4 * CG_M)
+        cg_names = ("r3d_cg_spmv_kernel", "r3d_cg_update_kernel")
+        traffic = rocprof_us = None
+        if pmc is not None and all(k in pmc for k in cg_names):
+            traffic = 1024.0 * sum(pmc[k]["fetch_kb_per_launch"] + pmc[k]["write_kb_per_launch"] for k in cg_names)
+        if prof is not None:
+            us = [v[2] for k, v in prof.items() if k.split("(")[0] in cg_names]
+            rocprof_us = sum(us) if len(us) == 2 else None
+        roof = dict(kernel="r3d_cg_spmv_kernel + r3d_cg_update_kernel (one iteration of the two-level CG of the label "
+                           "propagation; entry point %s)" % kern,
+                    bound="hbm", achieved=by / t_iter / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t_iter / 1e9 / HBM_PEAK_GBS,
+                    traffic=traffic, avg_launch_ms=t_iter * 1e3, algorithmic_mb_per_launch=by / 1e6,
+                    algorithmic_gflop_per_launch=fl / 1e9, csr_nnz=nnz, nodes=n_nodes,
+                    iterations_per_episode=cg_mean * (2 if train else 1), rocprofv3_kernel_us=rocprof_us,
+                    frac_kernel_time_only=(by / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rocprof_us else None,
+                    rocprofv3_summary=prof_name, pmc_summary=pmc_name,
+                    lp_solve_ms_per_episode=cg_mean * (2 if train else 1) * t_iter * 1e3,
+                    note=("avg_launch_ms is event-measured over back-to-back DEPENDENT launches, so it contains the two "
+                          "launch gaps of an iteration; rocprofv3_kernel_us is the pair's in-kernel time from the committed "
+                          "--kernel-trace summary of this workload (null when none is committed; that average includes the "
+                          "launches past convergence, which return at once); traffic = FETCH_SIZE + "
+                          "WRITE_SIZE of the pair from the committed PMC passes of this workload (raw counters); the matrix "
+                          "(%.1f MB) is L2 / Infinity-Cache resident between launches" % (nnz * 6 / 1e6)))
     if roof is None:
         fl, by, bound, launches = algorithmic_work(kern, cfg, n_nodes, cg_mean, train)
         t_launch = per_step_ms[kern] * 1e-3 / launches
