@@ -143,9 +143,17 @@ long r3d_colstats_ws_words(long M, int C);
 int r3d_colstats(const float* X, long ldx, const float* DY, long lddy, long M, int C, int mode, const float* scale,
                  const float* shift, const float* mean, const float* invstd, int act, float* sums_out /*[2][C]*/,
                  float* ws, void* stream);
+/* rec (optional): instead of updating the running statistics, record (batch mean, unbiased batch variance) as 2 C floats at
+ * rec + *rec_index_dev * rec_stride; r3d_bn_running_update then applies n_records such records in order, bit for bit
+ * what the updates would have given one after the other (captured episodes of several streams record, the owner
+ * applies them in episode order after the step). */
 int r3d_bn_fold(const float* sums, double count, int C, const float* gamma, const float* beta, float eps,
                 float momentum, float* running_mean /*opt*/, float* running_var /*opt*/, float* mean, float* invstd,
-                float* scale, float* shift, void* stream);
+                float* scale, float* shift, float* rec /*opt*/, const int32_t* rec_index_dev /*opt*/, long rec_stride,
+                void* stream);
+int r3d_bn_running_update(const float* rec, int n_records, long rec_stride, int C, float momentum,
+                          const float* bias /*opt: conv bias in front of the BatchNorm*/, float* running_mean,
+                          float* running_var, void* stream);
 int r3d_affine_act(const float* Z, long ldz, long M, int C, const float* scale, const float* shift, int act, float* Y,
                    long ldy, void* stream);
 int r3d_bn_bwd_apply(const float* Z, long ldz, const float* DY, long lddy, long M, int C, const float* scale,

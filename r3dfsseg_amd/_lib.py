@@ -53,7 +53,8 @@ _SIGS = {
     "r3d_colreduce": (c_i, [c_f, c_i, c_i, c_f, c_f]),
     "r3d_colstats_ws_words": (c_l, [c_l, c_i]),
     "r3d_colstats": (c_i, [c_f, c_l, c_f, c_l, c_l, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_f]),
-    "r3d_bn_fold": (c_i, [c_f, c_d, c_i, c_f, c_f, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "r3d_bn_fold": (c_i, [c_f, c_d, c_i, c_f, c_f, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_f]),
+    "r3d_bn_running_update": (c_i, [c_f, c_i, c_l, c_i, c_fl, c_f, c_f, c_f, c_f]),
     "r3d_affine_act": (c_i, [c_f, c_l, c_l, c_i, c_f, c_f, c_i, c_f, c_l, c_f]),
     "r3d_bn_bwd_apply": (c_i, [c_f, c_l, c_f, c_l, c_l, c_i, c_f, c_f, c_f, c_f, c_i, c_f, c_d, c_f, c_l, c_f]),
     "r3d_gemm_tn_ws_words": (c_l, [c_l, c_i, c_i]),

@@ -111,7 +111,8 @@ __global__ void r3d_bn_fold_kernel(const float* __restrict__ sums, double count,
                                    const float* __restrict__ beta, float eps, float momentum,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
-                                   float* __restrict__ shift) {
+                                   float* __restrict__ shift, float* __restrict__ rec, const int* __restrict__ rec_index,
+                                   long rec_stride) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double m = (double)sums[c] / count;
@@ -123,12 +124,48 @@ __global__ void r3d_bn_fold_kernel(const float* __restrict__ sums, double count,
   const float sc = gamma[c] * is;
   scale[c] = sc;
   shift[c] = beta[c] - (float)m * sc;
-  if (running_mean) {
+  const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+  if (rec) {  // captured episodes: the batch statistics are recorded, r3d_bn_running_update applies them in episode order
+    float* r = rec + (long)(rec_index ? *rec_index : 0) * rec_stride;
+    r[c] = (float)m;
+    r[C + c] = (float)unb;
+  } else if (running_mean) {
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
-    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
   }
 }
+
+// The running-statistics updates of n_records recorded batches, applied in record order exactly as r3d_bn_fold_kernel
+// (and nn.BatchNorm) would have applied them one after the other; bias (optional): a conv bias in front of the
+// BatchNorm shifts the batch mean it sees by exactly that bias.
+__global__ void r3d_bn_running_update_kernel(const float* __restrict__ rec, int n_records, long rec_stride, int C, float momentum,
+                                             const float* __restrict__ bias, float* __restrict__ running_mean,
+                                             float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float rm = running_mean[c], rv = running_var[c];
+  const float mb = bias ? momentum * bias[c] : 0.f;
+  for (int k0 = 0; k0 < n_records; k0 += 8) {  // 16 loads in flight; the update order stays the record order
+    float mv[8], vv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long o = (long)min(k0 + u, n_records - 1) * rec_stride;
+      mv[u] = rec[o + c];
+      vv[u] = rec[o + C + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (k0 + u < n_records) {
+        rm = (1.f - momentum) * rm + momentum * mv[u];
+        if (bias) rm = rm + mb;
+        rv = (1.f - momentum) * rv + momentum * vv[u];
+      }
+    }
+  }
+  running_mean[c] = rm;
+  running_var[c] = rv;
+}
+
 
 // ---- y = act(scale * z + shift), elementwise over (M, C) ---------------------------------------
 __global__ void r3d_affine_act_kernel(const float* __restrict__ Z, long ldz, long M, int C,
@@ -326,11 +363,23 @@ extern "C" int r3d_colreduce(const float* part, int chunks, int C, float* sums_o
 
 extern "C" int r3d_bn_fold(const float* sums, double count, int C, const float* gamma, const float* beta, float eps,
                            float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
-                           float* scale, float* shift, void* stream) {
+                           float* scale, float* shift, float* rec, const int32_t* rec_index_dev, long rec_stride,
+                           void* stream) {
   R3D_REQUIRE(sums && gamma && beta && mean && invstd && scale && shift && C > 0 && count > 0, "r3d_bn_fold: bad arguments");
+  R3D_REQUIRE(!rec || rec_stride >= 2L * C, "r3d_bn_fold: a record holds 2 C floats");
   hipLaunchKernelGGL(r3d_bn_fold_kernel, dim3(r3d_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, count, C, gamma,
-                     beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+                     beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, rec, rec_index_dev, rec_stride);
   R3D_LAUNCH_CHECK("r3d_bn_fold");
+  return R3D_OK;
+}
+
+extern "C" int r3d_bn_running_update(const float* rec, int n_records, long rec_stride, int C, float momentum, const float* bias,
+                                     float* running_mean, float* running_var, void* stream) {
+  R3D_REQUIRE(rec && running_mean && running_var && n_records > 0 && C > 0 && rec_stride >= 2L * C,
+              "r3d_bn_running_update: bad arguments");
+  hipLaunchKernelGGL(r3d_bn_running_update_kernel, dim3(r3d_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, rec, n_records,
+                     rec_stride, C, momentum, bias, running_mean, running_var);
+  R3D_LAUNCH_CHECK("r3d_bn_running_update");
   return R3D_OK;
 }
 

@@ -39,13 +39,14 @@ class DPTrainer:
         self.model.train()
         self.redone = False
         if self.graphs is not None:
-            total = self.graphs.run(episodes)
+            total = self.graphs.run(episodes, apply_bn=False)
             bad, overflow, _, _ = self.graphs.step_status()
             if bad or overflow:
-                total = self._eager_pass(episodes, logger, conservative=True)
+                total = self._eager_pass(episodes, logger, conservative=True)  # updates the running statistics itself
                 self.redone = True
                 self.n_redone += 1
             else:
+                self.graphs.apply_running_stats(len(episodes))
                 torch.sum(self.rows, 0, out=self.bucket.store)
         else:
             total = self._eager_pass(episodes, logger, conservative=False)

@@ -20,8 +20,9 @@ Frozen-sequence consequences, all checked or documented:
     adds its "did not converge / survivor buffer overflowed" flags into per-step device counters: ``step_status()``
     (one host wait, used by the trainer before every optimiser step) and ``check()`` read them;
   * the attention-dropout seed advances in device memory (slot.seed_dev), not in a Python counter;
-  * BatchNorm running statistics are updated by slot 0 only (shared buffers, concurrent slots would race);
-    the batch statistics used for normalisation are per episode either way.
+  * BatchNorm running statistics: a replay RECORDS its batch statistics (train_ops.BNRecorder: shared buffers, concurrent
+    slots would race) and the owner applies the records in episode order after the step -- bit for bit the running
+    statistics of the reference's one-episode-at-a-time schedule (tests/test_gpu_graph.py).
 
 The CG launch budget is adaptive without re-capturing: launches after convergence return at once but still cost
 ~2.5 us of queue time each, so ``run()`` reads -- one step late, through a pinned buffer, never blocking -- the largest
@@ -68,6 +69,8 @@ class EpisodeGraphs:
         self._mx_decay = 0                  # slowly decaying maximum of the iteration counts (budget adaptation)
         self.slots = []
         self.ev_start = torch.cuda.Event()
+        self.max_episodes = 256             # episodes of one run() the BatchNorm records are sized for
+        self.bn_records = train_ops.BNRecorder(self.max_episodes, dev) if train else None
         saved_slot = model._slot
         buffers = {k: v.clone() for k, v in model.named_buffers()}  # warm-up passes must not leak into BN statistics
         was_training = model.training
@@ -78,6 +81,7 @@ class EpisodeGraphs:
         finally:
             model._slot = saved_slot
             train_ops.update_running_stats = True
+            train_ops.bn_recorder = None
             model.train(was_training)
         with torch.no_grad():
             for k, v in model.named_buffers():
@@ -118,7 +122,7 @@ class EpisodeGraphs:
         sl.bad, sl.knn_overflow, sl.cg_iters, sl.cg_max = (self.counters[s, i] for i in range(4))
         st = EpisodeSlot(s)
         st.fixed_budget = self.lp_budget
-        st.update_running = (s == 0)
+        sl.ep2 = torch.zeros(1, device=dev, dtype=torch.int32)  # 2 x (index of the episode inside its run())
         # one-launch FPS only while all slots' FPS grids fit the chip together (head_proto.hip, 2b)
         fps_blocks = (model.n_way * model.k_shot * model.n_points + 255) // 256 + model.n_way + 1
         # 2 workgroups of the one-launch FPS fit a CU at D <= 192 (234 VGPRs), 1 above: 512 / 256 slots on the chip.
@@ -134,7 +138,9 @@ class EpisodeGraphs:
                 off += p.numel()
         sl.state = st
         model._slot = st
-        train_ops.update_running_stats = st.update_running
+        if self.train:
+            self.bn_records.index_dev = sl.ep2
+            train_ops.bn_recorder = self.bn_records
         cur = torch.cuda.current_stream()
         sl.stream.wait_stream(cur)
         with torch.cuda.stream(sl.stream):
@@ -223,10 +229,17 @@ class EpisodeGraphs:
             m.encoder._fold()
             m.base_learner._fold()
 
-    def run(self, episodes, logits_out=None):
+    def apply_running_stats(self, n_episodes):
+        """Fold the BatchNorm batch statistics the last run() recorded into the running statistics, in episode order."""
+        if self.train:
+            self.bn_records.apply(n_episodes)
+
+    def run(self, episodes, logits_out=None, apply_bn=True):
         """Replay one graph per episode, round-robin over the slots, and join the slot streams into the current
         stream.  logits_out: optional (len(episodes), n_q, n_classes, N) buffer receiving every episode's query
-        logits.  Returns the device scalar sum of the episodes' losses."""
+        logits.  apply_bn=False: the caller applies the recorded BatchNorm statistics itself (apply_running_stats), e.g.
+        only once it knows that the step is kept.  Returns the device scalar sum of the episodes' losses."""
+        assert len(episodes) <= self.max_episodes
         main = torch.cuda.current_stream()
         self._adapt_budget()
         self.reset()
@@ -243,12 +256,16 @@ class EpisodeGraphs:
                     dst.copy_(src, non_blocking=True)
                     if src.is_cuda:
                         src.record_stream(sl.stream)
+                if self.train:
+                    sl.ep2.fill_(2 * e)
                 sl.graph.replay()
                 if logits_out is not None:
                     logits_out[e].copy_(sl.logits, non_blocking=True)
         for sl in self.slots[:min(G, len(episodes))]:
             sl.done.record(sl.stream)
             main.wait_event(sl.done)
+        if apply_bn:
+            self.apply_running_stats(len(episodes))
         total = self.slots[0].loss_sum
         for sl in self.slots[1:min(G, len(episodes))]:
             total = total + sl.loss_sum

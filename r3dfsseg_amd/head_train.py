@@ -111,7 +111,11 @@ def explicit_train_episode(model, episode, grad_sink, loss_weight=0.1):
         params = T.encoder_params(model)
         cs, cq, cc, ch = (SimpleNamespace(param_list=params) for _ in range(4))
         sx = support_x.reshape(S, model.in_channels, N)
+        if T.bn_recorder is not None:
+            T.bn_recorder.pass_id = 0
         sfeat = T.EncoderTrainFn.forward(cs, sx, model, seed)
+        if T.bn_recorder is not None:
+            T.bn_recorder.pass_id = 1
         qfeat = T.EncoderTrainFn.forward(cq, query_x, model, seed + 1)
         closs = contrast.ContrastFn.forward(cc, sfeat, model.proj.weight, model.proj.bias, model, support_y, support_flag)
         lploss = HeadLPFn.forward(ch, sfeat, qfeat, model, support_y, query_y)

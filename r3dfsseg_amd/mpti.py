@@ -23,7 +23,6 @@ class EpisodeSlot:
         self.last = None            # (key, HeadBuffers) of the latest forward through this slot
         self.seed_dev = None        # int32 device word added to the dropout seed (None: host-side counter)
         self.fixed_budget = None    # CG launches per solve when the launch sequence is frozen in a graph
-        self.update_running = True  # does this slot's training forward update BatchNorm running statistics?
         self.fps_one_launch = True  # persistent one-launch FPS (needs its grid co-resident, see head_proto.hip)
 
 

@@ -14,9 +14,42 @@ from . import _lib, ops
 from .ops import _p, _rows, _st, _timed
 
 BN_EPS, BN_MOM = 1e-5, 0.1
-# False while a training forward must leave the BatchNorm running statistics alone (episode slots other than
-# slot 0 of episode_graph.EpisodeGraphs: concurrent read-modify-write of the shared buffers would race)
+# False while a training forward must leave the BatchNorm running statistics alone
 update_running_stats = True
+
+
+class BNRecorder:
+    """Batch statistics of captured episodes.  Several episodes are in flight on separate streams, so a replay must not
+    read-modify-write the shared running statistics; it RECORDS (batch mean, unbiased variance) of every BatchNorm call
+    instead -- record 2 e + p for episode e of the step, p = 0 the support pass, 1 the query pass (mpti.py:434,436) --
+    and `apply()` folds the records into the running statistics in exactly that order after the step: bit for bit what
+    the reference's one-episode-at-a-time schedule gives."""
+
+    def __init__(self, max_episodes, device):
+        self.max_records = 2 * max_episodes
+        self.device = device
+        self.tables = {}        # BatchNorm module -> (records (max_records, 2, C), conv bias or None)
+        self.pass_id = 0
+        self.index_dev = None   # int32 device word of the replaying slot: 2 e
+
+    def slot_for(self, bnmod, bias):
+        if bnmod not in self.tables:
+            rec = torch.zeros(self.max_records, 2, bnmod.num_features, device=self.device, dtype=torch.float32)
+            self.tables[bnmod] = (rec, bias.detach() if bias is not None else None)
+        return self.tables[bnmod][0]
+
+    def apply(self, n_episodes):
+        lib = _lib.load()
+        assert 2 * n_episodes <= self.max_records
+        with torch.no_grad():
+            for bnmod, (rec, bias) in self.tables.items():
+                C = bnmod.num_features
+                _lib.check(lib.r3d_bn_running_update(_p(rec), 2 * n_episodes, 2 * C, C, BN_MOM, _p(bias),
+                                                     _p(bnmod.running_mean), _p(bnmod.running_var), _st()))
+                bnmod.num_batches_tracked += 2 * n_episodes
+
+
+bn_recorder = None  # set by episode_graph.EpisodeGraphs around the capture of a training episode
 
 
 def _f(n, dev):
@@ -45,10 +78,15 @@ def bn_fold(sums, count, bnmod, bias=None):
     C = bnmod.num_features
     dev = sums.device
     mean, invstd, scale, shift = _f(C, dev), _f(C, dev), _f(C, dev), _f(C, dev)
-    upd = update_running_stats
+    rec = bn_recorder
+    upd = update_running_stats and rec is None
+    rec_ptr, rec_idx, rec_stride = None, None, 0
+    if rec is not None:
+        table = rec.slot_for(bnmod, bias)
+        rec_ptr, rec_idx, rec_stride = _p(table[rec.pass_id]), _p(rec.index_dev), 2 * C
     _lib.check(_lib.load().r3d_bn_fold(_p(sums), float(count), C, _p(bnmod.weight), _p(bnmod.bias), BN_EPS, BN_MOM,
                                        _p(bnmod.running_mean) if upd else None, _p(bnmod.running_var) if upd else None,
-                                       _p(mean), _p(invstd), _p(scale), _p(shift), _st()))
+                                       _p(mean), _p(invstd), _p(scale), _p(shift), rec_ptr, rec_idx, rec_stride, _st()))
     if upd:
         if bias is not None:
             bnmod.running_mean.add_(BN_MOM * bias.detach())

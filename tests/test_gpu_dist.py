@@ -97,8 +97,8 @@ def test_two_ranks_of_dptrainer_equal_one_rank(slots):
     assert torch.equal(out[0]["grad"], out[1]["grad"])
     scale = want_grad.abs().max().item()
     err = (out[0]["grad"] - want_grad).abs().max().item() / scale
-    # eager ranks: only the summation order over episodes (and the float atomics of the EdgeConv scatter) differ
-    assert err <= (1e-5 if slots == 0 else 2e-3), err
+    # every kernel of the step sums in a fixed order: only the order of the sum over episodes differs between the runs
+    assert err <= 1e-5, err
     assert torch.equal(out[0]["params"], out[1]["params"])
     perr = (out[0]["params"] - want_params).abs().max().item()
     assert perr <= 2e-3, perr  # one Adam step of lr 1e-3: sign-level agreement of the update

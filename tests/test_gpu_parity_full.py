@@ -291,4 +291,4 @@ def test_config4_training_step_on_C_graphs_match_eager():
     assert bad == 0 and overflow == 0
     assert abs(float(total) - tot) <= 1e-4 * max(1.0, abs(tot))
     err = (rows.sum(0) - want).abs().max().item() / want.abs().max().item()
-    assert err < 2e-3, err
+    assert err < 1e-5, err
