@@ -33,21 +33,22 @@ def _lp_residual(model):
     return (r.norm(dim=0) / Y.norm(dim=0).clamp(min=1e-30)).cpu().numpy(), n, nnz
 
 
-@pytest.mark.parametrize("workload,noise", [("S", 0.0), ("S", 0.4), ("C", 0.2)])
-def test_full_size_eval_properties(workload, noise):
+@pytest.mark.parametrize("workload,noise,ev", [("S", 0.0, False), ("S", 0.4, True), ("C", 0.2, False), ("C", 0.4, True)])
+def test_full_size_eval_properties(workload, noise, ev):
+    """ev = True: the eval_noise.py path (clean-shot detection on, the reference's 'ood' noise rules)."""
     cfg = S.workload_cfg(workload)
     m = _model(cfg)
-    data, _ = S.make_episode(cfg, seed=77, noise_ratio=noise)
+    data, _ = S.make_episode(cfg, seed=77, noise_ratio=noise, noise_mode="ood" if ev else None)
     sx, sy, qx, qy = [t.cuda() for t in data[:4]]
     with torch.no_grad():
-        l1, loss1 = m(sx, sy, qx, qy)
+        l1, loss1 = m(sx, sy, qx, qy, eval=ev)
         iters = None
         if not m.lp_converged():  # the caller's protocol (MPTILearner_V3.test): re-run with the full budget
             iters = m.lp_max_iter
-            l1, loss1 = m(sx, sy, qx, qy, lp_iters=iters)
+            l1, loss1 = m(sx, sy, qx, qy, eval=ev, lp_iters=iters)
             assert m.lp_converged()
         res, n, nnz = _lp_residual(m)
-        l2, loss2 = m(sx, sy, qx, qy, lp_iters=iters)
+        l2, loss2 = m(sx, sy, qx, qy, eval=ev, lp_iters=iters)
     assert torch.equal(l1, l2) and torch.equal(loss1, loss2)                  # deterministic, idempotent
     assert torch.isfinite(l1).all() and l1.shape == (cfg["n_way"], cfg["n_way"] + 1, cfg["pc_npts"])
     assert (res[:cfg["n_way"] + 1] < 2e-5).all(), res                          # Z solves (I - alpha S) Z = Y
