@@ -8,7 +8,9 @@
  * Conventions
  *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
  *     (PyTorch caching allocator in practice), borrowed for the duration of the call;
- *   - kernels never allocate; scratch is passed in (sizes from the *_ws_words helpers);
+ *   - kernels never allocate; scratch is passed in (sizes from the *_ws_words helpers); the entry points whose scratch is
+ *     carved into many arrays (prototypes, label propagation, contrastive loss, reverse neighbour list) also take its
+ *     size in words and return an error for a short buffer instead of writing past it;
  *   - every function enqueues on `stream` (a hipStream_t passed as void*) and returns
  *     immediately: 0 = OK, non-zero = error, message in r3d_last_error_string();
  *   - no host synchronisation anywhere: data-dependent counts (points per class,
@@ -97,7 +99,7 @@ int r3d_head_prototypes(const int32_t* support_y /*(n_way*k_shot,N)*/, const int
                         const float* qfeat /*(n_q*N,ldq)*/, long ldq, int n_way, int k_shot, int N, int D,
                         int n_query_pts, int k, float* nodes, long ldn, float* node_labels /*(n_cap,4)*/,
                         int32_t* desc, int32_t* assign_out /*opt (2*S*N)*/, int32_t* cluster_count /*opt (n_cap)*/,
-                        int32_t* ws, int flags, void* stream);
+                        int32_t* ws, long ws_words, int flags, void* stream);
 
 /* ---- affinity + label propagation (models/mpti.py:717-776) ---------------------------
  * nbr (n_cap, kp1) from r3d_knn_topk mode 1 (column 0 is dropped as in mpti.py:736).
@@ -113,7 +115,7 @@ long r3d_lp_ws_words(int n_cap, int kp1);
 int r3d_lp_ws_offsets(int n_cap, int kp1, long* out6);
 int r3d_label_propagate(const float* nodes, long ldn, int D, const int32_t* nbr, int kp1, const float* Y,
                         const int32_t* n_dev, const int32_t* n_proto_dev, int n_cap, float sigma, float alpha,
-                        int max_iter, float tol, float* Z, int32_t* ws, int32_t* stats_out, void* stream);
+                        int max_iter, float tol, float* Z, int32_t* ws, long ws_words, int32_t* stats_out, void* stream);
 
 /* Captured episodes: enable the CG kernel nodes (three per iteration) of iterations < budget in an instantiated hipGraph holding
  * r3d_label_propagate / r3d_label_propagate_bwd launches, disable the rest (no dispatch for them).  graph: the
@@ -184,7 +186,7 @@ int r3d_edge_select(float* zmax /*in: max, out: selected z*/, const float* zmin,
 /* reverse neighbour list (for every point the edges that name it, ascending): rev_ws = r3d_edge_reverse_ws_words int32
  * words.  The backward gathers along it instead of scattering with float atomics: deterministic gradients. */
 long r3d_edge_reverse_ws_words(int B, int N, int K);
-int r3d_edge_reverse(const int32_t* idx, int B, int N, int K, int32_t* rev_ws, void* stream);
+int r3d_edge_reverse(const int32_t* idx, int B, int N, int K, int32_t* rev_ws, long ws_words, void* stream);
 int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float* s1, const float* t1, const float* mean1,
                      const float* invstd1, const float* W2, const float* s2, const float* t2, const float* mean2,
                      const float* invstd2, const float* bn2_sums, const float* dout, long lddo, const int32_t* argmax,
@@ -207,7 +209,7 @@ int r3d_ce_grad(const float* Z, const int32_t* n_proto_dev, int n_cap, int n_que
                 const int64_t* labels, const float* gscale_dev, float* G, void* stream);
 int r3d_label_propagate_bwd(const float* nodes, long ldn, int D, int kp1, const float* Z, const float* G,
                             const int32_t* n_dev, int n_cap, float sigma, float alpha, int max_iter, float tol, float* lam,
-                            float* dnodes, long ldd, int32_t* ws, int32_t* stats_out, void* stream);
+                            float* dnodes, long ldd, int32_t* ws, long ws_words, int32_t* stats_out, void* stream);
 int r3d_head_prototypes_bwd(const float* dnodes, long ldd, int n_way, int k_shot, int N, int D, int n_query_pts,
                             const int32_t* desc, const int32_t* assign, const int32_t* cluster_count, const int32_t* ws,
                             float* dsfeat, long lds_, float* dqfeat, long ldq, void* stream);
@@ -218,7 +220,7 @@ int r3d_head_prototypes_bwd(const float* dnodes, long ldd, int n_way, int k_shot
 long r3d_contrast_ws_words(int n_way, int k_shot, int N);
 int r3d_contrast_fwd(const float* feat, long ldf, int D, const int32_t* support_y, const int32_t* support_flag, int n_way,
                      int k_shot, int N, const float* W, const float* bias, float temp, float* loss_out, float* ws,
-                     void* stream);
+                     long ws_words, void* stream);
 int r3d_contrast_bwd(int D, int n_way, int k_shot, int N, const float* gscale_dev, float* dfeat, long ldd, float* dW,
                      float* db, float* ws, void* stream);
 /* training-only debug metrics (mpti.py:515-568): out4 = query_acc_LP, query_acc_original, clean_ratio_LP_avg,

@@ -39,11 +39,11 @@ _SIGS = {
     "r3d_head_proto_ws_words": (c_l, [c_i, c_i, c_i]),
     "r3d_head_proto_ws_offsets": (c_i, [c_i, c_i, c_i, ctypes.POINTER(c_l)]),
     "r3d_head_prototypes": (c_i, [c_f, c_f, c_f, c_l, c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_l,
-                                  c_f, c_f, c_f, c_f, c_f, c_i, c_f]),
+                                  c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_f]),
     "r3d_lp_ws_words": (c_l, [c_i, c_i]),
     "r3d_lp_ws_offsets": (c_i, [c_i, c_i, ctypes.POINTER(c_l)]),
     "r3d_label_propagate": (c_i, [c_f, c_l, c_i, c_f, c_i, c_f, c_f, c_f, c_i, c_fl, c_fl, c_i, c_fl, c_f, c_f,
-                                  c_f, c_f]),
+                                  c_l, c_f, c_f]),
     "r3d_graph_set_lp_budget": (c_i, [c_f, c_f, c_i, ctypes.POINTER(c_i)]),
     "r3d_pointwise_conv_acc": (c_i, [c_f, c_l, c_f, c_l, c_i, c_i, c_f, c_f, c_i, c_f, c_l, c_f]),
     "r3d_edgeconv_train_fwd_minmax": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
@@ -64,15 +64,15 @@ _SIGS = {
     "r3d_edge_stats1": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f]),
     "r3d_edgeconv_train_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_l, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f]),
     "r3d_edge_reverse_ws_words": (c_l, [c_i, c_i, c_i]),
-    "r3d_edge_reverse": (c_i, [c_f, c_i, c_i, c_i, c_f, c_f]),
+    "r3d_edge_reverse": (c_i, [c_f, c_i, c_i, c_i, c_f, c_l, c_f]),
     "r3d_edgeconv_bwd": (c_i, [c_f] * 13 + [c_l, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "r3d_attention_fwd_train": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_fl, c_u, c_f, c_f, c_f]),
     "r3d_attention_bwd": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_l, c_f, c_fl, c_u, c_f, c_fl, c_f, c_l, c_f, c_f]),
     "r3d_ce_grad": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),
-    "r3d_label_propagate_bwd": (c_i, [c_f, c_l, c_i, c_i, c_f, c_f, c_f, c_i, c_fl, c_fl, c_i, c_fl, c_f, c_f, c_l, c_f, c_f, c_f]),
+    "r3d_label_propagate_bwd": (c_i, [c_f, c_l, c_i, c_i, c_f, c_f, c_f, c_i, c_fl, c_fl, c_i, c_fl, c_f, c_f, c_l, c_f, c_l, c_f, c_f]),
     "r3d_head_prototypes_bwd": (c_i, [c_f, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_l, c_f, c_l, c_f]),
     "r3d_contrast_ws_words": (c_l, [c_i, c_i, c_i]),
-    "r3d_contrast_fwd": (c_i, [c_f, c_l, c_i, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_fl, c_f, c_f, c_f]),
+    "r3d_contrast_fwd": (c_i, [c_f, c_l, c_i, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_fl, c_f, c_f, c_l, c_f]),
     "r3d_contrast_bwd": (c_i, [c_i, c_i, c_i, c_i, c_f, c_f, c_l, c_f, c_f, c_f, c_f]),
     "r3d_train_metrics": (c_i, [c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f]),
     "r3d_clean_ws_words": (c_l, [c_i, c_i]),

@@ -18,7 +18,7 @@ class ContrastFn(torch.autograd.Function):
         sf = support_flag.reshape(S).to(torch.int32).contiguous()
         Wc, bc = W.detach().contiguous(), b.detach().contiguous()
         _lib.check(lib.r3d_contrast_fwd(_p(sfeat), sfeat.stride(0), D, _p(sy), _p(sf), model.n_way, model.k_shot, N, _p(Wc),
-                                        _p(bc), 0.1, _p(loss), _p(ws), _st()))
+                                        _p(bc), 0.1, _p(loss), _p(ws), ws.numel(), _st()))
         ctx.ws, ctx.model, ctx.shape = ws, model, sfeat.shape
         return loss
 

@@ -474,8 +474,10 @@ static CtWs ct_carve(float* ws, int n_way, int k_shot, int N) {
 // loss_out: device float.  ws keeps everything the backward needs.
 extern "C" int r3d_contrast_fwd(const float* feat, long ldf, int D, const int32_t* support_y, const int32_t* support_flag,
                                 int n_way, int k_shot, int N, const float* W, const float* bias, float temp,
-                                float* loss_out, float* ws, void* stream) {
+                                float* loss_out, float* ws, long ws_words, void* stream) {
   R3D_REQUIRE(feat && support_y && support_flag && W && bias && loss_out && ws, "r3d_contrast_fwd: null pointer");
+  R3D_REQUIRE(ws_words >= r3d_contrast_ws_words(n_way, k_shot, N), "r3d_contrast_fwd: workspace of %ld words is shorter than "
+              "r3d_contrast_ws_words(%d, %d, %d)", ws_words, n_way, k_shot, N);
   R3D_REQUIRE(n_way >= 1 && n_way <= 3 && (k_shot + 2) * CT_K <= CT_MAXV && D <= CT_DMAX && N <= CT_NMAX,
               "r3d_contrast_fwd: unsupported shape n_way=%d k_shot=%d D=%d N=%d", n_way, k_shot, D, N);
   const CtWs c = ct_carve(ws, n_way, k_shot, N);

@@ -786,9 +786,11 @@ static int bwd1_launch(int K, long units, hipStream_t st, const float* PQ, const
 // Reverse neighbour list of a layer's kNN lists (used by r3d_edgeconv_bwd): rev_ws = B*N + 1 offsets followed by B*N*K
 // edge ids.  Deterministic; no reference counterpart (autograd's scatter-add does this implicitly, dgcnn.py:38).
 extern "C" long r3d_edge_reverse_ws_words(int B, int N, int K) { return (long)B * N + 1 + (long)B * N * K + 16; }
-extern "C" int r3d_edge_reverse(const int32_t* idx, int B, int N, int K, int32_t* rev_ws, void* stream) {
+extern "C" int r3d_edge_reverse(const int32_t* idx, int B, int N, int K, int32_t* rev_ws, long ws_words, void* stream) {
   R3D_REQUIRE(idx && rev_ws, "r3d_edge_reverse: null pointer");
   R3D_REQUIRE(B > 0 && N > 0 && K > 0 && (long)B * N * K < 0x7fffffffL, "r3d_edge_reverse: bad shape B=%d N=%d K=%d", B, N, K);
+  R3D_REQUIRE(ws_words >= r3d_edge_reverse_ws_words(B, N, K), "r3d_edge_reverse: workspace of %ld words is shorter than "
+              "r3d_edge_reverse_ws_words(%d, %d, %d)", ws_words, B, N, K);
   hipLaunchKernelGGL(r3d_edge_reverse_kernel, dim3(r3d_cdiv(N, RV_RANGE), B), dim3(1024), 0, (hipStream_t)stream, idx, N, K, B,
                      rev_ws, rev_ws + (long)B * N + 1);
   R3D_LAUNCH_CHECK("r3d_edge_reverse");

@@ -1034,9 +1034,12 @@ static int lp_solve(const LpWs& L, const float* RHS, const int32_t* n_dev, int n
 
 extern "C" int r3d_label_propagate(const float* nodes, long ldn, int D, const int32_t* nbr, int kp1,
                                    const float* Y, const int32_t* n_dev, const int32_t* n_proto_dev, int n_cap, float sigma,
-                                   float alpha, int max_iter, float tol, float* Z, int32_t* ws,
+                                   float alpha, int max_iter, float tol, float* Z, int32_t* ws, long ws_words,
                                    int32_t* stats_out, void* stream) {
   R3D_REQUIRE(nodes && nbr && Y && n_dev && n_proto_dev && Z && ws, "r3d_label_propagate: null pointer");
+  R3D_REQUIRE(n_cap > 0 && kp1 >= 2 && ws_words >= r3d_lp_ws_words(n_cap, kp1),
+              "r3d_label_propagate: workspace of %ld words, r3d_lp_ws_words(%d, %d) = %ld needed", ws_words, n_cap, kp1,
+              n_cap > 0 && kp1 >= 2 ? r3d_lp_ws_words(n_cap, kp1) : -1L);
   R3D_REQUIRE((ldn & 3) == 0 && ((uintptr_t)nodes & 15) == 0,
               "r3d_label_propagate: node rows are read as float4: ldn must be a multiple of 4 and nodes 16-byte aligned");
   R3D_REQUIRE(n_cap > 0 && n_cap <= 32768 && D > 0 && D <= 256 && (D & 3) == 0 && kp1 >= 2,
@@ -1203,8 +1206,11 @@ __global__ void r3d_ce_grad_kernel(const float4* __restrict__ Z, const int* __re
 // G (n_cap,4) = dL/dZ (from r3d_ce_grad); lam scratch (n_cap,4); dnodes (n_cap, ldd) out.
 extern "C" int r3d_label_propagate_bwd(const float* nodes, long ldn, int D, int kp1, const float* Z, const float* G,
                                        const int32_t* n_dev, int n_cap, float sigma, float alpha, int max_iter, float tol,
-                                       float* lam, float* dnodes, long ldd, int32_t* ws, int32_t* stats_out, void* stream) {
+                                       float* lam, float* dnodes, long ldd, int32_t* ws, long ws_words, int32_t* stats_out,
+                                       void* stream) {
   R3D_REQUIRE(nodes && Z && G && n_dev && lam && dnodes && ws, "r3d_label_propagate_bwd: null pointer");
+  R3D_REQUIRE(n_cap > 0 && kp1 >= 2 && ws_words >= r3d_lp_ws_words(n_cap, kp1),
+              "r3d_label_propagate_bwd: workspace of %ld words is shorter than r3d_lp_ws_words(%d, %d)", ws_words, n_cap, kp1);
   R3D_REQUIRE((ldn & 3) == 0 && ((uintptr_t)nodes & 15) == 0 && ((uintptr_t)ws & 15) == 0 && ((uintptr_t)Z & 15) == 0 &&
                   ((uintptr_t)G & 15) == 0 && ((uintptr_t)lam & 15) == 0,
               "r3d_label_propagate_bwd: ldn must be a multiple of 4; nodes, ws, Z, G, lam 16-byte aligned");

@@ -636,11 +636,14 @@ extern "C" int r3d_head_prototypes(const int32_t* support_y, const int32_t* shot
                                    long ldf, const float* featT, const float* qfeat, long ldq, int n_way,
                                    int k_shot, int N, int D, int n_query_pts, int k, float* nodes, long ldn,
                                    float* node_labels, int32_t* desc, int32_t* assign_out,
-                                   int32_t* cluster_count, int32_t* ws, int flags, void* stream) {
+                                   int32_t* cluster_count, int32_t* ws, long ws_words, int flags, void* stream) {
   R3D_REQUIRE(support_y && feat && featT && qfeat && nodes && node_labels && desc && ws,
               "r3d_head_prototypes: null pointer");
   int rc = check_geom("r3d_head_prototypes", n_way, k_shot, N, D);
   if (rc) return rc;
+  R3D_REQUIRE(ws_words >= r3d_head_proto_ws_words(n_way, k_shot, N),
+              "r3d_head_prototypes: workspace of %ld words, r3d_head_proto_ws_words = %ld needed", ws_words,
+              r3d_head_proto_ws_words(n_way, k_shot, N));
   R3D_REQUIRE(k >= 1 && k <= HP_MAXK, "r3d_head_prototypes: k=%d unsupported (1..%d)", k, HP_MAXK);
   hipStream_t st = (hipStream_t)stream;
   SegGeom g{n_way, k_shot, N};

@@ -52,7 +52,7 @@ class HeadLPFn(torch.autograd.Function):
                                                _p(hb.desc[ops.HD_N_NODES:]), hb.n_cap, float(model.sigma), 0.99,
                                                int(min(model.lp_max_iter, ctx.budget + max(4, ctx.budget // 4))), float(model.lp_tol), _p(lam),
                                                _p(dnodes), D,
-                                               _p(hb.lp_ws), _p(hb.stats_bwd), _st()))
+                                               _p(hb.lp_ws), hb.lp_ws.numel(), _p(hb.stats_bwd), _st()))
         dsfeat = torch.zeros(ctx.shapes[0], device=dev, dtype=torch.float32)
         dqfeat = torch.empty(ctx.shapes[1], device=dev, dtype=torch.float32)
         _lib.check(lib.r3d_head_prototypes_bwd(_p(dnodes), D, model.n_way, model.k_shot, N, D, n_q * N, _p(hb.desc),

@@ -249,7 +249,8 @@ def head_prototypes(hb, support_y, shot_keep, sfeat_pm, sfeatT, qfeat_pm):
         _lib.check(_lib.load().r3d_head_prototypes(
             _p(support_y), _p(shot_keep), _p(sfeat_pm), ldf, _p(sfeatT), _p(qfeat_pm), ldq, hb.n_way, hb.k_shot,
             hb.N, hb.D, hb.n_q_pts, hb.k_sub, _p(hb.nodes), hb.nodes.stride(0), _p(hb.Y), _p(hb.desc),
-            _p(hb.assign), _p(hb.cluster_count), _p(hb.proto_ws), HEAD_FPS_ONE_LAUNCH if hb.fps_one_launch else 0, _st()))
+            _p(hb.assign), _p(hb.cluster_count), _p(hb.proto_ws), hb.proto_ws.numel(),
+            HEAD_FPS_ONE_LAUNCH if hb.fps_one_launch else 0, _st()))
 
 
 def label_propagate(hb, nbr, sigma, alpha=0.99, max_iter=200, tol=1e-6):
@@ -258,7 +259,7 @@ def label_propagate(hb, nbr, sigma, alpha=0.99, max_iter=200, tol=1e-6):
         _lib.check(_lib.load().r3d_label_propagate(
             _p(hb.nodes), hb.nodes.stride(0), hb.D, _p(nbr), hb.kp1, _p(hb.Y), _p(hb.desc[HD_N_NODES:]),
             _p(hb.desc[HD_N_PROTO:]), hb.n_cap, float(sigma), float(alpha), int(max_iter), float(tol), _p(hb.Z),
-            _p(hb.lp_ws), _p(hb.stats), _st()))
+            _p(hb.lp_ws), hb.lp_ws.numel(), _p(hb.stats), _st()))
     return hb.Z
 
 

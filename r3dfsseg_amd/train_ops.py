@@ -222,7 +222,7 @@ def edgeconv_train_bwd(saved, dout, B, N, dx_acc):
     rev = torch.empty(lib.r3d_edge_reverse_ws_words(B, N, K), device=dev, dtype=torch.int32)
     with _timed("edgeconv_bwd"):
         # the reverse neighbour list: the input gradient is a gather over incoming edges (deterministic, no float atomics)
-        _lib.check(lib.r3d_edge_reverse(_p(idx), B, N, K, _p(rev), _st()))
+        _lib.check(lib.r3d_edge_reverse(_p(idx), B, N, K, _p(rev), rev.numel(), _st()))
         _lib.check(lib.r3d_edgeconv_bwd(_p(PQ), _p(idx), _p(bn1[0]), _p(bn1[1]), _p(bn1[2]), _p(bn1[3]), _p(W2), _p(bn2[0]),
                                         _p(bn2[1]), _p(bn2[2]), _p(bn2[3]), _p(bn2_sums), _p(dout), dout.stride(0),
                                         _p(argmax), B, N, K, _p(DY1), _p(BE), _p(rev), _p(dW2), _p(bn1_sums), _p(dPQ),

@@ -15,7 +15,7 @@ def _reverse(idx):
     lib = _lib.load()
     B, N, K = idx.shape
     ws = torch.full((lib.r3d_edge_reverse_ws_words(B, N, K),), -7, device="cuda", dtype=torch.int32)
-    _lib.check(lib.r3d_edge_reverse(ops._p(idx), B, N, K, ops._p(ws), ops._st()))
+    _lib.check(lib.r3d_edge_reverse(ops._p(idx), B, N, K, ops._p(ws), ws.numel(), ops._st()))
     torch.cuda.synchronize()
     ws = ws.cpu().numpy()
     return ws[:B * N + 1], ws[B * N + 1:B * N + 1 + B * N * K]
@@ -70,3 +70,21 @@ def test_edgeconv_input_gradient_is_bit_identical_run_to_run():
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert torch.equal(a, b)
+
+
+def test_short_workspace_is_an_error_not_an_overrun():
+    from r3dfsseg_amd import _lib, ops
+    lib = _lib.load()
+    idx = torch.zeros(2, 64, 8, device="cuda", dtype=torch.int32)
+    ws = torch.empty(lib.r3d_edge_reverse_ws_words(2, 64, 8) - 1, device="cuda", dtype=torch.int32)
+    assert lib.r3d_edge_reverse(ops._p(idx), 2, 64, 8, ops._p(ws), ws.numel(), ops._st()) != 0
+    assert b"workspace" in lib.r3d_last_error_string()
+    hb = ops.HeadBuffers(2, 1, 256, 512, 100, 200, 192, "cuda")
+    hb.desc[ops.HD_N_PROTO] = 10
+    hb.desc[ops.HD_N_NODES] = 522
+    nbr = torch.zeros(hb.n_cap, hb.kp1, device="cuda", dtype=torch.int32)
+    short = hb.lp_ws[:hb.lp_ws.numel() - 64]
+    rc = lib.r3d_label_propagate(ops._p(hb.nodes), hb.nodes.stride(0), hb.D, ops._p(nbr), hb.kp1, ops._p(hb.Y),
+                                 ops._p(hb.desc[ops.HD_N_NODES:]), ops._p(hb.desc[ops.HD_N_PROTO:]), hb.n_cap, 1.0, 0.99, 10, 1e-6,
+                                 ops._p(hb.Z), ops._p(short), short.numel(), ops._p(hb.stats), ops._st())
+    assert rc != 0 and b"workspace" in lib.r3d_last_error_string()
