@@ -239,6 +239,9 @@ def main():
         f[0] = f[0] * hb.stats_bwd[0].clamp(max=1)  # forward AND adjoint solve converged
         lp_flags.append(f)
 
+    def train_step_single_graph(i):  # the reference's schedule (one episode per optimiser step) as ONE hipGraph replay
+        trainer.step(batch(i, 1))
+
     def eval_step(i):
         model.eval()
         eval_graphs.run([ep[:4] for ep in batch(i, E)])
@@ -301,6 +304,8 @@ def main():
             n_e = max(args.steps * E // 4, 8)
             el1, _ = timed(train_step_eager, n_e, 3)
             extra["single_episode_eager_step_episodes_per_sec"] = n_e * world / el1
+            el1g, _ = timed(train_step_single_graph, n_e, 3)  # what MPTILearner_V3.train does with episode_graphs on
+            extra["single_episode_graph_step_episodes_per_sec"] = n_e * world / el1g
         else:
             E = 1
             elapsed, cg = timed(train_step_eager, args.steps, args.warmup)

@@ -44,12 +44,14 @@ class _Slot:
 
 
 class EpisodeGraphs:
-    def __init__(self, model, example, n_slots=4, train=False, lp_budget=None, grad_rows=None, loss_weight=0.1):
+    def __init__(self, model, example, n_slots=4, train=False, lp_budget=None, grad_rows=None, loss_weight=0.1,
+                 eval_flag=False):
         """example: one episode (list of tensors, train layout loader.py:1666-1671 or the 4-tensor test layout
         (support_x, support_y, query_x, query_y)) fixing shapes and dtypes.  grad_rows: (n_slots, n_params[+1])
         fp32 buffer, row s receives slot s's gradients (train only)."""
         self.model, self.train, self.n_slots = model, train, n_slots
         self.loss_weight = loss_weight
+        self.eval_flag = eval_flag          # eval graphs: forward(..., eval=True), the clean-shot detection of eval_noise.py
         dev = next(model.parameters()).device
         self.params = [p for p in model.parameters() if p.requires_grad]
         if train:
@@ -95,14 +97,18 @@ class EpisodeGraphs:
         model = self.model
         if self.train:
             from .head_train import explicit_train_episode
-            loss, sl.logits, _ = explicit_train_episode(model, sl.inputs, sl.grad_views, self.loss_weight)
+            loss, sl.logits, metrics, lp, con = explicit_train_episode(model, sl.inputs, sl.grad_views, self.loss_weight)
             sl.loss_sum += loss
+            # the last episode's parts of the reference's train() tuple (mpti_learner.py:78), for the one-slot learner path
+            sl.parts[0].copy_(lp); sl.parts[1].copy_(con)
+            for i in range(4):
+                sl.parts[2 + i].copy_(metrics[i])
             hb = model._slot.last[1]
             ok = hb.stats[0] * hb.stats_bwd[0].clamp(max=1)
         else:
             sx, sy, qx, qy = sl.inputs[:4]
             with torch.no_grad():
-                logits, loss = model(sx, sy, qx, qy)
+                logits, loss = model(sx, sy, qx, qy, eval=self.eval_flag)
             sl.loss_sum += loss
             hb = model._slot.last[1]
             ok = hb.stats[0]
@@ -119,6 +125,7 @@ class EpisodeGraphs:
         sl.done = torch.cuda.Event()
         sl.inputs = [t.to(dev).clone() for t in example]
         sl.loss_sum = torch.zeros((), device=dev)
+        sl.parts = torch.zeros(6, device=dev)  # lp_loss, contrast loss, the four debug metrics of the last replay
         sl.bad, sl.knn_overflow, sl.cg_iters, sl.cg_max = (self.counters[s, i] for i in range(4))
         st = EpisodeSlot(s)
         st.fixed_budget = self.lp_budget

@@ -85,6 +85,7 @@ def mpti_train_forward(model, support_x, support_y, query_x, query_y, gt_support
     lp_loss = HeadLPFn.apply(sfeat, qfeat, model, support_y, query_y)
     logits = model._train_logits
     metrics = contrast.train_debug_metrics(model, support_y, gt_support_y, query_y, gt_query_y, logger)
+    model._last_train_parts = (lp_loss.detach(), contrast_loss.detach(), metrics)
     return (logits, lp_loss, contrast_loss) + metrics
 
 
@@ -94,7 +95,7 @@ def explicit_train_episode(model, episode, grad_sink, loss_weight=0.1):
     with plain namespaces as their ctx, then their backward halves in dependency order, and every parameter
     gradient is ADDED into grad_sink[i] (views in the order of model.parameters(), requires_grad only).
     Same kernels, same results as ``loss = lp + loss_weight * contrast; loss.backward()``
-    (models/mpti_learner.py:66-68).  Returns (loss, logits, metrics[4])."""
+    (models/mpti_learner.py:66-68).  Returns (loss, logits, metrics[4], lp_loss, contrast_loss)."""
     from types import SimpleNamespace
     from . import contrast
     (support_x, support_y, query_x, query_y, _sc, _qc, gt_support_y, gt_query_y, _bx, _by, support_flag) = episode
@@ -141,4 +142,4 @@ def explicit_train_episode(model, episode, grad_sink, loss_weight=0.1):
                 dst += [grad_sink[index[id(model.proj.weight)]], grad_sink[index[id(model.proj.bias)]]]
                 src += [dWp, dbp]
             torch._foreach_add_(dst, src)
-    return loss, logits, metrics
+    return loss, logits, metrics, lploss, closs

@@ -4,6 +4,12 @@ Identical constructor, attributes (.model/.optimizer/.lr_scheduler) and train()/
 signatures and return tuples (mpti_learner.py:50-102), so mpti_train_noise.py and
 eval_noise.py run against it unchanged.  A checkpoint path of the literal string
 "synthetic" initialises from r3dfsseg_amd.synthetic (no dataset/checkpoint files here).
+
+The reference's schedule is one episode per call.  An episode is ~900 kernel launches, so issued one by one from
+Python the GPU idles ~70 % of the step; with ``args.episode_graphs`` (default on) train() / test() capture the
+episode's launch sequence into ONE hipGraph on first use (shapes are fixed per run) and replay it afterwards -- same
+kernels, same results, same return values.  Anything the graph cannot serve (other shapes, a solver miss) falls back
+to the eager launches.
 """
 import torch
 from torch import optim
@@ -18,6 +24,9 @@ class MPTILearner_V3(object):
         if not torch.cuda.is_available():
             raise RuntimeError("MPTILearner_V3 needs an MI355X: the forward pass has no CPU path")
         self.model.cuda()
+        self.episode_graphs = bool(getattr(args, 'episode_graphs', True))
+        self._trainer = None          # DPTrainer with one captured slot (train)
+        self._eval_graphs = {}        # eval flag -> EpisodeGraphs with one captured slot (test)
         synthetic = 'synthetic' in (getattr(args, 'pretrain_checkpoint_path', None), getattr(args, 'model_checkpoint_path', None))
         if synthetic:
             from . import synthetic as S
@@ -42,7 +51,46 @@ class MPTILearner_V3(object):
         else:
             raise ValueError('Wrong GraphLearner mode (%s)! Option:train/test' % mode)
 
+    @staticmethod
+    def _same_layout(tensors, example):
+        return len(tensors) == len(example) and all(
+            a.shape == b.shape and a.dtype == b.dtype for a, b in zip(tensors, example))
+
+    def _train_graph(self, data, logger):
+        """One episode through the captured launch sequence: forward + backward, status check, Adam (DPTrainer.step
+        with one slot and one episode is exactly mpti_learner.py:60-72).  None when the graph cannot serve the call."""
+        from .dp_train import DPTrainer
+        if self._trainer is None:
+            self._trainer = DPTrainer(self, n_slots=1, example=data)
+        sl = self._trainer.graphs.slots[0]
+        if not self._same_layout(data, sl.inputs):
+            return None
+        loss = self._trainer.step([data], logger=logger)
+        if self._trainer.redone:  # the conservative eager pass ran instead: its results live in the eager buffers
+            return self._tuple_from_eager(loss, data)
+        lp, con, m0, m1, m2, m3 = sl.parts.unbind(0)
+        query_y = data[3]
+        correct = torch.eq(sl.logits.argmax(dim=1), query_y).sum().item()  # the step's host sync (mpti_learner.py:75)
+        accuracy = correct / (query_y.shape[0] * query_y.shape[1])
+        if logger is not None:
+            v = sl.parts[2:].tolist()
+            logger.cprint('after label propagation: QUERY prediction acc: {:.3f}, original_acc: {:.3f}'.format(v[0], v[1]))
+            logger.cprint('after label propagation: clean_ratio_LP: {:.3f}, clean_ratio_original: {:.3f}'.format(v[2], v[3]))
+        return (loss, lp.clone(), con.clone(), accuracy, m0.clone(), m1.clone(), m2.clone(), m3.clone())
+
+    def _tuple_from_eager(self, loss, data):
+        m = self.model
+        query_y = data[3]
+        correct = torch.eq(m._train_logits.argmax(dim=1), query_y).sum().item()
+        accuracy = correct / (query_y.shape[0] * query_y.shape[1])
+        lp, con, metrics = m._last_train_parts
+        return (loss, lp, con, accuracy) + tuple(metrics)
+
     def train(self, data, logger):
+        if self.episode_graphs:
+            out = self._train_graph(data, logger)
+            if out is not None:
+                return out
         [support_x, support_y, query_x, query_y, support_c, query_c, gt_support_y, gt_query_y, bg_pcd_x, bg_pcd_y,
          support_flag] = data
         self.model.train()
@@ -53,7 +101,8 @@ class MPTILearner_V3(object):
                                                 bg_pcd_y=bg_pcd_y, support_c=support_c, support_flag=support_flag,
                                                 lp_iters=lp_iters)
             loss = lp_loss + 0.1 * contrastive_loss
-            self.optimizer.zero_grad()
+            # (once a gradient bucket exists the parameters' .grad tensors are views into it: zero them in place)
+            self.optimizer.zero_grad(set_to_none=self._trainer is None)
             loss.backward()
             # the CG solves (forward and adjoint) run on a launch budget and the 201-NN / FPS fast paths can report
             # overflow / time-out: never step Adam on an inexact gradient.  One host read per step, where the
@@ -72,7 +121,30 @@ class MPTILearner_V3(object):
         return (loss, lp_loss, contrastive_loss, accuracy, query_acc_LP, query_acc_original, clean_ratio_LP_avg,
                 original_clean_ratio)
 
+    def _test_graph(self, data, eval):
+        from .episode_graph import EpisodeGraphs
+        episode = list(data[:4])
+        g = self._eval_graphs.get(bool(eval))
+        if g is None:
+            self.model.eval()
+            g = self._eval_graphs[bool(eval)] = EpisodeGraphs(self.model, episode, n_slots=1, train=False, eval_flag=bool(eval))
+        sl = g.slots[0]
+        if not self._same_layout(episode, sl.inputs):
+            return None
+        loss = g.run([episode])
+        bad, overflow, _, _ = g.step_status()  # host wait: the reference synchronises here too (mpti_learner.py:99)
+        if bad or overflow:
+            return None                          # the eager path below redoes the episode on the conservative schedule
+        pred = sl.logits.argmax(dim=1)
+        query_y = data[3]
+        correct = torch.eq(pred, query_y).sum().item()
+        return pred, loss.clone(), correct / (query_y.shape[0] * query_y.shape[1])
+
     def test(self, data, sampled_classes, step=None, path=None, eval=False):
+        if self.episode_graphs:
+            out = self._test_graph(data, eval)
+            if out is not None:
+                return out
         [support_x, support_y, query_x, query_y, _, _, gt_support_y] = data
         self.model.eval()
         with torch.no_grad():

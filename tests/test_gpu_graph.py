@@ -159,3 +159,35 @@ def test_running_statistics_of_a_graph_step_equal_the_sequential_schedule():
     for k, v in m.named_buffers():
         assert torch.equal(v, want[k]), k
     assert int(m.encoder.conv.layer[1].num_batches_tracked) == 2 * len(eps)
+
+
+def test_learner_graph_path_equals_eager_path():
+    """MPTILearner_V3.train / .test with episode_graphs (one captured hipGraph per call) against the same learner with
+    eager launches: same return tuples, same weights after three optimiser steps, same predictions."""
+    from r3dfsseg_amd.mpti_learner import MPTILearner_V3
+    cfg = S.make_cfg(n_way=2, k_shot=2, pc_npts=512, pretrain_checkpoint_path="synthetic", model_checkpoint_path=None,
+                     lr=1e-3, step_size=5000, gamma=0.5)
+    eps = _episodes(cfg, 3)
+    outs = {}
+    for mode in (False, True):
+        L = MPTILearner_V3(SimpleNamespace(**dict(cfg, episode_graphs=mode)), mode="train")
+        L.model.att_learner.dropout.p = 0.0
+        tuples = []
+        for ep in eps:
+            t = L.train(ep, None)
+            assert len(t) == 8
+            tuples.append([float(v) for v in t])
+        pred, loss, acc = L.test(eps[0][:7], [3, 6], eval=True)
+        pred2, loss2, acc2 = L.test(eps[1][:7], [3, 6], eval=False)
+        outs[mode] = (tuples, torch.cat([p.detach().reshape(-1) for p in L.model.parameters()]).cpu(),
+                      {k: v.cpu().clone() for k, v in L.model.named_buffers()}, pred.cpu(), float(loss), acc, pred2.cpu(), acc2)
+        assert (L._trainer is not None) == mode and (len(L._eval_graphs) == 2) == mode
+    te, tg = outs[False][0], outs[True][0]
+    for a, b in zip(te, tg):
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-5)
+    perr = (outs[False][1] - outs[True][1]).abs().max().item()
+    assert perr < 2e-5, perr
+    for k in outs[False][2]:
+        np.testing.assert_allclose(outs[False][2][k].float().numpy(), outs[True][2][k].float().numpy(), rtol=1e-4, atol=1e-5)
+    assert torch.equal(outs[False][3], outs[True][3]) and torch.equal(outs[False][6], outs[True][6])
+    assert abs(outs[False][4] - outs[True][4]) < 1e-4 and outs[False][5] == outs[True][5] and outs[False][7] == outs[True][7]
