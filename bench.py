@@ -285,7 +285,7 @@ def main():
                 msg = ("%s: %d episode(s) with unconverged label propagation / FPS time-out (CG max %d of budget %d), "
                        "%d with 201-NN survivor overflow" % (step_fn.__name__, graphs.last_unconverged, it_max, enabled,
                                                              graphs.last_knn_overflow))
-                if step_fn is train_step:  # DPTrainer.step fails closed: it redid those steps exactly, inside the timed region
+                if step_fn in (train_step, train_step_single_graph):  # DPTrainer.step fails closed: it redid those steps exactly, inside the timed region
                     redone_notes.append(msg + " -- redone on the conservative schedule before the optimiser step")
                 else:
                     invalid.append(msg)
@@ -304,7 +304,7 @@ def main():
             n_e = max(args.steps * E // 4, 8)
             el1, _ = timed(train_step_eager, n_e, 3)
             extra["single_episode_eager_step_episodes_per_sec"] = n_e * world / el1
-            el1g, _ = timed(train_step_single_graph, n_e, 3)  # what MPTILearner_V3.train does with episode_graphs on
+            el1g, _ = timed(train_step_single_graph, n_e, 3, trainer.graphs)  # what MPTILearner_V3.train does with episode_graphs on
             extra["single_episode_graph_step_episodes_per_sec"] = n_e * world / el1g
         else:
             E = 1
