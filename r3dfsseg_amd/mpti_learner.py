@@ -5,11 +5,14 @@ signatures and return tuples (mpti_learner.py:50-102), so mpti_train_noise.py an
 eval_noise.py run against it unchanged.  A checkpoint path of the literal string
 "synthetic" initialises from r3dfsseg_amd.synthetic (no dataset/checkpoint files here).
 
-The reference's schedule is one episode per call.  An episode is ~900 kernel launches, so issued one by one from
-Python the GPU idles ~70 % of the step; with ``args.episode_graphs`` (default on) train() / test() capture the
-episode's launch sequence into ONE hipGraph on first use (shapes are fixed per run) and replay it afterwards -- same
-kernels, same results, same return values.  Anything the graph cannot serve (other shapes, a solver miss) falls back
-to the eager launches.
+The reference's schedule is one episode per call.  With ``args.episode_graphs = True`` (default off) train() / test()
+capture the episode's launch sequence into ONE hipGraph on first use (shapes are fixed per run) and replay it afterwards
+-- same kernels, same results, same return values (tests/test_gpu_graph.py); anything the graph cannot serve (other
+shapes, a solver miss) falls back to the eager launches.  Measured at workload S: 86 episodes/s against 92 with eager
+launches -- a single episode is a chain of ~440 dependent launches whose cost is the ~8 us from one kernel's end to the
+next one's start, which a graph replay does not shorten; what the option buys is a free host thread (the replay costs
+~0.3 ms of host time against ~9 ms of Python launch calls), e.g. for the data loader.  Throughput comes from episodes in
+flight (dp_train.DPTrainer, episode_graph.EpisodeGraphs), not from this switch.
 """
 import torch
 from torch import optim
@@ -24,7 +27,7 @@ class MPTILearner_V3(object):
         if not torch.cuda.is_available():
             raise RuntimeError("MPTILearner_V3 needs an MI355X: the forward pass has no CPU path")
         self.model.cuda()
-        self.episode_graphs = bool(getattr(args, 'episode_graphs', True))
+        self.episode_graphs = bool(getattr(args, 'episode_graphs', False))
         self._trainer = None          # DPTrainer with one captured slot (train)
         self._eval_graphs = {}        # eval flag -> EpisodeGraphs with one captured slot (test)
         synthetic = 'synthetic' in (getattr(args, 'pretrain_checkpoint_path', None), getattr(args, 'model_checkpoint_path', None))
