@@ -29,6 +29,8 @@ _SIGS = {
     "r3d_copy_cols": (c_i, [c_f, c_l, c_f, c_l, c_l, c_i, c_f]),
     "r3d_sqnorm": (c_i, [c_f, c_l, c_l, c_i, c_f, c_f]),
     "r3d_knn_topk": (c_i, [c_f, c_l, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "r3d_knn_split_ws_words": (c_l, [c_i, c_i, c_i]),
+    "r3d_knn_topk_split": (c_i, [c_f, c_l, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_f]),
     "r3d_pointwise_conv": (c_i, [c_f, c_l, c_f, c_l, c_i, c_i, c_f, c_f, c_i, c_f, c_l, c_f]),
     "r3d_edgeconv_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f, c_f]),
     "r3d_attention_ws_words": (c_l, [c_i, c_i]),

@@ -554,8 +554,14 @@ __global__ __launch_bounds__(64 * KB_WAVES) __attribute__((amdgpu_waves_per_eu(K
 void r3d_knn_append_kernel(
     const float* __restrict__ xT, long ldT, int N, int C, int k, int mode, const int* __restrict__ n_dev,
     const float* __restrict__ nrm, int* __restrict__ idx_out, float* __restrict__ score_out,
-    int* __restrict__ status, int* __restrict__ tile_flags) {
+    int* __restrict__ status, int* __restrict__ tile_flags, int nsplit, int* __restrict__ idx_tmp,
+    float* __restrict__ sc_tmp) {
+  // nsplit > 1 (gridDim.z): the CANDIDATE axis is dealt to nsplit workgroups per query tile (sub-tile s goes to
+  // workgroup s % nsplit); each selects its own top-k -- its tau is a lower bound of the k-th best score of ITS
+  // candidates, which is <= the k-th best of all of them -- into idx_tmp / sc_tmp, and r3d_knn_merge_kernel merges the
+  // sorted lists.  For the 138 query tiles of workload S this fills the 256 CUs instead of half of them.
   constexpr int KB_GROUPS = KB_WAVES * 32;
+  const int z = blockIdx.z;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int cnt_s[32];
   __shared__ float tau_s[32];
@@ -587,13 +593,13 @@ void r3d_knn_append_kernel(
   }
   __syncthreads();
 
-  const int nsub = (n + 31) / 32;
+  const int nsub = ((n + 31) / 32 - z + nsplit - 1) / nsplit;  // sub-tiles of this workgroup: z, z + nsplit, ...
   const int my_sub = (nsub - w + KB_WAVES - 1) / KB_WAVES;  // sub-tiles of this wave (w < nsub assumed below)
   const int T = (w < nsub) ? my_sub * nch : 0;              // (sub-tile, chunk) units
 
   int stride = KB_SAMPLE;  // sub-tile stride of the running pass (pass A: the sample; pass B: 1)
   auto bload = [&](int t, float (&bf)[KCH]) {
-    const int st = w + KB_WAVES * stride * (t / nch), ch = (t % nch);
+    const int st = (w + KB_WAVES * stride * (t / nch)) * nsplit + z, ch = (t % nch);
     const int cand = 32 * st + j;
     const bool ok = cand < n;
     const int cc = min(cand, n - 1);
@@ -659,7 +665,7 @@ void r3d_knn_append_kernel(
   auto finishA = [&](int t) {
     if ((t % nch) != nch - 1) return;
     f32x16 sc;
-    scores(w + KB_WAVES * stride * (t / nch), sc);
+    scores((w + KB_WAVES * stride * (t / nch)) * nsplit + z, sc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float x = sc[r];
@@ -725,7 +731,7 @@ void r3d_knn_append_kernel(
   bool overflow = false;
   auto finishB = [&](int t) {
     if ((t % nch) != nch - 1) return;
-    const int st = w + KB_WAVES * (t / nch);
+    const int st = (w + KB_WAVES * (t / nch)) * nsplit + z;
     f32x16 sc;
     scores(st, sc);
 #pragma unroll
@@ -807,15 +813,71 @@ void r3d_knn_append_kernel(
         }
       }
     }
+    if (nsplit == 1) {
 #pragma unroll
-    for (int i = 0; i < KB_CAP / 64; ++i) {
-      if (64 * i + lane < M && rank[i] < k) {
-        idx_out[((long)b * N + row) * k + rank[i]] = mi[i];
-        if (score_out) score_out[((long)b * N + row) * k + rank[i]] = mv[i];
+      for (int i = 0; i < KB_CAP / 64; ++i) {
+        if (64 * i + lane < M && rank[i] < k) {
+          idx_out[((long)b * N + row) * k + rank[i]] = mi[i];
+          if (score_out) score_out[((long)b * N + row) * k + rank[i]] = mv[i];
+        }
+      }
+    } else {
+      const long o = (((long)z * gridDim.y + b) * N + row) * k;
+#pragma unroll
+      for (int i = 0; i < KB_CAP / 64; ++i) {
+        if (64 * i + lane < M && rank[i] < k) {
+          idx_tmp[o + rank[i]] = mi[i];
+          sc_tmp[o + rank[i]] = mv[i];
+        }
+      }
+      for (int t = min(M, k) + lane; t < k; t += 64) {  // fewer than k survivors (a part with < k candidates)
+        idx_tmp[o + t] = 0x7fffffff;
+        sc_tmp[o + t] = -INFINITY;
       }
     }
   }
   KSTAMP(13);
+}
+
+// Merge of the nsplit sorted top-k lists of a row (r3d_knn_append_kernel with nsplit > 1): an entry's final rank is
+// its own rank plus, for every other list, the number of that list's entries that beat it (binary search; the lists
+// hold disjoint candidates, so keys never tie across lists).  One wave per row, lists in LDS.  Keys as in the rank
+// phase: (order-preserving score bits, complemented index), larger = better.
+__global__ __launch_bounds__(256) void r3d_knn_merge_kernel(const int* __restrict__ idx_tmp, const float* __restrict__ sc_tmp,
+                                                            int nsplit, long rows, int k, const int* __restrict__ n_dev, int N,
+                                                            int* __restrict__ idx_out, float* __restrict__ score_out) {
+  __shared__ unsigned long long keys[4][2][256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 4 + w;
+  if (row >= rows) return;
+  if (n_dev && (int)(row % N) >= min(*n_dev, N)) return;  // rows beyond n are not queried
+  // nsplit == 2 (the only configuration launched)
+  for (int p = 0; p < 2; ++p)
+    for (int t = lane; t < k; t += 64) {
+      const long o = ((long)p * rows + row) * k + t;
+      const float v = sc_tmp[o];
+      const int id = idx_tmp[o];
+      keys[w][p][t] = id == 0x7fffffff ? 0ull
+                                       : (((unsigned long long)f2key(v + 0.0f) << 32) | (0x7fffffffu - (unsigned)id));
+    }
+  __builtin_amdgcn_wave_barrier();
+  for (int p = 0; p < 2; ++p)
+    for (int t = lane; t < k; t += 64) {
+      const unsigned long long mine = keys[w][p][t];
+      if (mine == 0ull) continue;
+      const unsigned long long* other = keys[w][1 - p];
+      int lo = 0, hi = k;  // number of entries of the other list with a larger key (lists are sorted descending)
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (other[mid] > mine) lo = mid + 1; else hi = mid;
+      }
+      const int rank = t + lo;
+      if (rank < k) {
+        const long o = ((long)p * rows + row) * k + t;
+        idx_out[row * k + rank] = idx_tmp[o];
+        if (score_out) score_out[row * k + rank] = sc_tmp[o];
+      }
+    }
 }
 
 static size_t knn_append_lds_bytes(int C, int waves, int cap, int top, int kch = 32) {
@@ -846,7 +908,7 @@ static size_t knn_lds_bytes(int C) {
 template <int WAVES, int CAP, int TOP, int KCH, int SAMPLE, bool FULLC, int SMODE>
 static int knn_append_launch_mode(dim3 grid, size_t lds, hipStream_t st, const float* xT, long ldT, int N, int C, int k,
                                   const int* n_valid_dev, const float* nrm, int* idx_out, float* score_out, int* status,
-                                  int* tile_flags) {
+                                  int* tile_flags, int nsplit = 1, int* idx_tmp = nullptr, float* sc_tmp = nullptr) {
   static size_t attr = 0;
   if (lds > attr) {
     hipError_t e = hipFuncSetAttribute((const void*)r3d_knn_append_kernel<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, SMODE>,
@@ -855,18 +917,20 @@ static int knn_append_launch_mode(dim3 grid, size_t lds, hipStream_t st, const f
     attr = lds;
   }
   hipLaunchKernelGGL((r3d_knn_append_kernel<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, SMODE>), grid, dim3(64 * WAVES), lds, st, xT, ldT,
-                     N, C, k, SMODE, n_valid_dev, nrm, idx_out, score_out, status, tile_flags);
+                     N, C, k, SMODE, n_valid_dev, nrm, idx_out, score_out, status, tile_flags, nsplit, idx_tmp, sc_tmp);
   return R3D_OK;
 }
 template <int WAVES, int CAP, int TOP, int KCH, int SAMPLE, bool FULLC>
 static int knn_append_launch(dim3 grid, size_t lds, hipStream_t st, const float* xT, long ldT, int N, int C, int k, int mode,
                              const int* n_valid_dev, const float* nrm, int* idx_out, float* score_out, int* status,
-                             int* tile_flags) {
+                             int* tile_flags, int nsplit = 1, int* idx_tmp = nullptr, float* sc_tmp = nullptr) {
   return mode == R3D_SCORE_DGCNN
              ? knn_append_launch_mode<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, R3D_SCORE_DGCNN>(grid, lds, st, xT, ldT, N, C, k, n_valid_dev,
-                                                                                            nrm, idx_out, score_out, status, tile_flags)
+                                                                                            nrm, idx_out, score_out, status, tile_flags,
+                                                                                            nsplit, idx_tmp, sc_tmp)
              : knn_append_launch_mode<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, R3D_SCORE_L2>(grid, lds, st, xT, ldT, N, C, k, n_valid_dev, nrm,
-                                                                                         idx_out, score_out, status, tile_flags);
+                                                                                         idx_out, score_out, status, tile_flags, nsplit,
+                                                                                         idx_tmp, sc_tmp);
 }
 
 extern "C" int r3d_sqnorm(const float* x, long ldx, long rows, int C, float* out, void* stream) {
@@ -894,9 +958,26 @@ extern "C" long r3d_knn_norm_ws_words(int B, int N) { return (long)B * N + (long
 // status: optional device int.  With k > 32 a non-NULL status selects the append-and-rank
 // kernel; bit 0 set afterwards = its survivor buffer overflowed and the result is unusable
 // (re-run with status == NULL for the insertion kernel).
+// floats of split_ws for r3d_knn_topk_split (two partial top-k lists per row: indices and scores)
+extern "C" long r3d_knn_split_ws_words(int B, int N, int k) { return 4L * B * N * k + 64; }
+
+extern "C" int r3d_knn_topk_split(const float* x, long ldx, const float* x_cm, int B, int N, int C, int k, int mode,
+                                  const int* n_valid_dev, float* norm_ws, float* cm_ws, int32_t* idx_out,
+                                  float* score_out, int32_t* status, float* split_ws, long split_ws_words, void* stream);
+
 extern "C" int r3d_knn_topk(const float* x, long ldx, const float* x_cm, int B, int N, int C, int k, int mode,
                             const int* n_valid_dev, float* norm_ws, float* cm_ws, int32_t* idx_out,
                             float* score_out, int32_t* status, void* stream) {
+  return r3d_knn_topk_split(x, ldx, x_cm, B, N, C, k, mode, n_valid_dev, norm_ws, cm_ws, idx_out, score_out, status, nullptr, 0,
+                            stream);
+}
+
+// r3d_knn_topk with an optional scratch for the large-k streamed kernel: when the query tiles alone cannot fill the
+// chip (B * ceil(N / 32) <= 192 workgroups) and split_ws holds r3d_knn_split_ws_words(B, N, k) floats, the candidate
+// axis is split over two workgroups per tile and the two sorted lists are merged by a second small kernel.
+extern "C" int r3d_knn_topk_split(const float* x, long ldx, const float* x_cm, int B, int N, int C, int k, int mode,
+                                  const int* n_valid_dev, float* norm_ws, float* cm_ws, int32_t* idx_out,
+                                  float* score_out, int32_t* status, float* split_ws, long split_ws_words, void* stream) {
   R3D_REQUIRE((x || x_cm) && norm_ws && idx_out, "r3d_knn_topk: null pointer");
   R3D_REQUIRE(B > 0 && N > 0 && C > 0 && (!x || ldx >= C), "r3d_knn_topk: bad shape B=%d N=%d C=%d ldx=%ld", B, N, C, ldx);
   R3D_REQUIRE(k > 0 && k <= N && k <= 256, "r3d_knn_topk: unsupported k=%d (need 1..min(N,256))", k);
@@ -967,13 +1048,22 @@ extern "C" int r3d_knn_topk(const float* x, long ldx, const float* x_cm, int B, 
     hipLaunchKernelGGL(r3d_sqnorm_cm_kernel, dim3(r3d_cdiv(N, 256), B), dim3(256), 0, st, xT, ldT, C, N, norm_ws);
     r3d_zero_words(status, 1, st);
     {
-      const dim3 gb(r3d_cdiv(N, 32), B);
+      const int tiles = r3d_cdiv(N, 32);
+      // two workgroups per query tile when the tiles alone leave CUs idle and every half still holds >= 2 k candidates
+      const bool split = split_ws && (long)tiles * B <= 192 && N >= 4 * k && split_ws_words >= r3d_knn_split_ws_words(B, N, k);
+      const int nsplit = split ? 2 : 1;
+      const dim3 gb(tiles, B, nsplit);
+      int* idx_tmp = (int*)split_ws;
+      float* sc_tmp = split_ws ? split_ws + 2L * B * N * k : nullptr;
       const int rc = C % 64 == 0
                          ? knn_append_launch<8, 384, 2, 32, 1, true>(gb, knn_big_lds_bytes(C), st, xT, ldT, N, C, k, mode, n_valid_dev,
-                                                                     norm_ws, idx_out, score_out, status, nullptr)
+                                                                     norm_ws, idx_out, score_out, status, nullptr, nsplit, idx_tmp, sc_tmp)
                          : knn_append_launch<8, 384, 2, 32, 1, false>(gb, knn_big_lds_bytes(C), st, xT, ldT, N, C, k, mode, n_valid_dev,
-                                                                      norm_ws, idx_out, score_out, status, nullptr);
+                                                                      norm_ws, idx_out, score_out, status, nullptr, nsplit, idx_tmp, sc_tmp);
       if (rc) return rc;
+      if (split)
+        hipLaunchKernelGGL(r3d_knn_merge_kernel, dim3(r3d_cdiv((long)B * N, 4)), dim3(256), 0, st, idx_tmp, sc_tmp, 2,
+                           (long)B * N, k, n_valid_dev, N, idx_out, score_out);
     }
     R3D_LAUNCH_CHECK("r3d_knn_topk(big)");
     return R3D_OK;

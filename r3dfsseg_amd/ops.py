@@ -148,9 +148,14 @@ def knn(x_pm, B, N, k, mode=SCORE_DGCNN, n_valid=None, return_scores=False, x_cm
             cm_ws = torch.empty(B * C * _lib.load().r3d_cm_pitch(N), device=dev, dtype=torch.float32)
     else:
         x_cm = None
+    lib = _lib.load()
+    split_ws, split_words = None, 0
+    if k > 32 and status is not None and B * ((N + 31) // 32) <= 192:  # the large-k kernel may split the candidate axis
+        split_words = lib.r3d_knn_split_ws_words(B, N, k)
+        split_ws = torch.empty(split_words, device=dev, dtype=torch.float32)
     with _timed("knn_topk_l2" if mode == SCORE_L2 else "knn_topk"):
-        _lib.check(_lib.load().r3d_knn_topk(_p(x_pm), ld, _p(x_cm), B, N, C, k, mode, _p(n_valid), _p(norm),
-                                            _p(cm_ws), _p(idx), _p(sc), _p(status), _st()))
+        _lib.check(lib.r3d_knn_topk_split(_p(x_pm), ld, _p(x_cm), B, N, C, k, mode, _p(n_valid), _p(norm), _p(cm_ws),
+                                          _p(idx), _p(sc), _p(status), _p(split_ws), split_words, _st()))
     return (idx, sc) if return_scores else idx
 
 
