@@ -57,8 +57,8 @@ int r3d_knn_topk(const float* x, long ldx, const float* x_cm, int B, int N, int 
                  const int32_t* n_valid_dev, float* norm_ws, float* cm_ws, int32_t* idx_out, float* score_out,
                  int32_t* status, void* stream);
 /* the same with a scratch of r3d_knn_split_ws_words(B, N, k) floats: for k > 32 with status != NULL and so few query
- * tiles that they cannot fill the chip (the head's 201-NN: 138 tiles for 256 CUs), the candidate axis is dealt to two
- * workgroups per tile and their sorted lists are merged -- same result, bit for bit */
+ * tiles that even twice as many workgroups fit the chip in one round (2 B ceil(N/32) <= 256), the candidate axis is
+ * dealt to two workgroups per tile and their sorted lists are merged -- same result, bit for bit */
 long r3d_knn_split_ws_words(int B, int N, int k);
 int r3d_knn_topk_split(const float* x, long ldx, const float* x_cm, int B, int N, int C, int k, int mode,
                        const int32_t* n_valid_dev, float* norm_ws, float* cm_ws, int32_t* idx_out, float* score_out,

@@ -559,7 +559,7 @@ void r3d_knn_append_kernel(
   // nsplit > 1 (gridDim.z): the CANDIDATE axis is dealt to nsplit workgroups per query tile (sub-tile s goes to
   // workgroup s % nsplit); each selects its own top-k -- its tau is a lower bound of the k-th best score of ITS
   // candidates, which is <= the k-th best of all of them -- into idx_tmp / sc_tmp, and r3d_knn_merge_kernel merges the
-  // sorted lists.  For the 138 query tiles of workload S this fills the 256 CUs instead of half of them.
+  // sorted lists.  Used while 2 x tiles <= 256 workgroups (one workgroup per CU: 123 KB of LDS).
   constexpr int KB_GROUPS = KB_WAVES * 32;
   const int z = blockIdx.z;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -973,7 +973,7 @@ extern "C" int r3d_knn_topk(const float* x, long ldx, const float* x_cm, int B, 
 }
 
 // r3d_knn_topk with an optional scratch for the large-k streamed kernel: when the query tiles alone cannot fill the
-// chip (B * ceil(N / 32) <= 192 workgroups) and split_ws holds r3d_knn_split_ws_words(B, N, k) floats, the candidate
+// chip even when doubled (2 B ceil(N / 32) <= 256 workgroups) and split_ws holds r3d_knn_split_ws_words(B, N, k) floats, the candidate
 // axis is split over two workgroups per tile and the two sorted lists are merged by a second small kernel.
 extern "C" int r3d_knn_topk_split(const float* x, long ldx, const float* x_cm, int B, int N, int C, int k, int mode,
                                   const int* n_valid_dev, float* norm_ws, float* cm_ws, int32_t* idx_out,
@@ -1049,8 +1049,10 @@ extern "C" int r3d_knn_topk_split(const float* x, long ldx, const float* x_cm, i
     r3d_zero_words(status, 1, st);
     {
       const int tiles = r3d_cdiv(N, 32);
-      // two workgroups per query tile when the tiles alone leave CUs idle and every half still holds >= 2 k candidates
-      const bool split = split_ws && (long)tiles * B <= 192 && N >= 4 * k && split_ws_words >= r3d_knn_split_ws_words(B, N, k);
+      // two workgroups per query tile when BOTH halves of every tile still fit the chip in one round (the kernel's
+      // 123 KB of LDS admit one workgroup per CU: at workload S, 138 tiles -> 276 workgroups ran as two rounds, 489 us
+      // against 412 us unsplit) and every half still holds >= 2 k candidates
+      const bool split = split_ws && 2L * tiles * B <= 256 && N >= 4 * k && split_ws_words >= r3d_knn_split_ws_words(B, N, k);
       const int nsplit = split ? 2 : 1;
       const dim3 gb(tiles, B, nsplit);
       int* idx_tmp = (int*)split_ws;

@@ -150,7 +150,7 @@ def knn(x_pm, B, N, k, mode=SCORE_DGCNN, n_valid=None, return_scores=False, x_cm
         x_cm = None
     lib = _lib.load()
     split_ws, split_words = None, 0
-    if k > 32 and status is not None and B * ((N + 31) // 32) <= 192:  # the large-k kernel may split the candidate axis
+    if k > 32 and status is not None and 2 * B * ((N + 31) // 32) <= 256:  # the large-k kernel may split the candidate axis
         split_words = lib.r3d_knn_split_ws_words(B, N, k)
         split_ws = torch.empty(split_words, device=dev, dtype=torch.float32)
     with _timed("knn_topk_l2" if mode == SCORE_L2 else "knn_topk"):
