@@ -432,8 +432,6 @@ __global__ __launch_bounds__(256) void r3d_edgeconv_train_fwd2_kernel(
 // compaction over the edges instead.  Neighbour ids are clamped to the cloud like everywhere else.
 #define RV_RANGE 256
 #define RV_CAP 12288
-#define RV_REG 48  // list entries per thread the CACHE variant keeps in registers (clouds of up to 49 152 edges)
-template <bool CACHE>
 __global__ __launch_bounds__(1024) void r3d_edge_reverse_kernel(const int* __restrict__ idx, int N, int K, int n_clouds,
                                                                 int* __restrict__ rev_ptr, int* __restrict__ rev) {
   __shared__ int cnt[RV_RANGE];
@@ -451,33 +449,16 @@ __global__ __launch_bounds__(1024) void r3d_edge_reverse_kernel(const int* __res
   if (tid == 0) below_s = 0;
   __syncthreads();
   int my_below = 0;
-  // CACHE: the cloud's whole list sits in registers (RV_REG entries per thread, requested in one batch: the count and
-  // the fill pass then cost no memory round trip; reading the list twice in trips of 8 was ~20 of the kernel's 41 us).
-  // Entry u of thread tid is edge tid + 1024 u; -1 marks "beyond E", targets are stored relative to r0 + 1.
-  int jr[CACHE ? RV_REG : 1];
-  if (CACHE) {
+  for (long e0 = tid; e0 < E; e0 += 8 * 1024) {  // 8 list entries in flight per thread and trip
+    int jv[8];
 #pragma unroll
-    for (int u = 0; u < RV_REG; ++u) jr[u] = lst[min((long)tid + 1024L * u, E - 1)];
+    for (int u = 0; u < 8; ++u) jv[u] = lst[min(e0 + 1024 * u, E - 1)];
 #pragma unroll
-    for (int u = 0; u < RV_REG; ++u) {
-      const int j = min(max(jr[u], 0), N - 1) - r0;
-      const bool ok = (long)tid + 1024L * u < E;
-      jr[u] = ok ? j : -0x40000000;
-      if (ok && j < 0) ++my_below;
-      if (ok && j >= 0 && j < nr) atomicAdd(&cnt[j], 1);
-    }
-  } else {
-    for (long e0 = tid; e0 < E; e0 += 8 * 1024) {  // 8 list entries in flight per thread and trip
-      int jv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) jv[u] = lst[min(e0 + 1024 * u, E - 1)];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int j = min(max(jv[u], 0), N - 1) - r0;
-        if (e0 + 1024 * u < E) {
-          if (j < 0) ++my_below;
-          else if (j < nr) atomicAdd(&cnt[j], 1);
-        }
+    for (int u = 0; u < 8; ++u) {
+      const int j = min(max(jv[u], 0), N - 1) - r0;
+      if (e0 + 1024 * u < E) {
+        if (j < 0) ++my_below;
+        else if (j < nr) atomicAdd(&cnt[j], 1);
       }
     }
   }
@@ -549,23 +530,15 @@ __global__ __launch_bounds__(1024) void r3d_edge_reverse_kernel(const int* __res
     }
     if (tid < RV_RANGE) cur[tid] = (tid >= a && tid < b) ? off[tid] - off[a] : 0;
     __syncthreads();
-    if (CACHE) {
+    for (long e0 = tid; e0 < E; e0 += 8 * 1024) {
+      int jv[8];
 #pragma unroll
-      for (int u = 0; u < RV_REG; ++u) {
-        const int j = jr[u];
-        if (j >= a && j < b) buf[atomicAdd(&cur[j], 1)] = tid + 1024 * u;  // arbitrary order inside a segment: ranked below
-      }
-    } else {
-      for (long e0 = tid; e0 < E; e0 += 8 * 1024) {
-        int jv[8];
+      for (int u = 0; u < 8; ++u) jv[u] = lst[min(e0 + 1024 * u, E - 1)];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) jv[u] = lst[min(e0 + 1024 * u, E - 1)];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int j = min(max(jv[u], 0), N - 1) - r0;
-          if (e0 + 1024 * u < E && j >= a && j < b)
-            buf[atomicAdd(&cur[j], 1)] = (int)(e0 + 1024 * u);  // arbitrary order inside a segment: ranked below
-        }
+      for (int u = 0; u < 8; ++u) {
+        const int j = min(max(jv[u], 0), N - 1) - r0;
+        if (e0 + 1024 * u < E && j >= a && j < b)
+          buf[atomicAdd(&cur[j], 1)] = (int)(e0 + 1024 * u);  // arbitrary order inside a segment: ranked below
       }
     }
     __syncthreads();
@@ -818,12 +791,8 @@ extern "C" int r3d_edge_reverse(const int32_t* idx, int B, int N, int K, int32_t
   R3D_REQUIRE(B > 0 && N > 0 && K > 0 && (long)B * N * K < 0x7fffffffL, "r3d_edge_reverse: bad shape B=%d N=%d K=%d", B, N, K);
   R3D_REQUIRE(ws_words >= r3d_edge_reverse_ws_words(B, N, K), "r3d_edge_reverse: workspace of %ld words is shorter than "
               "r3d_edge_reverse_ws_words(%d, %d, %d)", ws_words, B, N, K);
-  if ((long)N * K <= 1024L * RV_REG)
-    hipLaunchKernelGGL(r3d_edge_reverse_kernel<true>, dim3(r3d_cdiv(N, RV_RANGE), B), dim3(1024), 0, (hipStream_t)stream, idx, N,
-                       K, B, rev_ws, rev_ws + (long)B * N + 1);
-  else
-    hipLaunchKernelGGL(r3d_edge_reverse_kernel<false>, dim3(r3d_cdiv(N, RV_RANGE), B), dim3(1024), 0, (hipStream_t)stream, idx, N,
-                       K, B, rev_ws, rev_ws + (long)B * N + 1);
+  hipLaunchKernelGGL(r3d_edge_reverse_kernel, dim3(r3d_cdiv(N, RV_RANGE), B), dim3(1024), 0, (hipStream_t)stream, idx, N, K, B,
+                     rev_ws, rev_ws + (long)B * N + 1);
   R3D_LAUNCH_CHECK("r3d_edge_reverse");
   return R3D_OK;
 }
