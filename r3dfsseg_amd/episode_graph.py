@@ -136,7 +136,8 @@ class EpisodeGraphs:
         # HIP runs the streams on GPU_MAX_HW_QUEUES (default 4) hardware queues, one kernel at a time per queue, so at
         # most that many FPS grids are ever resident together, whatever the number of slots
         in_flight = min(self.n_slots, int(os.environ.get("GPU_MAX_HW_QUEUES", "4")))
-        st.fps_one_launch = in_flight * fps_blocks <= (500 if model.feat_dim <= 192 else 250)
+        st.fps_one_launch = (in_flight * fps_blocks <= (500 if model.feat_dim <= 192 else 250)
+                             and os.environ.get("R3D_FPS_PER_ROUND") is None)  # A/B switch: one launch per FPS round
         if self.train:
             st.seed_dev = torch.full((1,), 7919 * (s + 1), device=dev, dtype=torch.int32)
             off, sl.grad_views = 0, []
