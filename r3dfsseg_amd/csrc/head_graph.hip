@@ -538,6 +538,10 @@ static __device__ __forceinline__ void cg_store_sc1(float* p, float v) {
   __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+static __device__ __forceinline__ float cg_load_sc1(const float* p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
 static __device__ __forceinline__ void cg_load_mw_column(const float* __restrict__ MW, int row0, int n_cap, float (&m)[64]) {
   const int a = threadIdx.x & 63, w = threadIdx.x >> 6;
   // rows < n_cap exist and rows in [n, n_cap) are zero (r3d_cg_mw_kernel); beyond n_cap the index is clamped
@@ -603,9 +607,10 @@ static __device__ __forceinline__ void cg_reduce_step(const float* __restrict__ 
     for (int u = 0; u < 16; ++u) {
       const long b = min(b0 + u, nblk - 1);
       const bool ok = b0 + u < nblk;
-      tv[u] = r3d_keep(pa[b * HG_PART], ok);
-      t2v[u] = r3d_keep(pa[b * HG_PART + HG_M * HG_NC], ok);
-      rv[u] = r3d_keep(part[b * HG_PART + (threadIdx.x & 3)], ok);
+      // sc1 loads: the partials were stored write-through by other workgroups of THIS launch (cg_delivered_last)
+      tv[u] = r3d_keep(cg_load_sc1(pa + b * HG_PART), ok);
+      t2v[u] = r3d_keep(cg_load_sc1(pa + b * HG_PART + HG_M * HG_NC), ok);
+      rv[u] = r3d_keep(cg_load_sc1(part + b * HG_PART + (threadIdx.x & 3)), ok);
     }
 #pragma unroll
     for (int u = 0; u < 16; ++u) { t += tv[u]; t2 += t2v[u]; rrp += rv[u]; }
@@ -644,25 +649,22 @@ static __device__ __forceinline__ void cg_reduce_step(const float* __restrict__ 
   }
 }
 
-// Was this workgroup the last of its launch to deliver its partials?  The in-launch hand-off recipe of the CDNA guide
-// (cdna_hip_programming.md, Guideline 16 / split-K combine, counter form with write-through payload): sc1 stores of the
-// partials (cg_block_partials) -> EVERY storing wave drains its stores (s_waitcnt vmcnt(0)) -> workgroup barrier -> lane
-// 0: relaxed agent-scope ticket add (no release fence: nothing dirty to write back); the workgroup that draws the last
-// ticket: lane 0 ONE agent-scope acquire + drain -> workgroup barrier -> every wave reads the partials with plain loads.
-// (The XCDs' L2 caches are not coherent with each other; `__threadfence()` in every workgroup is the measured-slower
-// form.)  Every launch that reaches this point adds exactly `nblk` tickets, so "last" is ticket % nblk == nblk - 1
-// without resetting the counter between the launches of a solve.
+// Was this workgroup the last of its launch to deliver its partials?  The in-launch hand-off of the CDNA guide
+// (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "visibility", counter form, first table row): the partials
+// are stored write-through (sc1, cg_block_partials) -> EVERY storing wave drains its stores (s_waitcnt vmcnt(0)) ->
+// workgroup barrier -> lane 0: relaxed agent-scope ticket add (no release fence: nothing dirty to write back); the
+// workgroup whose add came last reads the partials with sc1 loads ONLY (cg_reduce_step), after a workgroup barrier its
+// adding wave joins -- so no acquire (cache invalidate) is needed either.  One workgroup per CU (18 - 128 workgroups),
+// hipMalloc'ed memory, 4-byte stores and loads: the measured-valid form.  (The XCDs' L2 caches are not coherent with each
+// other; `__threadfence()` in every workgroup is the measured-slower form.)  Every launch that reaches this point adds
+// exactly `nblk` tickets, so "last" is ticket % nblk == nblk - 1 without resetting the counter inside a solve.
 static __device__ __forceinline__ bool cg_delivered_last(CgState* __restrict__ cg, int nblk, int* flag) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned t = __hip_atomic_fetch_add(&cg->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (t + 1u) % (unsigned)nblk == 0u;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    *flag = last;
+    *flag = (t + 1u) % (unsigned)nblk == 0u;  // (the returned value is used: the add has returned before any load below)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler only: no load moves above the add
   }
   __syncthreads();
   return *flag != 0;
