@@ -460,7 +460,7 @@ __global__ __launch_bounds__(128) void r3d_cg_epart_kernel(const float* __restri
 // E^-1 in fp64 by Gauss-Jordan elimination on [E | I].  Thread (row = tid >> 4, column group = 4 * (tid & 15)) keeps its
 // 4 + 4 entries in registers for the whole elimination; per step the owners of pivot row k and of column k publish
 // them through double-buffered LDS, so a step costs ONE workgroup barrier.
-__global__ __launch_bounds__(1024) void r3d_cg_einv_kernel(const float* __restrict__ Epart, double* __restrict__ Einv) {
+__global__ __launch_bounds__(1024) void r3d_cg_einv_kernel(const float* __restrict__ Epart, float* __restrict__ Einv) {
   __shared__ double S0[HG_M][HG_M + 1];
   __shared__ double prow[2][2 * HG_M];  // pivot row of [A | B], already scaled by 1 / pivot
   __shared__ double pcol[2][HG_M];      // column k of A
@@ -525,7 +525,9 @@ __global__ __launch_bounds__(1024) void r3d_cg_einv_kernel(const float* __restri
   for (int c = 0; c < 4; ++c) S0[row][cg + c] = b[c];
   __syncthreads();
 #pragma unroll
-  for (int c = 0; c < 4; ++c) Einv[row * HG_M + cg + c] = 0.5 * (S0[row][cg + c] + S0[cg + c][row]);
+  for (int c = 0; c < 4; ++c) Einv[row * HG_M + cg + c] = (float)(0.5 * (S0[row][cg + c] + S0[cg + c][row]));  // the
+  // inverse is computed in fp64 and stored in fp32: it is a preconditioner (its rounding changes no solution), and the
+  // vector kernels hold a column of it in registers
 }
 
 // ---- 5d. per-workgroup partials of a residual block: rr, t = W^T r, t2 = (M W)^T r.
@@ -593,7 +595,7 @@ static __device__ __forceinline__ void cg_block_partials(const float4* rs, const
 // The reduction step between U and S, run by the workgroup that delivered its partials last.
 // phase 0: c0 = E^-1 W^T b, bb (partials of b itself); phase 1: mu, rz, beta, convergence test before iteration `it`.
 // ev: column a = tid & 63 of E^-1 in registers (loaded by the caller at kernel start).
-static __device__ __forceinline__ void cg_reduce_step(const float* __restrict__ part, int nblk, const double (&ev)[HG_M],
+static __device__ __forceinline__ void cg_reduce_step(const float* __restrict__ part, int nblk, const float (&ev)[HG_M],
                                                       int phase, int it, float tol2, CgState* __restrict__ cg, double* d_s,
                                                       float* t_s, float* rr_s) {
   const int a = threadIdx.x & 63, c = threadIdx.x >> 6;
@@ -601,10 +603,11 @@ static __device__ __forceinline__ void cg_reduce_step(const float* __restrict__ 
   const float bbv = cg->bb[threadIdx.x & 3];
   float t = 0.f, t2 = 0.f, rrp = 0.f;
   const float* pa = part + 4 + a * HG_NC + c;
-  for (int b0 = 0; b0 < nblk; b0 += 16) {  // 16 workgroups' partials in flight per trip; the add order stays fixed
-    float tv[16], t2v[16], rv[16];
+  for (int b0 = 0; b0 < nblk; b0 += 32) {  // 32 workgroups' partials in flight per trip (ONE trip at workload S: each
+    // trip is a ~2 us round trip to the memory side); the add order stays fixed
+    float tv[32], t2v[32], rv[32];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < 32; ++u) {
       const long b = min(b0 + u, nblk - 1);
       const bool ok = b0 + u < nblk;
       // sc1 loads: the partials were stored write-through by other workgroups of THIS launch (cg_delivered_last)
@@ -613,7 +616,7 @@ static __device__ __forceinline__ void cg_reduce_step(const float* __restrict__ 
       rv[u] = r3d_keep(cg_load_sc1(part + b * HG_PART + (threadIdx.x & 3)), ok);
     }
 #pragma unroll
-    for (int u = 0; u < 16; ++u) { t += tv[u]; t2 += t2v[u]; rrp += rv[u]; }
+    for (int u = 0; u < 32; ++u) { t += tv[u]; t2 += t2v[u]; rrp += rv[u]; }
   }
   if (threadIdx.x < HG_NC) rr_s[threadIdx.x] = rrp;
   d_s[a * HG_NC + c] = phase == 0 ? (double)t : (double)t - (double)t2;
@@ -629,7 +632,7 @@ static __device__ __forceinline__ void cg_reduce_step(const float* __restrict__ 
   }
   double mm = 0.0;
 #pragma unroll
-  for (int b = 0; b < HG_M; ++b) mm += ev[b] * d_s[b * HG_NC + c];
+  for (int b = 0; b < HG_M; ++b) mm += (double)ev[b] * d_s[b * HG_NC + c];
   const float mu = (float)mm;
   float tm = t_s[a * HG_NC + c] * mu;
   tm = r3d_wave_sum(tm);  // one wave = one column c
@@ -670,7 +673,7 @@ static __device__ __forceinline__ bool cg_delivered_last(CgState* __restrict__ c
   return *flag != 0;
 }
 
-static __device__ __forceinline__ void cg_load_einv_column(const double* __restrict__ Einv, double (&ev)[HG_M]) {
+static __device__ __forceinline__ void cg_load_einv_column(const float* __restrict__ Einv, float (&ev)[HG_M]) {
   const int a = threadIdx.x & 63;  // E^-1 is symmetric: column a read as row-strided, coalesced over the lanes
 #pragma unroll
   for (int b = 0; b < HG_M; ++b) ev[b] = Einv[b * HG_M + a];
@@ -683,7 +686,7 @@ __global__ __launch_bounds__(256) void r3d_cg_init_kernel(const float4* __restri
                                                           const int* __restrict__ n_dev, int n_cap, int mode,
                                                           float4* __restrict__ x, float4* __restrict__ r,
                                                           float4* __restrict__ p, float4* __restrict__ q,
-                                                          float* __restrict__ part, const double* __restrict__ Einv, float tol2,
+                                                          float* __restrict__ part, const float* __restrict__ Einv, float tol2,
                                                           CgState* __restrict__ cg) {
   __shared__ float4 sm[4];
   __shared__ float4 rs[HG_UROWS];
@@ -699,7 +702,7 @@ __global__ __launch_bounds__(256) void r3d_cg_init_kernel(const float4* __restri
   __shared__ float4 dot_s[HG_UROWS];
   const int row0 = blockIdx.x * HG_UROWS;
   float m[64];
-  double ev[HG_M];
+  float ev[HG_M];
   cg_load_einv_column(Einv, ev);
   if (mode == 1) cg_load_mw_column(MW, row0, n_cap, m);
   const int n = min(*n_dev, n_cap);
@@ -840,7 +843,7 @@ __global__ __launch_bounds__(256) void r3d_cg_spmv_kernel(
 __global__ __launch_bounds__(256) void r3d_cg_update_kernel(
     const int* __restrict__ n_dev, int n_cap, int it, int nblk_pq, const float* __restrict__ dinv, const int* __restrict__ agg,
     const float* __restrict__ MW, const float4* __restrict__ p, const float4* __restrict__ q, float4* __restrict__ x,
-    float4* __restrict__ r, const float4* __restrict__ part_pq, float* __restrict__ part, const double* __restrict__ Einv,
+    float4* __restrict__ r, const float4* __restrict__ part_pq, float* __restrict__ part, const float* __restrict__ Einv,
     float tol2, CgState* __restrict__ cg) {
   __shared__ float4 sm[4];
   __shared__ float4 rs[HG_UROWS];
@@ -855,7 +858,7 @@ __global__ __launch_bounds__(256) void r3d_cg_update_kernel(
   const int i = row0 + threadIdx.x;
   const int ic = min(i, n_cap - 1);
   float m[64];
-  double ev[HG_M];
+  float ev[HG_M];
   cg_load_mw_column(MW, row0, n_cap, m);
   cg_load_einv_column(Einv, ev);
   const float4 pi = p[ic], qi = q[ic];
@@ -938,7 +941,7 @@ struct LpWs {
   int *row_len, *row_ptr, *agg;
   hg_col_t* col;
   float *val, *dinv, *wdir, *MW, *Epart, *part;
-  double* Einv;
+  float* Einv;
   float4 *r, *p, *q, *part_pq;
   CgState* cg;
   long words, total;
@@ -965,7 +968,7 @@ static LpWs lp_carve(int32_t* ws, int n_cap, int kp1) {
   L.MW = (float*)wp; wp += (long)n_cap * HG_M;
   L.Epart = (float*)wp; wp += (long)HG_EBLOCKS * HG_M * HG_M;
   align4();
-  L.Einv = (double*)wp; wp += 2L * HG_M * HG_M;
+  L.Einv = (float*)wp; wp += (long)HG_M * HG_M;
   L.part = (float*)wp; wp += hg_vblocks(n_cap) * HG_PART;
   align4();
   L.r = (float4*)wp; wp += 4L * n_cap;
