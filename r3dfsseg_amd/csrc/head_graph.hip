@@ -595,10 +595,16 @@ static __device__ __forceinline__ void cg_block_partials(const float4* rs, const
 // The reduction step between U and S, run by the workgroup that delivered its partials last.
 // phase 0: c0 = E^-1 W^T b, bb (partials of b itself); phase 1: mu, rz, beta, convergence test before iteration `it`.
 // ev: column a = tid & 63 of E^-1 in registers (loaded by the caller at kernel start).
-static __device__ __forceinline__ void cg_reduce_step(const float* __restrict__ part, int nblk, const float (&ev)[HG_M],
+static __device__ __forceinline__ void cg_reduce_step(const float* __restrict__ part, int nblk, const float* __restrict__ Einv,
                                                       int phase, int it, float tol2, CgState* __restrict__ cg, double* d_s,
                                                       float* t_s, float* rr_s) {
   const int a = threadIdx.x & 63, c = threadIdx.x >> 6;
+  // column a of E^-1 (symmetric: read as row-strided, coalesced over the lanes), requested together with the partials.
+  // (Measured with phase stamps: prefetching it in EVERY workgroup at kernel start put 64 more loads in front of the
+  // alpha-dependent work of all 18 workgroups -- the 63-deep vmcnt queue turns that into a third load round.)
+  float ev[HG_M];
+#pragma unroll
+  for (int b = 0; b < HG_M; ++b) ev[b] = Einv[b * HG_M + a];
   const float rz_old = cg->rz[c];
   const float bbv = cg->bb[threadIdx.x & 3];
   float t = 0.f, t2 = 0.f, rrp = 0.f;
@@ -630,10 +636,13 @@ static __device__ __forceinline__ void cg_reduce_step(const float* __restrict__ 
       return;
     }
   }
-  double mm = 0.0;
+  double m4[4] = {0.0, 0.0, 0.0, 0.0};  // four independent fp64 chains (a single 64-long chain is 64 dependent DFMAs)
 #pragma unroll
-  for (int b = 0; b < HG_M; ++b) mm += (double)ev[b] * d_s[b * HG_NC + c];
-  const float mu = (float)mm;
+  for (int b = 0; b < HG_M; b += 4) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m4[e] += (double)ev[b + e] * d_s[(b + e) * HG_NC + c];
+  }
+  const float mu = (float)((m4[0] + m4[1]) + (m4[2] + m4[3]));
   float tm = t_s[a * HG_NC + c] * mu;
   tm = r3d_wave_sum(tm);  // one wave = one column c
   cg->mu[a * HG_NC + c] = mu;
@@ -673,12 +682,6 @@ static __device__ __forceinline__ bool cg_delivered_last(CgState* __restrict__ c
   return *flag != 0;
 }
 
-static __device__ __forceinline__ void cg_load_einv_column(const float* __restrict__ Einv, float (&ev)[HG_M]) {
-  const int a = threadIdx.x & 63;  // E^-1 is symmetric: column a read as row-strided, coalesced over the lanes
-#pragma unroll
-  for (int b = 0; b < HG_M; ++b) ev[b] = Einv[b * HG_M + a];
-}
-
 // mode 0: partials of b itself (rr = ||b||^2, t = W^T b).  mode 1: x0 = W c0, r0 = b - (M W) c0, p = q = 0, partials
 // of r0.  c0 = cg->mu.
 __global__ __launch_bounds__(256) void r3d_cg_init_kernel(const float4* __restrict__ B, const float* __restrict__ dinv,
@@ -702,8 +705,6 @@ __global__ __launch_bounds__(256) void r3d_cg_init_kernel(const float4* __restri
   __shared__ float4 dot_s[HG_UROWS];
   const int row0 = blockIdx.x * HG_UROWS;
   float m[64];
-  float ev[HG_M];
-  cg_load_einv_column(Einv, ev);
   if (mode == 1) cg_load_mw_column(MW, row0, n_cap, m);
   const int n = min(*n_dev, n_cap);
   if (mode == 1) mu_s[threadIdx.x] = cg->mu[threadIdx.x];
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(256) void r3d_cg_init_kernel(const float4* __restri
   }
   __syncthreads();
   cg_block_partials(rs, us, ag, row0, n, m, mode == 1, part + (long)blockIdx.x * HG_PART, sm, wpart);
-  if (cg_delivered_last(cg, gridDim.x, &last_s)) cg_reduce_step(part, gridDim.x, ev, mode, 0, tol2, cg, d_s, t_s, rr_s);
+  if (cg_delivered_last(cg, gridDim.x, &last_s)) cg_reduce_step(part, gridDim.x, Einv, mode, 0, tol2, cg, d_s, t_s, rr_s);
 }
 
 // S: p = r + u mu[agg] + beta p ; q = (r - alpha S r) + (M W) mu + beta q ; partial <p, q>.
@@ -838,6 +839,18 @@ __global__ __launch_bounds__(256) void r3d_cg_spmv_kernel(
   }
 }
 
+#ifdef CG_STAMPS  // phase stamps of the update kernel (tools/cg_stamps.py; never in the product build)
+__device__ unsigned long long g_cg_dbg[32];
+#define CSTAMP(i) do { if (it == 3 && threadIdx.x == 0 && blockIdx.x == 0) g_cg_dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CSTAMP_LAST(i) do { if (it == 3 && threadIdx.x == 0) g_cg_dbg[16 + i] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int r3d_cg_debug_read(unsigned long long* out32) {
+  return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_cg_dbg), sizeof(g_cg_dbg)) == hipSuccess ? 0 : 1;
+}
+#else
+#define CSTAMP(i)
+#define CSTAMP_LAST(i)
+#endif
+
 // U: alpha = rz / <p,q> ; x += alpha p ; r -= alpha q ; partials of the new residual.
 // 18 workgroups at workload S: pure latency, so every load that does not depend on alpha is issued first.
 __global__ __launch_bounds__(256) void r3d_cg_update_kernel(
@@ -858,9 +871,8 @@ __global__ __launch_bounds__(256) void r3d_cg_update_kernel(
   const int i = row0 + threadIdx.x;
   const int ic = min(i, n_cap - 1);
   float m[64];
-  float ev[HG_M];
+  CSTAMP(0);
   cg_load_mw_column(MW, row0, n_cap, m);
-  cg_load_einv_column(Einv, ev);
   const float4 pi = p[ic], qi = q[ic];
   float4 xi = x[ic], ri = r[ic];
   const float dv = dinv[ic];
@@ -869,6 +881,7 @@ __global__ __launch_bounds__(256) void r3d_cg_update_kernel(
   const float4 rz = *reinterpret_cast<const float4*>(cg->rz);
   const int n = min(*n_dev, n_cap);
   const float4 pq = reduce_partials(part_pq, nblk_pq, sm);
+  CSTAMP(1);
   if (done) return;  // uniform
   float4 al;
   al.x = pq.x > 0.f ? rz.x / pq.x : 0.f;
@@ -888,9 +901,17 @@ __global__ __launch_bounds__(256) void r3d_cg_update_kernel(
   }
   rs[threadIdx.x] = ri; us[threadIdx.x] = u; ag[threadIdx.x] = a;
   __syncthreads();
+  CSTAMP(2);
   cg_block_partials(rs, us, ag, row0, n, m, true, part + (long)blockIdx.x * HG_PART, sm, wpart);
+  CSTAMP(3);
   // the convergence test / coefficients of iteration it + 1
-  if (cg_delivered_last(cg, gridDim.x, &last_s)) cg_reduce_step(part, gridDim.x, ev, 1, it + 1, tol2, cg, d_s, t_s, rr_s);
+  const bool last = cg_delivered_last(cg, gridDim.x, &last_s);
+  CSTAMP(4);
+  if (last) {
+    CSTAMP_LAST(0);
+    cg_reduce_step(part, gridDim.x, Einv, 1, it + 1, tol2, cg, d_s, t_s, rr_s);
+    CSTAMP_LAST(1);
+  }
 }
 
 // ---------------------------------------------------------------------------
