@@ -147,6 +147,10 @@ int r3d_pointwise_conv_acc(const float* X, long ldx, const float* W, long M, int
 long r3d_pointwise_conv_stats_ws_words(long M, int Co);
 int r3d_pointwise_conv_stats(const float* X, long ldx, const float* W, long M, int K, int Co, float* Out, long ldo,
                              float* sums_out /*[2][Co]*/, float* ws, void* stream);
+/* the same with separate statistics for rows [0, M_first) and [M_first, M) (support and query clouds of an episode in
+ * one launch; mpti.py:434,436 normalise them separately).  M_first: a positive multiple of 64. */
+int r3d_pointwise_conv_stats2(const float* X, long ldx, const float* W, long M, int K, int Co, float* Out, long ldo,
+                              long M_first, float* sums_a /*[2][Co]*/, float* sums_b /*[2][Co]*/, float* ws, void* stream);
 int r3d_colreduce(const float* part /*[chunks][2][C]*/, int chunks, int C, float* sums_out /*[2][C]*/, void* stream);
 long r3d_colstats_ws_words(long M, int C);
 int r3d_colstats(const float* X, long ldx, const float* DY, long lddy, long M, int C, int mode, const float* scale,

@@ -297,9 +297,11 @@ def pairwise_distance_v18(x1, x2, eps=1e-6):
     return torch.norm(x1 - x2 + eps, 2, 1)
 
 
-def affinity(node_feat, k, sigma, return_knn=False):
+def affinity(node_feat, k, sigma, return_knn=False, nbr_override=None):
+    """nbr_override: optional (n, k+1) neighbour lists used instead of this function's own choice (parity tests inject
+    the device's lists after checking them, so that a near-tie decides the same edge on both sides)."""
     n, d = node_feat.shape
-    I = knn_l2(node_feat, k + 1)[:, 1:]  # drop column 0, whatever it is
+    I = (knn_l2(node_feat, k + 1) if nbr_override is None else nbr_override)[:, 1:]  # drop column 0, whatever it is
     knn_feat = node_feat[I.reshape(-1)].view(n, k, d)
     dist = pairwise_distance_v18(node_feat[:, :, None], knn_feat.transpose(1, 2))
     sim = torch.exp(-0.5 * (dist / sigma) ** 2)
@@ -470,7 +472,7 @@ def mpti_forward(sd, cfg, support_x, support_y, query_x, query_y, gt_support_y=N
 
 
 def mpti_head(sd, cfg, sfeat, qfeat, support_x, support_y, query_y, gt_support_y=None, gt_query_y=None,
-              train=False, eval=False, support_flag=None, return_aux=False):
+              train=False, eval=False, support_flag=None, return_aux=False, nbr_override=None):
     """Everything of MPTI_SelfAtten.forward behind the two getFeatures calls (models/mpti.py:438-577).
     sfeat (n_way*k_shot, d, N), qfeat (n_q, d, N) channel-major as getFeatures returns them."""
     n_way, k_shot, N = cfg["n_way"], cfg["k_shot"], cfg["pc_npts"]
@@ -503,7 +505,7 @@ def mpti_head(sd, cfg, sfeat, qfeat, support_x, support_y, query_y, gt_support_y
     Y = torch.zeros(n_nodes, n_classes)
     Y[:n_proto] = plab
     node_feat = torch.cat((protos, qfeat), 0)
-    A, nbr, _ = affinity(node_feat, cfg["k_connect"], cfg["sigma"], return_knn=True)
+    A, nbr, _ = affinity(node_feat, cfg["k_connect"], cfg["sigma"], return_knn=True, nbr_override=nbr_override)
     Z = label_propagate(A, Y)
     qpred = Z[n_proto:].view(-1, query_y.shape[1], n_classes).transpose(1, 2)
     loss = F.cross_entropy(qpred, query_y)

@@ -52,6 +52,7 @@ _SIGS = {
     "r3d_edge_select": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_f, c_l, c_f]),
     "r3d_pointwise_conv_stats_ws_words": (c_l, [c_l, c_i]),
     "r3d_pointwise_conv_stats": (c_i, [c_f, c_l, c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_f, c_f]),
+    "r3d_pointwise_conv_stats2": (c_i, [c_f, c_l, c_f, c_l, c_i, c_i, c_f, c_l, c_l, c_f, c_f, c_f, c_f]),
     "r3d_colreduce": (c_i, [c_f, c_i, c_i, c_f, c_f]),
     "r3d_colstats_ws_words": (c_l, [c_l, c_i]),
     "r3d_colstats": (c_i, [c_f, c_l, c_f, c_l, c_l, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_f]),

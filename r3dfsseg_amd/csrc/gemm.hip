@@ -154,6 +154,23 @@ extern "C" int r3d_pointwise_conv_stats(const float* X, long ldx, const float* W
   return r3d_colreduce(ws, r3d_cdiv(M, G_BM), Co, sums_out, stream);
 }
 
+// The same over TWO row segments with separate batch statistics (the support clouds and the query clouds of an episode
+// go through one GEMM launch, mpti.py:434,436 keep their BatchNorm statistics apart): rows [0, M_first) -> sums_a,
+// rows [M_first, M) -> sums_b.  M_first must be a multiple of the 64-row tile.
+extern "C" int r3d_pointwise_conv_stats2(const float* X, long ldx, const float* W, long M, int K, int Co, float* Out,
+                                         long ldo, long M_first, float* sums_a, float* sums_b, float* ws, void* stream) {
+  R3D_REQUIRE(sums_a && sums_b && ws, "r3d_pointwise_conv_stats2: null pointer");
+  R3D_REQUIRE(M_first > 0 && M_first < M && M_first % G_BM == 0,
+              "r3d_pointwise_conv_stats2: first segment of %ld rows (of %ld) must be a positive multiple of %d", M_first, M,
+              G_BM);
+  int rc = pointwise_launch(X, ldx, W, M, K, Co, nullptr, nullptr, R3D_ACT_NONE, Out, ldo, 0, ws, stream);
+  if (rc) return rc;
+  const int tiles_a = (int)(M_first / G_BM);
+  rc = r3d_colreduce(ws, tiles_a, Co, sums_a, stream);
+  if (rc) return rc;
+  return r3d_colreduce(ws + (long)tiles_a * 2 * Co, r3d_cdiv(M, G_BM) - tiles_a, Co, sums_b, stream);
+}
+
 // Out += act(scale * X W^T + shift): gradient accumulation into a (slice of a) wider buffer
 extern "C" int r3d_pointwise_conv_acc(const float* X, long ldx, const float* W, long M, int K, int Co,
                                       const float* scale, const float* shift, int act, float* Out,

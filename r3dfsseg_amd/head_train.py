@@ -23,6 +23,8 @@ class HeadLPFn(torch.autograd.Function):
                       status=None if model._lp_force else hb.knn_status)
         if model._lp_force:
             hb.knn_status.zero_()
+        if model._trace is not None:
+            model._trace["nbr"] = nbr
         # same launch-budget policy as eval (mpti.py: _lp_next_budget); MPTILearner_V3.train / DPTrainer.step check
         # lp_converged(backward=True) before the optimiser step and redo the episode on this conservative schedule
         ctx.budget = model._lp_next_budget()
@@ -53,8 +55,10 @@ class HeadLPFn(torch.autograd.Function):
                                                int(min(model.lp_max_iter, ctx.budget + max(4, ctx.budget // 4))), float(model.lp_tol), _p(lam),
                                                _p(dnodes), D,
                                                _p(hb.lp_ws), hb.lp_ws.numel(), _p(hb.stats_bwd), _st()))
-        dsfeat = torch.zeros(ctx.shapes[0], device=dev, dtype=torch.float32)
-        dqfeat = torch.empty(ctx.shapes[1], device=dev, dtype=torch.float32)
+        # one buffer, support rows then query rows: the encoder backward takes it whole when both passes share launches
+        dfeat = torch.empty(ctx.shapes[0][0] + ctx.shapes[1][0], D, device=dev, dtype=torch.float32)
+        dsfeat, dqfeat = dfeat[:ctx.shapes[0][0]], dfeat[ctx.shapes[0][0]:]
+        dsfeat.zero_()
         _lib.check(lib.r3d_head_prototypes_bwd(_p(dnodes), D, model.n_way, model.k_shot, N, D, n_q * N, _p(hb.desc),
                                                _p(hb.assign), _p(hb.cluster_count), _p(hb.proto_ws), _p(dsfeat), D,
                                                _p(dqfeat), D, _st()))
@@ -75,8 +79,11 @@ def mpti_train_forward(model, support_x, support_y, query_x, query_y, gt_support
         seed = model._drop_seed
     sx = support_x.reshape(S, model.in_channels, N)
     # two getFeatures calls, each with its own BatchNorm batch statistics (mpti.py:434,436)
-    sfeat = T.get_features_train(model, sx, seed)
-    qfeat = T.get_features_train(model, query_x, seed + 1)
+    if T.shared_launches_ok(model, S):  # ... through one launch sequence over the S + Q clouds
+        sfeat, qfeat = T.get_features_train(model, torch.cat((sx, query_x), 0), seed, seg_clouds=[S, query_x.shape[0]])
+    else:
+        sfeat = T.get_features_train(model, sx, seed)
+        qfeat = T.get_features_train(model, query_x, seed + 1)
     if model._trace is not None:  # parity tests read the features and, after backward(), their gradients
         sfeat.retain_grad()
         qfeat.retain_grad()
@@ -112,12 +119,18 @@ def explicit_train_episode(model, episode, grad_sink, loss_weight=0.1):
         params = T.encoder_params(model)
         cs, cq, cc, ch = (SimpleNamespace(param_list=params) for _ in range(4))
         sx = support_x.reshape(S, model.in_channels, N)
-        if T.bn_recorder is not None:
-            T.bn_recorder.pass_id = 0
-        sfeat = T.EncoderTrainFn.forward(cs, sx, model, seed)
-        if T.bn_recorder is not None:
-            T.bn_recorder.pass_id = 1
-        qfeat = T.EncoderTrainFn.forward(cq, query_x, model, seed + 1)
+        shared = T.shared_launches_ok(model, S)
+        if shared:  # both getFeatures calls through one launch sequence (BatchNorm statistics stay per call)
+            cs.seg_clouds = [S, query_x.shape[0]]
+            feat = T.EncoderTrainFn.forward(cs, torch.cat((sx, query_x), 0), model, seed)
+            sfeat, qfeat = feat[:S * N], feat[S * N:]
+        else:
+            if T.bn_recorder is not None:
+                T.bn_recorder.pass_id = 0
+            sfeat = T.EncoderTrainFn.forward(cs, sx, model, seed)
+            if T.bn_recorder is not None:
+                T.bn_recorder.pass_id = 1
+            qfeat = T.EncoderTrainFn.forward(cq, query_x, model, seed + 1)
         closs = contrast.ContrastFn.forward(cc, sfeat, model.proj.weight, model.proj.bias, model, support_y, support_flag)
         lploss = HeadLPFn.forward(ch, sfeat, qfeat, model, support_y, query_y)
         logits = model._train_logits
@@ -128,11 +141,15 @@ def explicit_train_episode(model, episode, grad_sink, loss_weight=0.1):
         dsf_c, dWp, dbp = contrast.ContrastFn.backward(cc, one * loss_weight)[:3]
         dsf, dqf = HeadLPFn.backward(ch, one)[:2]
         dsf.add_(dsf_c)
-        gs = T.EncoderTrainFn.backward(cs, dsf)[3:]
-        gq = T.EncoderTrainFn.backward(cq, dqf)[3:]
+        if shared:  # dsf | dqf are the two halves of one buffer (HeadLPFn.backward)
+            dfeat = dsf._base
+            assert dfeat is not None and dfeat is dqf._base and dfeat.shape[0] == feat.shape[0]
+            passes = (T.EncoderTrainFn.backward(cs, dfeat)[3:],)
+        else:
+            passes = (T.EncoderTrainFn.backward(cs, dsf)[3:], T.EncoderTrainFn.backward(cq, dqf)[3:])
         index = {id(p): i for i, p in enumerate(q for q in model.parameters() if q.requires_grad)}
-        # two multi-tensor adds: a destination must not appear twice inside one foreach launch
-        for k, grads in enumerate((gs, gq)):
+        # one multi-tensor add per pass: a destination must not appear twice inside one foreach launch
+        for k, grads in enumerate(passes):
             dst, src = [], []
             for p, g in zip(params, grads):
                 if g is not None:
