@@ -30,6 +30,13 @@ extern "C" {
 
 const char* r3d_last_error_string(void);
 int r3d_abi_version(void);
+/* Arithmetic of the GEMM-shaped kernels that decide no index (self-attention forward / backward): 0 = fp32 matrix core
+ * (v_mfma_f32_32x32x2_f32), 1 = every fp32 operand cut into three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per product
+ * block accumulated in fp32 (fp32-level accuracy at 2.67x the matrix rate; csrc/common.h).  kNN scores, which decide
+ * indices, always run on the fp32 core.  Default 1.  Process-wide; call before the first launch.  The attention entry
+ * points use mode 1 only when they are given a workspace (the packed operands live there). */
+int r3d_set_matrix_arith(int mode);
+int r3d_get_matrix_arith(void);
 
 /* ---- layout conversion at the forward() boundary (models/mpti.py:433-437) -------- */
 int r3d_cm_to_pm(const float* in /*(B,C,N)*/, int B, int C, int N, float* out /*(B*N,ld)*/, long ld, void* stream);

@@ -9,7 +9,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libr3d_hip.so")
+LIB_PATH = os.environ.get("R3D_LIB") or os.path.join(_HERE, "libr3d_hip.so")  # R3D_LIB: probe builds (tools/probe)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "r3d.h")
 
 c_f = ctypes.c_void_p      # device pointers travel as void*
@@ -37,6 +37,8 @@ _SIGS = {
     "r3d_knn_norm_ws_words": (c_l, [c_i, c_i]),
     "r3d_attention_fwd": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_f, c_f]),
     "r3d_head_desc_words": (c_i, []),
+    "r3d_set_matrix_arith": (c_i, [c_i]),
+    "r3d_get_matrix_arith": (c_i, []),
     "r3d_head_max_k": (c_i, []),
     "r3d_head_proto_ws_words": (c_l, [c_i, c_i, c_i]),
     "r3d_head_proto_ws_offsets": (c_i, [c_i, c_i, c_i, ctypes.POINTER(c_l)]),
@@ -119,6 +121,11 @@ def load():
         fn.argtypes = args
         setattr(lib, name, fn)
     _lib = lib
+    mode = os.environ.get("R3D_MATRIX_ARITH")  # "fp32" | "bf16x3": see r3d_set_matrix_arith in include/r3d.h
+    if mode is not None:
+        if mode not in ("fp32", "bf16x3"):
+            raise RuntimeError("R3D_MATRIX_ARITH=%r: expected fp32 or bf16x3" % mode)
+        check(lib.r3d_set_matrix_arith(1 if mode == "bf16x3" else 0))
     return lib
 
 

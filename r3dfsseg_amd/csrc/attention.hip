@@ -17,8 +17,10 @@
 //     r3d_acc_row(r): both halves feed one MFMA k-pair, no data movement).
 // 4 waves share the K/V tiles through double-buffered LDS.
 #include "common.h"
+#include <type_traits>
 
 #define AT_LD 65
+#define AT_PROW 68  // floats per row of a forward partial: 64 o + m + l, padded to 16-byte rows
 
 // Dropout keep decision of attention weight (row = b*N + query, key): a stateless integer hash, so the
 // backward kernels regenerate the same mask (reference: nn.Dropout(0.1) on the attention matrix,
@@ -32,7 +34,7 @@ static __device__ __forceinline__ bool attn_keep(unsigned seed, unsigned row, un
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void r3d_attention_fwd_kernel(
     const float* __restrict__ qkv, long ld, int N, float* __restrict__ out, long ldo,
     float* __restrict__ lse_out, float p_drop, unsigned seed, const unsigned* __restrict__ seed_dev,
-    int tiles_per_split, float* __restrict__ part /* split > 1: [split][M][66] = unnormalised o | m | l */) {
+    int tiles_per_split, float* __restrict__ part /* split > 1: [split][M][AT_PROW] = unnormalised o | m | l */) {
   if (seed_dev) seed += *seed_dev;  // per-replay seed of a captured hipGraph lives in device memory
   const unsigned thresh = p_drop > 0.f ? (unsigned)(p_drop * 4294967296.0) : 0u;
   const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
@@ -143,12 +145,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void r
   }
   if (!q_ok) return;
   if (part) {  // partial (o, m, l) of this key range; r3d_attention_combine_kernel merges the splits
-    float* prow = part + ((long)blockIdx.z * gridDim.y * N + base + q_row) * 66;
+    float* prow = part + ((long)blockIdx.z * gridDim.y * N + base + q_row) * AT_PROW;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ch = r3d_acc_row(r, lane);
-      prow[ch] = o0[r];
-      prow[32 + ch] = o1[r];
+    for (int g = 0; g < 4; ++g) {  // registers 4g .. 4g+3 are 4 consecutive channels: 16-byte stores
+      const int ch = 8 * g + 4 * (lane >> 5);
+      *reinterpret_cast<float4*>(prow + ch) = make_float4(o0[4 * g], o0[4 * g + 1], o0[4 * g + 2], o0[4 * g + 3]);
+      *reinterpret_cast<float4*>(prow + 32 + ch) = make_float4(o1[4 * g], o1[4 * g + 1], o1[4 * g + 2], o1[4 * g + 3]);
     }
     if (lane < 32) { prow[64] = m_run; prow[65] = l_run; }
     return;
@@ -164,6 +166,377 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void r
   if (lse_out && lane < 32) lse_out[base + q_row] = m_run + __logf(l_run);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same forward on the bf16 matrix core, fp32 values as three bf16 pieces (common.h "bf16 x 3"): 48 bf16 MFMAs per
+// 32-key tile and wave (1536 cycles) in place of 64 fp32 MFMAs (4096 cycles).
+// The operands arrive already cut: r3d_bx3_pack_kernel turns a 64-column block of a point-major fp32 matrix into
+// rows of [piece 0..2][64] bf16 (384 B per point), so staging is a copy and the cut is paid once per element, not once
+// per workgroup that streams it.
+// LDS: per piece a K image [key][64 ch] (rows of 72 bf16) and a V^T image [ch][32 key slots] (rows of 40 bf16).  The
+// key slots of V^T are ordered so that the 8 keys a lane half holds in S^T accumulator registers 8s .. 8s+7 (rows
+// (r & 3) + 8 (r >> 2) + 4 half) are 8 consecutive slots: P^T goes from the accumulator registers into the B operand
+// with no data movement, as in the fp32 kernel, and the A operand (V^T) is one ds_read_b128 per piece.
+#define AB_KLD 72
+#define AB_VLD 40
+#define AB_KPLANE (32 * AB_KLD)
+#define AB_VPLANE (64 * AB_VLD)
+#define AB_ROW 192  // bf16 per point of a packed operand: 3 pieces x 64 channels
+// slot of key kk (0..31) of a tile in a transposed image: kk = 8 g + 4 h + i  ->  16 (g >> 1) + 8 h + 4 (g & 1) + i
+static __device__ __forceinline__ int ab_key_slot(int kk) {
+  return 16 * (kk >> 4) + 8 * ((kk >> 2) & 1) + 4 * ((kk >> 3) & 1) + (kk & 3);
+}
+
+// dst[row][piece][c] = piece of src[row][col0 + c], c < 64.  One thread: 8 channels of a row.
+__global__ void r3d_bx3_pack_kernel(const float* __restrict__ src, long ld, int col0, long M,
+                                    unsigned short* __restrict__ dst) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * 8) return;
+  const long row = i >> 3;
+  const int c0 = (int)(i & 7) * 8;
+  const float* p = src + row * ld + col0 + c0;
+  const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
+  const float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+  const r3d_bx3 f = r3d_bx3_split8(x);
+  unsigned short* d = dst + row * AB_ROW + c0;
+  *reinterpret_cast<r3d_u32x4*>(d) = f.h;
+  *reinterpret_cast<r3d_u32x4*>(d + 64) = f.m;
+  *reinterpret_cast<r3d_u32x4*>(d + 128) = f.l;
+}
+static void bx3_pack(const float* src, long ld, int col0, long M, unsigned short* dst, hipStream_t st) {
+  hipLaunchKernelGGL(r3d_bx3_pack_kernel, dim3(r3d_cdiv(M * 8, 256)), dim3(256), 0, st, src, ld, col0, M, dst);
+}
+static __device__ __forceinline__ r3d_u32x4 ab_mask(r3d_u32x4 v, bool ok) {
+  const unsigned m = ok ? 0xffffffffu : 0u;
+  v[0] &= m; v[1] &= m; v[2] &= m; v[3] &= m;
+  return v;
+}
+// B[k = channel 16 st + 8 half + e][j = row] fragments of one packed row (the lane's own query / key), 4 k-steps
+static __device__ __forceinline__ void ab_load_row_frags(const unsigned short* __restrict__ row, int half, bool ok,
+                                                         r3d_bx3 (&f)[4]) {
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const unsigned short* p = row + 16 * st + 8 * half;
+    f[st].h = ab_mask(*reinterpret_cast<const r3d_u32x4*>(p), ok);
+    f[st].m = ab_mask(*reinterpret_cast<const r3d_u32x4*>(p + 64), ok);
+    f[st].l = ab_mask(*reinterpret_cast<const r3d_u32x4*>(p + 128), ok);
+  }
+}
+// Staging of one 32-row tile of a packed operand.  Row-major image: thread copies three 16-B chunks (chunk c of the
+// tile's 768: row c / 24, piece (c % 24) / 8, channels 8 (c % 8) ..).  Transposed image: thread takes rows 2 kp, 2 kp + 1
+// x 4 channels of every piece (8-B loads) and writes (row pair) words into [ch][slot].
+struct ab_rm_regs { r3d_u32x4 c[3]; };
+struct ab_tr_regs { uint2 r0[3], r1[3]; };
+// rows [row0, row0 + 32) of cloud `base`; a tile that crosses N takes the masked path (uniform branch)
+static __device__ __forceinline__ void ab_load_rm(const unsigned short* __restrict__ X, long base, int row0, int N, int tid,
+                                                  ab_rm_regs& g) {
+  const unsigned short* t0 = X + (base + row0) * AB_ROW;
+  if (row0 + 32 <= N) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g.c[i] = *reinterpret_cast<const r3d_u32x4*>(t0 + 8 * (tid + 256 * i));  // 12 KB contiguous
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int c = tid + 256 * i, r = c / 24;
+      const bool ok = row0 + r < N;
+      g.c[i] = ab_mask(*reinterpret_cast<const r3d_u32x4*>(ok ? t0 + 8 * c : X + base * AB_ROW), ok);
+    }
+  }
+}
+static __device__ __forceinline__ void ab_store_rm(unsigned short* img /* 3 planes of 32 x AB_KLD */, int tid,
+                                                   const ab_rm_regs& g) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = tid + 256 * i, r = c / 24, rem = c - 24 * r, piece = rem >> 3, c8 = rem & 7;
+    *reinterpret_cast<r3d_u32x4*>(img + piece * AB_KPLANE + r * AB_KLD + 8 * c8) = g.c[i];
+  }
+}
+static __device__ __forceinline__ void ab_load_tr(const unsigned short* __restrict__ X, long base, int row0, int N, int tid,
+                                                  ab_tr_regs& g) {
+  const int kp = tid & 15, c0 = (tid >> 4) * 4;
+  const int ra = row0 + 2 * kp, rb = ra + 1;
+  if (row0 + 32 <= N) {
+    const unsigned short* pa = X + (base + ra) * AB_ROW + c0;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      g.r0[p] = *reinterpret_cast<const uint2*>(pa + 64 * p);
+      g.r1[p] = *reinterpret_cast<const uint2*>(pa + AB_ROW + 64 * p);
+    }
+  } else {
+    const unsigned short* pa = X + (base + min(ra, N - 1)) * AB_ROW + c0;
+    const unsigned short* pb = X + (base + min(rb, N - 1)) * AB_ROW + c0;
+    const unsigned ma = ra < N ? 0xffffffffu : 0u, mb = rb < N ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      uint2 a = *reinterpret_cast<const uint2*>(pa + 64 * p), b = *reinterpret_cast<const uint2*>(pb + 64 * p);
+      g.r0[p] = make_uint2(a.x & ma, a.y & ma);
+      g.r1[p] = make_uint2(b.x & mb, b.y & mb);
+    }
+  }
+}
+static __device__ __forceinline__ void ab_store_tr(unsigned short* img /* 3 planes of 64 x AB_VLD */, int tid,
+                                                   const ab_tr_regs& g) {
+  const int kp = tid & 15, c0 = (tid >> 4) * 4;
+  unsigned short* d = img + c0 * AB_VLD + ab_key_slot(2 * kp);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    // words: x = channels c0, c0+1 ; y = channels c0+2, c0+3 of one row  ->  (row a, row b) pairs per channel
+    *reinterpret_cast<unsigned*>(d + p * AB_VPLANE) = __builtin_amdgcn_perm(g.r1[p].x, g.r0[p].x, 0x05040100u);
+    *reinterpret_cast<unsigned*>(d + p * AB_VPLANE + AB_VLD) = __builtin_amdgcn_perm(g.r1[p].x, g.r0[p].x, 0x07060302u);
+    *reinterpret_cast<unsigned*>(d + p * AB_VPLANE + 2 * AB_VLD) = __builtin_amdgcn_perm(g.r1[p].y, g.r0[p].y, 0x05040100u);
+    *reinterpret_cast<unsigned*>(d + p * AB_VPLANE + 3 * AB_VLD) = __builtin_amdgcn_perm(g.r1[p].y, g.r0[p].y, 0x07060302u);
+  }
+}
+// A fragment (3 pieces) of k-step `st` from an image whose rows are this lane's A row: row-major image -> channels,
+// transposed image -> key slots
+static __device__ __forceinline__ r3d_bx3 ab_frag(const unsigned short* p, int plane) {
+  r3d_bx3 a;
+  a.h = *reinterpret_cast<const r3d_u32x4*>(p);
+  a.m = *reinterpret_cast<const r3d_u32x4*>(p + plane);
+  a.l = *reinterpret_cast<const r3d_u32x4*>(p + 2 * plane);
+  return a;
+}
+static __device__ __forceinline__ r3d_bx3 ab_split_acc(const f32x16& s, int sI) {
+  const float px[8] = {s[8 * sI], s[8 * sI + 1], s[8 * sI + 2], s[8 * sI + 3],
+                       s[8 * sI + 4], s[8 * sI + 5], s[8 * sI + 6], s[8 * sI + 7]};
+  return r3d_bx3_split8(px);
+}
+
+// ---- LDS images filled by the LDS-DMA (global_load_lds, 16 B per lane, no VGPR and no ds_write on the way)
+// A 32-row tile of one piece is 4 KB of unpadded 128-B rows; one DMA instruction fills 8 rows (lane L -> row L / 8,
+// 16-B position L % 8) and the lane's SOURCE address chooses which chunk lands there, so the image is swizzled for free:
+//   chunk c (8 channels) of row r sits at position c ^ g(r),  g(r) = 4 ((r >> 1) & 1) | ((r >> 2) & 3).
+// One image serves both kinds of read, conflict-free under the LDS bank rules (64 banks; ds_read_b128 in four 16-lane
+// groups, ds_read_b64_tr_b16 per 32-lane half):
+//   row read  (A[i = image row][k = channel]):  ds_read_b128, lane = row; inside a 16-lane group the 8 even and the 8 odd
+//             rows have 8 distinct g;
+//   col read  (A[i = channel][k = image row]):  ds_read_b64_tr_b16 takes 4 rows x 16 channels per 16 lanes and hands
+//             them over transposed; rows q and q + 2 of an aligned group of 4 differ in bit 2 of g, so the two rows of
+//             equal bank parity use different halves of the 128-B row.
+#define AG_PIECE 2048  // bf16 per piece image (32 rows x 64)
+#define AG_TILE (3 * AG_PIECE)
+typedef __attribute__((address_space(3))) void* ag_lds_ptr;
+typedef short ag_s16x4 __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ int ag_swz(int r) { return 4 * ((r >> 1) & 1) | ((r >> 2) & 3); }
+// wave w of 4 fills row group w (rows 8w .. 8w+7) of the three piece images of tile rows [row0, row0 + 32) of X.
+// ag_dma_off: the lane's byte offset inside a full tile (fixed for the kernel); the tile base is wave-uniform, so the
+// DMA takes the scalar-base + 32-bit-offset address form and a full tile costs no vector arithmetic at all.
+static __device__ __forceinline__ unsigned ag_dma_off(int w, int lane) {
+  const int r = 8 * w + (lane >> 3), pos = lane & 7;
+  return (unsigned)(r * AB_ROW + 8 * (pos ^ ag_swz(r))) * 2u;
+}
+static __device__ __forceinline__ void ag_dma_tile(const unsigned short* __restrict__ X, long base, int row0, int N,
+                                                   unsigned short* img, int w, int lane, unsigned off) {
+  const char* tile = reinterpret_cast<const char*>(X + (base + row0) * AB_ROW);
+  if (row0 + 32 <= N) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      __builtin_amdgcn_global_load_lds(tile + off + 128 * p, (ag_lds_ptr)(img + p * AG_PIECE + 512 * w), 16, 0, 0);
+  } else {  // rows past N: any finite row of the cloud (the kernels mask what such rows produce)
+    const int r = 8 * w + (lane >> 3);
+    const char* src = tile + off - (long)(r - min(r, N - 1 - row0)) * (AB_ROW * 2);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      __builtin_amdgcn_global_load_lds(src + 128 * p, (ag_lds_ptr)(img + p * AG_PIECE + 512 * w), 16, 0, 0);
+  }
+}
+// element offsets of this lane's fragments inside an image (fixed for the kernel)
+struct ag_offs {
+  int row[4];     // row read, k-step st: row lane & 31, channels 16 st + 8 half ..
+  int col[2][2];  // col read, channel block cc, second index j: image rows 4 half + 8 j + q (+ 16 sI)
+};
+static __device__ __forceinline__ ag_offs ag_make_offs(int lane) {
+  ag_offs o;
+  const int k = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int st = 0; st < 4; ++st) o.row[st] = k * 64 + 8 * ((2 * st + half) ^ ag_swz(k));
+  const int g16 = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = 4 * half + 8 * j + q;  // + 16 sI: ag_swz is periodic in 16 rows
+      o.col[cc][j] = r * 64 + 8 * ((4 * cc + 2 * g16 + (p >> 1)) ^ ag_swz(r)) + 4 * (p & 1);
+    }
+  return o;
+}
+static __device__ __forceinline__ r3d_bx3 ag_row_frag(const unsigned short* img, const ag_offs& o, int st) {
+  return ab_frag(img + o.row[st], AG_PIECE);
+}
+// A[i = channel 32 cc + (lane & 31)][k = image rows 16 sI + 4 half + {0..3, 8..11}]: the rows an accumulator lane half
+// holds in registers 8 sI .. 8 sI + 7
+static __device__ __forceinline__ r3d_bx3 ag_col_frag(const unsigned short* img, const ag_offs& o, int sI, int cc) {
+  const unsigned short* a0 = img + o.col[cc][0] + 16 * 64 * sI;
+  const unsigned short* a1 = img + o.col[cc][1] + 16 * 64 * sI;
+  r3d_bx3 f;
+  r3d_u32x4* pieces[3] = {&f.h, &f.m, &f.l};
+#pragma unroll
+  for (int pc = 0; pc < 3; ++pc) {
+    const ag_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ag_s16x4*)(a0 + pc * AG_PIECE));
+    const ag_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ag_s16x4*)(a1 + pc * AG_PIECE));
+    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+    (*pieces[pc])[0] = l2.x; (*pieces[pc])[1] = l2.y; (*pieces[pc])[2] = h2.x; (*pieces[pc])[3] = h2.y;
+  }
+  return f;
+}
+
+// Software pipeline of one wave: the S^T MFMAs of tile t + 1 are issued beside the softmax of tile t (independent
+// accumulators), the P^T V MFMAs of tile t beside the second half of the P cut, so the VALU work sits in the issue slots
+// the matrix core leaves free (an MFMA holds the issue port for 8 of its 32 cycles).  K is staged two tiles ahead, V one,
+// by the LDS-DMA; one barrier per tile.  DROP: dropout compiled in (training with p > 0).
+#ifdef ATT_STAMPS  // phase clocks of one wave (tools/probe/att_stamps.py); never in the shipped library
+__device__ unsigned long long g_att_dbg[16];
+extern "C" int r3d_attention_debug_read(unsigned long long* out16) {
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_att_dbg), sizeof(g_att_dbg)) == hipSuccess ? 0 : 1;
+}
+#define ASTAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); dbg_acc[i] += now_ - dbg_last; dbg_last = now_; } while (0)
+#else
+#define ASTAMP(i)
+#endif
+template <bool DROP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void r3d_attention_fwd_bx3_kernel(
+    const unsigned short* __restrict__ Qp, const unsigned short* __restrict__ Kp, const unsigned short* __restrict__ Vp,
+    int N, float* __restrict__ out, long ldo, float* __restrict__ lse_out, float p_drop, unsigned seed,
+    const unsigned* __restrict__ seed_dev, int tiles_per_split, float* __restrict__ part) {
+  if (seed_dev) seed += *seed_dev;
+  const unsigned thresh = DROP ? (unsigned)(p_drop * 4294967296.0) : 0u;
+  const float keep_scale = DROP ? 1.f / (1.f - p_drop) : 1.f;
+  __shared__ __attribute__((aligned(16))) unsigned short Ks[2][AG_TILE];
+  __shared__ __attribute__((aligned(16))) unsigned short Vs[2][AG_TILE];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
+  const int b = blockIdx.y;
+  const long base = (long)b * N;
+  const int q_row = blockIdx.x * 128 + 32 * w + (lane & 31);
+  const bool q_ok = q_row < N;
+  r3d_bx3 bq[4];
+  ab_load_row_frags(Qp + (base + min(q_row, N - 1)) * AB_ROW, half, q_ok, bq);
+  f32x16 o0, o1, s_a, s_b;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; s_a[r] = 0.f; }
+  const float LOG2E = 1.4426950408889634f;
+  float m_run = -INFINITY, l_run = 0.f;  // m_run in the log2 domain: max of s * log2(e)
+  const int t_beg = blockIdx.z * tiles_per_split;
+  const int ntiles = min((N + 31) / 32, t_beg + tiles_per_split);
+  const ag_offs offs = ag_make_offs(lane);
+  auto s_tile = [&](int t, f32x16& s) {  // S^T = K Q^T of tile t
+#pragma unroll
+    for (int st = 0; st < 4; ++st) s = r3d_bx3_mma(ag_row_frag(Ks[t & 1], offs, st), bq[st], s);
+  };
+  const unsigned koff = ag_dma_off(w, lane), voff = koff;
+  // prologue: K(t_beg), K(t_beg + 1), V(t_beg) into LDS; S of the first tile
+  ag_dma_tile(Kp, base, 32 * t_beg, N, Ks[t_beg & 1], w, lane, koff);
+  ag_dma_tile(Vp, base, 32 * t_beg, N, Vs[t_beg & 1], w, lane, voff);
+  if (t_beg + 1 < ntiles) ag_dma_tile(Kp, base, 32 * (t_beg + 1), N, Ks[(t_beg + 1) & 1], w, lane, koff);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  s_tile(t_beg, s_a);
+  __syncthreads();  // the first step's DMA reuses the buffer of K(t_beg)
+#ifdef ATT_STAMPS
+  unsigned long long dbg_acc[6] = {0, 0, 0, 0, 0, 0}, dbg_last = __builtin_amdgcn_s_memtime();
+  const unsigned long long dbg_t0 = dbg_last, dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  // s_cur: S of tile t (computed one step ago); s_next receives S of tile t + 1
+  auto step = [&](int t, f32x16& s_cur, f32x16& s_next, auto HAS1, auto HAS2, auto MASK) {
+    constexpr bool has1 = decltype(HAS1)::value, has2 = decltype(HAS2)::value, mask = decltype(MASK)::value;
+    ASTAMP(5);
+    // K(t) was consumed one step ago (S of tile t ran beside the softmax of t - 1), V(t - 1) as well
+    if (has2) ag_dma_tile(Kp, base, 32 * (t + 2), N, Ks[t & 1], w, lane, koff);
+    if (has1) ag_dma_tile(Vp, base, 32 * (t + 1), N, Vs[(t + 1) & 1], w, lane, voff);
+    ASTAMP(0);
+    // ---- block A: S of the next tile beside the softmax of this one
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_next[r] = 0.f;
+    if (has1) s_tile(t + 1, s_next);
+    f32x16 s = s_cur;
+    if (mask) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (32 * t + r3d_acc_row(r, lane) >= N) s[r] = -INFINITY;
+    }
+    float mt = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) mt = fmaxf(fmaxf(mt, s[r]), s[r + 1]);
+    mt = fmaxf(mt, s[15]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32)) * LOG2E;
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // raw v_exp_f32: arguments <= 0, underflow to 0 is right
+    float lt = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -m_new));
+      lt += s[r];
+    }
+    lt += __shfl_xor(lt, 32);
+    l_run = l_run * alpha + lt;
+    if (DROP) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        s[r] = attn_keep(seed, (unsigned)(base + q_row), (unsigned)(32 * t + r3d_acc_row(r, lane)), thresh) ? s[r] * keep_scale : 0.f;
+    }
+    const r3d_bx3 pf0 = ab_split_acc(s, 0);
+    ASTAMP(1);
+    if (__any(m_new != m_run)) {  // wave-uniform: the running maximum rarely moves after the first tiles
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    }
+    m_run = m_new;
+    // ---- block B: O^T += V^T P^T (accumulator registers 8 sI .. 8 sI + 7 are the B fragment of k-step sI) beside the
+    // second half of the cut
+    const unsigned short* vimg = Vs[t & 1];
+    o0 = r3d_bx3_mma(ag_col_frag(vimg, offs, 0, 0), pf0, o0);
+    o1 = r3d_bx3_mma(ag_col_frag(vimg, offs, 0, 1), pf0, o1);
+    const r3d_bx3 pf1 = ab_split_acc(s, 1);
+    o0 = r3d_bx3_mma(ag_col_frag(vimg, offs, 1, 0), pf1, o0);
+    o1 = r3d_bx3_mma(ag_col_frag(vimg, offs, 1, 1), pf1, o1);
+    ASTAMP(2);
+    __builtin_amdgcn_s_waitcnt(0);  // this wave's DMA has landed
+    ASTAMP(3);
+    __syncthreads();
+    ASTAMP(4);
+  };
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+  int t = t_beg;
+  for (; t + 3 < ntiles; t += 2) {  // two steps per trip: the S accumulators swap roles instead of being copied
+    step(t, s_a, s_b, T_{}, T_{}, F_{});
+    step(t + 1, s_b, s_a, T_{}, T_{}, F_{});
+  }
+  if (t + 2 < ntiles) { step(t, s_a, s_b, T_{}, T_{}, F_{}); ++t; s_a = s_b; }
+  if (t + 1 < ntiles) { step(t, s_a, s_b, T_{}, F_{}, F_{}); ++t; s_a = s_b; }
+  if (32 * (t + 1) > N) step(t, s_a, s_b, F_{}, F_{}, T_{});
+  else step(t, s_a, s_b, F_{}, F_{}, F_{});
+
+#ifdef ATT_STAMPS
+  if (tid == 0 && blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0) {
+    for (int i = 0; i < 6; ++i) g_att_dbg[i] = dbg_acc[i];
+    g_att_dbg[6] = __builtin_amdgcn_s_memtime() - dbg_t0;
+    g_att_dbg[7] = __builtin_amdgcn_s_memrealtime() - dbg_r0;
+    g_att_dbg[8] = ntiles - t_beg;
+  }
+#endif
+  if (!q_ok) return;
+  const float LN2 = 0.6931471805599453f;
+  if (part) {
+    float* prow = part + ((long)blockIdx.z * gridDim.y * N + base + q_row) * AT_PROW;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {  // registers 4g .. 4g+3 are 4 consecutive channels: 16-byte stores
+      const int ch = 8 * g + 4 * (lane >> 5);
+      *reinterpret_cast<float4*>(prow + ch) = make_float4(o0[4 * g], o0[4 * g + 1], o0[4 * g + 2], o0[4 * g + 3]);
+      *reinterpret_cast<float4*>(prow + 32 + ch) = make_float4(o1[4 * g], o1[4 * g + 1], o1[4 * g + 2], o1[4 * g + 3]);
+    }
+    if (lane < 32) { prow[64] = m_run * LN2; prow[65] = l_run; }
+    return;
+  }
+  const float inv = 1.f / l_run;
+  float* orow = out + (base + q_row) * ldo;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int ch = r3d_acc_row(r, lane);
+    orow[ch] = o0[r] * inv;
+    orow[32 + ch] = o1[r] * inv;
+  }
+  if (lse_out && lane < 32) lse_out[base + q_row] = m_run * LN2 + __logf(l_run);
+}
+
 // merge the key splits of the forward: m = max m_z, l = sum l_z e^(m_z - m), o = sum o_z e^(m_z - m) / l
 __global__ void r3d_attention_combine_kernel(const float* __restrict__ part, int nsplit, long M, float* __restrict__ out,
                                              long ldo, float* __restrict__ lse_out) {
@@ -171,10 +544,10 @@ __global__ void r3d_attention_combine_kernel(const float* __restrict__ part, int
   const int lane = threadIdx.x & 63;
   if (row >= M) return;
   float m = -INFINITY;
-  for (int z = 0; z < nsplit; ++z) m = fmaxf(m, part[((long)z * M + row) * 66 + 64]);
+  for (int z = 0; z < nsplit; ++z) m = fmaxf(m, part[((long)z * M + row) * AT_PROW + 64]);
   float l = 0.f, o = 0.f;
   for (int z = 0; z < nsplit; ++z) {
-    const float* pr = part + ((long)z * M + row) * 66;
+    const float* pr = part + ((long)z * M + row) * AT_PROW;
     const float sc = __expf(pr[64] - m);
     l += pr[65] * sc;
     o += pr[lane] * sc;
@@ -206,16 +579,20 @@ static int attention_split(int B, int N, int slots) {
   }
   return best;
 }
-enum { ATT_FWD = 0, ATT_BWD_KV = 1, ATT_BWD_Q = 2 };
+enum { ATT_FWD = 0, ATT_BWD_KV = 1, ATT_BWD_Q = 2, ATT_FWD_BX3 = 3, ATT_BWD_KV_BX3 = 4, ATT_BWD_Q_BX3 = 5, ATT_N = 6 };
 static int attention_slots(int which);  // defined below the kernels
-extern "C" long r3d_attention_ws_words(int B, int N) {
-  // forward: split * M * 66; backward: M (row dots) + split * M * 128 (dK | dV partials, reused for dQ)
+// forward: split * M * AT_PROW; backward: M (row dots) + split * M * 128 (dK | dV partials, reused for dQ)
+static long attention_part_words(int B, int N) {
   int smax = 1;
-  for (int w = 0; w < 3; ++w) {
+  for (int w = 0; w < ATT_N; ++w) {
     const int sp = attention_split(B, N, attention_slots(w));
     smax = sp > smax ? sp : smax;
   }
-  return (long)B * N * (1 + 128L * smax) + 64;
+  return (((long)B * N * (1 + 128L * smax) + 63) / 64) * 64;
+}
+extern "C" long r3d_attention_ws_words(int B, int N) {
+  // ... followed by the packed bf16 x 3 operands (q | k | v | dO: 96 words per point each)
+  return attention_part_words(B, N) + 4L * B * N * (AB_ROW / 2) + 64;
 }
 
 static int attention_launch(const float* qkv, long ld, int B, int N, float* out, long ldo, float* lse_out, float p_drop,
@@ -225,13 +602,25 @@ static int attention_launch(const float* qkv, long ld, int B, int N, float* out,
               "r3d_attention_fwd: bad shape B=%d N=%d ld=%ld ldo=%ld", B, N, ld, ldo);
   R3D_REQUIRE(((uintptr_t)qkv & 15) == 0, "r3d_attention_fwd: qkv must be 16-byte aligned");
   R3D_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "r3d_attention_fwd: dropout probability %f out of range", p_drop);
-  const int split = ws ? attention_split(B, N, attention_slots(ATT_FWD)) : 1;
+  const bool bx3 = g_r3d_matrix_arith == 1 && ws;  // the packed operands live in the workspace
+  const int split = ws ? attention_split(B, N, attention_slots(bx3 ? ATT_FWD_BX3 : ATT_FWD)) : 1;
   const int ntiles = r3d_cdiv(N, 32);
   const int tps = r3d_cdiv(ntiles, split);
   const int nz = r3d_cdiv(ntiles, tps);  // no empty split
   dim3 grid(r3d_cdiv(N, 128), B, nz);
-  hipLaunchKernelGGL(r3d_attention_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, ld, N, out,
-                     ldo, lse_out, p_drop, seed, seed_dev, tps, nz > 1 ? ws : nullptr);
+  if (bx3) {
+    const long M = (long)B * N;
+    unsigned short* pk = reinterpret_cast<unsigned short*>(ws + attention_part_words(B, N));
+    for (int i = 0; i < 3; ++i) bx3_pack(qkv, ld, 64 * i, M, pk + i * M * AB_ROW, (hipStream_t)stream);
+    if (p_drop > 0.f)
+      hipLaunchKernelGGL(r3d_attention_fwd_bx3_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, pk, pk + M * AB_ROW,
+                         pk + 2 * M * AB_ROW, N, out, ldo, lse_out, p_drop, seed, seed_dev, tps, nz > 1 ? ws : nullptr);
+    else
+      hipLaunchKernelGGL(r3d_attention_fwd_bx3_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, pk, pk + M * AB_ROW,
+                         pk + 2 * M * AB_ROW, N, out, ldo, lse_out, p_drop, seed, seed_dev, tps, nz > 1 ? ws : nullptr);
+  } else
+    hipLaunchKernelGGL(r3d_attention_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, ld, N, out,
+                       ldo, lse_out, p_drop, seed, seed_dev, tps, nz > 1 ? ws : nullptr);
   if (nz > 1) {
     const long M = (long)B * N;
     hipLaunchKernelGGL(r3d_attention_combine_kernel, dim3(r3d_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, ws, nz, M,
@@ -378,6 +767,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   }
   if (!key_ok) return;
   float* drow = part ? part + ((long)blockIdx.z * gridDim.y * N + base + key) * 128 - 64 : dqkv + (base + key) * ldd;
+  if (part) {  // 16-byte rows: registers 4g .. 4g+3 are 4 consecutive channels
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 8 * g + 4 * h;
+      *reinterpret_cast<float4*>(drow + 64 + c) = make_float4(dk0[4 * g], dk0[4 * g + 1], dk0[4 * g + 2], dk0[4 * g + 3]);
+      *reinterpret_cast<float4*>(drow + 96 + c) = make_float4(dk1[4 * g], dk1[4 * g + 1], dk1[4 * g + 2], dk1[4 * g + 3]);
+      *reinterpret_cast<float4*>(drow + 128 + c) = make_float4(dv0[4 * g], dv0[4 * g + 1], dv0[4 * g + 2], dv0[4 * g + 3]);
+      *reinterpret_cast<float4*>(drow + 160 + c) = make_float4(dv1[4 * g], dv1[4 * g + 1], dv1[4 * g + 2], dv1[4 * g + 3]);
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int c = r3d_acc_row(r, lane);
@@ -496,11 +896,222 @@ __global__ __launch_bounds__(256) void r3d_attention_bwd_q_kernel(
   if (!q_ok) return;
   float* drow = part ? part + ((long)blockIdx.z * gridDim.y * N + base + q_row) * 64 : dqkv + (base + q_row) * ldd;
   const float osc = part ? 1.f : q_scale;  // partials stay unscaled; r3d_attention_sum_kernel applies q_scale
+  if (part) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 8 * g + 4 * h;
+      *reinterpret_cast<float4*>(drow + c) = make_float4(dq0[4 * g], dq0[4 * g + 1], dq0[4 * g + 2], dq0[4 * g + 3]);
+      *reinterpret_cast<float4*>(drow + 32 + c) = make_float4(dq1[4 * g], dq1[4 * g + 1], dq1[4 * g + 2], dq1[4 * g + 3]);
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int c = r3d_acc_row(r, lane);
     drow[c] = dq0[r] * osc;  // gradient w.r.t. the UNscaled q map output (q' = q * q_scale)
     drow[32 + c] = dq1[r] * osc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The two backward kernels on the bf16 matrix core (common.h "bf16 x 3"): operands packed by r3d_bx3_pack_kernel,
+// streamed tiles staged by the LDS-DMA into dual-use images (row reads for the products that sum over channels, column
+// reads for the products that sum over the tile's rows), stationary operands as B fragments in registers, P~ / dS cut
+// into pieces straight from the accumulator registers.  96 (kv) and 72 (q) bf16 MFMAs per 32-row tile and wave against
+// 128 and 96 fp32 MFMAs of twice the cycles.
+template <bool DROP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r3d_attention_bwd_kv_bx3_kernel(
+    const unsigned short* __restrict__ Qp, const unsigned short* __restrict__ Kp, const unsigned short* __restrict__ Vp,
+    const unsigned short* __restrict__ Gp /* dO */, int N, const float* __restrict__ lse, const float* __restrict__ Dv,
+    float* __restrict__ dqkv, long ldd, float p_drop, unsigned seed, const unsigned* __restrict__ seed_dev,
+    int tiles_per_split, float* __restrict__ part) {
+  if (seed_dev) seed += *seed_dev;
+  __shared__ __attribute__((aligned(16))) unsigned short Qs[2][AG_TILE];
+  __shared__ __attribute__((aligned(16))) unsigned short Gs[2][AG_TILE];
+  __shared__ float Ls[2][32], Ds[2][32];  // lse * log2(e) and D of the tile's queries
+  const unsigned thresh = DROP ? (unsigned)(p_drop * 4294967296.0) : 0u;
+  const float keep_scale = DROP ? 1.f / (1.f - p_drop) : 1.f;
+  const float LOG2E = 1.4426950408889634f;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, j = lane & 31;
+  const int b = blockIdx.y;
+  const long base = (long)b * N;
+  const int key = blockIdx.x * 128 + 32 * w + j;  // this lane's key column
+  const bool key_ok = key < N;
+  r3d_bx3 bk[4], bv[4];  // B[k = ch][j = key] fragments of K and V
+  ab_load_row_frags(Kp + (base + min(key, N - 1)) * AB_ROW, h, key_ok, bk);
+  ab_load_row_frags(Vp + (base + min(key, N - 1)) * AB_ROW, h, key_ok, bv);
+  f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
+  const ag_offs offs = ag_make_offs(lane);
+  const unsigned doff = ag_dma_off(w, lane);
+  const int t_beg = blockIdx.z * tiles_per_split;
+  const int ntiles = min((N + 31) / 32, t_beg + tiles_per_split);
+  float lreg = 0.f, dreg = 0.f;
+  auto load_rows = [&](int q0) {
+    if (tid < 32) {
+      const int q2 = min(q0 + tid, N - 1);
+      lreg = lse[base + q2] * LOG2E;
+      dreg = Dv[base + q2];
+    }
+  };
+  ag_dma_tile(Qp, base, 32 * t_beg, N, Qs[t_beg & 1], w, lane, doff);
+  ag_dma_tile(Gp, base, 32 * t_beg, N, Gs[t_beg & 1], w, lane, doff);
+  load_rows(32 * t_beg);
+  if (tid < 32) { Ls[t_beg & 1][tid] = lreg; Ds[t_beg & 1][tid] = dreg; }
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  for (int t = t_beg; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) {
+      ag_dma_tile(Qp, base, 32 * (t + 1), N, Qs[buf ^ 1], w, lane, doff);
+      ag_dma_tile(Gp, base, 32 * (t + 1), N, Gs[buf ^ 1], w, lane, doff);
+      load_rows(32 * (t + 1));
+    }
+    // S[query][key] = Q' K^T ; dP~[query][key] = dO V^T   (rows = queries of the tile, column = this lane's key)
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      s = r3d_bx3_mma(ag_row_frag(Qs[buf], offs, st), bk[st], s);
+      dp = r3d_bx3_mma(ag_row_frag(Gs[buf], offs, st), bv[st], dp);
+    }
+    // P~ (dropped, scaled) stays in s, dS goes to dp
+    const bool tail = 32 * (t + 1) > N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ql = r3d_acc_row(r, lane);
+      float p = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -Ls[buf][ql]));
+      p = r3d_keep(p, key_ok && !(tail && 32 * t + ql >= N));
+      float keep = 1.f;
+      if (DROP) keep = attn_keep(seed, (unsigned)(base + 32 * t + ql), (unsigned)key, thresh) ? keep_scale : 0.f;
+      s[r] = p * keep;
+      dp[r] = p * (dp[r] * keep - Ds[buf][ql]);
+    }
+    // dV^T[c][key] += sum_q dO[q][c] P~[q][key] ;  dK^T[c][key] += sum_q Q'[q][c] dS[q][key]
+#pragma unroll
+    for (int sI = 0; sI < 2; ++sI) {
+      const r3d_bx3 pf = ab_split_acc(s, sI);
+      dv0 = r3d_bx3_mma(ag_col_frag(Gs[buf], offs, sI, 0), pf, dv0);
+      dv1 = r3d_bx3_mma(ag_col_frag(Gs[buf], offs, sI, 1), pf, dv1);
+      const r3d_bx3 df = ab_split_acc(dp, sI);
+      dk0 = r3d_bx3_mma(ag_col_frag(Qs[buf], offs, sI, 0), df, dk0);
+      dk1 = r3d_bx3_mma(ag_col_frag(Qs[buf], offs, sI, 1), df, dk1);
+    }
+    if (t + 1 < ntiles && tid < 32) { Ls[buf ^ 1][tid] = lreg; Ds[buf ^ 1][tid] = dreg; }
+    __builtin_amdgcn_s_waitcnt(0);  // this wave's DMA has landed
+    __syncthreads();
+  }
+  if (!key_ok) return;
+  float* drow = part ? part + ((long)blockIdx.z * gridDim.y * N + base + key) * 128 - 64 : dqkv + (base + key) * ldd;
+  if (part) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 8 * g + 4 * h;
+      *reinterpret_cast<float4*>(drow + 64 + c) = make_float4(dk0[4 * g], dk0[4 * g + 1], dk0[4 * g + 2], dk0[4 * g + 3]);
+      *reinterpret_cast<float4*>(drow + 96 + c) = make_float4(dk1[4 * g], dk1[4 * g + 1], dk1[4 * g + 2], dk1[4 * g + 3]);
+      *reinterpret_cast<float4*>(drow + 128 + c) = make_float4(dv0[4 * g], dv0[4 * g + 1], dv0[4 * g + 2], dv0[4 * g + 3]);
+      *reinterpret_cast<float4*>(drow + 160 + c) = make_float4(dv1[4 * g], dv1[4 * g + 1], dv1[4 * g + 2], dv1[4 * g + 3]);
+    }
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int c = r3d_acc_row(r, lane);
+    drow[64 + c] = dk0[r];
+    drow[64 + 32 + c] = dk1[r];
+    drow[128 + c] = dv0[r];
+    drow[128 + 32 + c] = dv1[r];
+  }
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r3d_attention_bwd_q_bx3_kernel(
+    const unsigned short* __restrict__ Qp, const unsigned short* __restrict__ Kp, const unsigned short* __restrict__ Vp,
+    const unsigned short* __restrict__ Gp /* dO */, int N, const float* __restrict__ lse, const float* __restrict__ Dv,
+    float* __restrict__ dqkv, long ldd, float p_drop, unsigned seed, const unsigned* __restrict__ seed_dev, float q_scale,
+    int tiles_per_split, float* __restrict__ part) {
+  if (seed_dev) seed += *seed_dev;
+  __shared__ __attribute__((aligned(16))) unsigned short Ks[2][AG_TILE];
+  __shared__ __attribute__((aligned(16))) unsigned short Vs[2][AG_TILE];
+  const unsigned thresh = DROP ? (unsigned)(p_drop * 4294967296.0) : 0u;
+  const float keep_scale = DROP ? 1.f / (1.f - p_drop) : 1.f;
+  const float LOG2E = 1.4426950408889634f;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, j = lane & 31;
+  const int b = blockIdx.y;
+  const long base = (long)b * N;
+  const int q_row = blockIdx.x * 128 + 32 * w + j;
+  const bool q_ok = q_row < N;
+  r3d_bx3 bq[4], bg[4];  // B[k = ch][j = query] fragments of Q' and dO
+  ab_load_row_frags(Qp + (base + min(q_row, N - 1)) * AB_ROW, h, q_ok, bq);
+  ab_load_row_frags(Gp + (base + min(q_row, N - 1)) * AB_ROW, h, q_ok, bg);
+  const float my_lse2 = lse[base + min(q_row, N - 1)] * LOG2E;
+  const float my_D = Dv[base + min(q_row, N - 1)];
+  f32x16 dq0, dq1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
+  const ag_offs offs = ag_make_offs(lane);
+  const unsigned doff = ag_dma_off(w, lane);
+  const int t_beg = blockIdx.z * tiles_per_split;
+  const int ntiles = min((N + 31) / 32, t_beg + tiles_per_split);
+  ag_dma_tile(Kp, base, 32 * t_beg, N, Ks[t_beg & 1], w, lane, doff);
+  ag_dma_tile(Vp, base, 32 * t_beg, N, Vs[t_beg & 1], w, lane, doff);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  for (int t = t_beg; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) {
+      ag_dma_tile(Kp, base, 32 * (t + 1), N, Ks[buf ^ 1], w, lane, doff);
+      ag_dma_tile(Vp, base, 32 * (t + 1), N, Vs[buf ^ 1], w, lane, doff);
+    }
+    // S^T[key][query] = K Q'^T ; dP~^T[key][query] = V dO^T
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      s = r3d_bx3_mma(ag_row_frag(Ks[buf], offs, st), bq[st], s);
+      dp = r3d_bx3_mma(ag_row_frag(Vs[buf], offs, st), bg[st], dp);
+    }
+    const bool tail = 32 * (t + 1) > N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kl = r3d_acc_row(r, lane);
+      float p = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -my_lse2));
+      p = r3d_keep(p, q_ok && !(tail && 32 * t + kl >= N));
+      float keep = 1.f;
+      if (DROP) keep = attn_keep(seed, (unsigned)(base + q_row), (unsigned)(32 * t + kl), thresh) ? keep_scale : 0.f;
+      s[r] = p * (dp[r] * keep - my_D);  // dS^T
+    }
+    // dQ'^T[c][query] += sum_key K[key][c] dS^T[key][query]
+#pragma unroll
+    for (int sI = 0; sI < 2; ++sI) {
+      const r3d_bx3 df = ab_split_acc(s, sI);
+      dq0 = r3d_bx3_mma(ag_col_frag(Ks[buf], offs, sI, 0), df, dq0);
+      dq1 = r3d_bx3_mma(ag_col_frag(Ks[buf], offs, sI, 1), df, dq1);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+  }
+  if (!q_ok) return;
+  float* drow = part ? part + ((long)blockIdx.z * gridDim.y * N + base + q_row) * 64 : dqkv + (base + q_row) * ldd;
+  if (part) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 8 * g + 4 * h;
+      *reinterpret_cast<float4*>(drow + c) = make_float4(dq0[4 * g], dq0[4 * g + 1], dq0[4 * g + 2], dq0[4 * g + 3]);
+      *reinterpret_cast<float4*>(drow + 32 + c) = make_float4(dq1[4 * g], dq1[4 * g + 1], dq1[4 * g + 2], dq1[4 * g + 3]);
+    }
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int c = r3d_acc_row(r, lane);
+    drow[c] = dq0[r] * q_scale;  // gradient w.r.t. the UNscaled q map output (q' = q * q_scale)
+    drow[32 + c] = dq1[r] * q_scale;
   }
 }
 
@@ -518,6 +1129,44 @@ extern "C" int r3d_attention_bwd(const float* qkv, long ld, int B, int N, const 
   const long M = (long)B * N;
   hipLaunchKernelGGL(r3d_attention_rowdot_kernel, dim3(r3d_cdiv(M, 4)), dim3(256), 0, st, dO, lddo, O, ldo, M, ws);
   const int ntiles = r3d_cdiv(N, 32);
+  if (g_r3d_matrix_arith == 1) {
+    unsigned short* pk = reinterpret_cast<unsigned short*>(ws + attention_part_words(B, N));
+    const unsigned short *Qp = pk, *Kp = pk + M * AB_ROW, *Vp = pk + 2 * M * AB_ROW, *Gp = pk + 3 * M * AB_ROW;
+    for (int i = 0; i < 3; ++i) bx3_pack(qkv, ld, 64 * i, M, pk + i * M * AB_ROW, st);
+    bx3_pack(dO, lddo, 0, M, pk + 3 * M * AB_ROW, st);
+    {
+      const int tps = r3d_cdiv(ntiles, attention_split(B, N, attention_slots(ATT_BWD_KV_BX3)));
+      const int nz = r3d_cdiv(ntiles, tps);
+      float* part = nz > 1 ? ws + M : nullptr;
+      dim3 grid(r3d_cdiv(N, 128), B, nz);
+      if (p_drop > 0.f)
+        hipLaunchKernelGGL(r3d_attention_bwd_kv_bx3_kernel<true>, grid, dim3(256), 0, st, Qp, Kp, Vp, Gp, N, lse, ws, dqkv, ldd,
+                           p_drop, seed, seed_dev, tps, part);
+      else
+        hipLaunchKernelGGL(r3d_attention_bwd_kv_bx3_kernel<false>, grid, dim3(256), 0, st, Qp, Kp, Vp, Gp, N, lse, ws, dqkv, ldd,
+                           p_drop, seed, seed_dev, tps, part);
+      if (part)
+        hipLaunchKernelGGL(r3d_attention_sum_kernel, dim3(r3d_cdiv(M * 128, 256)), dim3(256), 0, st, part, nz, M, 128, 1.f, dqkv,
+                           ldd, 64);
+    }
+    {
+      const int tps = r3d_cdiv(ntiles, attention_split(B, N, attention_slots(ATT_BWD_Q_BX3)));
+      const int nz = r3d_cdiv(ntiles, tps);
+      float* part = nz > 1 ? ws + M : nullptr;
+      dim3 grid(r3d_cdiv(N, 128), B, nz);
+      if (p_drop > 0.f)
+        hipLaunchKernelGGL(r3d_attention_bwd_q_bx3_kernel<true>, grid, dim3(256), 0, st, Qp, Kp, Vp, Gp, N, lse, ws, dqkv, ldd,
+                           p_drop, seed, seed_dev, q_scale, tps, part);
+      else
+        hipLaunchKernelGGL(r3d_attention_bwd_q_bx3_kernel<false>, grid, dim3(256), 0, st, Qp, Kp, Vp, Gp, N, lse, ws, dqkv, ldd,
+                           p_drop, seed, seed_dev, q_scale, tps, part);
+      if (part)
+        hipLaunchKernelGGL(r3d_attention_sum_kernel, dim3(r3d_cdiv(M * 64, 256)), dim3(256), 0, st, part, nz, M, 64, q_scale, dqkv,
+                           ldd, 0);
+    }
+    R3D_LAUNCH_CHECK("r3d_attention_bwd");
+    return R3D_OK;
+  }
   {
     const int tps = r3d_cdiv(ntiles, attention_split(B, N, attention_slots(ATT_BWD_KV)));
     const int nz = r3d_cdiv(ntiles, tps);
@@ -546,13 +1195,16 @@ extern "C" int r3d_attention_bwd(const float* qkv, long ld, int B, int N, const 
 // workgroups (256 threads) of each attention kernel the chip holds at once; the defaults stand in when there is no
 // device to ask (host-only sizing calls)
 static int attention_slots(int which) {
-  static int cache[3] = {0, 0, 0};
+  static int cache[ATT_N] = {0, 0, 0, 0, 0, 0};
   if (cache[which]) return cache[which];
-  const int fallback[3] = {512, 256, 512};
+  const int fallback[ATT_N] = {512, 256, 512, 768, 512, 512};
   int per_cu = 0, dev = 0;
   hipDeviceProp_t prop;
   hipError_t e = hipErrorUnknown;
   if (which == ATT_FWD) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, r3d_attention_fwd_kernel, 256, 0);
+  else if (which == ATT_FWD_BX3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, r3d_attention_fwd_bx3_kernel<false>, 256, 0);
+  else if (which == ATT_BWD_KV_BX3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, r3d_attention_bwd_kv_bx3_kernel<false>, 256, 0);
+  else if (which == ATT_BWD_Q_BX3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, r3d_attention_bwd_q_bx3_kernel<false>, 256, 0);
   else if (which == ATT_BWD_KV) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, r3d_attention_bwd_kv_kernel, 256, 0);
   else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, r3d_attention_bwd_q_kernel, 256, 0);
   if (e == hipSuccess && per_cu > 0 && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)

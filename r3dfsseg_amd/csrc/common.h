@@ -63,6 +63,57 @@ static __device__ __forceinline__ float r3d_keep(float v, bool keep) {
   return __uint_as_float(__float_as_uint(v) & (keep ? 0xffffffffu : 0u));
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 products on the bf16 matrix core ("bf16 x 3").  An fp32 value is cut into three bf16 pieces by TRUNCATION,
+//   x = hi + mid + lo  exactly  (24 significant bits = 8 + 8 + 8; x - hi and (x - hi) - mid are exact in fp32),
+// and a product block a.b is summed from the six piece products of weight >= 2^-16,
+//   hi.hi + hi.mid + mid.hi + mid.mid + hi.lo + lo.hi        (dropped: mid.lo, lo.mid, lo.lo <= 2^-23 |a||b|),
+// each a v_mfma_f32_32x32x16_bf16 accumulating in fp32.  Six bf16 MFMAs cover K = 16 in 6 x 32 cycles where
+// v_mfma_f32_32x32x2_f32 needs 8 x 64: 2.67x the fp32 matrix rate at fp32-level accuracy (relative error of a product
+// 2^-22 against 2^-24).  Only kernels that decide NO index use it (kNN scores stay on the fp32 core, bit-exact).
+// A fragment is 8 bf16 per lane and piece: r3d_bx3 holds the three u32x4 of one k-step.
+typedef unsigned r3d_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 r3d_bf16x8 __attribute__((ext_vector_type(8)));
+extern int g_r3d_matrix_arith;  // 0: fp32 MFMA everywhere; 1: bf16 x 3 in the kernels that have that form (error.hip)
+
+// pieces of two values, packed as (x1 << 16 | x0) bf16 pairs
+static __device__ __forceinline__ void r3d_bx3_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+  const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+  const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+  const float t0 = r0 - __uint_as_float(v0 & 0xffff0000u), t1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+  h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+  m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+  l = __builtin_amdgcn_perm(__float_as_uint(t1), __float_as_uint(t0), 0x07060302u);
+}
+struct r3d_bx3 {
+  r3d_u32x4 h, m, l;
+};
+static __device__ __forceinline__ r3d_bx3 r3d_bx3_split8(const float* x) {
+  r3d_bx3 f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned h, m, l;
+    r3d_bx3_split2(x[2 * i], x[2 * i + 1], h, m, l);
+    f.h[i] = h; f.m[i] = m; f.l[i] = l;
+  }
+  return f;
+}
+static __device__ __forceinline__ f32x16 r3d_mfma_bf16(r3d_u32x4 a, r3d_u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(r3d_bf16x8, a), __builtin_bit_cast(r3d_bf16x8, b), c, 0,
+                                                 0, 0);
+}
+// c += A B over one k-step of 16, both operands in pieces (smallest terms first)
+static __device__ __forceinline__ f32x16 r3d_bx3_mma(const r3d_bx3& a, const r3d_bx3& b, f32x16 c) {
+  c = r3d_mfma_bf16(a.l, b.h, c);
+  c = r3d_mfma_bf16(a.h, b.l, c);
+  c = r3d_mfma_bf16(a.m, b.m, c);
+  c = r3d_mfma_bf16(a.m, b.h, c);
+  c = r3d_mfma_bf16(a.h, b.m, c);
+  c = r3d_mfma_bf16(a.h, b.h, c);
+  return c;
+}
+
 static inline int r3d_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Device-to-device fill / copy as plain KERNELS.  The library's launch sequences are frozen into hipGraphs
