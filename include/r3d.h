@@ -219,6 +219,11 @@ int r3d_attention_fwd_train(const float* qkv, long ld, int B, int N, float* out,
 int r3d_attention_bwd(const float* qkv, long ld, int B, int N, const float* O, long ldo, const float* dO, long lddo,
                       const float* lse, float p_drop, unsigned seed, const unsigned* seed_dev, float q_scale, float* dqkv,
                       long ldd, float* ws /* r3d_attention_ws_words(B, N) floats */, void* stream);
+/* the same; ws_holds_packed_qkv != 0: ws is the workspace r3d_attention_fwd_train ran with on this qkv, untouched since
+ * (the bf16 x 3 kernels reuse the packed q | k | v pieces it holds instead of cutting them again) */
+int r3d_attention_bwd_ws(const float* qkv, long ld, int B, int N, const float* O, long ldo, const float* dO, long lddo,
+                         const float* lse, float p_drop, unsigned seed, const unsigned* seed_dev, float q_scale,
+                         float* dqkv, long ldd, float* ws, int ws_holds_packed_qkv, void* stream);
 
 /* head backward (reference: autograd through models/mpti.py:488-512,571).  r3d_ce_grad -> G = dL/dZ (scaled by the
  * device scalar *gscale); r3d_label_propagate_bwd: adjoint CG solve on the graph r3d_label_propagate left in ws,

@@ -186,24 +186,25 @@ static __device__ __forceinline__ int ab_key_slot(int kk) {
   return 16 * (kk >> 4) + 8 * ((kk >> 2) & 1) + 4 * ((kk >> 3) & 1) + (kk & 3);
 }
 
-// dst[row][piece][c] = piece of src[row][col0 + c], c < 64.  One thread: 8 channels of a row.
-__global__ void r3d_bx3_pack_kernel(const float* __restrict__ src, long ld, int col0, long M,
+// dst[blk][row][piece][c] = piece of src[row][64 blk + c], c < 64, blk < nblk.  One thread: 8 channels of a row.
+__global__ void r3d_bx3_pack_kernel(const float* __restrict__ src, long ld, int nblk, long M,
                                     unsigned short* __restrict__ dst) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= M * 8) return;
-  const long row = i >> 3;
-  const int c0 = (int)(i & 7) * 8;
-  const float* p = src + row * ld + col0 + c0;
+  if (i >= M * 8 * nblk) return;
+  const int c8 = (int)(i % (8 * nblk));  // consecutive threads walk a row: coalesced reads
+  const long row = i / (8 * nblk);
+  const int blk = c8 >> 3, c0 = (c8 & 7) * 8;
+  const float* p = src + row * ld + 64 * blk + c0;
   const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
   const float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
   const r3d_bx3 f = r3d_bx3_split8(x);
-  unsigned short* d = dst + row * AB_ROW + c0;
+  unsigned short* d = dst + ((long)blk * M + row) * AB_ROW + c0;
   *reinterpret_cast<r3d_u32x4*>(d) = f.h;
   *reinterpret_cast<r3d_u32x4*>(d + 64) = f.m;
   *reinterpret_cast<r3d_u32x4*>(d + 128) = f.l;
 }
-static void bx3_pack(const float* src, long ld, int col0, long M, unsigned short* dst, hipStream_t st) {
-  hipLaunchKernelGGL(r3d_bx3_pack_kernel, dim3(r3d_cdiv(M * 8, 256)), dim3(256), 0, st, src, ld, col0, M, dst);
+static void bx3_pack(const float* src, long ld, int nblk, long M, unsigned short* dst, hipStream_t st) {
+  hipLaunchKernelGGL(r3d_bx3_pack_kernel, dim3(r3d_cdiv(M * 8 * nblk, 256)), dim3(256), 0, st, src, ld, nblk, M, dst);
 }
 static __device__ __forceinline__ r3d_u32x4 ab_mask(r3d_u32x4 v, bool ok) {
   const unsigned m = ok ? 0xffffffffu : 0u;
@@ -611,7 +612,7 @@ static int attention_launch(const float* qkv, long ld, int B, int N, float* out,
   if (bx3) {
     const long M = (long)B * N;
     unsigned short* pk = reinterpret_cast<unsigned short*>(ws + attention_part_words(B, N));
-    for (int i = 0; i < 3; ++i) bx3_pack(qkv, ld, 64 * i, M, pk + i * M * AB_ROW, (hipStream_t)stream);
+    bx3_pack(qkv, ld, 3, M, pk, (hipStream_t)stream);  // q | k | v; a backward given the same workspace finds them there
     if (p_drop > 0.f)
       hipLaunchKernelGGL(r3d_attention_fwd_bx3_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, pk, pk + M * AB_ROW,
                          pk + 2 * M * AB_ROW, N, out, ldo, lse_out, p_drop, seed, seed_dev, tps, nz > 1 ? ws : nullptr);
@@ -1118,9 +1119,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
 // dqkv (B*N, ldd >= 192): gradients of the q | k | v GEMM outputs (before the 1/sqrt(d) scale of q).
 // O: forward output (B*N, ldo); lse: saved log-sum-exp; ws: r3d_attention_ws_words(B, N) floats (row dots + the
 // partial dK | dV / dQ of the streamed-axis split).
-extern "C" int r3d_attention_bwd(const float* qkv, long ld, int B, int N, const float* O, long ldo, const float* dO,
-                                 long lddo, const float* lse, float p_drop, unsigned seed, const unsigned* seed_dev,
-                                 float q_scale, float* dqkv, long ldd, float* ws, void* stream) {
+// ws_holds_packed_qkv: ws is the workspace the forward of the SAME qkv ran with (r3d_attention_fwd_train) and nothing
+// has written to it since: its packed q | k | v pieces are reused instead of cut again (bf16 x 3 arithmetic only).
+extern "C" int r3d_attention_bwd_ws(const float* qkv, long ld, int B, int N, const float* O, long ldo, const float* dO,
+                                    long lddo, const float* lse, float p_drop, unsigned seed, const unsigned* seed_dev,
+                                    float q_scale, float* dqkv, long ldd, float* ws, int ws_holds_packed_qkv, void* stream) {
   R3D_REQUIRE(qkv && O && dO && lse && dqkv && ws, "r3d_attention_bwd: null pointer");
   R3D_REQUIRE(B > 0 && N > 0 && ld >= 192 && ld % 4 == 0 && lddo % 4 == 0 && ldd >= 192 && ldo >= 64,
               "r3d_attention_bwd: bad shape");
@@ -1132,8 +1135,8 @@ extern "C" int r3d_attention_bwd(const float* qkv, long ld, int B, int N, const 
   if (g_r3d_matrix_arith == 1) {
     unsigned short* pk = reinterpret_cast<unsigned short*>(ws + attention_part_words(B, N));
     const unsigned short *Qp = pk, *Kp = pk + M * AB_ROW, *Vp = pk + 2 * M * AB_ROW, *Gp = pk + 3 * M * AB_ROW;
-    for (int i = 0; i < 3; ++i) bx3_pack(qkv, ld, 64 * i, M, pk + i * M * AB_ROW, st);
-    bx3_pack(dO, lddo, 0, M, pk + 3 * M * AB_ROW, st);
+    if (!ws_holds_packed_qkv) bx3_pack(qkv, ld, 3, M, pk, st);
+    bx3_pack(dO, lddo, 1, M, pk + 3 * M * AB_ROW, st);
     {
       const int tps = r3d_cdiv(ntiles, attention_split(B, N, attention_slots(ATT_BWD_KV_BX3)));
       const int nz = r3d_cdiv(ntiles, tps);
@@ -1189,6 +1192,11 @@ extern "C" int r3d_attention_bwd(const float* qkv, long ld, int B, int N, const 
   }
   R3D_LAUNCH_CHECK("r3d_attention_bwd");
   return R3D_OK;
+}
+extern "C" int r3d_attention_bwd(const float* qkv, long ld, int B, int N, const float* O, long ldo, const float* dO,
+                                 long lddo, const float* lse, float p_drop, unsigned seed, const unsigned* seed_dev,
+                                 float q_scale, float* dqkv, long ldd, float* ws, void* stream) {
+  return r3d_attention_bwd_ws(qkv, ld, B, N, O, ldo, dO, lddo, lse, p_drop, seed, seed_dev, q_scale, dqkv, ldd, ws, 0, stream);
 }
 
 

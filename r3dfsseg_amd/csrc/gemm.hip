@@ -134,6 +134,7 @@ static int pointwise_launch(const float* X, long ldx, const float* W, long M, in
                             const float* shift, int act, float* Out, long ldo, int accumulate, float* stats_part,
                             void* stream);
 
+
 extern "C" int r3d_pointwise_conv(const float* X, long ldx, const float* W, long M, int K, int Co,
                                   const float* scale, const float* shift, int act, float* Out,
                                   long ldo, void* stream) {

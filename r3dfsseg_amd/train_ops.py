@@ -347,7 +347,7 @@ class EncoderTrainFn(torch.autograd.Function):
             for b0, Bs in _segments(seg_clouds or [B]):
                 model._trace.setdefault("idx", []).append([sv[1][b0:b0 + Bs] for sv in ec_saved])
                 model._trace.setdefault("argmax", []).append([sv[7][b0 * N:(b0 + Bs) * N] for sv in ec_saved])
-        ctx.saved = (ec_saved, mlp_saved, base_saved, cat, level2, Wqkv, qkv, lse, feat)
+        ctx.saved = (ec_saved, mlp_saved, base_saved, cat, level2, Wqkv, qkv, lse, feat, aws)
         return feat
 
     @staticmethod
@@ -355,7 +355,7 @@ class EncoderTrainFn(torch.autograd.Function):
         model = ctx.model
         enc, base, att = model.encoder, model.base_learner, model.att_learner
         B, N, seed, p_drop = ctx.dims
-        ec_saved, mlp_saved, base_saved, cat, level2, Wqkv, qkv, lse, feat = ctx.saved
+        ec_saved, mlp_saved, base_saved, cat, level2, Wqkv, qkv, lse, feat, aws = ctx.saved
         lib = _lib.load()
         dev = dfeat.device
         M = B * N
@@ -376,11 +376,10 @@ class EncoderTrainFn(torch.autograd.Function):
             d = dX
         # --- SelfAttention (attention.py:39-46)
         dqkv = torch.empty(M, 192, device=dev, dtype=torch.float32)
-        ws = _f(lib.r3d_attention_ws_words(B, N), dev)
-        with _timed("attention_bwd"):
-            _lib.check(lib.r3d_attention_bwd(_p(qkv), 192, B, N, _p(feat[:, 64:128]), feat.stride(0), _p(dfeat[:, 64:128]),
-                                             dfeat.stride(0), _p(lse), p_drop, ctypes.c_uint(seed & 0xffffffff),
-                                             _p(ctx.seed_dev), 1.0 / att.temperature, _p(dqkv), 192, _p(ws), _st()))
+        with _timed("attention_bwd"):  # the forward's workspace, kept since: its packed q | k | v pieces are reused
+            _lib.check(lib.r3d_attention_bwd_ws(_p(qkv), 192, B, N, _p(feat[:, 64:128]), feat.stride(0), _p(dfeat[:, 64:128]),
+                                                dfeat.stride(0), _p(lse), p_drop, ctypes.c_uint(seed & 0xffffffff),
+                                                _p(ctx.seed_dev), 1.0 / att.temperature, _p(dqkv), 192, _p(aws), 1, _st()))
         dWqkv = gemm_tn(dqkv, level2)
         for k, m in enumerate((att.q_map, att.k_map, att.v_map)):
             g[m.weight] = dWqkv[64 * k:64 * (k + 1)].reshape(m.weight.shape)

@@ -31,7 +31,13 @@ def _run(lib, mode, qkv, B, N, dO, p_drop=0.0, seed=0):
         _lib.check(lib.r3d_attention_fwd_train(_p(qkv), 192, B, N, _p(out), 64, _p(lse), p_drop, seed, None, _p(ws), _st()))
         _lib.check(lib.r3d_attention_bwd(_p(qkv), 192, B, N, _p(out), 64, _p(dO), 64, _p(lse), p_drop, seed, None, 1.0,
                                          _p(dqkv), 192, _p(ws), _st()))
+        # the backward on the forward's workspace (packed q | k | v reused): same result, bit for bit
+        _lib.check(lib.r3d_attention_fwd_train(_p(qkv), 192, B, N, _p(out), 64, _p(lse), p_drop, seed, None, _p(ws), _st()))
+        dqkv2 = torch.empty_like(dqkv)
+        _lib.check(lib.r3d_attention_bwd_ws(_p(qkv), 192, B, N, _p(out), 64, _p(dO), 64, _p(lse), p_drop, seed, None, 1.0,
+                                            _p(dqkv2), 192, _p(ws), 1, _st()))
         torch.cuda.synchronize()
+        assert torch.equal(dqkv, dqkv2)
     finally:
         _lib.check(lib.r3d_set_matrix_arith(1))
     return out, dqkv
