@@ -35,6 +35,8 @@ int r3d_abi_version(void);
  * block accumulated in fp32 (fp32-level accuracy at 2.67x the matrix rate; csrc/common.h).  kNN scores, which decide
  * indices, always run on the fp32 core.  Default 1.  Process-wide; call before the first launch.  The attention entry
  * points use mode 1 only when they are given a workspace (the packed operands live there). */
+/* test utility: fills the chip's LDS with `pattern` (no result of this library may depend on stale LDS contents) */
+int r3d_debug_poison_lds(unsigned pattern, unsigned* sink /* 1 device word */, void* stream);
 int r3d_set_matrix_arith(int mode);
 int r3d_get_matrix_arith(void);
 

@@ -14,7 +14,14 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libr3d_hip.so")
 SOURCES = ["error.hip", "knn.hip", "gemm.hip", "edgeconv.hip", "attention.hip", "head_proto.hip",
            "head_graph.hip", "aux_heads.hip", "train_ops.hip", "edgeconv_train.hip", "contrast.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall",
+# No packed fp32 vector arithmetic (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32), neither from the SLP vectoriser nor from
+# float2 / float4 source arithmetic: measured on MI355X (profiles/r02_experiments.md, section 9), a wave executing them
+# beside waves of a bf16-MFMA-dense kernel on the same SIMD got wrong results in lanes 48-63 of one half of the pair --
+# the label-propagation graph weights came out wrong in ~20 % of the solves that ran beside the bf16 x 3 attention
+# kernels, and never once in a build without these instructions.  (The host pass prints "'-packed-fp32-ops' is not a
+# recognized feature" for the second flag: it only applies to the device pass.)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
+         "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-Wall",
          "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value"]
 
 

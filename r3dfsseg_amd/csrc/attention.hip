@@ -325,8 +325,12 @@ static __device__ __forceinline__ unsigned ag_dma_off(int w, int lane) {
   const int r = 8 * w + (lane >> 3), pos = lane & 7;
   return (unsigned)(r * AB_ROW + 8 * (pos ^ ag_swz(r))) * 2u;
 }
+#ifndef ATT_ABL
+#define ATT_ABL 0  // probe builds (tools/probe/att_ablate.sh): 1 no LDS-DMA, 2 plain instead of transposed LDS reads, 4 no MFMA
+#endif
 static __device__ __forceinline__ void ag_dma_tile(const unsigned short* __restrict__ X, long base, int row0, int N,
                                                    unsigned short* img, int w, int lane, unsigned off) {
+  if (ATT_ABL & 1) return;
   const char* tile = reinterpret_cast<const char*>(X + (base + row0) * AB_ROW);
   if (row0 + 32 <= N) {
 #pragma unroll
@@ -372,8 +376,13 @@ static __device__ __forceinline__ r3d_bx3 ag_col_frag(const unsigned short* img,
   r3d_u32x4* pieces[3] = {&f.h, &f.m, &f.l};
 #pragma unroll
   for (int pc = 0; pc < 3; ++pc) {
+#if ATT_ABL & 2
+    const ag_s16x4 lo = *reinterpret_cast<const ag_s16x4*>(a0 + pc * AG_PIECE);
+    const ag_s16x4 hi = *reinterpret_cast<const ag_s16x4*>(a1 + pc * AG_PIECE);
+#else
     const ag_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ag_s16x4*)(a0 + pc * AG_PIECE));
     const ag_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ag_s16x4*)(a1 + pc * AG_PIECE));
+#endif
     const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
     (*pieces[pc])[0] = l2.x; (*pieces[pc])[1] = l2.y; (*pieces[pc])[2] = h2.x; (*pieces[pc])[3] = h2.y;
   }
@@ -394,7 +403,7 @@ extern "C" int r3d_attention_debug_read(unsigned long long* out16) {
 #define ASTAMP(i)
 #endif
 template <bool DROP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void r3d_attention_fwd_bx3_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r3d_attention_fwd_bx3_kernel(
     const unsigned short* __restrict__ Qp, const unsigned short* __restrict__ Kp, const unsigned short* __restrict__ Vp,
     int N, float* __restrict__ out, long ldo, float* __restrict__ lse_out, float p_drop, unsigned seed,
     const unsigned* __restrict__ seed_dev, int tiles_per_split, float* __restrict__ part) {

@@ -45,6 +45,19 @@ static __device__ __forceinline__ float r3d_readlane_f(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
+// Sum over aligned groups of 8 lanes, every lane gets the total: three DPP steps inside the VALU (lane ^ 1, lane ^ 2,
+// mirror of the 8-lane half row).  No LDS crossbar (ds_bpermute / ds_swizzle), so nothing another workgroup does to the
+// CU's LDS pipeline can reach it.
+static __device__ __forceinline__ float r3d_sum8_dpp(float v) {
+  int x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true));  // row_half_mirror
+  return v;
+}
+
 static __device__ __forceinline__ float r3d_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -100,6 +113,10 @@ static __device__ __forceinline__ r3d_bx3 r3d_bx3_split8(const float* x) {
   return f;
 }
 static __device__ __forceinline__ f32x16 r3d_mfma_bf16(r3d_u32x4 a, r3d_u32x4 b, f32x16 c) {
+#if defined(ATT_ABL) && (ATT_ABL & 4)
+  c[0] += __uint_as_float(a[0] ^ b[1]);  // probe build: no matrix core
+  return c;
+#endif
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(r3d_bf16x8, a), __builtin_bit_cast(r3d_bf16x8, b), c, 0,
                                                  0, 0);
 }

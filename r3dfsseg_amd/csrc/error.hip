@@ -25,3 +25,19 @@ extern "C" int r3d_set_matrix_arith(int mode) {
   return R3D_OK;
 }
 extern "C" int r3d_get_matrix_arith(void) { return g_r3d_matrix_arith; }
+
+// Test utility: leave `pattern` in every byte of LDS the chip has (64 KB per workgroup, enough workgroups to visit every
+// CU several times).  A kernel that reads LDS it has not written sees this instead of whatever ran before it: the tests
+// use it to show that no result depends on stale LDS contents.
+__global__ __launch_bounds__(256) void r3d_lds_poison_kernel(unsigned pattern, unsigned* __restrict__ sink) {
+  __shared__ unsigned buf[16384];
+  for (int i = threadIdx.x; i < 16384; i += 256) buf[i] = pattern;
+  __syncthreads();
+  if (buf[(threadIdx.x * 61 + blockIdx.x) & 16383] != pattern) sink[0] = 1;  // keeps the stores alive
+}
+extern "C" int r3d_debug_poison_lds(unsigned pattern, unsigned* sink, void* stream) {
+  R3D_REQUIRE(sink, "r3d_debug_poison_lds: null pointer");
+  hipLaunchKernelGGL(r3d_lds_poison_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, pattern, sink);
+  R3D_LAUNCH_CHECK("r3d_debug_poison_lds");
+  return R3D_OK;
+}

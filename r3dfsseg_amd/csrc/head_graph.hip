@@ -185,11 +185,8 @@ __global__ __launch_bounds__(256) void r3d_graph_weights_kernel(
         b = __builtin_fmaf(d2, d2, b);
       }
     }
-#pragma unroll
-    for (int o = 1; o < 8; o <<= 1) {
-      a += __shfl_xor(a, o);
-      b += __shfl_xor(b, o);
-    }
+    a = r3d_sum8_dpp(a);  // the eight lanes of an entry
+    b = r3d_sum8_dpp(b);
     const bool out_ij = (outb[(long)i * words + (j >> 5)] >> (j & 31)) & 1u;
     const bool out_ji = (outb[(long)j * words + (i >> 5)] >> (i & 31)) & 1u;
     float wij = 0.f, wji = 0.f;

@@ -90,3 +90,27 @@ def test_synthetic_episode_contract():
     assert flag.shape == (2, 5) and (flag[:, 3:] == 99).all()
     d2, _ = S.make_episode(cfg, 1, noise_ratio=0.4, train=True)
     assert all(torch.equal(a, b) for a, b in zip(data, d2))  # same seed, same bytes
+
+
+def test_no_packed_fp32_arithmetic_in_the_device_code(tmp_path):
+    """The library is built without v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 (r3dfsseg_amd/build.py says why: wrong
+    results in a wave running them beside bf16-MFMA-dense waves, measured on MI355X).  Disassemble every gfx950 code
+    object of the built library and look."""
+    import glob
+    import shutil
+    import subprocess
+    from r3dfsseg_amd import _lib
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(objdump) and os.path.exists(_lib.LIB_PATH)):
+        pytest.skip("llvm-objdump or the built library is not here")
+    so = shutil.copy(_lib.LIB_PATH, str(tmp_path / "lib.so"))
+    subprocess.run([objdump, "--offloading", so], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    objs = glob.glob(str(tmp_path / "lib.so.*gfx950"))
+    assert len(objs) >= 8, objs
+    n_mfma = 0
+    for o in objs:
+        dis = subprocess.run([objdump, "-d", o], check=True, capture_output=True, text=True).stdout
+        n_mfma += dis.count("v_mfma_")
+        for op in ("v_pk_fma_f32", "v_pk_add_f32", "v_pk_mul_f32"):
+            assert op not in dis, (op, os.path.basename(o))
+    assert n_mfma > 100  # it really was the device code

@@ -1,0 +1,106 @@
+"""Episodes run several at a time on separate HIP streams (episode_graph.py), so kernels of different episodes share
+CUs and SIMDs.  No result may depend on what runs beside it: label-propagation solves on one stream while the bf16 x 3
+attention kernels (bf16-MFMA-dense) or the fp32 ones keep another stream busy must equal the solve alone bit for bit.
+(This failed in ~20 % of the solves while the library still contained packed fp32 VALU arithmetic -- build.py.)"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_label_propagation_is_not_disturbed_by_attention_on_another_stream():
+    from r3dfsseg_amd import _lib
+    from r3dfsseg_amd.ops import _p
+    lib = _lib.load()
+    n, kp1, D = 4396, 201, 192
+    torch.manual_seed(0)
+    cent = torch.randn(3, D, device="cuda") * 0.5
+    x = (cent[torch.randint(0, 3, (n,), device="cuda")] + torch.randn(n, D, device="cuda") * 0.12).contiguous()
+    Y = torch.zeros(n, 4, device="cuda")
+    Y[torch.arange(300), torch.randint(0, 3, (300,))] = 1
+    nd = torch.tensor([n], device="cuda", dtype=torch.int32)
+    npd = torch.tensor([300], device="cuda", dtype=torch.int32)
+    norm = torch.empty(lib.r3d_knn_norm_ws_words(1, n), device="cuda")
+    cm = torch.empty(D * lib.r3d_cm_pitch(n), device="cuda")
+    nbr = torch.empty(n, kp1, device="cuda", dtype=torch.int32)
+    st = torch.zeros(1, device="cuda", dtype=torch.int32)
+    _lib.check(lib.r3d_knn_topk(_p(x), D, None, 1, n, D, kp1, 1, _p(nd), _p(norm), _p(cm), _p(nbr), None, _p(st), None))
+    ws = torch.empty(lib.r3d_lp_ws_words(n, kp1), device="cuda", dtype=torch.int32)
+    B, N = 12, 2048
+    qkv = torch.randn(B * N, 192, device="cuda")
+    dO = torch.randn(B * N, 64, device="cuda")
+    aws = torch.empty(lib.r3d_attention_ws_words(B, N), device="cuda")
+    out = torch.empty(B * N, 64, device="cuda")
+    lse = torch.empty(B * N, device="cuda")
+    dqkv = torch.empty(B * N, 192, device="cuda")
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+
+    def solves(k):
+        res = []
+        with torch.cuda.stream(sa):
+            for _ in range(k):
+                Z = torch.empty(n, 4, device="cuda")
+                stats = torch.zeros(2, device="cuda", dtype=torch.int32)
+                _lib.check(lib.r3d_label_propagate(_p(x), D, D, _p(nbr), kp1, _p(Y), _p(nd), _p(npd), n, 1.0, 0.99, 200, 1e-6,
+                                                   _p(Z), _p(ws), ws.numel(), _p(stats), sa.cuda_stream))
+                res.append((Z, stats))
+        return res
+
+    def attention(k):
+        with torch.cuda.stream(sb):
+            for _ in range(k):
+                _lib.check(lib.r3d_attention_fwd_train(_p(qkv), 192, B, N, _p(out), 64, _p(lse), 0.1, 7, None, _p(aws),
+                                                       sb.cuda_stream))
+                _lib.check(lib.r3d_attention_bwd_ws(_p(qkv), 192, B, N, _p(out), 64, _p(dO), 64, _p(lse), 0.1, 7, None, 0.125,
+                                                    _p(dqkv), 192, _p(aws), 1, sb.cuda_stream))
+
+    ref = solves(2)
+    torch.cuda.synchronize()
+    Zref, sref = ref[0][0].clone(), ref[0][1].tolist()
+    assert sref[0] == 1 and torch.equal(ref[1][0], Zref)
+    try:
+        for mode in (1, 0):
+            _lib.check(lib.r3d_set_matrix_arith(mode))
+            differ = 0
+            for rep in range(3):
+                attention(40)
+                got = solves(50)
+                torch.cuda.synchronize()
+                differ += sum(1 for Z, s in got if s.tolist() != sref or not torch.equal(Z, Zref))
+            assert differ == 0, (mode, differ)
+    finally:
+        _lib.check(lib.r3d_set_matrix_arith(1))
+
+
+def test_attention_results_do_not_depend_on_other_streams():
+    from r3dfsseg_amd import _lib
+    from r3dfsseg_amd.ops import _p
+    lib = _lib.load()
+    B, N, S = 12, 2048, 4
+    torch.manual_seed(3)
+    qkv = torch.randn(B * N, 192, device="cuda")
+    dO = torch.randn(B * N, 64, device="cuda")
+
+    def bufs():
+        return dict(ws=torch.empty(lib.r3d_attention_ws_words(B, N), device="cuda"), out=torch.empty(B * N, 64, device="cuda"),
+                    lse=torch.empty(B * N, device="cuda"), dqkv=torch.empty(B * N, 192, device="cuda"))
+
+    def run(b, st):
+        _lib.check(lib.r3d_attention_fwd_train(_p(qkv), 192, B, N, _p(b["out"]), 64, _p(b["lse"]), 0.1, 7, None, _p(b["ws"]), st))
+        _lib.check(lib.r3d_attention_bwd_ws(_p(qkv), 192, B, N, _p(b["out"]), 64, _p(dO), 64, _p(b["lse"]), 0.1, 7, None, 0.125,
+                                            _p(b["dqkv"]), 192, _p(b["ws"]), 1, st))
+
+    ref = bufs()
+    run(ref, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(S)]
+    bs = [bufs() for _ in range(S)]
+    for rep in range(5):
+        for s, b in zip(streams, bs):
+            with torch.cuda.stream(s):
+                run(b, s.cuda_stream)
+        torch.cuda.synchronize()
+        for b in bs:
+            for name in ("out", "lse", "dqkv"):
+                assert torch.equal(b[name], ref[name]), (rep, name)
