@@ -40,6 +40,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector peak
+BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
 OPS = ["knn_topk", "knn_topk_l2", "pointwise_conv", "edgeconv", "attention", "head_prototypes", "label_propagate",
        "gemm_tn", "edgeconv_bwd", "attention_bwd", "bn_stats", "label_propagate_bwd"]
@@ -109,11 +110,13 @@ MAIN_KERNEL = {
     "knn_topk": "r3d_knn_append_kernel<4, 128, 1, ...> (DGCNN kNN, k = 20)",
     "knn_topk_l2": "r3d_knn_append_kernel<8, 384, 2, ...> (201-NN of the graph nodes)",
     "pointwise_conv": "r3d_pointwise_gemm_kernel", "edgeconv": "r3d_edgeconv_kernel / r3d_edgeconv_train_fwd2_kernel",
-    "attention": "r3d_attention_fwd_kernel", "head_prototypes": "r3d_fps_persistent_kernel",
+    "attention": "r3d_attention_fwd_bx3_kernel (bf16 x 3; fp32 arithmetic: r3d_attention_fwd_kernel)",
+    "head_prototypes": "r3d_fps_persistent_kernel",
     "label_propagate": "r3d_cg_spmv_kernel + r3d_cg_update_kernel",
     "label_propagate_bwd": "r3d_cg_spmv_kernel + r3d_cg_update_kernel",
     "gemm_tn": "r3d_gemm_tn_kernel", "edgeconv_bwd": "r3d_edgeconv_bwd1_kernel + r3d_edgeconv_bwd2_kernel",
-    "attention_bwd": "r3d_attention_bwd_kv_kernel + r3d_attention_bwd_q_kernel", "bn_stats": "r3d_colpartial_kernel",
+    "attention_bwd": "r3d_attention_bwd_kv_bx3_kernel + r3d_attention_bwd_q_bx3_kernel (fp32 arithmetic: ..._kv_kernel + ..._q_kernel)",
+    "bn_stats": "r3d_colpartial_kernel",
 }
 
 
@@ -426,6 +429,8 @@ def main():
                     note="warm-cache repeat timing: the entry point's launches are issued again 8 times back to back on the "
                          "same buffers between one HIP event pair on the launch stream (inputs L2 / Infinity-Cache warm)")
     # every entry point against both ceilings (north_star: HBM GB/s for kNN / EdgeConv, MFMA utilisation for attention)
+    from r3dfsseg_amd import _lib as _l0
+    bx3_attention = _l0.load().r3d_get_matrix_arith() == 1
     rooflines = {"_note": "warm-cache repeat timings (8 back-to-back relaunches per region on identical buffers): "
                           "hbm_gbs is algorithmic bytes / device time, not HBM traffic"}
     for op, ms in per_step_ms.items():
@@ -434,6 +439,12 @@ def main():
         rooflines[op] = dict(bound=bnd, ms_per_step=round(ms, 4), calls_per_step=calls,
                              hbm_gbs=round(b_ / sec / 1e9, 1), frac_hbm=round(b_ / sec / 1e9 / HBM_PEAK_GBS, 4),
                              fp32_tflops=round(f_ / sec / 1e12, 2), frac_mfma=round(f_ / sec / 1e12 / F32_MFMA_PEAK_TF, 4))
+        if op in ("attention", "attention_bwd") and bx3_attention:
+            # six bf16 MFMA products per fp32 product: the matrix-core work actually issued, against the dense bf16 peak
+            rooflines[op].update(matrix_arith="bf16 x 3", bf16_tflops_issued=round(6 * f_ / sec / 1e12, 1),
+                                 frac_mfma=round(6 * f_ / sec / 1e12 / BF16_MFMA_PEAK_TF, 4),
+                                 frac_mfma_note="issued bf16 MFMA flops (6 per fp32 product) / 2500 TFLOP/s dense bf16 peak; "
+                                                "fp32_tflops is the useful fp32-equivalent rate")
     breakdown = {k: round(v, 4) for k, v in sorted(per_step_ms.items(), key=lambda kv: -kv[1])}
 
     cpu = None

@@ -129,14 +129,19 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_head_gather_kernel(const float* 
   for (int p0 = 0; p0 < HP_BLOCK; p0 += 64) {
     const int posb = bis * HP_BLOCK + p0;
     if (posb >= count) break;
+    // the 16 list entries of this wave once per 64 positions, then per channel block every row load issued before the
+    // first LDS store (a loop of one dependent load per trip is a chain of round trips on this small grid)
+    int gp[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) gp[i] = comp[g.off(seg) + min(posb + w + 4 * i, count - 1)];
     for (int c0 = 0; c0 < D; c0 += 64) {
       __syncthreads();
-      for (int r = w; r < 64; r += 4) {
-        const int pos = posb + r;
-        const int gp = comp[g.off(seg) + min(pos, count - 1)];
-        const int c = c0 + lane;
-        t[r][lane] = feat[(long)gp * ldf + min(c, D - 1)];
-      }
+      const int c = min(c0 + lane, D - 1);
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = feat[(long)gp[i] * ldf + c];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[w + 4 * i][lane] = v[i];
       __syncthreads();
       for (int r = w; r < 64; r += 4) {
         const int c = c0 + r;
