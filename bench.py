@@ -55,11 +55,14 @@ def algorithmic_work(op, cfg, n_nodes, cg_iters, train):
     n_q = n_way * cfg.get("n_queries", 1)
     K, D = cfg["dgcnn_k"], 192
     M = (S_ + n_q) * N
-    passes = 2 if train else 1
+    passes = 2 if train else 1   # launches per op where BatchNorm keeps the two getFeatures calls apart
+    from r3dfsseg_amd import train_ops as _T
+    shared = train and _T.SHARED_LAUNCHES and (S_ * N) % 64 == 0
+    joint = 1 if (shared or not train) else 2  # kNN, GEMMs and attention run once over all clouds
     conv_shapes = [(cfg["pc_in_dim"], 128), (64, 128), (64, 128), (192, 512), (512, 256), (256, 128), (128, 64), (256, 192)]
     if op == "knn_topk":  # per pass 3 launches: C = 9, 64, 64; sum over clouds of 2 N^2 C
         Cs = [cfg["pc_in_dim"], 64, 64]
-        return sum(2.0 * (S_ + n_q) * N * N * C for C in Cs), sum(M * C * 4 + M * K * 4 for C in Cs), "mfma", 3 * passes
+        return sum(2.0 * (S_ + n_q) * N * N * C for C in Cs), sum(M * C * 4 + M * K * 4 for C in Cs), "mfma", 3 * joint
     if op == "knn_topk_l2":
         kp1 = cfg["k_connect"] + 1
         return 2.0 * n_nodes * n_nodes * D, n_nodes * D * 4 + n_nodes * kp1 * 4, "mfma", 1
@@ -71,15 +74,15 @@ def algorithmic_work(op, cfg, n_nodes, cg_iters, train):
     if op == "pointwise_conv":
         f = sum(2.0 * M * k * co for k, co in conv_shapes)
         b = sum(M * k * 4 + M * co * 4 + k * co * 4 for k, co in conv_shapes)
-        return (f * 2, b * 2, "mfma", 2 * len(conv_shapes) * passes) if train else (f, b, "mfma", len(conv_shapes))
+        return (f * 2, b * 2, "mfma", 2 * len(conv_shapes) * joint) if train else (f, b, "mfma", len(conv_shapes))
     if op == "attention":
-        return 4.0 * (S_ + n_q) * N * N * 64, M * 192 * 4 + M * 64 * 4, "mfma", passes
+        return 4.0 * (S_ + n_q) * N * N * 64, M * 192 * 4 + M * 64 * 4, "mfma", joint
     if op == "attention_bwd":  # S recomputed twice, dP twice, dV, dK, dQ: 14 N^2 d per cloud
-        return 14.0 * (S_ + n_q) * N * N * 64, M * (192 + 64 + 64 + 192) * 4, "mfma", passes
+        return 14.0 * (S_ + n_q) * N * N * 64, M * (192 + 64 + 64 + 192) * 4, "mfma", joint
     if op == "gemm_tn":  # weight gradients of every conv: 2 M K Co each
         shapes = conv_shapes[:]
         return (sum(2.0 * M * k * co for k, co in shapes), sum(M * (k + co) * 4 + k * co * 4 for k, co in shapes), "mfma",
-                len(shapes) * passes)
+                len(shapes) * joint)
     if op == "edgeconv_bwd":  # three edge GEMMs (z2 recompute, dh1, dW2) + dy1 round trip
         return 3 * M * K * (3 * 2.0 * 64 * 64), 3 * (M * 128 * 4 * 2 + 2 * M * K * 64 * 4 + M * 64 * 8), "mfma", 3 * passes
     if op == "bn_stats":  # column statistics: every activation / gradient matrix read once
