@@ -213,6 +213,13 @@ int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float* s1, const
                      int B, int N, int K, float* DY1 /*(B*N*K,64) scratch*/, float* BE /*(B*N,128) scratch*/,
                      const int32_t* rev_ws /* r3d_edge_reverse of the same idx */, float* dW2, float* bn1_sums,
                      float* dPQ, float* ws, void* stream);
+/* the same for clouds [b0, b0 + B) of a batch of B_total clouds whose reverse list (rev_ws) was built by ONE
+ * r3d_edge_reverse call over all B_total clouds; every other pointer addresses this call's own clouds */
+int r3d_edgeconv_bwd_at(const float* PQ, const int32_t* idx, const float* s1, const float* t1, const float* mean1,
+                        const float* invstd1, const float* W2, const float* s2, const float* t2, const float* mean2,
+                        const float* invstd2, const float* bn2_sums, const float* dout, long lddo, const int32_t* argmax,
+                        int B, int N, int K, float* DY1, float* BE, const int32_t* rev_ws, int B_total, int b0, float* dW2,
+                        float* bn1_sums, float* dPQ, float* ws, void* stream);
 
 /* attention with dropout on the weights (attention.py:45) and flash-style backward */
 /* effective dropout seed = seed + *seed_dev (seed_dev may be NULL); a captured hipGraph bumps *seed_dev per replay */

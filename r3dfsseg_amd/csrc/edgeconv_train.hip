@@ -568,8 +568,9 @@ template <int RT>
 __global__ __launch_bounds__(256) void r3d_edgeconv_bwd2_kernel(
     const float* __restrict__ PQ, const float* __restrict__ s1, const float* __restrict__ mean1,
     const float* __restrict__ invstd1, const float* __restrict__ bn1_sums /* [2][64] */, const float* __restrict__ DY1,
-    const float* __restrict__ BE, const int* __restrict__ rev_ptr, const int* __restrict__ rev, long total_points,
+    const float* __restrict__ BE, const int* __restrict__ rev_ptr, const int* __restrict__ rev, int e_off, long total_points,
     float* __restrict__ dPQ /* (M,128), every entry written */) {
+  // rev holds edge ids of the batch the reverse list was built for; this call's clouds start e_off edges into it
   constexpr int K = 4 * RT;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const double E = (double)total_points * K;
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(256) void r3d_edgeconv_bwd2_kernel(
       float dv[16], qv[16];
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
-        const int e = __builtin_amdgcn_readlane(my_e, t);
+        const int e = __builtin_amdgcn_readlane(my_e, t) - e_off;
         dv[t] = DY1[(long)e * 64 + lane];
         qv[t] = PQ[(long)(e / K) * 128 + 64 + lane];
       }
@@ -801,11 +802,16 @@ extern "C" int r3d_edge_reverse(const int32_t* idx, int B, int N, int K, int32_t
 // caller with r3d_colstats mode 1 on zmax).  Outputs: dW2 (64,64), bn1_sums [2][64] (sum dy1, sum dy1*ehat1),
 // dPQ (B*N,128) (every entry written).  Scratch: DY1 B*N*K*64 floats, BE B*N*128 floats; rev_ws from r3d_edge_reverse
 // on the same idx.
-extern "C" int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float* s1, const float* t1, const float* mean1,
-                                const float* invstd1, const float* W2, const float* s2, const float* t2,
-                                const float* mean2, const float* invstd2, const float* bn2_sums, const float* dout,
-                                long lddo, const int32_t* argmax, int B, int N, int K, float* DY1, float* BE,
-                                const int32_t* rev_ws, float* dW2, float* bn1_sums, float* dPQ, float* ws, void* stream) {
+// r3d_edgeconv_bwd_at: the same for clouds [b0, b0 + B) of a batch of B_total clouds whose reverse list rev_ws was built
+// in ONE r3d_edge_reverse call (every other pointer is this call's own clouds): the support and the query clouds of a
+// training episode have separate BatchNorm statistics, hence separate calls, but share the list build.
+extern "C" int r3d_edgeconv_bwd_at(const float* PQ, const int32_t* idx, const float* s1, const float* t1, const float* mean1,
+                                   const float* invstd1, const float* W2, const float* s2, const float* t2,
+                                   const float* mean2, const float* invstd2, const float* bn2_sums, const float* dout,
+                                   long lddo, const int32_t* argmax, int B, int N, int K, float* DY1, float* BE,
+                                   const int32_t* rev_ws, int B_total, int b0, float* dW2, float* bn1_sums, float* dPQ,
+                                   float* ws, void* stream) {
+  R3D_REQUIRE(b0 >= 0 && B > 0 && b0 + B <= B_total, "r3d_edgeconv_bwd_at: clouds [%d, %d) of %d", b0, b0 + B, B_total);
   R3D_REQUIRE(PQ && idx && s1 && t1 && mean1 && invstd1 && W2 && s2 && t2 && mean2 && invstd2 && bn2_sums && dout &&
                   argmax && DY1 && BE && rev_ws && dW2 && bn1_sums && dPQ && ws,
               "r3d_edgeconv_bwd: null pointer");
@@ -820,12 +826,13 @@ extern "C" int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float
   // partial layout: dW2 (4096) | sum dy1 (64) | sum dy1*ehat1 (64)
   hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(r3d_cdiv(ET_PART, 64)), dim3(1024), 0, st, ws, grid, ET_PART, dW2, 4096,
                      bn1_sums);
-  const int32_t* rev_ptr = rev_ws;
-  const int32_t* rev = rev_ws + (long)B * N + 1;
+  const int32_t* rev_ptr = rev_ws + (long)b0 * N;
+  const int32_t* rev = rev_ws + (long)B_total * N + 1;
+  const int e_off = (int)((long)b0 * N * K);
 #define E2_CASE(RT)                                                                                                    \
   case RT:                                                                                                             \
     hipLaunchKernelGGL(r3d_edgeconv_bwd2_kernel<RT>, dim3(1024), dim3(256), 0, st, PQ, s1, mean1, invstd1, bn1_sums, DY1, BE, \
-                       rev_ptr, rev, (long)B * N, dPQ);                                                                \
+                       rev_ptr, rev, e_off, (long)B * N, dPQ);                                                         \
     break
   switch (K / 4) {
     E2_CASE(1); E2_CASE(2); E2_CASE(3); E2_CASE(4); E2_CASE(5); E2_CASE(6); E2_CASE(7); E2_CASE(8);
@@ -833,4 +840,12 @@ extern "C" int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float
 #undef E2_CASE
   R3D_LAUNCH_CHECK("r3d_edgeconv_bwd");
   return R3D_OK;
+}
+extern "C" int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float* s1, const float* t1, const float* mean1,
+                                const float* invstd1, const float* W2, const float* s2, const float* t2,
+                                const float* mean2, const float* invstd2, const float* bn2_sums, const float* dout,
+                                long lddo, const int32_t* argmax, int B, int N, int K, float* DY1, float* BE,
+                                const int32_t* rev_ws, float* dW2, float* bn1_sums, float* dPQ, float* ws, void* stream) {
+  return r3d_edgeconv_bwd_at(PQ, idx, s1, t1, mean1, invstd1, W2, s2, t2, mean2, invstd2, bn2_sums, dout, lddo, argmax, B, N, K,
+                             DY1, BE, rev_ws, B, 0, dW2, bn1_sums, dPQ, ws, stream);
 }

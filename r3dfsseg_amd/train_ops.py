@@ -260,6 +260,11 @@ def edgeconv_train_bwd(saved, dout, B, N, dx_acc):
     M = B * N
     dPQ = _f(M * 128, dev).view(M, 128)
     ws = _f(lib.r3d_edgeconv_train_ws_words(), dev)
+    # the reverse neighbour list of ALL clouds in one launch: the input gradient is a gather over incoming edges
+    # (deterministic, no float atomics); the segments below differ in their BatchNorm statistics only
+    rev = torch.empty(lib.r3d_edge_reverse_ws_words(B, N, K), device=dev, dtype=torch.int32)
+    with _timed("edgeconv_bwd"):
+        _lib.check(lib.r3d_edge_reverse(_p(idx3), B, N, K, _p(rev), rev.numel(), _st()))
     tot = None
     for s, (b0, Bs) in enumerate(_segments(seg_clouds)):
         r0, r1 = b0 * N, (b0 + Bs) * N
@@ -269,14 +274,11 @@ def edgeconv_train_bwd(saved, dout, B, N, dx_acc):
         bn2_sums = colstats(zmax[r0:r1], 64, mode=1, DY=do, bn=bn2, act=ops.ACT_LRELU)
         DY1, BE = _f(Ms * K * 64, dev), _f(Ms * 128, dev)
         dW2, bn1_sums = _f(64 * 64, dev), _f(128, dev)
-        rev = torch.empty(lib.r3d_edge_reverse_ws_words(Bs, N, K), device=dev, dtype=torch.int32)
         with _timed("edgeconv_bwd"):
-            # the reverse neighbour list: the input gradient is a gather over incoming edges (deterministic, no float atomics)
-            _lib.check(lib.r3d_edge_reverse(_p(ix), Bs, N, K, _p(rev), rev.numel(), _st()))
-            _lib.check(lib.r3d_edgeconv_bwd(_p(PQ[r0:r1]), _p(ix), _p(bn1[0]), _p(bn1[1]), _p(bn1[2]), _p(bn1[3]), _p(W2),
-                                            _p(bn2[0]), _p(bn2[1]), _p(bn2[2]), _p(bn2[3]), _p(bn2_sums), _p(do),
-                                            do.stride(0), _p(argmax[r0:r1]), Bs, N, K, _p(DY1), _p(BE), _p(rev), _p(dW2),
-                                            _p(bn1_sums), _p(dPQ[r0:r1]), _p(ws), _st()))
+            _lib.check(lib.r3d_edgeconv_bwd_at(_p(PQ[r0:r1]), _p(ix), _p(bn1[0]), _p(bn1[1]), _p(bn1[2]), _p(bn1[3]), _p(W2),
+                                               _p(bn2[0]), _p(bn2[1]), _p(bn2[2]), _p(bn2[3]), _p(bn2_sums), _p(do),
+                                               do.stride(0), _p(argmax[r0:r1]), Bs, N, K, _p(DY1), _p(BE), _p(rev), B, b0,
+                                               _p(dW2), _p(bn1_sums), _p(dPQ[r0:r1]), _p(ws), _st()))
         part = (dW2, bn1_sums, bn2_sums)
         tot = part if tot is None else tuple(a + b for a, b in zip(tot, part))
     dW2, bn1_sums, bn2_sums = tot
