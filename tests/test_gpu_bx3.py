@@ -22,6 +22,7 @@ def _ref(qkv, B, N, dO):
 def _run(lib, mode, qkv, B, N, dO, p_drop=0.0, seed=0):
     from r3dfsseg_amd import _lib
     from r3dfsseg_amd.ops import _p, _st
+    before = lib.r3d_get_matrix_arith()
     _lib.check(lib.r3d_set_matrix_arith(mode))
     try:
         ws = torch.empty(lib.r3d_attention_ws_words(B, N), device="cuda")
@@ -39,7 +40,7 @@ def _run(lib, mode, qkv, B, N, dO, p_drop=0.0, seed=0):
         torch.cuda.synchronize()
         assert torch.equal(dqkv, dqkv2)
     finally:
-        _lib.check(lib.r3d_set_matrix_arith(1))
+        _lib.check(lib.r3d_set_matrix_arith(before))
     return out, dqkv
 
 
@@ -81,6 +82,9 @@ def test_dropout_mask_is_the_same_in_both_arithmetics():
 def test_arith_mode_is_validated():
     from r3dfsseg_amd import _lib
     lib = _lib.load()
+    import os
+    before = lib.r3d_get_matrix_arith()
+    assert before == (0 if os.environ.get("R3D_MATRIX_ARITH") == "fp32" else 1)  # bf16 x 3 unless the environment says fp32
     assert lib.r3d_set_matrix_arith(7) != 0
     assert "r3d_set_matrix_arith" in lib.r3d_last_error_string().decode()
-    assert lib.r3d_get_matrix_arith() == 1
+    assert lib.r3d_get_matrix_arith() == before

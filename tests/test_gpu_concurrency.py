@@ -59,6 +59,7 @@ def test_label_propagation_is_not_disturbed_by_attention_on_another_stream():
     torch.cuda.synchronize()
     Zref, sref = ref[0][0].clone(), ref[0][1].tolist()
     assert sref[0] == 1 and torch.equal(ref[1][0], Zref)
+    before = lib.r3d_get_matrix_arith()
     try:
         for mode in (1, 0):
             _lib.check(lib.r3d_set_matrix_arith(mode))
@@ -70,7 +71,7 @@ def test_label_propagation_is_not_disturbed_by_attention_on_another_stream():
                 differ += sum(1 for Z, s in got if s.tolist() != sref or not torch.equal(Z, Zref))
             assert differ == 0, (mode, differ)
     finally:
-        _lib.check(lib.r3d_set_matrix_arith(1))
+        _lib.check(lib.r3d_set_matrix_arith(before))
 
 
 def test_attention_results_do_not_depend_on_other_streams():
