@@ -167,24 +167,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void r
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The same forward on the bf16 matrix core, fp32 values as three bf16 pieces (common.h "bf16 x 3"): 48 bf16 MFMAs per
-// 32-key tile and wave (1536 cycles) in place of 64 fp32 MFMAs (4096 cycles).
-// The operands arrive already cut: r3d_bx3_pack_kernel turns a 64-column block of a point-major fp32 matrix into
-// rows of [piece 0..2][64] bf16 (384 B per point), so staging is a copy and the cut is paid once per element, not once
-// per workgroup that streams it.
-// LDS: per piece a K image [key][64 ch] (rows of 72 bf16) and a V^T image [ch][32 key slots] (rows of 40 bf16).  The
-// key slots of V^T are ordered so that the 8 keys a lane half holds in S^T accumulator registers 8s .. 8s+7 (rows
-// (r & 3) + 8 (r >> 2) + 4 half) are 8 consecutive slots: P^T goes from the accumulator registers into the B operand
-// with no data movement, as in the fp32 kernel, and the A operand (V^T) is one ds_read_b128 per piece.
-#define AB_KLD 72
-#define AB_VLD 40
-#define AB_KPLANE (32 * AB_KLD)
-#define AB_VPLANE (64 * AB_VLD)
+// The same attention on the bf16 matrix core, fp32 values as three bf16 pieces (common.h "bf16 x 3"): 48 bf16 MFMAs per
+// 32-key tile and wave of the forward (1536 cycles) in place of 64 fp32 MFMAs (4096 cycles).
+// The operands arrive already cut: r3d_bx3_pack_kernel turns 64-column blocks of a point-major fp32 matrix into rows of
+// [piece 0..2][64] bf16 (384 B per point), so the cut is paid once per element, not once per workgroup that streams it,
+// and staging is a copy (by the LDS-DMA, below).
 #define AB_ROW 192  // bf16 per point of a packed operand: 3 pieces x 64 channels
-// slot of key kk (0..31) of a tile in a transposed image: kk = 8 g + 4 h + i  ->  16 (g >> 1) + 8 h + 4 (g & 1) + i
-static __device__ __forceinline__ int ab_key_slot(int kk) {
-  return 16 * (kk >> 4) + 8 * ((kk >> 2) & 1) + 4 * ((kk >> 3) & 1) + (kk & 3);
-}
 
 // dst[blk][row][piece][c] = piece of src[row][64 blk + c], c < 64, blk < nblk.  One thread: 8 channels of a row.
 __global__ void r3d_bx3_pack_kernel(const float* __restrict__ src, long ld, int nblk, long M,
@@ -222,73 +210,7 @@ static __device__ __forceinline__ void ab_load_row_frags(const unsigned short* _
     f[st].l = ab_mask(*reinterpret_cast<const r3d_u32x4*>(p + 128), ok);
   }
 }
-// Staging of one 32-row tile of a packed operand.  Row-major image: thread copies three 16-B chunks (chunk c of the
-// tile's 768: row c / 24, piece (c % 24) / 8, channels 8 (c % 8) ..).  Transposed image: thread takes rows 2 kp, 2 kp + 1
-// x 4 channels of every piece (8-B loads) and writes (row pair) words into [ch][slot].
-struct ab_rm_regs { r3d_u32x4 c[3]; };
-struct ab_tr_regs { uint2 r0[3], r1[3]; };
-// rows [row0, row0 + 32) of cloud `base`; a tile that crosses N takes the masked path (uniform branch)
-static __device__ __forceinline__ void ab_load_rm(const unsigned short* __restrict__ X, long base, int row0, int N, int tid,
-                                                  ab_rm_regs& g) {
-  const unsigned short* t0 = X + (base + row0) * AB_ROW;
-  if (row0 + 32 <= N) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) g.c[i] = *reinterpret_cast<const r3d_u32x4*>(t0 + 8 * (tid + 256 * i));  // 12 KB contiguous
-  } else {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int c = tid + 256 * i, r = c / 24;
-      const bool ok = row0 + r < N;
-      g.c[i] = ab_mask(*reinterpret_cast<const r3d_u32x4*>(ok ? t0 + 8 * c : X + base * AB_ROW), ok);
-    }
-  }
-}
-static __device__ __forceinline__ void ab_store_rm(unsigned short* img /* 3 planes of 32 x AB_KLD */, int tid,
-                                                   const ab_rm_regs& g) {
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int c = tid + 256 * i, r = c / 24, rem = c - 24 * r, piece = rem >> 3, c8 = rem & 7;
-    *reinterpret_cast<r3d_u32x4*>(img + piece * AB_KPLANE + r * AB_KLD + 8 * c8) = g.c[i];
-  }
-}
-static __device__ __forceinline__ void ab_load_tr(const unsigned short* __restrict__ X, long base, int row0, int N, int tid,
-                                                  ab_tr_regs& g) {
-  const int kp = tid & 15, c0 = (tid >> 4) * 4;
-  const int ra = row0 + 2 * kp, rb = ra + 1;
-  if (row0 + 32 <= N) {
-    const unsigned short* pa = X + (base + ra) * AB_ROW + c0;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      g.r0[p] = *reinterpret_cast<const uint2*>(pa + 64 * p);
-      g.r1[p] = *reinterpret_cast<const uint2*>(pa + AB_ROW + 64 * p);
-    }
-  } else {
-    const unsigned short* pa = X + (base + min(ra, N - 1)) * AB_ROW + c0;
-    const unsigned short* pb = X + (base + min(rb, N - 1)) * AB_ROW + c0;
-    const unsigned ma = ra < N ? 0xffffffffu : 0u, mb = rb < N ? 0xffffffffu : 0u;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      uint2 a = *reinterpret_cast<const uint2*>(pa + 64 * p), b = *reinterpret_cast<const uint2*>(pb + 64 * p);
-      g.r0[p] = make_uint2(a.x & ma, a.y & ma);
-      g.r1[p] = make_uint2(b.x & mb, b.y & mb);
-    }
-  }
-}
-static __device__ __forceinline__ void ab_store_tr(unsigned short* img /* 3 planes of 64 x AB_VLD */, int tid,
-                                                   const ab_tr_regs& g) {
-  const int kp = tid & 15, c0 = (tid >> 4) * 4;
-  unsigned short* d = img + c0 * AB_VLD + ab_key_slot(2 * kp);
-#pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    // words: x = channels c0, c0+1 ; y = channels c0+2, c0+3 of one row  ->  (row a, row b) pairs per channel
-    *reinterpret_cast<unsigned*>(d + p * AB_VPLANE) = __builtin_amdgcn_perm(g.r1[p].x, g.r0[p].x, 0x05040100u);
-    *reinterpret_cast<unsigned*>(d + p * AB_VPLANE + AB_VLD) = __builtin_amdgcn_perm(g.r1[p].x, g.r0[p].x, 0x07060302u);
-    *reinterpret_cast<unsigned*>(d + p * AB_VPLANE + 2 * AB_VLD) = __builtin_amdgcn_perm(g.r1[p].y, g.r0[p].y, 0x05040100u);
-    *reinterpret_cast<unsigned*>(d + p * AB_VPLANE + 3 * AB_VLD) = __builtin_amdgcn_perm(g.r1[p].y, g.r0[p].y, 0x07060302u);
-  }
-}
-// A fragment (3 pieces) of k-step `st` from an image whose rows are this lane's A row: row-major image -> channels,
-// transposed image -> key slots
+// the three pieces of a fragment: 16 bytes each, `plane` bf16 apart
 static __device__ __forceinline__ r3d_bx3 ab_frag(const unsigned short* p, int plane) {
   r3d_bx3 a;
   a.h = *reinterpret_cast<const r3d_u32x4*>(p);
