@@ -247,3 +247,40 @@ def test_learner_train_step_runs_and_descends():
     print("train losses:", losses)
     assert losses[-1] < losses[0]
     assert int(L.model.encoder.conv.layer[1].num_batches_tracked.item()) == 12  # two getFeatures calls per step
+
+
+@pytest.mark.parametrize("N", [512, 40])
+def test_shared_launch_sequence_equals_two_sequences(N):
+    """mpti.py:434,436 call getFeatures twice; the training path runs both calls through one launch sequence when the
+    support block ends on a 64-row tile (N = 512) and falls back to two sequences otherwise (N = 40).  Either way the
+    result must be the reference's: same losses, running statistics bit for bit, gradients equal up to LeakyReLU kinks."""
+    from r3dfsseg_amd import train_ops as T
+    from r3dfsseg_amd.mpti import MPTI_SelfAtten
+    cfg = S.make_cfg(n_way=2, k_shot=2, pc_npts=N)
+    data, _ = S.make_episode(cfg, seed=11, noise_ratio=0.5, train=True)
+    ep = [t.cuda() for t in data]
+    res = {}
+    before = T.SHARED_LAUNCHES
+    try:
+        for shared in (False, True):
+            T.SHARED_LAUNCHES = shared
+            m = MPTI_SelfAtten(SimpleNamespace(**cfg))
+            m.load_state_dict(S.make_state_dict(cfg, 123))
+            m.cuda().train()
+            m.att_learner.dropout.p = 0.0
+            assert T.shared_launches_ok(m, cfg["n_way"] * cfg["k_shot"]) == (shared and N == 512)
+            out = m(ep[0], ep[1], ep[2], ep[3], gt_support_y=ep[6], gt_query_y=ep[7], train=True, support_flag=ep[10],
+                    lp_iters=m.lp_max_iter)
+            (out[1] + 0.1 * out[2]).backward()
+            assert m.lp_converged(backward=True)
+            res[shared] = dict(lp=out[1].item(), cl=out[2].item(),
+                               grads={n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None},
+                               stats={n: b.clone() for n, b in m.named_buffers()})
+    finally:
+        T.SHARED_LAUNCHES = before
+    a, b = res[False], res[True]
+    assert abs(a["lp"] - b["lp"]) <= 1e-5 * max(1.0, abs(a["lp"])) and abs(a["cl"] - b["cl"]) <= 1e-5 * max(1.0, abs(a["cl"]))
+    for n_ in a["stats"]:
+        assert torch.equal(a["stats"][n_], b["stats"][n_]), n_
+    for n_ in a["grads"]:
+        assert _rel(b["grads"][n_], a["grads"][n_]) <= 2e-3, (n_, _rel(b["grads"][n_], a["grads"][n_]))
