@@ -480,13 +480,15 @@ def main():
     matrix_arith = ("self-attention: fp32 operands as three bf16 pieces on the bf16 MFMA, six products per block, fp32 "
                     "accumulate (fp32-level accuracy); every other GEMM and all index-deciding scores: fp32 MFMA"
                     if _l.load().r3d_get_matrix_arith() == 1 else "fp32 MFMA everywhere")
+    dtype_str = ("f32 (self-attention products: bf16x3 split on the bf16 MFMA, fp32 accumulate; every index-deciding kernel "
+                 "and every other GEMM: fp32 MFMA)" if _l.load().r3d_get_matrix_arith() == 1 else "f32")
     out = {
         "metric": "episodes/sec %s %d-way %d-shot %d-pt (MPTI+attention, %s)" % (
             "ScanNet" if args.workload == "C" else "S3DIS", cfg["n_way"], cfg["k_shot"], N,
             "train step: forward+backward+grad all-reduce+Adam" if train else "eval forward"),
         "value": eps, "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "matrix_arith": matrix_arith, "data": "synthetic",
+        "vs_baseline": None, "dtype": dtype_str, "matrix_arith": matrix_arith, "data": "synthetic",
         "config": {"workload": "%s: %d-way %d-shot %d pts, %d clouds/episode, %d episode(s)/step/rank (%s), mode=%s" % (
             args.workload, cfg["n_way"], cfg["k_shot"], N, B, E,
             "%d in flight as hipGraphs on HIP streams" % G if G else "eager launches", args.mode),
