@@ -12,19 +12,40 @@ INTO the existing parameter storage (captured episode hipGraphs hold raw pointer
 weight caches the kernels read are invalidated so that the next forward re-derives them.
 """
 import os
+import pickle
 
 import torch
 
 TRAIN_KEYS = ('iteration', 'model_state_dict', 'optimizer_state_dict', 'loss', 'IoU')
 
 
+def _numpy_scalar_globals():
+    """Allow-list for the restricted unpickler: the reference writes 'IoU' / 'loss' as numpy scalars
+    (mpti_train_noise.py:135-152), which pickle as numpy's `scalar` reconstructor plus a dtype -- data, no code.  Files
+    written under numpy < 2 name the reconstructor numpy.core.multiarray.scalar, newer ones numpy._core.multiarray.scalar."""
+    import numpy as np
+    import numpy._core.multiarray as ncm
+    allowed = [ncm.scalar, (ncm.scalar, 'numpy.core.multiarray.scalar'), np.dtype]
+    for t in (np.float64, np.float32, np.float16, np.int64, np.int32, np.bool_):
+        allowed.append(type(np.dtype(t)))
+    return allowed
+
+
 def _read(path):
+    """torch.load with the restricted unpickler (tensors, containers and numpy scalars only).  A file that needs
+    anything else is refused -- pre-trained checkpoints of this model are passed around between groups, and a pickle
+    can run code -- unless R3D_TRUST_CHECKPOINTS=1 explicitly opts into the full unpickler (logged)."""
     if not os.path.isfile(path):
         raise FileNotFoundError(path)
     try:
-        return torch.load(path, map_location='cpu', weights_only=True)
-    except Exception:
-        # reference checkpoints store 'IoU' / 'loss' as numpy scalars, which the restricted unpickler refuses
+        with torch.serialization.safe_globals(_numpy_scalar_globals()):
+            return torch.load(path, map_location='cpu', weights_only=True)
+    except pickle.UnpicklingError as err:
+        if os.environ.get('R3D_TRUST_CHECKPOINTS') != '1':
+            raise RuntimeError('%s needs more than tensors and numpy scalars to unpickle (%s); set '
+                               'R3D_TRUST_CHECKPOINTS=1 only if you trust where the file came from' % (
+                                   path, str(err).splitlines()[0]))
+        print('WARNING: %s loaded with the unrestricted unpickler (R3D_TRUST_CHECKPOINTS=1)' % path)
         return torch.load(path, map_location='cpu', weights_only=False)
 
 

@@ -133,3 +133,32 @@ def test_learner_from_checkpoint_matches_direct_load_and_graphs_follow(tmp_path)
     torch.cuda.synchronize()
     assert g.check()[0] == 0
     np.testing.assert_allclose(out[0].cpu().numpy(), want.cpu().numpy(), atol=2e-5, rtol=1e-5)
+
+
+class _Evil:
+    def __reduce__(self):  # what a crafted checkpoint.tar would carry: a call executed by the unpickler
+        return (os.getenv, ("HOME",))
+
+
+def test_crafted_pickle_is_refused(tmp_path, monkeypatch):
+    """A checkpoint that needs more than tensors / containers / numpy scalars must not reach the full unpickler
+    unless the caller opts in (pre-trained files of this model come from third parties)."""
+    from r3dfsseg_amd.mpti import MPTI_SelfAtten
+    cfg = _args()
+    sd = S.make_state_dict(cfg, 5)
+    torch.save({"iteration": 1, "model_state_dict": sd, "IoU": 0.0, "loss": _Evil()},
+               os.path.join(str(tmp_path), "checkpoint.tar"))
+    m = MPTI_SelfAtten(SimpleNamespace(**cfg))
+    monkeypatch.delenv("R3D_TRUST_CHECKPOINTS", raising=False)
+    with pytest.raises(ValueError):   # the reference's error type for an unusable checkpoint path
+        CK.load_model_checkpoint(m, str(tmp_path), mode="test")
+    with pytest.raises(RuntimeError, match="R3D_TRUST_CHECKPOINTS"):
+        CK._read(os.path.join(str(tmp_path), "checkpoint.tar"))
+    monkeypatch.setenv("R3D_TRUST_CHECKPOINTS", "1")  # explicit opt-in: loads (and says so)
+    CK.load_model_checkpoint(m, str(tmp_path), mode="test")
+    # numpy scalars written by an older numpy (reconstructor under numpy.core) stay loadable without the opt-in
+    monkeypatch.delenv("R3D_TRUST_CHECKPOINTS")
+    torch.save({"iteration": 3, "model_state_dict": sd, "IoU": np.float32(0.25), "loss": np.float64(1.5)},
+               os.path.join(str(tmp_path), "checkpoint.tar"))
+    CK.load_model_checkpoint(m, str(tmp_path), mode="test")
+    assert m.checkpoint_meta["iteration"] == 3 and abs(m.checkpoint_meta["IoU"] - 0.25) < 1e-7
