@@ -55,10 +55,8 @@ def algorithmic_work(op, cfg, n_nodes, cg_iters, train):
     n_q = n_way * cfg.get("n_queries", 1)
     K, D = cfg["dgcnn_k"], 192
     M = (S_ + n_q) * N
-    passes = 2 if train else 1   # launches per op where BatchNorm keeps the two getFeatures calls apart
-    from r3dfsseg_amd import train_ops as _T
-    shared = train and _T.SHARED_LAUNCHES and (S_ * N) % 64 == 0
-    joint = 1 if (shared or not train) else 2  # kNN, GEMMs and attention run once over all clouds
+    passes = 1   # (BatchNorm keeps the getFeatures calls apart as segments inside one launch)
+    joint = 1  # kNN, GEMMs, attention and the edge passes run once over all clouds
     conv_shapes = [(cfg["pc_in_dim"], 128), (64, 128), (64, 128), (192, 512), (512, 256), (256, 128), (128, 64), (256, 192)]
     if op == "knn_topk":  # per pass 3 launches: C = 9, 64, 64; sum over clouds of 2 N^2 C
         Cs = [cfg["pc_in_dim"], 64, 64]

@@ -18,7 +18,16 @@
  *   - activations are POINT-MAJOR fp32 matrices (one point per row, `ld*` = row stride in
  *     floats); the reference's channel-major (B, C, N) tensors are converted at the
  *     forward() boundary by r3d_cm_to_pm / r3d_pm_to_cm;
- *   - indices are int32.
+ *   - indices are int32;
+ *   - BATCHES OF EPISODES (ABI version 3).  Episodes are independent units (the reference runs one per step,
+ *     mpti_train_noise.py:57-98); here E of them go through ONE launch sequence.  Encoder side: the clouds of the batch
+ *     are rows of one matrix, episode after episode, [S support clouds | Q query clouds] each; BatchNorm keeps the
+ *     statistics of every getFeatures call apart (models/mpti.py:434,436), so the `_seg` entry points take the two
+ *     alternating segment sizes (rows_a = S N, rows_b = Q N, or in clouds) -- segment 2 e + p is call p of episode e,
+ *     rows_b == 0 means equal segments -- and address the BatchNorm vectors of segment s at (pointer + s * bn_stride).
+ *     Head side: the `_batched` entry points take n_ep and the stride of every per-episode array (capacity sized).
+ *     A segment's / an episode's results do not depend on the batch it runs in: reductions are partitioned by the
+ *     segment's own size and summed relative to its first element.
  */
 #ifndef R3D_H
 #define R3D_H
@@ -73,6 +82,12 @@ int r3d_knn_topk_split(const float* x, long ldx, const float* x_cm, int B, int N
                        const int32_t* n_valid_dev, float* norm_ws, float* cm_ws, int32_t* idx_out, float* score_out,
                        int32_t* status, float* split_ws, long split_ws_words, void* stream);
 
+/* B point sets with their own valid counts: set b has n_valid_dev[b * n_valid_stride] rows (the graph nodes of B episodes'
+ * label-propagation systems, each at its capacity N).  status: ONE word for the batch. */
+int r3d_knn_topk_batched(const float* x, long ldx, const float* x_cm, int B, int N, int C, int k, int mode,
+                         const int32_t* n_valid_dev, int n_valid_stride, float* norm_ws, float* cm_ws, int32_t* idx_out,
+                         float* score_out, int32_t* status, float* split_ws, long split_ws_words, void* stream);
+
 /* ---- 1x1 convolution + folded BatchNorm/bias + activation ---------------------------
  * models/dgcnn.py:64-80 conv1d, models/mpti.py:18-40 BaseLearner, models/attention.py:39-41.
  * Out[m][j] = act(scale[j] * sum_k X[m][k] W[j][k] + shift[j]); act 0 none, 1 ReLU, 2 LeakyReLU(0.2).
@@ -117,6 +132,17 @@ int r3d_head_prototypes(const int32_t* support_y /*(n_way*k_shot,N)*/, const int
                         int32_t* desc, int32_t* assign_out /*opt (2*S*N)*/, int32_t* cluster_count /*opt (n_cap)*/,
                         int32_t* ws, long ws_words, int flags, void* stream);
 
+/* n_ep episodes in one launch sequence (every pointer addresses episode 0).  Strides between consecutive episodes:
+ * support_y / shot_keep / desc / assign / cluster_count / ws in int32 words (ws_stride even, >= the scratch size), feat /
+ * qfeat / nodes in ROWS.  fps_group: episodes whose farthest-point samplings share one persistent launch (their workgroups
+ * must be co-resident: ~500 workgroup slots at D <= 192, 250 above; an episode needs ceil(S N / 256) + n_way + 1). */
+int r3d_head_prototypes_batched(int n_ep, int fps_group, const int32_t* support_y, long sy_stride, const int32_t* shot_keep,
+                                long keep_stride, const float* feat, long ldf, long feat_ep_rows, const float* qfeat, long ldq,
+                                long qfeat_ep_rows, int n_way, int k_shot, int N, int D, int n_query_pts, int k, float* nodes,
+                                long ldn, long nodes_ep_rows, float* node_labels, int32_t* desc, long desc_stride,
+                                int32_t* assign_out, long assign_stride, int32_t* cluster_count, long ccount_stride,
+                                int32_t* ws, long ws_words, long ws_stride, int flags, void* stream);
+
 /* ---- affinity + label propagation (models/mpti.py:717-776) ---------------------------
  * nbr (n_cap, kp1) from r3d_knn_topk mode 1 (column 0 is dropped as in mpti.py:736).
  * Z = (I - alpha D^-1/2 A D^-1/2)^-1 Y (all columns at once), A the symmetrised gaussian kNN affinity with zero
@@ -133,6 +159,14 @@ int r3d_label_propagate(const float* nodes, long ldn, int D, const int32_t* nbr,
                         const int32_t* n_dev, const int32_t* n_proto_dev, int n_cap, float sigma, float alpha,
                         int max_iter, float tol, float* Z, int32_t* ws, long ws_words, int32_t* stats_out, void* stream);
 
+/* n_ep systems at once: system e = rows [e n_cap, (e + 1) n_cap) of nodes / nbr / Y / Z, counts at n_dev[e desc_stride] /
+ * n_proto_dev[e desc_stride], scratch ws + e ws_stride (a multiple of 4 words, >= r3d_lp_ws_words), {converged, iterations}
+ * at stats_out + e stats_stride.  Every CG launch serves all systems (two launches per iteration for the whole batch). */
+int r3d_label_propagate_batched(int n_ep, const float* nodes, long ldn, int D, const int32_t* nbr, int kp1, const float* Y,
+                                const int32_t* n_dev, const int32_t* n_proto_dev, long desc_stride, int n_cap, float sigma,
+                                float alpha, int max_iter, float tol, float* Z, int32_t* ws, long ws_words, long ws_stride,
+                                int32_t* stats_out, long stats_stride, void* stream);
+
 /* Captured episodes: enable the CG kernel nodes (three per iteration) of iterations < budget in an instantiated hipGraph holding
  * r3d_label_propagate / r3d_label_propagate_bwd launches, disable the rest (no dispatch for them).  graph: the
  * hipGraph_t the hipGraphExec_t graph_exec was instantiated from.  n_cg (optional, host): CG nodes found.
@@ -143,6 +177,11 @@ int r3d_graph_set_lp_budget(void* graph, void* graph_exec, int budget, int* n_cg
 int r3d_query_logits_ce(const float* Z, const int32_t* n_proto_dev, int n_q, int N, int n_classes,
                         const int64_t* labels /*opt (n_q,N)*/, float* logits /*(n_q,n_classes,N)*/,
                         float* loss_out /*opt*/, int32_t* pred_out /*opt (n_q*N)*/, void* stream);
+
+/* per system of a batch: Z rows [e z_ep_rows, ...) -> logits / loss / pred number e of the batch arrays */
+int r3d_query_logits_ce_batched(int n_ep, const float* Z, long z_ep_rows, const int32_t* n_proto_dev, long desc_stride, int n_q,
+                                int N, int n_classes, const int64_t* labels, float* logits, float* loss_out, int32_t* pred_out,
+                                void* stream);
 
 /* ==== training mode (BatchNorm with batch statistics, backward) =======================
  * A conv+BN+act layer: z = r3d_pointwise_conv (no affine) -> r3d_colstats mode 0 -> r3d_bn_fold ->
@@ -160,7 +199,12 @@ int r3d_pointwise_conv_stats(const float* X, long ldx, const float* W, long M, i
  * one launch; mpti.py:434,436 normalise them separately).  M_first: a positive multiple of 64. */
 int r3d_pointwise_conv_stats2(const float* X, long ldx, const float* W, long M, int K, int Co, float* Out, long ldo,
                               long M_first, float* sums_a /*[2][Co]*/, float* sums_b /*[2][Co]*/, float* ws, void* stream);
+/* ... and over the alternating row segments of a batch of episodes (rows_a, rows_b multiples of 64): ONE GEMM launch,
+ * sums_out [seg][2][Co] */
+int r3d_pointwise_conv_stats_seg(const float* X, long ldx, const float* W, long M, int K, int Co, float* Out, long ldo,
+                                 long rows_a, long rows_b, float* sums_out, float* ws, void* stream);
 int r3d_colreduce(const float* part /*[chunks][2][C]*/, int chunks, int C, float* sums_out /*[2][C]*/, void* stream);
+int r3d_colreduce_seg(const float* part, int count_a, int count_b, int n_seg, int C, float* sums_out /*[seg][2][C]*/, void* stream);
 long r3d_colstats_ws_words(long M, int C);
 int r3d_colstats(const float* X, long ldx, const float* DY, long lddy, long M, int C, int mode, const float* scale,
                  const float* shift, const float* mean, const float* invstd, int act, float* sums_out /*[2][C]*/,
@@ -173,6 +217,21 @@ int r3d_bn_fold(const float* sums, double count, int C, const float* gamma, cons
                 float momentum, float* running_mean /*opt*/, float* running_var /*opt*/, float* mean, float* invstd,
                 float* scale, float* shift, float* rec /*opt*/, const int32_t* rec_index_dev /*opt*/, long rec_stride,
                 void* stream);
+/* the segmented forms (sums / outputs [seg][...], BatchNorm vectors of segment s at pointer + s * bn_stride, running
+ * statistics or records updated in segment order = the reference's order of getFeatures calls) */
+long r3d_colstats_seg_ws_words(long M, int C, long rows_a, long rows_b);
+int r3d_colstats_seg(const float* X, long ldx, const float* DY, long lddy, long M, int C, long rows_a, long rows_b, int mode,
+                     const float* scale, const float* shift, const float* mean, const float* invstd, long bn_stride, int act,
+                     float* sums_out /*[seg][2][C]*/, float* ws, void* stream);
+int r3d_bn_fold_seg(const float* sums /*[seg][2][C]*/, int n_seg, double count_a, double count_b, int C, const float* gamma,
+                    const float* beta, float eps, float momentum, float* running_mean /*opt*/, float* running_var /*opt*/,
+                    float* mean, float* invstd, float* scale, float* shift, long bn_stride, float* rec /*opt*/,
+                    const int32_t* rec_index_dev /*opt*/, long rec_stride, void* stream);
+int r3d_affine_act_seg(const float* Z, long ldz, long M, int C, long rows_a, long rows_b, const float* scale, const float* shift,
+                       long bn_stride, int act, float* Y, long ldy, void* stream);
+int r3d_bn_bwd_apply_seg(const float* Z, long ldz, const float* DY, long lddy, long M, int C, long rows_a, long rows_b,
+                         const float* scale, const float* shift, const float* mean, const float* invstd, long bn_stride, int act,
+                         const float* sums /*[seg][2][C]*/, double count_a, double count_b, float* DZ, long lddz, void* stream);
 int r3d_bn_running_update(const float* rec, int n_records, long rec_stride, int C, float momentum,
                           const float* bias /*opt: conv bias in front of the BatchNorm*/, float* running_mean,
                           float* running_var, void* stream);
@@ -186,40 +245,34 @@ int r3d_gemm_tn(const float* A, long lda, const float* B, long ldb, long M, int 
                 int accumulate, float* ws, void* stream);
 int r3d_add_cols(const float* src, long ld_src, float* dst, long ld_dst, long M, int C, void* stream);
 
-/* EdgeConv with batch statistics over all B*N*K edges (models/dgcnn.py:53-57 in train mode) and its
- * backward; PQ is the RAW point-wise GEMM [Wa x | (Wb-Wa) x]. */
-long r3d_edgeconv_train_ws_words(void);
-int r3d_edge_stats1(const float* PQ, const int32_t* idx, int B, int N, int K, float* sums_out /*[2][64]*/, float* ws,
-                    void* stream);
-int r3d_edgeconv_train_fwd(const float* PQ, const int32_t* idx, const float* s1, const float* t1, const float* W2,
-                           const float* s2, const float* t2, int mode /*1: stats of z2, 0: output*/, float* out, long ldo,
-                           int B, int N, int K, int32_t* argmax_out, float* zmax_out, float* sums_out, float* ws,
-                           void* stream);
+/* EdgeConv with batch statistics over the edges of every segment of clouds (models/dgcnn.py:53-57 in train mode; segments
+ * of clouds_a / clouds_b clouds alternating, clouds_b == 0: equal segments -- the S support and Q query clouds of every
+ * episode of a batch) and its backward; PQ is the RAW point-wise GEMM [Wa x | (Wb-Wa) x].  One launch per pass over ALL
+ * clouds; statistics are per segment ([seg][2][64]), BatchNorm vectors of segment s at pointer + s * bn_stride.
+ * ws: r3d_edgeconv_train_ws_words(B, N) floats. */
+long r3d_edgeconv_train_ws_words(int B, int N);
+int r3d_edge_stats1(const float* PQ, const int32_t* idx, int B, int N, int K, int clouds_a, int clouds_b,
+                    float* sums_out /*[seg][2][64]*/, float* ws, void* stream);
 /* one-pass training forward: z2 statistics + per point/channel max and min of z2 over the K edges; BatchNorm2 +
  * LeakyReLU is monotone per channel, so r3d_edge_select finishes the layer once the statistics are folded */
-int r3d_edgeconv_train_fwd_minmax(const float* PQ, const int32_t* idx, const float* s1, const float* t1,
-                                  const float* W2, int B, int N, int K, float* zmax, float* zmin, int32_t* argmax,
-                                  int32_t* argmin, float* sums_out /*[2][64]*/, float* ws, void* stream);
+int r3d_edgeconv_train_fwd_minmax(const float* PQ, const int32_t* idx, const float* s1, const float* t1, long bn_stride,
+                                  const float* W2, int B, int N, int K, int clouds_a, int clouds_b, float* zmax, float* zmin,
+                                  int32_t* argmax, int32_t* argmin, float* sums_out /*[seg][2][64]*/, float* ws, void* stream);
 int r3d_edge_select(float* zmax /*in: max, out: selected z*/, const float* zmin, int32_t* argmax /*in/out*/,
-                    const int32_t* argmin, const float* s2, const float* t2, long M, float* out, long ldo,
-                    void* stream);
+                    const int32_t* argmin, const float* s2, const float* t2, long bn_stride, long M, long rows_a, long rows_b,
+                    float* out, long ldo, void* stream);
 /* reverse neighbour list (for every point the edges that name it, ascending): rev_ws = r3d_edge_reverse_ws_words int32
  * words.  The backward gathers along it instead of scattering with float atomics: deterministic gradients. */
 long r3d_edge_reverse_ws_words(int B, int N, int K);
 int r3d_edge_reverse(const int32_t* idx, int B, int N, int K, int32_t* rev_ws, long ws_words, void* stream);
+/* bn2_sums [seg][2][64] in; dW2 (64,64) summed over the WHOLE batch, bn1_sums [seg][2][64], dPQ (B*N,128) out */
 int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float* s1, const float* t1, const float* mean1,
                      const float* invstd1, const float* W2, const float* s2, const float* t2, const float* mean2,
-                     const float* invstd2, const float* bn2_sums, const float* dout, long lddo, const int32_t* argmax,
-                     int B, int N, int K, float* DY1 /*(B*N*K,64) scratch*/, float* BE /*(B*N,128) scratch*/,
-                     const int32_t* rev_ws /* r3d_edge_reverse of the same idx */, float* dW2, float* bn1_sums,
-                     float* dPQ, float* ws, void* stream);
-/* the same for clouds [b0, b0 + B) of a batch of B_total clouds whose reverse list (rev_ws) was built by ONE
- * r3d_edge_reverse call over all B_total clouds; every other pointer addresses this call's own clouds */
-int r3d_edgeconv_bwd_at(const float* PQ, const int32_t* idx, const float* s1, const float* t1, const float* mean1,
-                        const float* invstd1, const float* W2, const float* s2, const float* t2, const float* mean2,
-                        const float* invstd2, const float* bn2_sums, const float* dout, long lddo, const int32_t* argmax,
-                        int B, int N, int K, float* DY1, float* BE, const int32_t* rev_ws, int B_total, int b0, float* dW2,
-                        float* bn1_sums, float* dPQ, float* ws, void* stream);
+                     const float* invstd2, long bn_stride, const float* bn2_sums, const float* dout, long lddo,
+                     const int32_t* argmax, int B, int N, int K, int clouds_a, int clouds_b,
+                     float* DY1 /*(B*N*K,64) scratch*/, float* BE /*(B*N,128) scratch*/,
+                     const int32_t* rev_ws /* r3d_edge_reverse of the same idx */, float* dW2, float* bn1_sums, float* dPQ,
+                     float* ws, void* stream);
 
 /* attention with dropout on the weights (attention.py:45) and flash-style backward */
 /* effective dropout seed = seed + *seed_dev (seed_dev may be NULL); a captured hipGraph bumps *seed_dev per replay */
@@ -234,6 +287,17 @@ int r3d_attention_bwd_ws(const float* qkv, long ld, int B, int N, const float* O
                          const float* lse, float p_drop, unsigned seed, const unsigned* seed_dev, float q_scale,
                          float* dqkv, long ldd, float* ws, int ws_holds_packed_qkv, void* stream);
 
+/* batches of episodes: clouds [e seed_group, (e + 1) seed_group) are episode e, whose dropout mask is the one a call on
+ * those clouds alone draws with seed + 2 e (the one-episode schedule advances its seed by 2 per episode); outputs are
+ * bit for bit those of that call (p_drop = 0: the inference forward of a batch) */
+long r3d_attention_ws_words_ep(int B, int N, int seed_group); /* workspace of the _ep calls: the key-axis split is the one
+                                                                * of ONE episode (seed_group clouds), whatever the batch */
+int r3d_attention_fwd_train_ep(const float* qkv, long ld, int B, int N, float* out, long ldo, float* lse_out, float p_drop,
+                               unsigned seed, const unsigned* seed_dev, int seed_group, float* ws, void* stream);
+int r3d_attention_bwd_ep(const float* qkv, long ld, int B, int N, const float* O, long ldo, const float* dO, long lddo,
+                         const float* lse, float p_drop, unsigned seed, const unsigned* seed_dev, int seed_group, float q_scale,
+                         float* dqkv, long ldd, float* ws, int ws_holds_packed_qkv, void* stream);
+
 /* head backward (reference: autograd through models/mpti.py:488-512,571).  r3d_ce_grad -> G = dL/dZ (scaled by the
  * device scalar *gscale); r3d_label_propagate_bwd: adjoint CG solve on the graph r3d_label_propagate left in ws,
  * then gradients w.r.t. the node features; r3d_head_prototypes_bwd: cluster-mean / query-row backward. */
@@ -246,6 +310,20 @@ int r3d_head_prototypes_bwd(const float* dnodes, long ldd, int n_way, int k_shot
                             const int32_t* desc, const int32_t* assign, const int32_t* cluster_count, const int32_t* ws,
                             float* dsfeat, long lds_, float* dqfeat, long ldq, void* stream);
 
+/* the same for n_ep episodes (layouts as the forward `_batched` calls; G, lam, dnodes: n_cap rows per system; *gscale_dev
+ * scales every episode alike: the step's loss is the SUM of the episodes' losses) */
+int r3d_ce_grad_batched(int n_ep, const float* Z, const int32_t* n_proto_dev, long desc_stride, int n_cap, int n_query_pts,
+                        int n_classes, const int64_t* labels, const float* gscale_dev, float* G, void* stream);
+int r3d_label_propagate_bwd_batched(int n_ep, const float* nodes, long ldn, int D, int kp1, const float* Z, const float* G,
+                                    const int32_t* n_dev, long desc_stride, int n_cap, float sigma, float alpha, int max_iter,
+                                    float tol, float* lam, float* dnodes, long ldd, int32_t* ws, long ws_words, long ws_stride,
+                                    int32_t* stats_out, long stats_stride, void* stream);
+int r3d_head_prototypes_bwd_batched(int n_ep, const float* dnodes, long ldd, long nodes_ep_rows, int n_way, int k_shot, int N,
+                                    int D, int n_query_pts, const int32_t* desc, long desc_stride, const int32_t* assign,
+                                    long assign_stride, const int32_t* cluster_count, long ccount_stride, const int32_t* ws,
+                                    long ws_stride, float* dsfeat, long lds_, long dsfeat_ep_rows, float* dqfeat, long ldq,
+                                    long dqfeat_ep_rows, void* stream);
+
 /* per-way supervised contrastive loss, train only (models/mpti.py:226-313): per shot FPS(4) prototypes of the
  * foreground points -> proj Linear(D,128) -> L2 normalise -> SupCon(temp); mean over ways.  ws keeps what
  * r3d_contrast_bwd needs (prototype gradients, assignments, per-way parameter gradients). */
@@ -255,6 +333,17 @@ int r3d_contrast_fwd(const float* feat, long ldf, int D, const int32_t* support_
                      long ws_words, void* stream);
 int r3d_contrast_bwd(int D, int n_way, int k_shot, int N, const float* gscale_dev, float* dfeat, long ldd, float* dW,
                      float* db, float* ws, void* stream);
+/* n_ep episodes: features of episode e at feat + e feat_ep_rows ldf, masks / flags entry e of (n_ep, S, N) / (n_ep, S),
+ * scratch ws + e ws_stride, loss_out[e]; the backward sums dW / db over the batch */
+int r3d_contrast_fwd_batched(int n_ep, const float* feat, long ldf, long feat_ep_rows, int D, const int32_t* support_y,
+                             const int32_t* support_flag, int n_way, int k_shot, int N, const float* W, const float* bias,
+                             float temp, float* loss_out, float* ws, long ws_words, long ws_stride, void* stream);
+int r3d_contrast_bwd_batched(int n_ep, int D, int n_way, int k_shot, int N, const float* gscale_dev, float* dfeat, long ldd,
+                             long dfeat_ep_rows, float* dW, float* db, float* ws, long ws_stride, void* stream);
+int r3d_train_metrics_batched(int n_ep, const int32_t* pred, const int64_t* query_y, const int64_t* gt_query_y, int n_query_pts,
+                              const float* Z, long z_ep_rows, const int32_t* desc, long desc_stride, const int32_t* proto_ws,
+                              long pws_stride, const int32_t* assign, long assign_stride, const int32_t* gt_support_y, int n_way,
+                              int k_shot, int N, float* out4 /*(n_ep,4)*/, void* stream);
 /* training-only debug metrics (mpti.py:515-568): out4 = query_acc_LP, query_acc_original, clean_ratio_LP_avg,
  * clean_ratio_original_avg */
 int r3d_train_metrics(const int32_t* pred, const int64_t* query_y, const int64_t* gt_query_y, int n_query_pts, const float* Z,
@@ -268,6 +357,10 @@ long r3d_clean_ws_words(int n_way, int k_shot);
 int r3d_clean_shot_detect(const float* feat /*(S*N,ldf)*/, long ldf, int D, const float* support_x /*(S,Cin,N)*/,
                           int Cin, const int32_t* support_y, int n_way, int k_shot, int N, int32_t* shot_keep,
                           float* dbg_cos_sum /*opt (n_way,2,4*k_shot)*/, int32_t* ws, void* stream);
+
+int r3d_clean_shot_detect_batched(int n_ep, const float* feat, long ldf, long feat_ep_rows, int D, const float* support_x,
+                                  int Cin, const int32_t* support_y, int n_way, int k_shot, int N, int32_t* shot_keep,
+                                  float* dbg_cos_sum, int32_t* ws, long ws_stride, void* stream);
 
 /* ---- ProtoNet head (models/protonet.py:295-349): masked average pooling + similarity ----
  * method 0 cosine * scaler, 1 -euclidean^2; anything else returns non-zero like the reference's

@@ -51,8 +51,8 @@ _SIGS = {
                                   c_l, c_f, c_f]),
     "r3d_graph_set_lp_budget": (c_i, [c_f, c_f, c_i, ctypes.POINTER(c_i)]),
     "r3d_pointwise_conv_acc": (c_i, [c_f, c_l, c_f, c_l, c_i, c_i, c_f, c_f, c_i, c_f, c_l, c_f]),
-    "r3d_edgeconv_train_fwd_minmax": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
-    "r3d_edge_select": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_f, c_l, c_f]),
+    "r3d_edgeconv_train_fwd_minmax": (c_i, [c_f, c_f, c_f, c_f, c_l, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "r3d_edge_select": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_l, c_l, c_l, c_f, c_l, c_f]),
     "r3d_pointwise_conv_stats_ws_words": (c_l, [c_l, c_i]),
     "r3d_pointwise_conv_stats": (c_i, [c_f, c_l, c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_f, c_f]),
     "r3d_pointwise_conv_stats2": (c_i, [c_f, c_l, c_f, c_l, c_i, c_i, c_f, c_l, c_l, c_f, c_f, c_f, c_f]),
@@ -66,13 +66,11 @@ _SIGS = {
     "r3d_gemm_tn_ws_words": (c_l, [c_l, c_i, c_i]),
     "r3d_gemm_tn": (c_i, [c_f, c_l, c_f, c_l, c_l, c_i, c_i, c_fl, c_f, c_i, c_f, c_f]),
     "r3d_add_cols": (c_i, [c_f, c_l, c_f, c_l, c_l, c_i, c_f]),
-    "r3d_edgeconv_train_ws_words": (c_l, []),
-    "r3d_edge_stats1": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f]),
-    "r3d_edgeconv_train_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_l, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f]),
+    "r3d_edgeconv_train_ws_words": (c_l, [c_i, c_i]),
+    "r3d_edge_stats1": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f]),
     "r3d_edge_reverse_ws_words": (c_l, [c_i, c_i, c_i]),
     "r3d_edge_reverse": (c_i, [c_f, c_i, c_i, c_i, c_f, c_l, c_f]),
-    "r3d_edgeconv_bwd": (c_i, [c_f] * 13 + [c_l, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
-    "r3d_edgeconv_bwd_at": (c_i, [c_f] * 13 + [c_l, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f]),
+    "r3d_edgeconv_bwd": (c_i, [c_f] * 11 + [c_l, c_f, c_f, c_l, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "r3d_attention_fwd_train": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_fl, c_u, c_f, c_f, c_f]),
     "r3d_attention_bwd": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_l, c_f, c_fl, c_u, c_f, c_fl, c_f, c_l, c_f, c_f]),
     "r3d_attention_bwd_ws": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_l, c_f, c_fl, c_u, c_f, c_fl, c_f, c_l, c_f, c_i, c_f]),
@@ -88,6 +86,32 @@ _SIGS = {
     "r3d_protonet_head": (c_i, [c_f, c_l, c_f, c_l, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_f, c_f, c_f]),
     "r3d_miou_accumulate": (c_i, [c_f, c_f, c_l, c_f, c_i, c_i, c_f, c_f]),
     "r3d_query_logits_ce": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f]),
+    # ---- ABI version 3: segments (training encoder) and batches of episodes (head)
+    "r3d_knn_topk_batched": (c_i, [c_f, c_l, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_f]),
+    "r3d_pointwise_conv_stats_seg": (c_i, [c_f, c_l, c_f, c_l, c_i, c_i, c_f, c_l, c_l, c_l, c_f, c_f, c_f]),
+    "r3d_colreduce_seg": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_f]),
+    "r3d_colstats_seg_ws_words": (c_l, [c_l, c_i, c_l, c_l]),
+    "r3d_colstats_seg": (c_i, [c_f, c_l, c_f, c_l, c_l, c_i, c_l, c_l, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_f, c_f]),
+    "r3d_bn_fold_seg": (c_i, [c_f, c_i, c_d, c_d, c_i, c_f, c_f, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_f, c_f, c_l, c_f]),
+    "r3d_affine_act_seg": (c_i, [c_f, c_l, c_l, c_i, c_l, c_l, c_f, c_f, c_l, c_i, c_f, c_l, c_f]),
+    "r3d_bn_bwd_apply_seg": (c_i, [c_f, c_l, c_f, c_l, c_l, c_i, c_l, c_l, c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_d, c_d, c_f, c_l, c_f]),
+    "r3d_attention_ws_words_ep": (c_l, [c_i, c_i, c_i]),
+    "r3d_attention_fwd_train_ep": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_fl, c_u, c_f, c_i, c_f, c_f]),
+    "r3d_attention_bwd_ep": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_l, c_f, c_fl, c_u, c_f, c_i, c_fl, c_f, c_l, c_f, c_i, c_f]),
+    "r3d_head_prototypes_batched": (c_i, [c_i, c_i, c_f, c_l, c_f, c_l, c_f, c_l, c_l, c_f, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_i,
+                                          c_f, c_l, c_l, c_f, c_f, c_l, c_f, c_l, c_f, c_l, c_f, c_l, c_l, c_i, c_f]),
+    "r3d_head_prototypes_bwd_batched": (c_i, [c_i, c_f, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_l, c_f, c_l, c_f, c_l, c_f, c_l,
+                                              c_f, c_l, c_l, c_f, c_l, c_l, c_f]),
+    "r3d_label_propagate_batched": (c_i, [c_i, c_f, c_l, c_i, c_f, c_i, c_f, c_f, c_f, c_l, c_i, c_fl, c_fl, c_i, c_fl, c_f, c_f,
+                                          c_l, c_l, c_f, c_l, c_f]),
+    "r3d_label_propagate_bwd_batched": (c_i, [c_i, c_f, c_l, c_i, c_i, c_f, c_f, c_f, c_l, c_i, c_fl, c_fl, c_i, c_fl, c_f, c_f,
+                                              c_l, c_f, c_l, c_l, c_f, c_l, c_f]),
+    "r3d_ce_grad_batched": (c_i, [c_i, c_f, c_f, c_l, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),
+    "r3d_query_logits_ce_batched": (c_i, [c_i, c_f, c_l, c_f, c_l, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f]),
+    "r3d_contrast_fwd_batched": (c_i, [c_i, c_f, c_l, c_l, c_i, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_fl, c_f, c_f, c_l, c_l, c_f]),
+    "r3d_contrast_bwd_batched": (c_i, [c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_l, c_l, c_f, c_f, c_f, c_l, c_f]),
+    "r3d_train_metrics_batched": (c_i, [c_i, c_f, c_f, c_f, c_i, c_f, c_l, c_f, c_l, c_f, c_l, c_f, c_l, c_f, c_i, c_i, c_i, c_f, c_f]),
+    "r3d_clean_shot_detect_batched": (c_i, [c_i, c_f, c_l, c_l, c_i, c_f, c_i, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_l, c_f]),
 }
 
 _lib = None

@@ -33,7 +33,7 @@ static __device__ __forceinline__ bool attn_keep(unsigned seed, unsigned row, un
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void r3d_attention_fwd_kernel(
     const float* __restrict__ qkv, long ld, int N, float* __restrict__ out, long ldo,
-    float* __restrict__ lse_out, float p_drop, unsigned seed, const unsigned* __restrict__ seed_dev,
+    float* __restrict__ lse_out, float p_drop, unsigned seed, const unsigned* __restrict__ seed_dev, int seed_group,
     int tiles_per_split, float* __restrict__ part /* split > 1: [split][M][AT_PROW] = unnormalised o | m | l */) {
   if (seed_dev) seed += *seed_dev;  // per-replay seed of a captured hipGraph lives in device memory
   const unsigned thresh = p_drop > 0.f ? (unsigned)(p_drop * 4294967296.0) : 0u;
@@ -43,6 +43,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void r
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int b = blockIdx.y;
   const long base = (long)b * N;
+  unsigned hbase = (unsigned)base;  // row id the dropout hash sees
+  if (seed_group > 0) {             // batch of episodes: every group of seed_group clouds is one episode with its own seed
+    const int ep_ = b / seed_group;
+    seed += 2u * (unsigned)ep_;
+    hbase = (unsigned)((b - ep_ * seed_group) * N);
+  }
   const int q_row = blockIdx.x * 128 + 32 * w + (lane & 31);
   const bool q_ok = q_row < N;
   // Q^T fragments: B[k = ch][j = query]
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void r
     if (thresh) {  // dropout acts on the normalised weights: numerator only, the row sum l stays undropped
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        s[r] = attn_keep(seed, (unsigned)(base + q_row), (unsigned)(32 * t + r3d_acc_row(r, lane)), thresh) ? s[r] * keep_scale : 0.f;
+        s[r] = attn_keep(seed, hbase + (unsigned)(q_row), (unsigned)(32 * t + r3d_acc_row(r, lane)), thresh) ? s[r] * keep_scale : 0.f;
     }
     // O^T += V^T P^T
     {
@@ -328,7 +334,7 @@ template <bool DROP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r3d_attention_fwd_bx3_kernel(
     const unsigned short* __restrict__ Qp, const unsigned short* __restrict__ Kp, const unsigned short* __restrict__ Vp,
     int N, float* __restrict__ out, long ldo, float* __restrict__ lse_out, float p_drop, unsigned seed,
-    const unsigned* __restrict__ seed_dev, int tiles_per_split, float* __restrict__ part) {
+    const unsigned* __restrict__ seed_dev, int seed_group, int tiles_per_split, float* __restrict__ part) {
   if (seed_dev) seed += *seed_dev;
   const unsigned thresh = DROP ? (unsigned)(p_drop * 4294967296.0) : 0u;
   const float keep_scale = DROP ? 1.f / (1.f - p_drop) : 1.f;
@@ -337,6 +343,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
   const int b = blockIdx.y;
   const long base = (long)b * N;
+  unsigned hbase = (unsigned)base;  // row id the dropout hash sees
+  if (seed_group > 0) {             // batch of episodes: every group of seed_group clouds is one episode with its own seed
+    const int ep_ = b / seed_group;
+    seed += 2u * (unsigned)ep_;
+    hbase = (unsigned)((b - ep_ * seed_group) * N);
+  }
   const int q_row = blockIdx.x * 128 + 32 * w + (lane & 31);
   const bool q_ok = q_row < N;
   r3d_bx3 bq[4];
@@ -402,7 +414,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
     if (DROP) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        s[r] = attn_keep(seed, (unsigned)(base + q_row), (unsigned)(32 * t + r3d_acc_row(r, lane)), thresh) ? s[r] * keep_scale : 0.f;
+        s[r] = attn_keep(seed, hbase + (unsigned)(q_row), (unsigned)(32 * t + r3d_acc_row(r, lane)), thresh) ? s[r] * keep_scale : 0.f;
     }
     const r3d_bx3 pf0 = ab_split_acc(s, 0);
     ASTAMP(1);
@@ -514,45 +526,52 @@ static int attention_split(int B, int N, int slots) {
 enum { ATT_FWD = 0, ATT_BWD_KV = 1, ATT_BWD_Q = 2, ATT_FWD_BX3 = 3, ATT_BWD_KV_BX3 = 4, ATT_BWD_Q_BX3 = 5, ATT_N = 6 };
 static int attention_slots(int which);  // defined below the kernels
 // forward: split * M * AT_PROW; backward: M (row dots) + split * M * 128 (dK | dV partials, reused for dQ)
-static long attention_part_words(int B, int N) {
+// Bs: the number of clouds the key-axis split is chosen for.  A batch of episodes is split like ONE episode (Bs = clouds
+// per episode), so a cloud's partials, their merge order and hence its output bits are the same whether its episode
+// runs alone or inside a batch; the price is partial traffic a large batch would not need (~1 % of a training step).
+static long attention_part_words(int B, int N, int Bs) {
   int smax = 1;
   for (int w = 0; w < ATT_N; ++w) {
-    const int sp = attention_split(B, N, attention_slots(w));
+    const int sp = attention_split(Bs, N, attention_slots(w));
     smax = sp > smax ? sp : smax;
   }
   return (((long)B * N * (1 + 128L * smax) + 63) / 64) * 64;
 }
-extern "C" long r3d_attention_ws_words(int B, int N) {
+extern "C" long r3d_attention_ws_words_ep(int B, int N, int group) {
   // ... followed by the packed bf16 x 3 operands (q | k | v | dO: 96 words per point each)
-  return attention_part_words(B, N) + 4L * B * N * (AB_ROW / 2) + 64;
+  return attention_part_words(B, N, group > 0 ? group : B) + 4L * B * N * (AB_ROW / 2) + 64;
 }
+extern "C" long r3d_attention_ws_words(int B, int N) { return r3d_attention_ws_words_ep(B, N, 0); }
 
 static int attention_launch(const float* qkv, long ld, int B, int N, float* out, long ldo, float* lse_out, float p_drop,
-                            unsigned seed, const unsigned* seed_dev, float* ws, void* stream) {
+                            unsigned seed, const unsigned* seed_dev, int seed_group, float* ws, void* stream) {
+  R3D_REQUIRE(seed_group >= 0 && (seed_group == 0 || B % seed_group == 0), "r3d_attention_fwd: %d clouds in groups of %d", B,
+              seed_group);
   R3D_REQUIRE(qkv && out, "r3d_attention_fwd: null pointer");
   R3D_REQUIRE(B > 0 && N > 0 && ld >= 192 && ld % 4 == 0 && ldo >= 64,
               "r3d_attention_fwd: bad shape B=%d N=%d ld=%ld ldo=%ld", B, N, ld, ldo);
   R3D_REQUIRE(((uintptr_t)qkv & 15) == 0, "r3d_attention_fwd: qkv must be 16-byte aligned");
   R3D_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "r3d_attention_fwd: dropout probability %f out of range", p_drop);
   const bool bx3 = g_r3d_matrix_arith == 1 && ws;  // the packed operands live in the workspace
-  const int split = ws ? attention_split(B, N, attention_slots(bx3 ? ATT_FWD_BX3 : ATT_FWD)) : 1;
+  const int Bs = seed_group > 0 ? seed_group : B;
+  const int split = ws ? attention_split(Bs, N, attention_slots(bx3 ? ATT_FWD_BX3 : ATT_FWD)) : 1;
   const int ntiles = r3d_cdiv(N, 32);
   const int tps = r3d_cdiv(ntiles, split);
   const int nz = r3d_cdiv(ntiles, tps);  // no empty split
   dim3 grid(r3d_cdiv(N, 128), B, nz);
   if (bx3) {
     const long M = (long)B * N;
-    unsigned short* pk = reinterpret_cast<unsigned short*>(ws + attention_part_words(B, N));
+    unsigned short* pk = reinterpret_cast<unsigned short*>(ws + attention_part_words(B, N, Bs));
     bx3_pack(qkv, ld, 3, M, pk, (hipStream_t)stream);  // q | k | v; a backward given the same workspace finds them there
     if (p_drop > 0.f)
       hipLaunchKernelGGL(r3d_attention_fwd_bx3_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, pk, pk + M * AB_ROW,
-                         pk + 2 * M * AB_ROW, N, out, ldo, lse_out, p_drop, seed, seed_dev, tps, nz > 1 ? ws : nullptr);
+                         pk + 2 * M * AB_ROW, N, out, ldo, lse_out, p_drop, seed, seed_dev, seed_group, tps, nz > 1 ? ws : nullptr);
     else
       hipLaunchKernelGGL(r3d_attention_fwd_bx3_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, pk, pk + M * AB_ROW,
-                         pk + 2 * M * AB_ROW, N, out, ldo, lse_out, p_drop, seed, seed_dev, tps, nz > 1 ? ws : nullptr);
+                         pk + 2 * M * AB_ROW, N, out, ldo, lse_out, p_drop, seed, seed_dev, seed_group, tps, nz > 1 ? ws : nullptr);
   } else
     hipLaunchKernelGGL(r3d_attention_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, ld, N, out,
-                       ldo, lse_out, p_drop, seed, seed_dev, tps, nz > 1 ? ws : nullptr);
+                       ldo, lse_out, p_drop, seed, seed_dev, seed_group, tps, nz > 1 ? ws : nullptr);
   if (nz > 1) {
     const long M = (long)B * N;
     hipLaunchKernelGGL(r3d_attention_combine_kernel, dim3(r3d_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, ws, nz, M,
@@ -565,7 +584,7 @@ static int attention_launch(const float* qkv, long ld, int B, int N, float* out,
 extern "C" int r3d_attention_fwd(const float* qkv, long ld, int B, int N, float* out, long ldo, float* lse_out,
                                  float* ws /* opt: r3d_attention_ws_words(B, N) floats enable the key split */,
                                  void* stream) {
-  return attention_launch(qkv, ld, B, N, out, ldo, lse_out, 0.f, 0u, nullptr, ws, stream);
+  return attention_launch(qkv, ld, B, N, out, ldo, lse_out, 0.f, 0u, nullptr, 0, ws, stream);
 }
 
 // training forward: dropout p_drop on the attention weights with the stateless mask of attn_keep.
@@ -573,7 +592,15 @@ extern "C" int r3d_attention_fwd(const float* qkv, long ld, int B, int N, float*
 extern "C" int r3d_attention_fwd_train(const float* qkv, long ld, int B, int N, float* out, long ldo, float* lse_out,
                                        float p_drop, unsigned seed, const unsigned* seed_dev, float* ws, void* stream) {
   R3D_REQUIRE(lse_out, "r3d_attention_fwd_train: lse_out is required (saved for the backward pass)");
-  return attention_launch(qkv, ld, B, N, out, ldo, lse_out, p_drop, seed, seed_dev, ws, stream);
+  return attention_launch(qkv, ld, B, N, out, ldo, lse_out, p_drop, seed, seed_dev, 0, ws, stream);
+}
+// the same over a batch of episodes: clouds [e * seed_group, (e + 1) * seed_group) are episode e, whose dropout mask is
+// the one a call on those clouds alone would draw with seed + 2 e (the eager schedule advances its seed by 2 per episode)
+extern "C" int r3d_attention_fwd_train_ep(const float* qkv, long ld, int B, int N, float* out, long ldo, float* lse_out,
+                                          float p_drop, unsigned seed, const unsigned* seed_dev, int seed_group, float* ws,
+                                          void* stream) {
+  R3D_REQUIRE(lse_out, "r3d_attention_fwd_train: lse_out is required (saved for the backward pass)");
+  return attention_launch(qkv, ld, B, N, out, ldo, lse_out, p_drop, seed, seed_dev, seed_group, ws, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -596,7 +623,7 @@ __global__ void r3d_attention_rowdot_kernel(const float* __restrict__ dO, long l
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r3d_attention_bwd_kv_kernel(
     const float* __restrict__ qkv, long ld, int N, const float* __restrict__ dO, long lddo, const float* __restrict__ lse,
     const float* __restrict__ Dv, float* __restrict__ dqkv, long ldd, float p_drop, unsigned seed,
-    const unsigned* __restrict__ seed_dev, int tiles_per_split, float* __restrict__ part /* [split][M][128] or NULL */) {
+    const unsigned* __restrict__ seed_dev, int seed_group, int tiles_per_split, float* __restrict__ part /* [split][M][128] or NULL */) {
   if (seed_dev) seed += *seed_dev;
   __shared__ float Qs[2][32 * AT_LD];
   __shared__ float Gs[2][32 * AT_LD];  // dO tile
@@ -607,6 +634,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   const int h = lane >> 5, j = lane & 31;
   const int b = blockIdx.y;
   const long base = (long)b * N;
+  unsigned hbase = (unsigned)base;  // row id the dropout hash sees
+  if (seed_group > 0) {             // batch of episodes: every group of seed_group clouds is one episode with its own seed
+    const int ep_ = b / seed_group;
+    seed += 2u * (unsigned)ep_;
+    hbase = (unsigned)((b - ep_ * seed_group) * N);
+  }
   const int key = blockIdx.x * 128 + 32 * w + j;  // this lane's key column
   const bool key_ok = key < N;
   float bk[32], bv[32];  // B[k = ch][j = key] fragments of K and V
@@ -677,7 +710,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
       const int q = 32 * t + ql;
       float p = (q < N && key_ok) ? __expf(s[r] - Ls[buf][ql]) : 0.f;
       float keep = 1.f;
-      if (thresh) keep = attn_keep(seed, (unsigned)(base + q), (unsigned)key, thresh) ? keep_scale : 0.f;
+      if (thresh) keep = attn_keep(seed, hbase + (unsigned)(q), (unsigned)key, thresh) ? keep_scale : 0.f;
       pt[r] = p * keep;
       s[r] = p * (dp[r] * keep - Ds[buf][ql]);  // dS
     }
@@ -735,7 +768,7 @@ __global__ void r3d_attention_sum_kernel(const float* __restrict__ part, int nsp
 __global__ __launch_bounds__(256) void r3d_attention_bwd_q_kernel(
     const float* __restrict__ qkv, long ld, int N, const float* __restrict__ dO, long lddo, const float* __restrict__ lse,
     const float* __restrict__ Dv, float* __restrict__ dqkv, long ldd, float p_drop, unsigned seed,
-    const unsigned* __restrict__ seed_dev, float q_scale, int tiles_per_split,
+    const unsigned* __restrict__ seed_dev, int seed_group, float q_scale, int tiles_per_split,
     float* __restrict__ part /* [split][M][64] unscaled, or NULL */) {
   if (seed_dev) seed += *seed_dev;
   __shared__ float Ks[2][32 * AT_LD];
@@ -746,6 +779,12 @@ __global__ __launch_bounds__(256) void r3d_attention_bwd_q_kernel(
   const int h = lane >> 5, j = lane & 31;
   const int b = blockIdx.y;
   const long base = (long)b * N;
+  unsigned hbase = (unsigned)base;  // row id the dropout hash sees
+  if (seed_group > 0) {             // batch of episodes: every group of seed_group clouds is one episode with its own seed
+    const int ep_ = b / seed_group;
+    seed += 2u * (unsigned)ep_;
+    hbase = (unsigned)((b - ep_ * seed_group) * N);
+  }
   const int q_row = blockIdx.x * 128 + 32 * w + j;
   const bool q_ok = q_row < N;
   float bq[32], bg[32];  // B[k = ch][j = query] fragments of Q' and dO
@@ -809,7 +848,7 @@ __global__ __launch_bounds__(256) void r3d_attention_bwd_q_kernel(
       const int key = 32 * t + r3d_acc_row(r, lane);
       const float p = (key < N && q_ok) ? __expf(s[r] - my_lse) : 0.f;
       float keep = 1.f;
-      if (thresh) keep = attn_keep(seed, (unsigned)(base + q_row), (unsigned)key, thresh) ? keep_scale : 0.f;
+      if (thresh) keep = attn_keep(seed, hbase + (unsigned)(q_row), (unsigned)key, thresh) ? keep_scale : 0.f;
       s[r] = p * (dp[r] * keep - my_D);  // dS^T
     }
     // dQ'^T[c][query] += sum_key K[key][c] dS^T[key][query]
@@ -855,7 +894,7 @@ template <bool DROP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r3d_attention_bwd_kv_bx3_kernel(
     const unsigned short* __restrict__ Qp, const unsigned short* __restrict__ Kp, const unsigned short* __restrict__ Vp,
     const unsigned short* __restrict__ Gp /* dO */, int N, const float* __restrict__ lse, const float* __restrict__ Dv,
-    float* __restrict__ dqkv, long ldd, float p_drop, unsigned seed, const unsigned* __restrict__ seed_dev,
+    float* __restrict__ dqkv, long ldd, float p_drop, unsigned seed, const unsigned* __restrict__ seed_dev, int seed_group,
     int tiles_per_split, float* __restrict__ part) {
   if (seed_dev) seed += *seed_dev;
   __shared__ __attribute__((aligned(16))) unsigned short Qs[2][AG_TILE];
@@ -868,6 +907,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   const int h = lane >> 5, j = lane & 31;
   const int b = blockIdx.y;
   const long base = (long)b * N;
+  unsigned hbase = (unsigned)base;  // row id the dropout hash sees
+  if (seed_group > 0) {             // batch of episodes: every group of seed_group clouds is one episode with its own seed
+    const int ep_ = b / seed_group;
+    seed += 2u * (unsigned)ep_;
+    hbase = (unsigned)((b - ep_ * seed_group) * N);
+  }
   const int key = blockIdx.x * 128 + 32 * w + j;  // this lane's key column
   const bool key_ok = key < N;
   r3d_bx3 bk[4], bv[4];  // B[k = ch][j = key] fragments of K and V
@@ -918,7 +963,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
       float p = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -Ls[buf][ql]));
       p = r3d_keep(p, key_ok && !(tail && 32 * t + ql >= N));
       float keep = 1.f;
-      if (DROP) keep = attn_keep(seed, (unsigned)(base + 32 * t + ql), (unsigned)key, thresh) ? keep_scale : 0.f;
+      if (DROP) keep = attn_keep(seed, hbase + (unsigned)(32 * t + ql), (unsigned)key, thresh) ? keep_scale : 0.f;
       s[r] = p * keep;
       dp[r] = p * (dp[r] * keep - Ds[buf][ql]);
     }
@@ -963,7 +1008,7 @@ template <bool DROP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r3d_attention_bwd_q_bx3_kernel(
     const unsigned short* __restrict__ Qp, const unsigned short* __restrict__ Kp, const unsigned short* __restrict__ Vp,
     const unsigned short* __restrict__ Gp /* dO */, int N, const float* __restrict__ lse, const float* __restrict__ Dv,
-    float* __restrict__ dqkv, long ldd, float p_drop, unsigned seed, const unsigned* __restrict__ seed_dev, float q_scale,
+    float* __restrict__ dqkv, long ldd, float p_drop, unsigned seed, const unsigned* __restrict__ seed_dev, int seed_group, float q_scale,
     int tiles_per_split, float* __restrict__ part) {
   if (seed_dev) seed += *seed_dev;
   __shared__ __attribute__((aligned(16))) unsigned short Ks[2][AG_TILE];
@@ -975,6 +1020,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   const int h = lane >> 5, j = lane & 31;
   const int b = blockIdx.y;
   const long base = (long)b * N;
+  unsigned hbase = (unsigned)base;  // row id the dropout hash sees
+  if (seed_group > 0) {             // batch of episodes: every group of seed_group clouds is one episode with its own seed
+    const int ep_ = b / seed_group;
+    seed += 2u * (unsigned)ep_;
+    hbase = (unsigned)((b - ep_ * seed_group) * N);
+  }
   const int q_row = blockIdx.x * 128 + 32 * w + j;
   const bool q_ok = q_row < N;
   r3d_bx3 bq[4], bg[4];  // B[k = ch][j = query] fragments of Q' and dO
@@ -1015,7 +1066,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
       float p = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -my_lse2));
       p = r3d_keep(p, q_ok && !(tail && 32 * t + kl >= N));
       float keep = 1.f;
-      if (DROP) keep = attn_keep(seed, (unsigned)(base + q_row), (unsigned)(32 * t + kl), thresh) ? keep_scale : 0.f;
+      if (DROP) keep = attn_keep(seed, hbase + (unsigned)(q_row), (unsigned)(32 * t + kl), thresh) ? keep_scale : 0.f;
       s[r] = p * (dp[r] * keep - my_D);  // dS^T
     }
     // dQ'^T[c][query] += sum_key K[key][c] dS^T[key][query]
@@ -1052,10 +1103,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
 // partial dK | dV / dQ of the streamed-axis split).
 // ws_holds_packed_qkv: ws is the workspace the forward of the SAME qkv ran with (r3d_attention_fwd_train) and nothing
 // has written to it since: its packed q | k | v pieces are reused instead of cut again (bf16 x 3 arithmetic only).
-extern "C" int r3d_attention_bwd_ws(const float* qkv, long ld, int B, int N, const float* O, long ldo, const float* dO,
+extern "C" int r3d_attention_bwd_ep(const float* qkv, long ld, int B, int N, const float* O, long ldo, const float* dO,
                                     long lddo, const float* lse, float p_drop, unsigned seed, const unsigned* seed_dev,
-                                    float q_scale, float* dqkv, long ldd, float* ws, int ws_holds_packed_qkv, void* stream) {
+                                    int seed_group, float q_scale, float* dqkv, long ldd, float* ws, int ws_holds_packed_qkv,
+                                    void* stream) {
   R3D_REQUIRE(qkv && O && dO && lse && dqkv && ws, "r3d_attention_bwd: null pointer");
+  R3D_REQUIRE(seed_group >= 0 && (seed_group == 0 || B % seed_group == 0), "r3d_attention_bwd: %d clouds in groups of %d", B,
+              seed_group);
   R3D_REQUIRE(B > 0 && N > 0 && ld >= 192 && ld % 4 == 0 && lddo % 4 == 0 && ldd >= 192 && ldo >= 64,
               "r3d_attention_bwd: bad shape");
   R3D_REQUIRE((((uintptr_t)qkv | (uintptr_t)dO) & 15) == 0, "r3d_attention_bwd: qkv and dO must be 16-byte aligned");
@@ -1063,37 +1117,38 @@ extern "C" int r3d_attention_bwd_ws(const float* qkv, long ld, int B, int N, con
   const long M = (long)B * N;
   hipLaunchKernelGGL(r3d_attention_rowdot_kernel, dim3(r3d_cdiv(M, 4)), dim3(256), 0, st, dO, lddo, O, ldo, M, ws);
   const int ntiles = r3d_cdiv(N, 32);
+  const int Bs = seed_group > 0 ? seed_group : B;
   if (g_r3d_matrix_arith == 1) {
-    unsigned short* pk = reinterpret_cast<unsigned short*>(ws + attention_part_words(B, N));
+    unsigned short* pk = reinterpret_cast<unsigned short*>(ws + attention_part_words(B, N, Bs));
     const unsigned short *Qp = pk, *Kp = pk + M * AB_ROW, *Vp = pk + 2 * M * AB_ROW, *Gp = pk + 3 * M * AB_ROW;
     if (!ws_holds_packed_qkv) bx3_pack(qkv, ld, 3, M, pk, st);
     bx3_pack(dO, lddo, 1, M, pk + 3 * M * AB_ROW, st);
     {
-      const int tps = r3d_cdiv(ntiles, attention_split(B, N, attention_slots(ATT_BWD_KV_BX3)));
+      const int tps = r3d_cdiv(ntiles, attention_split(Bs, N, attention_slots(ATT_BWD_KV_BX3)));
       const int nz = r3d_cdiv(ntiles, tps);
       float* part = nz > 1 ? ws + M : nullptr;
       dim3 grid(r3d_cdiv(N, 128), B, nz);
       if (p_drop > 0.f)
         hipLaunchKernelGGL(r3d_attention_bwd_kv_bx3_kernel<true>, grid, dim3(256), 0, st, Qp, Kp, Vp, Gp, N, lse, ws, dqkv, ldd,
-                           p_drop, seed, seed_dev, tps, part);
+                           p_drop, seed, seed_dev, seed_group, tps, part);
       else
         hipLaunchKernelGGL(r3d_attention_bwd_kv_bx3_kernel<false>, grid, dim3(256), 0, st, Qp, Kp, Vp, Gp, N, lse, ws, dqkv, ldd,
-                           p_drop, seed, seed_dev, tps, part);
+                           p_drop, seed, seed_dev, seed_group, tps, part);
       if (part)
         hipLaunchKernelGGL(r3d_attention_sum_kernel, dim3(r3d_cdiv(M * 128, 256)), dim3(256), 0, st, part, nz, M, 128, 1.f, dqkv,
                            ldd, 64);
     }
     {
-      const int tps = r3d_cdiv(ntiles, attention_split(B, N, attention_slots(ATT_BWD_Q_BX3)));
+      const int tps = r3d_cdiv(ntiles, attention_split(Bs, N, attention_slots(ATT_BWD_Q_BX3)));
       const int nz = r3d_cdiv(ntiles, tps);
       float* part = nz > 1 ? ws + M : nullptr;
       dim3 grid(r3d_cdiv(N, 128), B, nz);
       if (p_drop > 0.f)
         hipLaunchKernelGGL(r3d_attention_bwd_q_bx3_kernel<true>, grid, dim3(256), 0, st, Qp, Kp, Vp, Gp, N, lse, ws, dqkv, ldd,
-                           p_drop, seed, seed_dev, q_scale, tps, part);
+                           p_drop, seed, seed_dev, seed_group, q_scale, tps, part);
       else
         hipLaunchKernelGGL(r3d_attention_bwd_q_bx3_kernel<false>, grid, dim3(256), 0, st, Qp, Kp, Vp, Gp, N, lse, ws, dqkv, ldd,
-                           p_drop, seed, seed_dev, q_scale, tps, part);
+                           p_drop, seed, seed_dev, seed_group, q_scale, tps, part);
       if (part)
         hipLaunchKernelGGL(r3d_attention_sum_kernel, dim3(r3d_cdiv(M * 64, 256)), dim3(256), 0, st, part, nz, M, 64, q_scale, dqkv,
                            ldd, 0);
@@ -1102,27 +1157,33 @@ extern "C" int r3d_attention_bwd_ws(const float* qkv, long ld, int B, int N, con
     return R3D_OK;
   }
   {
-    const int tps = r3d_cdiv(ntiles, attention_split(B, N, attention_slots(ATT_BWD_KV)));
+    const int tps = r3d_cdiv(ntiles, attention_split(Bs, N, attention_slots(ATT_BWD_KV)));
     const int nz = r3d_cdiv(ntiles, tps);
     float* part = nz > 1 ? ws + M : nullptr;
     hipLaunchKernelGGL(r3d_attention_bwd_kv_kernel, dim3(r3d_cdiv(N, 128), B, nz), dim3(256), 0, st, qkv, ld, N, dO, lddo, lse, ws,
-                       dqkv, ldd, p_drop, seed, seed_dev, tps, part);
+                       dqkv, ldd, p_drop, seed, seed_dev, seed_group, tps, part);
     if (part)
       hipLaunchKernelGGL(r3d_attention_sum_kernel, dim3(r3d_cdiv(M * 128, 256)), dim3(256), 0, st, part, nz, M, 128, 1.f, dqkv,
                          ldd, 64);
   }
   {
-    const int tps = r3d_cdiv(ntiles, attention_split(B, N, attention_slots(ATT_BWD_Q)));
+    const int tps = r3d_cdiv(ntiles, attention_split(Bs, N, attention_slots(ATT_BWD_Q)));
     const int nz = r3d_cdiv(ntiles, tps);
     float* part = nz > 1 ? ws + M : nullptr;
     hipLaunchKernelGGL(r3d_attention_bwd_q_kernel, dim3(r3d_cdiv(N, 128), B, nz), dim3(256), 0, st, qkv, ld, N, dO, lddo, lse, ws,
-                       dqkv, ldd, p_drop, seed, seed_dev, q_scale, tps, part);
+                       dqkv, ldd, p_drop, seed, seed_dev, seed_group, q_scale, tps, part);
     if (part)
       hipLaunchKernelGGL(r3d_attention_sum_kernel, dim3(r3d_cdiv(M * 64, 256)), dim3(256), 0, st, part, nz, M, 64, q_scale, dqkv,
                          ldd, 0);
   }
   R3D_LAUNCH_CHECK("r3d_attention_bwd");
   return R3D_OK;
+}
+extern "C" int r3d_attention_bwd_ws(const float* qkv, long ld, int B, int N, const float* O, long ldo, const float* dO,
+                                    long lddo, const float* lse, float p_drop, unsigned seed, const unsigned* seed_dev,
+                                    float q_scale, float* dqkv, long ldd, float* ws, int ws_holds_packed_qkv, void* stream) {
+  return r3d_attention_bwd_ep(qkv, ld, B, N, O, ldo, dO, lddo, lse, p_drop, seed, seed_dev, 0, q_scale, dqkv, ldd, ws,
+                              ws_holds_packed_qkv, stream);
 }
 extern "C" int r3d_attention_bwd(const float* qkv, long ld, int B, int N, const float* O, long ldo, const float* dO,
                                  long lddo, const float* lse, float p_drop, unsigned seed, const unsigned* seed_dev,

@@ -17,7 +17,12 @@
 __global__ __launch_bounds__(256) void r3d_clean_boxsum_kernel(
     const float* __restrict__ feat /* (S*N, ldf) */, long ldf, int D, const float* __restrict__ support_x /* (S, Cin, N) */,
     int Cin, const int* __restrict__ support_y /* (S, N) */, int N, float* __restrict__ box_sum /* (S, 5, 256) */,
-    int* __restrict__ box_cnt /* (S, 5) */) {
+    int* __restrict__ box_cnt /* (S, 5) */, long feat_ep_rows, long ws_stride) {
+  {
+    const long ep = blockIdx.z, S_ = gridDim.x;  // batch of episodes: rows / scratch of episode ep
+    feat += ep * feat_ep_rows * ldf; support_x += ep * S_ * Cin * N; support_y += ep * S_ * N;
+    box_sum += ep * ws_stride; box_cnt += ep * ws_stride;
+  }
   __shared__ float red[4][6];
   __shared__ float bb[6];  // x_min, x_max, y_min, y_max, z_min, z_max
   __shared__ float psum[4][AH_DMAX];
@@ -99,7 +104,13 @@ __global__ __launch_bounds__(256) void r3d_clean_boxsum_kernel(
 __global__ __launch_bounds__(256) void r3d_clean_decide_kernel(const float* __restrict__ box_sum,
                                                                const int* __restrict__ box_cnt, int n_way, int k_shot,
                                                                int D, int* __restrict__ shot_keep /* (n_way*k_shot) */,
-                                                               float* __restrict__ dbg_cos_sum /* opt (n_way, 2, 4*k_shot) */) {
+                                                               float* __restrict__ dbg_cos_sum /* opt (n_way, 2, 4*k_shot) */,
+                                                               long ws_stride) {
+  {
+    const long ep = blockIdx.y;
+    box_sum += ep * ws_stride; box_cnt += ep * ws_stride; shot_keep += ep * n_way * k_shot;
+    if (dbg_cos_sum) dbg_cos_sum += ep * n_way * 2 * 4 * k_shot;
+  }
   __shared__ float seed[4 * AH_MAXK][AH_DMAX + 1];  // <= 4 seeds per shot
   __shared__ float rowsum[4 * AH_MAXK];
   __shared__ int seed_shot[4 * AH_MAXK];
@@ -281,22 +292,33 @@ __global__ void r3d_miou_accumulate_kernel(const int* __restrict__ pred, const l
 // ws: 5*256*S floats + 5*S ints.  shot_keep (n_way*k_shot) int32 out.  dbg optional (n_way,2,4*k_shot).
 extern "C" long r3d_clean_ws_words(int n_way, int k_shot) { return (long)n_way * k_shot * (AH_BOXES * AH_DMAX + AH_BOXES) + 64; }
 
-extern "C" int r3d_clean_shot_detect(const float* feat, long ldf, int D, const float* support_x, int Cin,
-                                     const int32_t* support_y, int n_way, int k_shot, int N, int32_t* shot_keep,
-                                     float* dbg_cos_sum, int32_t* ws, void* stream) {
+// n_ep episodes at once: episode e's support features start feat_ep_rows rows after episode e - 1's, its coordinates /
+// masks are entry e of (n_ep, S, Cin, N) / (n_ep, S, N) arrays, its scratch ws + e * ws_stride, its flags shot_keep + e * S
+extern "C" int r3d_clean_shot_detect_batched(int n_ep, const float* feat, long ldf, long feat_ep_rows, int D,
+                                             const float* support_x, int Cin, const int32_t* support_y, int n_way, int k_shot,
+                                             int N, int32_t* shot_keep, float* dbg_cos_sum, int32_t* ws, long ws_stride,
+                                             void* stream) {
   R3D_REQUIRE(feat && support_x && support_y && shot_keep && ws, "r3d_clean_shot_detect: null pointer");
   R3D_REQUIRE(n_way >= 1 && n_way * k_shot <= AH_MAXSHOT && k_shot <= AH_MAXK && D >= 1 && D <= AH_DMAX && Cin >= 3 && N >= 1,
               "r3d_clean_shot_detect: unsupported shape n_way=%d k_shot=%d D=%d", n_way, k_shot, D);
+  R3D_REQUIRE(n_ep >= 1 && n_ep <= 65535 && (n_ep == 1 || ws_stride >= r3d_clean_ws_words(n_way, k_shot)),
+              "r3d_clean_shot_detect: %d episodes, scratch stride %ld", n_ep, ws_stride);
   const int S = n_way * k_shot;
   float* box_sum = (float*)ws;
   int* box_cnt = ws + (long)S * AH_BOXES * AH_DMAX;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(r3d_clean_boxsum_kernel, dim3(S, AH_BOXES), dim3(256), 0, st, feat, ldf, D, support_x, Cin,
-                     support_y, N, box_sum, box_cnt);
-  hipLaunchKernelGGL(r3d_clean_decide_kernel, dim3(n_way), dim3(256), 0, st, box_sum, box_cnt, n_way, k_shot, D,
-                     shot_keep, dbg_cos_sum);
+  hipLaunchKernelGGL(r3d_clean_boxsum_kernel, dim3(S, AH_BOXES, n_ep), dim3(256), 0, st, feat, ldf, D, support_x, Cin,
+                     support_y, N, box_sum, box_cnt, feat_ep_rows, ws_stride);
+  hipLaunchKernelGGL(r3d_clean_decide_kernel, dim3(n_way, n_ep), dim3(256), 0, st, box_sum, box_cnt, n_way, k_shot, D,
+                     shot_keep, dbg_cos_sum, ws_stride);
   R3D_LAUNCH_CHECK("r3d_clean_shot_detect");
   return R3D_OK;
+}
+extern "C" int r3d_clean_shot_detect(const float* feat, long ldf, int D, const float* support_x, int Cin,
+                                     const int32_t* support_y, int n_way, int k_shot, int N, int32_t* shot_keep,
+                                     float* dbg_cos_sum, int32_t* ws, void* stream) {
+  return r3d_clean_shot_detect_batched(1, feat, ldf, 0, D, support_x, Cin, support_y, n_way, k_shot, N, shot_keep, dbg_cos_sum, ws,
+                                       0, stream);
 }
 
 // Z (n_q*N, 4) fp32 similarity rows (feed r3d_query_logits_ce with n_proto = 0).  ws: S*2*256 floats.

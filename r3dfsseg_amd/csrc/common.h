@@ -133,6 +133,35 @@ static __device__ __forceinline__ f32x16 r3d_bx3_mma(const r3d_bx3& a, const r3d
 
 static inline int r3d_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Row (or cloud) segments of a batch of episodes: segments of `a` and `b` units alternate, [a | b | a | b | ...]
+// (a = support part, b = query part of one episode; b == 0: every segment has `a` units).  Segment 2 e + p is part p of
+// episode e.  BatchNorm statistics, dropout seeds and every per-episode quantity of the training path are keyed by it.
+struct r3d_segmap {
+  long a, b;
+  __host__ __device__ bool odd(int seg) const { return b > 0 && (seg & 1); }
+  __host__ __device__ long seg_rows(int seg) const { return odd(seg) ? b : a; }
+  __host__ __device__ long seg_row0(int seg) const {
+    return b > 0 ? (long)(seg >> 1) * (a + b) + (odd(seg) ? a : 0) : (long)seg * a;
+  }
+  __host__ __device__ int seg_of_row(long r) const {
+    if (b == 0) return (int)(r / a);
+    const long p = r / (a + b);
+    return (int)(2 * p + ((r - p * (a + b)) >= a ? 1 : 0));
+  }
+  // the same for totals below 2^31 (every entry point checks): 32-bit division, a fraction of the VALU work of the
+  // 64-bit one, which matters in element-wise kernels that look a segment up per row
+  __device__ int seg_of_row32(int r) const {
+    const int A = (int)a, B = (int)b;
+    if (B == 0) return r / A;
+    const int p = r / (A + B);
+    return 2 * p + ((r - p * (A + B)) >= A ? 1 : 0);
+  }
+  __host__ __device__ int n_seg(long total) const { return (int)(b > 0 ? 2 * (total / (a + b)) : total / a); }
+  __host__ __device__ bool covers(long total) const {
+    return a > 0 && b >= 0 && total > 0 && total < 0x7fffffffL && total % (a + b) == 0;
+  }
+};
+
 // Device-to-device fill / copy as plain KERNELS.  The library's launch sequences are frozen into hipGraphs
 // (episode_graph.py); hipMemsetAsync / hipMemcpyAsync would become memset / memcpy graph nodes, and on this
 // stack (ROCm 7.2, measured with tools/fault_probe.py) a graph holding such nodes replayed wrongly once the
@@ -144,6 +173,15 @@ static __global__ void r3d_fill_words_kernel(unsigned* __restrict__ p, unsigned 
 }
 static __global__ void r3d_copy_words_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// the same fill for every episode of a batch: blockIdx.y = episode, its words start stride_words further on
+static __global__ void r3d_fill_words_ep_kernel(unsigned* __restrict__ p, unsigned v, long n, long stride_words) {
+  p += (long)blockIdx.y * stride_words;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+static inline void r3d_fill_words_ep(void* p, unsigned v, long n_words, int n_ep, long stride_words, hipStream_t st) {
+  const int g = (int)(n_words < 256L * 2048 ? (n_words + 255) / 256 : 2048);
+  hipLaunchKernelGGL(r3d_fill_words_ep_kernel, dim3(g > 0 ? g : 1, n_ep), dim3(256), 0, st, (unsigned*)p, v, n_words, stride_words);
 }
 static inline void r3d_zero_words(void* p, long n_words, hipStream_t st) {
   const int g = (int)(n_words < 256L * 2048 ? (n_words + 255) / 256 : 2048);

@@ -15,13 +15,26 @@
 #define CT_DMAX 256
 #define CT_NMAX 4096
 
+// Batches of episodes (round 3): blockIdx.y = episode; its arrays sit a stride further on (CtEp, elements of each
+// array; feature strides in ROWS).  The parameter gradients of the projection are summed over the batch in a fixed
+// order (episode, then way); everything else stays per episode.
+struct CtEp {
+  long feat, sy, flag, ws, loss;           // feature rows, support_y words, support_flag words, scratch floats, loss floats
+  long pred, qy, z, desc, pws, assign, gsy, out;  // train metrics: pred / labels / Z rows / descriptor / proto scratch / assign / gt masks / out4
+};
+
 // ---------------------------------------------------------------------------
 // A. per-shot prototypes
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void r3d_contrast_protos_kernel(
     const float* __restrict__ feat /* (S*N, ldf) */, long ldf, int D, const int* __restrict__ support_y, int N,
     float* __restrict__ protos /* (S, 4, 256) */, int* __restrict__ cnt /* (S, 4) */, int* __restrict__ m_out /* (S) */,
-    int* __restrict__ assign_out /* (S, N): cluster of the point or -1 */) {
+    int* __restrict__ assign_out /* (S, N): cluster of the point or -1 */, CtEp st) {
+  {
+    const long ep = blockIdx.y;
+    feat += ep * st.feat * ldf; support_y += ep * st.sy; protos += ep * st.ws; cnt += ep * st.ws; m_out += ep * st.ws;
+    assign_out += ep * st.ws;
+  }
   __shared__ int fg[CT_NMAX];            // compacted foreground point ids
   __shared__ float seedf[CT_K][CT_DMAX];
   __shared__ float red_v[4];
@@ -207,7 +220,12 @@ __global__ __launch_bounds__(256) void r3d_contrast_loss_kernel(
     int k_shot, int D, const float* __restrict__ W /* (128, D) */, const float* __restrict__ bias, float temp,
     float* __restrict__ loss_way /* (n_way) */, float* __restrict__ dW_way /* (n_way,128,256) */,
     float* __restrict__ db_way /* (n_way,128) */, float* __restrict__ dp_way /* (n_way, CT_MAXV, 256) */,
-    int* __restrict__ vec_src /* (n_way, CT_MAXV): shot*4 + proto, or -1 */) {
+    int* __restrict__ vec_src /* (n_way, CT_MAXV): shot*4 + proto, or -1 */, CtEp st) {
+  {
+    const long ep = blockIdx.y;
+    protos += ep * st.ws; m_arr += ep * st.ws; support_flag += ep * st.flag; loss_way += ep * st.ws; dW_way += ep * st.ws;
+    db_way += ep * st.ws; dp_way += ep * st.ws; vec_src += ep * st.ws;
+  }
   extern __shared__ __attribute__((aligned(16))) float ct_smem[];
   float (*P)[CT_DMAX + 1] = reinterpret_cast<float (*)[CT_DMAX + 1]>(ct_smem);
   float (*Y)[CT_PD + 1] = reinterpret_cast<float (*)[CT_PD + 1]>(ct_smem + CT_MAXV * (CT_DMAX + 1));            // y, then f
@@ -333,8 +351,9 @@ __global__ __launch_bounds__(256) void r3d_contrast_loss_kernel(
 }
 
 // loss = mean over ways (mpti.py:311)
-__global__ void r3d_contrast_mean_kernel(const float* __restrict__ loss_way, int n_way, float* __restrict__ loss) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
+__global__ void r3d_contrast_mean_kernel(const float* __restrict__ loss_way, int n_way, float* __restrict__ loss, CtEp st) {
+  loss_way += (long)blockIdx.x * st.ws; loss += (long)blockIdx.x * st.loss;
+  if (threadIdx.x == 0) {
     float s = 0.f;
     for (int w = 0; w < n_way; ++w) s += loss_way[w];
     *loss = s / (float)n_way;
@@ -346,26 +365,39 @@ __global__ void r3d_contrast_mean_kernel(const float* __restrict__ loss_way, int
 // ---------------------------------------------------------------------------
 __global__ void r3d_contrast_param_grad_kernel(const float* __restrict__ dW_way, const float* __restrict__ db_way, int n_way,
                                                int D, const float* __restrict__ gscale, float* __restrict__ dW,
-                                               float* __restrict__ db) {
+                                               float* __restrict__ db, int n_ep, CtEp st) {
+  // the projection's gradient of the whole batch: episodes in order, ways in order (one episode: the sum over its ways)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const float sc = gscale[0] / (float)n_way;
   if (i < CT_PD * D) {
     const int o = i / D, c = i - o * D;
-    float s = 0.f;
-    for (int w = 0; w < n_way; ++w) s += dW_way[((long)w * CT_PD + o) * CT_DMAX + c];
-    dW[i] = s * sc;
+    float tot = 0.f;
+    for (int e = 0; e < n_ep; ++e) {
+      float s = 0.f;
+      for (int w = 0; w < n_way; ++w) s += dW_way[(long)e * st.ws + ((long)w * CT_PD + o) * CT_DMAX + c];
+      tot = e == 0 ? s * sc : tot + s * sc;
+    }
+    dW[i] = tot;
   }
   if (i < CT_PD) {
-    float s = 0.f;
-    for (int w = 0; w < n_way; ++w) s += db_way[w * CT_PD + i];
-    db[i] = s * sc;
+    float tot = 0.f;
+    for (int e = 0; e < n_ep; ++e) {
+      float s = 0.f;
+      for (int w = 0; w < n_way; ++w) s += db_way[(long)e * st.ws + w * CT_PD + i];
+      tot = e == 0 ? s * sc : tot + s * sc;
+    }
+    db[i] = tot;
   }
 }
 
 __global__ __launch_bounds__(256) void r3d_contrast_point_grad_kernel(
     const float* __restrict__ dp_way, const int* __restrict__ vec_src, const int* __restrict__ cnt,
     const int* __restrict__ assign, int n_way, int N, int D, const float* __restrict__ gscale,
-    float* __restrict__ dfeat /* (S*N, ldd), zero-initialised */, long ldd) {
+    float* __restrict__ dfeat /* (S*N, ldd), zero-initialised */, long ldd, CtEp st) {
+  {
+    const long ep = blockIdx.y;
+    dp_way += ep * st.ws; vec_src += ep * st.ws; cnt += ep * st.ws; assign += ep * st.ws; dfeat += ep * st.feat * ldd;
+  }
   __shared__ float dproto[CT_K][CT_DMAX];
   const int shot = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // total gradient of this shot's prototypes: every use (own way, negative of another way), fixed order
@@ -394,7 +426,12 @@ __global__ __launch_bounds__(256) void r3d_contrast_point_grad_kernel(
 __global__ __launch_bounds__(256) void r3d_train_metrics_kernel(
     const int* __restrict__ pred, const long long* __restrict__ query_y, const long long* __restrict__ gt_query_y, int n_qpts,
     const float4* __restrict__ Z, const int* __restrict__ desc, const int* __restrict__ comp, const int* __restrict__ assign,
-    const int* __restrict__ gt_support_y, int n_way, int k_shot, int N, float* __restrict__ out) {
+    const int* __restrict__ gt_support_y, int n_way, int k_shot, int N, float* __restrict__ out, CtEp st) {
+  {
+    const long ep = blockIdx.x;
+    pred += ep * st.pred; query_y += ep * st.qy; gt_query_y += ep * st.qy; Z += ep * st.z; desc += ep * st.desc;
+    comp += ep * st.pws; assign += ep * st.assign; gt_support_y += ep * st.gsy; out += ep * st.out;
+  }
   __shared__ int acc[4];
   const int tid = threadIdx.x;
   float lp_sum = 0.f, orig_sum = 0.f;
@@ -471,19 +508,21 @@ static CtWs ct_carve(float* ws, int n_way, int k_shot, int N) {
   return c;
 }
 
-// loss_out: device float.  ws keeps everything the backward needs.
-extern "C" int r3d_contrast_fwd(const float* feat, long ldf, int D, const int32_t* support_y, const int32_t* support_flag,
-                                int n_way, int k_shot, int N, const float* W, const float* bias, float temp,
-                                float* loss_out, float* ws, long ws_words, void* stream) {
+// loss_out: device float per episode.  ws keeps everything the backward needs.
+static int contrast_fwd_impl(int n_ep, const CtEp& ep, const float* feat, long ldf, int D, const int32_t* support_y,
+                             const int32_t* support_flag, int n_way, int k_shot, int N, const float* W, const float* bias,
+                             float temp, float* loss_out, float* ws, long ws_words, void* stream) {
   R3D_REQUIRE(feat && support_y && support_flag && W && bias && loss_out && ws, "r3d_contrast_fwd: null pointer");
   R3D_REQUIRE(ws_words >= r3d_contrast_ws_words(n_way, k_shot, N), "r3d_contrast_fwd: workspace of %ld words is shorter than "
               "r3d_contrast_ws_words(%d, %d, %d)", ws_words, n_way, k_shot, N);
   R3D_REQUIRE(n_way >= 1 && n_way <= 3 && (k_shot + 2) * CT_K <= CT_MAXV && D <= CT_DMAX && N <= CT_NMAX,
               "r3d_contrast_fwd: unsupported shape n_way=%d k_shot=%d D=%d N=%d", n_way, k_shot, D, N);
+  R3D_REQUIRE(n_ep >= 1 && n_ep <= 65535 && (n_ep == 1 || ep.ws >= ws_words), "r3d_contrast_fwd: %d episodes, scratch stride %ld",
+              n_ep, ep.ws);
   const CtWs c = ct_carve(ws, n_way, k_shot, N);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(r3d_contrast_protos_kernel, dim3(n_way * k_shot), dim3(256), 0, st, feat, ldf, D, support_y, N, c.protos,
-                     c.cnt, c.m, c.assign);
+  hipLaunchKernelGGL(r3d_contrast_protos_kernel, dim3(n_way * k_shot, n_ep), dim3(256), 0, st, feat, ldf, D, support_y, N, c.protos,
+                     c.cnt, c.m, c.assign, ep);
   const size_t lds = sizeof(float) * CT_MAXV * (CT_DMAX + 1 + 2 * (CT_PD + 1) + CT_MAXV + 1);
   static bool attr = false;
   if (!attr) {
@@ -491,36 +530,78 @@ extern "C" int r3d_contrast_fwd(const float* feat, long ldf, int D, const int32_
     R3D_REQUIRE(e == hipSuccess, "r3d_contrast_fwd: cannot reserve %zu B of LDS", lds);
     attr = true;
   }
-  hipLaunchKernelGGL(r3d_contrast_loss_kernel, dim3(n_way), dim3(256), lds, st, c.protos, c.m, support_flag, n_way, k_shot, D, W,
-                     bias, temp, c.loss_way, c.dW_way, c.db_way, c.dp_way, c.vec_src);
-  hipLaunchKernelGGL(r3d_contrast_mean_kernel, dim3(1), dim3(64), 0, st, c.loss_way, n_way, loss_out);
+  hipLaunchKernelGGL(r3d_contrast_loss_kernel, dim3(n_way, n_ep), dim3(256), lds, st, c.protos, c.m, support_flag, n_way, k_shot, D,
+                     W, bias, temp, c.loss_way, c.dW_way, c.db_way, c.dp_way, c.vec_src, ep);
+  hipLaunchKernelGGL(r3d_contrast_mean_kernel, dim3(n_ep), dim3(64), 0, st, c.loss_way, n_way, loss_out, ep);
   R3D_LAUNCH_CHECK("r3d_contrast_fwd");
   return R3D_OK;
 }
+extern "C" int r3d_contrast_fwd(const float* feat, long ldf, int D, const int32_t* support_y, const int32_t* support_flag,
+                                int n_way, int k_shot, int N, const float* W, const float* bias, float temp,
+                                float* loss_out, float* ws, long ws_words, void* stream) {
+  const CtEp one{};
+  return contrast_fwd_impl(1, one, feat, ldf, D, support_y, support_flag, n_way, k_shot, N, W, bias, temp, loss_out, ws, ws_words,
+                           stream);
+}
+// n_ep episodes: episode e reads feature rows from feat + e * feat_ep_rows * ldf, masks / flags e of (n_ep, S, N) / (n_ep, S)
+// arrays, scratch ws + e * ws_stride floats, and writes loss_out[e]
+extern "C" int r3d_contrast_fwd_batched(int n_ep, const float* feat, long ldf, long feat_ep_rows, int D, const int32_t* support_y,
+                                        const int32_t* support_flag, int n_way, int k_shot, int N, const float* W,
+                                        const float* bias, float temp, float* loss_out, float* ws, long ws_words, long ws_stride,
+                                        void* stream) {
+  CtEp ep{};
+  ep.feat = feat_ep_rows; ep.sy = (long)n_way * k_shot * N; ep.flag = (long)n_way * k_shot; ep.ws = ws_stride; ep.loss = 1;
+  return contrast_fwd_impl(n_ep, ep, feat, ldf, D, support_y, support_flag, n_way, k_shot, N, W, bias, temp, loss_out, ws, ws_words,
+                           stream);
+}
 
-// dfeat (S*N, ldd) zero-initialised by the caller; dW (128, D), db (128); gscale: device float (dL/dloss)
-extern "C" int r3d_contrast_bwd(int D, int n_way, int k_shot, int N, const float* gscale_dev, float* dfeat, long ldd, float* dW,
-                                float* db, float* ws, void* stream) {
-  R3D_REQUIRE(gscale_dev && dfeat && dW && db && ws, "r3d_contrast_bwd: null pointer");
+// dfeat (S*N, ldd) zero-initialised by the caller; dW (128, D), db (128) summed over the batch; gscale: device float (dL/dloss)
+static int contrast_bwd_impl(int n_ep, const CtEp& ep, int D, int n_way, int k_shot, int N, const float* gscale_dev, float* dfeat,
+                             long ldd, float* dW, float* db, float* ws, void* stream) {
+  R3D_REQUIRE(gscale_dev && dfeat && dW && db && ws && n_ep >= 1 && n_ep <= 65535, "r3d_contrast_bwd: bad arguments");
   const CtWs c = ct_carve(ws, n_way, k_shot, N);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(r3d_contrast_param_grad_kernel, dim3(r3d_cdiv(CT_PD * D, 256)), dim3(256), 0, st, c.dW_way, c.db_way, n_way,
-                     D, gscale_dev, dW, db);
-  hipLaunchKernelGGL(r3d_contrast_point_grad_kernel, dim3(n_way * k_shot), dim3(256), 0, st, c.dp_way, c.vec_src, c.cnt,
-                     c.assign, n_way, N, D, gscale_dev, dfeat, ldd);
+                     D, gscale_dev, dW, db, n_ep, ep);
+  hipLaunchKernelGGL(r3d_contrast_point_grad_kernel, dim3(n_way * k_shot, n_ep), dim3(256), 0, st, c.dp_way, c.vec_src, c.cnt,
+                     c.assign, n_way, N, D, gscale_dev, dfeat, ldd, ep);
   R3D_LAUNCH_CHECK("r3d_contrast_bwd");
   return R3D_OK;
 }
+extern "C" int r3d_contrast_bwd(int D, int n_way, int k_shot, int N, const float* gscale_dev, float* dfeat, long ldd, float* dW,
+                                float* db, float* ws, void* stream) {
+  const CtEp one{};
+  return contrast_bwd_impl(1, one, D, n_way, k_shot, N, gscale_dev, dfeat, ldd, dW, db, ws, stream);
+}
+extern "C" int r3d_contrast_bwd_batched(int n_ep, int D, int n_way, int k_shot, int N, const float* gscale_dev, float* dfeat,
+                                        long ldd, long dfeat_ep_rows, float* dW, float* db, float* ws, long ws_stride,
+                                        void* stream) {
+  CtEp ep{};
+  ep.feat = dfeat_ep_rows; ep.ws = ws_stride;
+  return contrast_bwd_impl(n_ep, ep, D, n_way, k_shot, N, gscale_dev, dfeat, ldd, dW, db, ws, stream);
+}
 
+// out4 per episode (n_ep, 4).  Strides: pred / labels n_query_pts per episode, Z rows z_ep_rows, desc / proto scratch /
+// assign words, gt masks S*N per episode.
+extern "C" int r3d_train_metrics_batched(int n_ep, const int32_t* pred, const int64_t* query_y, const int64_t* gt_query_y,
+                                         int n_query_pts, const float* Z, long z_ep_rows, const int32_t* desc, long desc_stride,
+                                         const int32_t* proto_ws, long pws_stride, const int32_t* assign, long assign_stride,
+                                         const int32_t* gt_support_y, int n_way, int k_shot, int N, float* out4, void* stream) {
+  R3D_REQUIRE(pred && query_y && gt_query_y && Z && desc && proto_ws && assign && gt_support_y && out4 && n_ep >= 1,
+              "r3d_train_metrics: null pointer");
+  CtEp ep{};
+  ep.pred = n_query_pts; ep.qy = n_query_pts; ep.z = z_ep_rows; ep.desc = desc_stride; ep.pws = pws_stride;
+  ep.assign = assign_stride; ep.gsy = (long)n_way * k_shot * N; ep.out = 4;
+  hipLaunchKernelGGL(r3d_train_metrics_kernel, dim3(n_ep), dim3(256), 0, (hipStream_t)stream, pred, (const long long*)query_y,
+                     (const long long*)gt_query_y, n_query_pts, (const float4*)Z, desc, proto_ws, assign, gt_support_y, n_way,
+                     k_shot, N, out4, ep);
+  R3D_LAUNCH_CHECK("r3d_train_metrics");
+  return R3D_OK;
+}
 extern "C" int r3d_train_metrics(const int32_t* pred, const int64_t* query_y, const int64_t* gt_query_y, int n_query_pts,
                                  const float* Z, const int32_t* desc, const int32_t* proto_ws /* comp at offset 0 */,
                                  const int32_t* assign, const int32_t* gt_support_y, int n_way, int k_shot, int N,
                                  float* out4, void* stream) {
-  R3D_REQUIRE(pred && query_y && gt_query_y && Z && desc && proto_ws && assign && gt_support_y && out4,
-              "r3d_train_metrics: null pointer");
-  hipLaunchKernelGGL(r3d_train_metrics_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, (const long long*)query_y,
-                     (const long long*)gt_query_y, n_query_pts, (const float4*)Z, desc, proto_ws, assign, gt_support_y, n_way,
-                     k_shot, N, out4);
-  R3D_LAUNCH_CHECK("r3d_train_metrics");
-  return R3D_OK;
+  return r3d_train_metrics_batched(1, pred, query_y, gt_query_y, n_query_pts, Z, 0, desc, 0, proto_ws, 0, assign, 0, gt_support_y,
+                                   n_way, k_shot, N, out4, stream);
 }

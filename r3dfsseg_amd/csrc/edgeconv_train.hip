@@ -18,42 +18,73 @@
 //       dP[j] = s1 (sum_in dy1 - c_j n1 - n2 is1 (c_j (P[j] - mu1) + sum_in Q[i]))   over the c_j incoming edges of j
 //       one wave per point, plain stores, fixed summation order: deterministic.  (The first version scattered de1 with
 //       float atomics on 256-B rows: 3/4 of that kernel's time, and the one non-deterministic sum of the training step.)
+//
+// Batches of episodes (round 3).  All B clouds of a batch of episodes go through ONE launch per pass; BatchNorm keeps
+// the statistics of every getFeatures call apart (segments of clouds_a support clouds and clouds_b query clouds
+// alternating, common.h: r3d_segmap; segment 2 e + p = call p of episode e).  The unit of the statistics is the CHUNK =
+// EC_CHUNK consecutive points of one cloud: a workgroup takes whole chunks, writes one partial per chunk, and a segment's
+// sums are its chunks added in ascending order in fp64 -- the same numbers whether the episode runs alone or inside a
+// batch, and whatever the grid.  The BatchNorm vectors of segment s sit at (pointer + s * bn_stride).
 #include "edge_tile.h"
 
-#define ET_PTS 8
 #define ET_LD 65
 #define ET_MAXBLK 1024
+#define EC_CHUNK 32  // points per statistics chunk (8 units of 4 points)
 
 static __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : 0.2f * v; }
 
-// ---- BN1 statistics over edges: partial[block][2][64] ------------------------------------------
+// chunk -> its cloud and point range [p0, p1) (global rows).  32-bit and forced into scalar registers: the 64-bit
+// division of a uniform value is VALU code whose results otherwise stay in VGPRs for the whole unit loop (B N K < 2^31
+// is checked at the entry points, so rows and chunks fit an int).
+struct EcGeom {
+  int N, cpc;  // points per cloud, chunks per cloud
+  __host__ __device__ static EcGeom make(int N) { return EcGeom{N, (N + EC_CHUNK - 1) / EC_CHUNK}; }
+  __device__ void range(int chunk, int& cloud, int& p0, int& p1) const {
+    cloud = __builtin_amdgcn_readfirstlane(chunk / cpc);
+    p0 = __builtin_amdgcn_readfirstlane(cloud * N + (chunk - cloud * cpc) * EC_CHUNK);
+    p1 = __builtin_amdgcn_readfirstlane(min(p0 + EC_CHUNK, (cloud + 1) * N));
+  }
+};
+// segment of a cloud, as a scalar
+static __device__ __forceinline__ int ec_seg(const r3d_segmap& cs, int cloud) {
+  return __builtin_amdgcn_readfirstlane(cs.seg_of_row32(cloud));
+}
+
+// ---- BN1 statistics over edges: partial[chunk][2][64] ------------------------------------------
 template <int RT>
 __global__ __launch_bounds__(256) void r3d_edge_stats1_kernel(const float* __restrict__ PQ, const int* __restrict__ idx,
-                                                              int N, long total_points, float* __restrict__ part) {
+                                                              EcGeom gm, int n_chunks, float* __restrict__ part) {
   constexpr int K = 4 * RT;
   __shared__ float sa[4][64], sb[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float a = 0.f, b = 0.f;
-  for (long pt = (long)blockIdx.x * 4 + w; pt < total_points; pt += (long)gridDim.x * 4) {
-    const long cloud0 = (pt / N) * N;
-    const float q = PQ[pt * 128 + 64 + lane];
-    const int my_idx = min(max(idx[pt * K + min(lane, K - 1)], 0), N - 1);  // never gather outside the cloud, whatever the list holds
-    float pv[K];  // all K neighbour rows in flight (four at a time was a chain of K/4 L2 round trips per point)
+  const int N = gm.N;
+  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    int cloud, p0, p1;
+    gm.range(chunk, cloud, p0, p1);
+    const long cloud0 = (long)cloud * N;
+    float a = 0.f, b = 0.f;
+    for (int pt_ = p0 + w; pt_ < p1; pt_ += 4) {
+      const long pt = pt_;
+      const float q = PQ[pt * 128 + 64 + lane];
+      const int my_idx = min(max(idx[pt * K + min(lane, K - 1)], 0), N - 1);  // never gather outside the cloud, whatever the list holds
+      float pv[K];  // all K neighbour rows in flight (four at a time was a chain of K/4 L2 round trips per point)
 #pragma unroll
-    for (int t = 0; t < K; ++t) pv[t] = PQ[(cloud0 + __builtin_amdgcn_readlane(my_idx, t)) * 128 + lane];
+      for (int t = 0; t < K; ++t) pv[t] = PQ[(cloud0 + __builtin_amdgcn_readlane(my_idx, t)) * 128 + lane];
 #pragma unroll
-    for (int t = 0; t < K; ++t) {
-      const float e = pv[t] + q;
-      a += e;
-      b += e * e;
+      for (int t = 0; t < K; ++t) {
+        const float e = pv[t] + q;
+        a += e;
+        b += e * e;
+      }
     }
-  }
-  sa[w][lane] = a;
-  sb[w][lane] = b;
-  __syncthreads();
-  if (w == 0) {
-    part[((long)blockIdx.x * 2 + 0) * 64 + lane] = ((sa[0][lane] + sa[1][lane]) + sa[2][lane]) + sa[3][lane];
-    part[((long)blockIdx.x * 2 + 1) * 64 + lane] = ((sb[0][lane] + sb[1][lane]) + sb[2][lane]) + sb[3][lane];
+    sa[w][lane] = a;
+    sb[w][lane] = b;
+    __syncthreads();
+    if (w == 0) {
+      part[((long)chunk * 2 + 0) * 64 + lane] = ((sa[0][lane] + sa[1][lane]) + sa[2][lane]) + sa[3][lane];
+      part[((long)chunk * 2 + 1) * 64 + lane] = ((sb[0][lane] + sb[1][lane]) + sb[2][lane]) + sb[3][lane];
+    }
+    __syncthreads();
   }
 }
 
@@ -63,16 +94,22 @@ static __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
-// out[i] = sum over blocks of part[blk][i] in fp64.  64 consecutive outputs per workgroup (coalesced 256-B rows of
-// `part`), the block axis split over 16 waves (blocks w, w+16, ...; 8 loads in flight), wave totals combined in a
-// fixed order: deterministic.  (One wave per output with lanes striding over the blocks fetched a 128-B line per
-// 4 useful bytes: 20 us for the 768 x 4224 partials of the backward pass.)
-// Outputs i >= split go to out2[i - split] (the backward's dW2 | BN1 sums land in their own buffers).
-__global__ __launch_bounds__(1024) void r3d_part_reduce_kernel(const float* __restrict__ part, int nblk, int n,
-                                                               float* __restrict__ out, int split, float* __restrict__ out2) {
+// out[seg][i] = sum over the segment's partial rows part[row][i] in fp64.  64 consecutive outputs per workgroup
+// (coalesced 256-B rows of `part`), the row axis split over 16 waves (rows w, w+16, ... RELATIVE to the segment's first
+// row; 8 loads in flight), wave totals combined in a fixed order: deterministic, and independent of where the segment
+// sits in the batch.  (One wave per output with lanes striding over the rows fetched a 128-B line per 4 useful bytes:
+// 20 us for the 768 x 4224 partials of the backward pass.)  blockIdx.y = segment; its rows: count_a / count_b
+// alternating (count_b == 0: count_a each).  Outputs i >= split go to out2[seg][i - split].
+__global__ __launch_bounds__(1024) void r3d_part_reduce_kernel(const float* __restrict__ part, int count_a, int count_b, int n,
+                                                               float* __restrict__ out, long out_stride, int split,
+                                                               float* __restrict__ out2, long out2_stride) {
   __shared__ double sm[16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
+  const int seg = blockIdx.y;
+  const bool odd = count_b > 0 && (seg & 1);
+  const int nblk = odd ? count_b : count_a;
+  part += (count_b > 0 ? (long)(seg >> 1) * (count_a + count_b) + (odd ? count_a : 0) : (long)seg * count_a) * n;
   double s = 0.0;
   if (i < n) {
     int k = w;
@@ -91,270 +128,188 @@ __global__ __launch_bounds__(1024) void r3d_part_reduce_kernel(const float* __re
     double t = sm[0][lane];
 #pragma unroll
     for (int q = 1; q < 16; ++q) t += sm[q][lane];
-    if (i < split) out[i] = (float)t;
-    else out2[i - split] = (float)t;
-  }
-}
-
-// ---- two-pass forward (8-point units, 32x32x2): mode 0 = output (+argmax, z at argmax); mode 1 = statistics of
-//      z2.  The training path uses the ONE-pass kernel r3d_edgeconv_train_fwd2_kernel below instead: statistics of z2
-//      AND, per point and channel, max / min of the raw z2 over the K edges with their positions.  BatchNorm2 +
-//      LeakyReLU is monotone per channel (increasing for gamma*invstd > 0, decreasing for < 0), so once the statistics
-//      are folded the layer output is lrelu(s2 * (s2 > 0 ? zmax : zmin) + t2) -- r3d_edge_select -- and the edge
-//      GEMM is not computed twice.
-template <int MODE>
-__global__ __launch_bounds__(512) void r3d_edgeconv_train_fwd_kernel(
-    const float* __restrict__ PQ, const int* __restrict__ idx, const float* __restrict__ s1, const float* __restrict__ t1,
-    const float* __restrict__ W2, const float* __restrict__ s2, const float* __restrict__ t2, float* __restrict__ out,
-    long ldo, int N, int K, long total_points, int* __restrict__ argmax_out, float* __restrict__ zmax_out,
-    float* __restrict__ part /* mode 1: [grid][2][64] */) {
-  extern __shared__ __attribute__((aligned(16))) float H[];  // [8K][ET_LD], then W2 [64][ET_LD]
-  __shared__ float ps[16][2][64];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int nwaves = blockDim.x >> 6;
-  // W2 in LDS: its MFMA B fragments cost 64 VGPRs when held in registers, which together with the 32-deep gather
-  // left one workgroup per CU; from LDS two workgroups fit and overlap their gather / MFMA phases
-  float* W2s = H + ET_PTS * K * ET_LD;
-  for (int o = tid; o < 64 * 64; o += blockDim.x) W2s[(o >> 6) * ET_LD + (o & 63)] = W2[o];
-  __syncthreads();
-  const float sc1 = s1[lane], sh1 = t1[lane];
-  float za0 = 0.f, zb0 = 0.f, za1 = 0.f, zb1 = 0.f;  // mode 1: per-lane sums (channel lane&31 / +32)
-  const long units = total_points / ET_PTS;
-  for (long u = blockIdx.x; u < units; u += gridDim.x) {
-    const long pt0 = u * ET_PTS;
-    const long cloud0 = (pt0 / N) * N;
-    {
-      const int my_idx = min(max(idx[pt0 * K + 32 * w + (lane & 31)], 0), N - 1);  // never gather outside the cloud, whatever the list holds
-      float* hrow = H + (32 * w) * ET_LD;
-      // all 32 neighbour rows in flight at once (L2-latency bound gather); the point's own Q row per edge is an
-      // L1 hit and is loaded alongside
-#pragma unroll
-      for (int t0 = 0; t0 < 32; t0 += 16) {  // 32 loads in flight per step (two steps keep 3 waves per SIMD)
-        float pv[16], qv[16];
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          pv[t] = PQ[(cloud0 + __builtin_amdgcn_readlane(my_idx, t0 + t)) * 128 + lane];
-          qv[t] = PQ[(pt0 + (32 * w + t0 + t) / K) * 128 + 64 + lane];
-        }
-#pragma unroll
-        for (int t = 0; t < 16; ++t) hrow[(t0 + t) * ET_LD + lane] = lrelu(sc1 * (pv[t] + qv[t]) + sh1);
-      }
-    }
-    f32x16 a0, a1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
-    {
-      const float* ap = H + (32 * w + (lane & 31)) * ET_LD + (lane >> 5);
-      const float* bp0 = W2s + (lane & 31) * ET_LD + (lane >> 5);  // B[k][jo] = W2[jo][k]
-      const float* bp1 = bp0 + 32 * ET_LD;
-#pragma unroll 8
-      for (int s = 0; s < 32; ++s) {
-        const float a = ap[2 * s];
-        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp0[2 * s], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp1[2 * s], a1, 0, 0, 0);
-      }
-    }
-    if (MODE == 1) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { za0 += a0[r]; zb0 += a0[r] * a0[r]; za1 += a1[r]; zb1 += a1[r] * a1[r]; }
-    }
-    if (MODE == 0) {
-      // raw z2 back into this wave's LDS rows; BN2 + LeakyReLU are applied in the max loop so that the
-      // winner's z2 can be saved for the backward pass
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * w + r3d_acc_row(r, lane);
-        H[row * ET_LD + (lane & 31)] = a0[r];
-        H[row * ET_LD + 32 + (lane & 31)] = a1[r];
-      }
-      __syncthreads();
-      for (int o = tid; o < ET_PTS * 64; o += blockDim.x) {
-        const int pt = o >> 6, ch = o & 63;
-        const float sc = s2[ch], sh = t2[ch];
-        const float* hp = H + (pt * K) * ET_LD + ch;
-        float zb = hp[0];
-        float m = lrelu(sc * zb + sh);
-        int am = 0;
-        for (int t = 1; t < K; ++t) {
-          const float z = hp[t * ET_LD];
-          const float v = lrelu(sc * z + sh);
-          if (v > m) { m = v; am = t; zb = z; }
-        }
-        out[(pt0 + pt) * ldo + ch] = m;
-        if (argmax_out) argmax_out[(pt0 + pt) * 64 + ch] = am;
-        if (zmax_out) zmax_out[(pt0 + pt) * 64 + ch] = zb;
-      }
-      __syncthreads();
-    }
-  }
-  if (MODE == 1) {
-    // combine the two lane halves (same channel), then the waves, in a fixed order
-    za0 += __shfl_xor(za0, 32); zb0 += __shfl_xor(zb0, 32);
-    za1 += __shfl_xor(za1, 32); zb1 += __shfl_xor(zb1, 32);
-    if (lane < 32) { ps[w][0][lane] = za0; ps[w][1][lane] = zb0; ps[w][0][32 + lane] = za1; ps[w][1][32 + lane] = zb1; }
-    __syncthreads();
-    if (tid < 128) {
-      const int v = tid >> 6, c = tid & 63;
-      float s = 0.f;
-      for (int q = 0; q < nwaves; ++q) s += ps[q][v][c];
-      part[((long)blockIdx.x * 2 + v) * 64 + c] = s;
-    }
+    if (i < split) out[seg * out_stride + i] = (float)t;
+    else out2[seg * out2_stride + i - split] = (float)t;
   }
 }
 
 // ---- backward pass B1 -------------------------------------------------------------------------
 // 4-point units on 16x16x4 MFMA (edge_tile.h).  The dW2 edge contraction takes edge 16(s>>2) + 4g + (s&3) at step s
 // (conflict-free b32 reads of dz2, one b128 of h1 feeding four column tiles).
-// part layout per block: [0] dW2 partial 64*64, then [4096 + v*64 + c], v = 0: sum dy1, 1: sum dy1*ehat1
-#define ET_PART (64 * 64 + 2 * 64)
+// Partials: part_dw [block][64*64] (dW2 is summed over the whole batch: per workgroup), part_bn [chunk][2][64]
+// (v = 0: sum dy1, 1: sum dy1*ehat1; per chunk, reduced per segment).
+struct EcBn {  // BatchNorm vectors of both edge layers, segment s at + s * stride
+  const float *s1, *t1, *mean1, *invstd1, *s2, *t2, *mean2, *invstd2;
+  long stride;
+};
 template <int RT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT <= 5 ? 3 : 2))) void r3d_edgeconv_bwd1_kernel(
-    const float* __restrict__ PQ, const int* __restrict__ idx, const float* __restrict__ s1, const float* __restrict__ t1,
-    const float* __restrict__ mean1, const float* __restrict__ invstd1, const float* __restrict__ W2,
-    const float* __restrict__ s2, const float* __restrict__ t2, const float* __restrict__ mean2,
-    const float* __restrict__ invstd2, const float* __restrict__ bn2_sums /* [2][64]: sum dy2, sum dy2 zhat2 */,
-    const float* __restrict__ dout, long lddo, const int* __restrict__ argmax, int N, long total_points,
+    const float* __restrict__ PQ, const int* __restrict__ idx, EcBn bn, const float* __restrict__ W2,
+    const float* __restrict__ bn2_sums /* [seg][2][64]: sum dy2, sum dy2 zhat2 */, const float* __restrict__ dout, long lddo,
+    const int* __restrict__ argmax, EcGeom gm, r3d_segmap cs /* clouds */, int n_chunks,
     float* __restrict__ DY1 /* (total_points*K, 64) */, float* __restrict__ BE /* (total_points, 128): sum_t dy1 | sum_t ehat1 */,
-    float* __restrict__ part) {
+    float* __restrict__ part_dw, float* __restrict__ part_bn) {
   constexpr int K = 4 * RT, R = 16 * RT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* H = smem;                        // [R][E2_LD] h1
   float* G = smem + R * E2_LD;            // [R][E2_LD] dz2, later dy1
   float* dsm = G + R * E2_LD;             // [4][64] dout of the unit
   int* asm_ = (int*)(dsm + E2_PTS * 64);  // [4][64] argmax of the unit
+  float* bnc = (float*)(asm_ + E2_PTS * 64);  // [6][64] layer-2 BatchNorm values of the chunk's segment
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int n = lane & 15, g = lane >> 4;
   const int c = 16 * w + n;  // this lane's column of the z2 / dh1 tiles
-  const float sc1 = s1[lane], sh1 = t1[lane], mu1 = mean1[lane], is1 = invstd1[lane];
-  const double E = (double)total_points * K;
-  const float s2c = s2[c], t2c = t2[c], mu2c = mean2[c], is2c = invstd2[c];
-  const float m1c = (float)((double)bn2_sums[c] / E), m2c = (float)((double)bn2_sums[64 + c] / E);
+  const int N = gm.N;
   f32x4 dw[4];  // dW2 rows 16w + 4g + i, columns 4n + tj
 #pragma unroll
   for (int tj = 0; tj < 4; ++tj) dw[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float sdy = 0.f, sdye = 0.f;
-  const long units = total_points / E2_PTS;
-  for (long u = blockIdx.x; u < units; u += gridDim.x) {
-    const long pt0 = u * E2_PTS;
-    const long cloud0 = (pt0 / N) * N;
-    dsm[tid] = dout[(pt0 + w) * lddo + lane];
-    asm_[tid] = argmax[(pt0 + w) * 64 + lane];
-    // W2 fragments are re-read (L1 / L2 hits) in the phase that uses them: holding both sets for the whole loop
-    // costs 32 registers and the third workgroup per CU.  The opaque zero keeps the loads inside the loop.
-    int keep = 0;
-    asm volatile("" : "+v"(keep));
-    float Bf[16];
-    {
-      const float4* bz = (const float4*)(W2 + c * 64 + 16 * g + keep);  // z2[e][c] = sum_k h1[e][k] W2[c][k]
+  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    int cloud, p0, p1;
+    gm.range(chunk, cloud, p0, p1);
+    const long cloud0 = (long)cloud * N;
+    // the chunk's segment: its BatchNorm vectors (L1 / L2 hits after the first chunk of a segment)
+    const int seg = ec_seg(cs, cloud);
+    const long bo = (long)seg * bn.stride;
+    const float sc1 = bn.s1[bo + lane], sh1 = bn.t1[bo + lane], mu1 = bn.mean1[bo + lane], is1 = bn.invstd1[bo + lane];
+    // the six per-column values of layer 2 go through LDS: they are needed in one phase of a unit only, and as
+    // registers held across the whole unit they are what tips the kernel over 168 (three workgroups per CU)
+    if (tid < 64) {
+      const double E = (double)cs.seg_rows(seg) * N * K;  // edges of the segment
+      bnc[0 * 64 + tid] = bn.s2[bo + tid];
+      bnc[1 * 64 + tid] = bn.t2[bo + tid];
+      bnc[2 * 64 + tid] = bn.mean2[bo + tid];
+      bnc[3 * 64 + tid] = bn.invstd2[bo + tid];
+      bnc[4 * 64 + tid] = (float)((double)bn2_sums[(long)seg * 128 + tid] / E);
+      bnc[5 * 64 + tid] = (float)((double)bn2_sums[(long)seg * 128 + 64 + tid] / E);
+    }
+    float sdy = 0.f, sdye = 0.f;
+    for (int pt0_ = p0; pt0_ < p1; pt0_ += E2_PTS) {
+      const long pt0 = pt0_;
+      dsm[tid] = dout[(pt0 + w) * lddo + lane];
+      asm_[tid] = argmax[(pt0 + w) * 64 + lane];
+      // W2 fragments are re-read (L1 / L2 hits) in the phase that uses them: holding both sets for the whole loop
+      // costs 32 registers and the third workgroup per CU.  The opaque zero keeps the loads inside the loop.
+      int keep = 0;
+      asm volatile("" : "+v"(keep));
+      float Bf[16];
+      {
+        const float4* bz = (const float4*)(W2 + c * 64 + 16 * g + keep);  // z2[e][c] = sum_k h1[e][k] W2[c][k]
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const float4 v = bz[s4];
-        Bf[4 * s4] = v.x; Bf[4 * s4 + 1] = v.y; Bf[4 * s4 + 2] = v.z; Bf[4 * s4 + 3] = v.w;
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const float4 v = bz[s4];
+          Bf[4 * s4] = v.x; Bf[4 * s4 + 1] = v.y; Bf[4 * s4 + 2] = v.z; Bf[4 * s4 + 3] = v.w;
+        }
       }
-    }
-    float eh[K];  // ehat1 of the K edges of point w (this wave's rows), channel = lane
-    {
-      const int my_idx = min(max(idx[(pt0 + w) * K + min(lane, K - 1)], 0), N - 1);  // never gather outside the cloud, whatever the list holds
-      const float q = PQ[(pt0 + w) * 128 + 64 + lane];
-      float pv[K];
+      float eh[K];  // ehat1 of the K edges of point w (this wave's rows), channel = lane
+      {
+        const int my_idx = min(max(idx[(pt0 + w) * K + min(lane, K - 1)], 0), N - 1);  // never gather outside the cloud, whatever the list holds
+        const float q = PQ[(pt0 + w) * 128 + 64 + lane];
+        float pv[K];
 #pragma unroll
-      for (int t = 0; t < K; ++t) pv[t] = PQ[(cloud0 + __builtin_amdgcn_readlane(my_idx, t)) * 128 + lane];
-      float* hrow = H + (K * w) * E2_LD + lane;
+        for (int t = 0; t < K; ++t) pv[t] = PQ[(cloud0 + __builtin_amdgcn_readlane(my_idx, t)) * 128 + lane];
+        float* hrow = H + (K * w) * E2_LD + lane;
 #pragma unroll
-      for (int t = 0; t < K; ++t) {
-        const float e1 = pv[t] + q;
-        eh[t] = (e1 - mu1) * is1;
-        hrow[t * E2_LD] = lrelu(sc1 * e1 + sh1);
+        for (int t = 0; t < K; ++t) {
+          const float e1 = pv[t] + q;
+          eh[t] = (e1 - mu1) * is1;
+          hrow[t * E2_LD] = lrelu(sc1 * e1 + sh1);
+        }
       }
-    }
-    __syncthreads();  // H, dsm, asm_ complete
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 acc[RT];
-    e2_rowgemm<RT>(H, Bf, n, g, acc);
+      __syncthreads();  // H, dsm, asm_ complete
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 acc[RT];
+      e2_rowgemm<RT>(H, Bf, n, g, acc);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) Bf[s] = W2[(16 * g + s) * 64 + c + keep];  // dh1[e][c] = sum_k dz2[e][k] W2[k][c]
+      for (int s = 0; s < 16; ++s) Bf[s] = W2[(16 * g + s) * 64 + c + keep];  // dh1[e][c] = sum_k dz2[e][k] W2[k][c]
+      const float s2c = bnc[c], t2c = bnc[64 + c], mu2c = bnc[128 + c], is2c = bnc[192 + c], m1c = bnc[256 + c], m2c = bnc[320 + c];
 #pragma unroll
-    for (int t = 0; t < RT; ++t) {
+      for (int t = 0; t < RT; ++t) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int e = 16 * t + 4 * g + i;
-        const int pt = e / K, tt = e - pt * K;
-        const float z = acc[t][i];
-        const float uu = s2c * z + t2c;
-        const float dy = (asm_[pt * 64 + c] == tt) ? dsm[pt * 64 + c] * (uu > 0.f ? 1.f : 0.2f) : 0.f;
-        G[e * E2_LD + c] = s2c * (dy - m1c - ((z - mu2c) * is2c) * m2c);
+        for (int i = 0; i < 4; ++i) {
+          const int e = 16 * t + 4 * g + i;
+          const int pt = e / K, tt = e - pt * K;
+          const float z = acc[t][i];
+          const float uu = s2c * z + t2c;
+          const float dy = (asm_[pt * 64 + c] == tt) ? dsm[pt * 64 + c] * (uu > 0.f ? 1.f : 0.2f) : 0.f;
+          G[e * E2_LD + c] = s2c * (dy - m1c - ((z - mu2c) * is2c) * m2c);
+        }
       }
-    }
-    __syncthreads();  // dz2 complete
-    __builtin_amdgcn_sched_barrier(0);
-    e2_rowgemm<RT>(G, Bf, n, g, acc);
+      __syncthreads();  // dz2 complete
+      __builtin_amdgcn_sched_barrier(0);
+      e2_rowgemm<RT>(G, Bf, n, g, acc);
 #pragma unroll
-    for (int t = 0; t < RT; ++t) {
+      for (int t = 0; t < RT; ++t) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[t][i] *= (H[(16 * t + 4 * g + i) * E2_LD + c] > 0.f) ? 1.f : 0.2f;  // u1 > 0 <=> h1 > 0
-    }
-    // dW2 += dz2^T h1 over the unit's edges
+        for (int i = 0; i < 4; ++i) acc[t][i] *= (H[(16 * t + 4 * g + i) * E2_LD + c] > 0.f) ? 1.f : 0.2f;  // u1 > 0 <=> h1 > 0
+      }
+      // dW2 += dz2^T h1 over the unit's edges
 #pragma unroll 4
-    for (int s = 0; s < 4 * RT; ++s) {
-      const int e = 16 * (s >> 2) + 4 * g + (s & 3);
-      const float a = G[e * E2_LD + 16 * w + n];
-      const float4 b = *(const float4*)(H + e * E2_LD + 4 * n);
-      dw[0] = mfma16(a, b.x, dw[0]);
-      dw[1] = mfma16(a, b.y, dw[1]);
-      dw[2] = mfma16(a, b.z, dw[2]);
-      dw[3] = mfma16(a, b.w, dw[3]);
-    }
-    __syncthreads();  // every read of dz2 is done
-#pragma unroll
-    for (int t = 0; t < RT; ++t) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) G[(16 * t + 4 * g + i) * E2_LD + c] = acc[t][i];
-    }
-    __syncthreads();  // dy1 complete
-    {
-      float* drow = DY1 + ((pt0 + w) * K) * 64 + lane;
-      const float* grow = G + (K * w) * E2_LD + lane;
-      float bs = 0.f, es = 0.f;
-#pragma unroll
-      for (int t = 0; t < K; ++t) {
-        const float v = grow[t * E2_LD];
-        drow[t * 64] = v;
-        bs += v;
-        es += eh[t];
-        sdye += v * eh[t];
+      for (int s = 0; s < 4 * RT; ++s) {
+        const int e = 16 * (s >> 2) + 4 * g + (s & 3);
+        const float a = G[e * E2_LD + 16 * w + n];
+        const float4 b = *(const float4*)(H + e * E2_LD + 4 * n);
+        dw[0] = mfma16(a, b.x, dw[0]);
+        dw[1] = mfma16(a, b.y, dw[1]);
+        dw[2] = mfma16(a, b.z, dw[2]);
+        dw[3] = mfma16(a, b.w, dw[3]);
       }
-      sdy += bs;
-      BE[(pt0 + w) * 128 + lane] = bs;
-      BE[(pt0 + w) * 128 + 64 + lane] = es;
+      __syncthreads();  // every read of dz2 is done
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) G[(16 * t + 4 * g + i) * E2_LD + c] = acc[t][i];
+      }
+      __syncthreads();  // dy1 complete
+      {
+        float* drow = DY1 + ((pt0 + w) * K) * 64 + lane;
+        const float* grow = G + (K * w) * E2_LD + lane;
+        float bs = 0.f, es = 0.f;
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+          const float v = grow[t * E2_LD];
+          drow[t * 64] = v;
+          bs += v;
+          es += eh[t];
+          sdye += v * eh[t];
+        }
+        sdy += bs;
+        BE[(pt0 + w) * 128 + lane] = bs;
+        BE[(pt0 + w) * 128 + 64 + lane] = es;
+      }
+      // the next unit writes H / dsm / asm_ (last read before the third barrier) before its first barrier and G after it
     }
-    // the next unit writes H / dsm / asm_ (last read before the third barrier) before its first barrier and G after it
+    // the chunk's BatchNorm-1 partial: four waves (= four points per unit) in a fixed order.  dsm is free here: its last
+    // read (dz2) lies before the third barrier of the chunk's last unit; the barrier behind the store keeps the next
+    // chunk's first unit from overwriting it early.
+    float (*ps)[2][64] = (float (*)[2][64])dsm;  // [4][2][64] aliases dsm | asm_
+    ps[w][0][lane] = sdy;
+    ps[w][1][lane] = sdye;
+    __syncthreads();
+    if (tid < 128) {
+      const int v = tid >> 6, cc = tid & 63;
+      part_bn[((long)chunk * 2 + v) * 64 + cc] = ((ps[0][v][cc] + ps[1][v][cc]) + ps[2][v][cc]) + ps[3][v][cc];
+    }
+    __syncthreads();
   }
-  __syncthreads();
   // thread coordinates again from an opaque copy: carried across the loop they cost a register the loop needs
   int tid2 = threadIdx.x;
   asm volatile("" : "+v"(tid2));
-  const int lane2 = tid2 & 63, w2 = tid2 >> 6, n2 = tid2 & 15, g2 = (tid2 >> 4) & 3;
-  float (*ps)[2][64] = (float (*)[2][64])smem;  // [4][2][64] block partials (aliases H)
-  ps[w2][0][lane2] = sdy;
-  ps[w2][1][lane2] = sdye;
-  __syncthreads();
-  float* mypart = part + (long)blockIdx.x * ET_PART;
-  if (tid2 < 128) {
-    const int v = tid2 >> 6, cc = tid2 & 63;
-    mypart[4096 + v * 64 + cc] = ((ps[0][v][cc] + ps[1][v][cc]) + ps[2][v][cc]) + ps[3][v][cc];
-  }
+  const int w2 = tid2 >> 6, n2 = tid2 & 15, g2 = (tid2 >> 4) & 3;
+  float* mypart = part_dw + (long)blockIdx.x * 4096;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
     *(float4*)(mypart + (16 * w2 + 4 * g2 + i) * 64 + 4 * n2) = float4{dw[0][i], dw[1][i], dw[2][i], dw[3][i]};
 }
 
-// ---- one-pass training forward on the same 4-point / 16x16x4 unit (replaces MODE 2 of the 8-point kernel) ------
-// statistics of z2 and, per point and channel, max / min of the raw z2 over the K edges with their positions
+// ---- one-pass training forward on the same 4-point / 16x16x4 unit ---------------------------------------------
+// statistics of z2 (one partial per chunk) and, per point and channel, max / min of the raw z2 over the K edges with
+// their positions
 template <int RT>
 __global__ __launch_bounds__(256) void r3d_edgeconv_train_fwd2_kernel(
     const float* __restrict__ PQ, const int* __restrict__ idx, const float* __restrict__ s1, const float* __restrict__ t1,
-    const float* __restrict__ W2, int N, long total_points, int* __restrict__ argmax_out, float* __restrict__ zmax_out,
-    float* __restrict__ zmin_out, int* __restrict__ argmin_out, float* __restrict__ part /* [grid][2][64] */) {
+    long bn_stride, const float* __restrict__ W2, EcGeom gm, r3d_segmap cs /* clouds */, int n_chunks,
+    int* __restrict__ argmax_out, float* __restrict__ zmax_out, float* __restrict__ zmin_out, int* __restrict__ argmin_out,
+    float* __restrict__ part /* [chunk][2][64] */) {
   constexpr int K = 4 * RT, R = 16 * RT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* H = smem;              // [R][E2_LD] h1
@@ -362,62 +317,67 @@ __global__ __launch_bounds__(256) void r3d_edgeconv_train_fwd2_kernel(
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int n = lane & 15, g = lane >> 4;
   const int c = 16 * w + n;
+  const int N = gm.N;
   float Bz[16];
 #pragma unroll
   for (int s = 0; s < 16; ++s) Bz[s] = W2[c * 64 + 16 * g + s];  // z2[e][c] = sum_k h1[e][k] W2[c][k]
-  const float sc1 = s1[lane], sh1 = t1[lane];
-  float za = 0.f, zb = 0.f;
-  const long units = total_points / E2_PTS;
-  for (long u = blockIdx.x; u < units; u += gridDim.x) {
-    const long pt0 = u * E2_PTS;
-    const long cloud0 = (pt0 / N) * N;
-    {
-      const int my_idx = min(max(idx[(pt0 + w) * K + min(lane, K - 1)], 0), N - 1);  // never gather outside the cloud, whatever the list holds
-      const float q = PQ[(pt0 + w) * 128 + 64 + lane];
-      float pv[K];
+  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    int cloud, p0, p1;
+    gm.range(chunk, cloud, p0, p1);
+    const long cloud0 = (long)cloud * N;
+    const long bo = (long)ec_seg(cs, cloud) * bn_stride;
+    const float sc1 = s1[bo + lane], sh1 = t1[bo + lane];
+    float za = 0.f, zb = 0.f;
+    for (int pt0_ = p0; pt0_ < p1; pt0_ += E2_PTS) {
+      const long pt0 = pt0_;
+      {
+        const int my_idx = min(max(idx[(pt0 + w) * K + min(lane, K - 1)], 0), N - 1);  // never gather outside the cloud, whatever the list holds
+        const float q = PQ[(pt0 + w) * 128 + 64 + lane];
+        float pv[K];
 #pragma unroll
-      for (int t = 0; t < K; ++t) pv[t] = PQ[(cloud0 + __builtin_amdgcn_readlane(my_idx, t)) * 128 + lane];
-      float* hrow = H + (K * w) * E2_LD + lane;
+        for (int t = 0; t < K; ++t) pv[t] = PQ[(cloud0 + __builtin_amdgcn_readlane(my_idx, t)) * 128 + lane];
+        float* hrow = H + (K * w) * E2_LD + lane;
 #pragma unroll
-      for (int t = 0; t < K; ++t) hrow[t * E2_LD] = lrelu(sc1 * (pv[t] + q) + sh1);
-    }
-    __syncthreads();  // H complete; every wave is done scanning the previous unit's Z
-    f32x4 acc[RT];
-    e2_rowgemm<RT>(H, Bz, n, g, acc);
+        for (int t = 0; t < K; ++t) hrow[t * E2_LD] = lrelu(sc1 * (pv[t] + q) + sh1);
+      }
+      __syncthreads();  // H complete; every wave is done scanning the previous unit's Z
+      f32x4 acc[RT];
+      e2_rowgemm<RT>(H, Bz, n, g, acc);
 #pragma unroll
-    for (int t = 0; t < RT; ++t) {
+      for (int t = 0; t < RT; ++t) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float z = acc[t][i];
-        za += z;
-        zb += z * z;
-        Z[(16 * t + 4 * g + i) * E2_LD + c] = z;
+        for (int i = 0; i < 4; ++i) {
+          const float z = acc[t][i];
+          za += z;
+          zb += z * z;
+          Z[(16 * t + 4 * g + i) * E2_LD + c] = z;
+        }
+      }
+      __syncthreads();  // Z complete; H free for the next unit's gather
+      {
+        const float* zp = Z + (K * w) * E2_LD + lane;  // point w, channel lane
+        float zx = zp[0], zn = zx;
+        int ax = 0, an = 0;
+#pragma unroll
+        for (int t = 1; t < K; ++t) {
+          const float z = zp[t * E2_LD];
+          if (z > zx) { zx = z; ax = t; }
+          if (z < zn) { zn = z; an = t; }
+        }
+        const long o = (pt0 + w) * 64 + lane;
+        zmax_out[o] = zx;
+        zmin_out[o] = zn;
+        argmax_out[o] = ax;
+        argmin_out[o] = an;
       }
     }
-    __syncthreads();  // Z complete; H free for the next unit's gather
-    {
-      const float* zp = Z + (K * w) * E2_LD + lane;  // point w, channel lane
-      float zx = zp[0], zn = zx;
-      int ax = 0, an = 0;
-#pragma unroll
-      for (int t = 1; t < K; ++t) {
-        const float z = zp[t * E2_LD];
-        if (z > zx) { zx = z; ax = t; }
-        if (z < zn) { zn = z; an = t; }
-      }
-      const long o = (pt0 + w) * 64 + lane;
-      zmax_out[o] = zx;
-      zmin_out[o] = zn;
-      argmax_out[o] = ax;
-      argmin_out[o] = an;
+    // the four lane groups of a wave hold partial sums of the same 16 channels; wave w owns channels 16w..16w+15
+    za += __shfl_xor(za, 16); zb += __shfl_xor(zb, 16);
+    za += __shfl_xor(za, 32); zb += __shfl_xor(zb, 32);
+    if (g == 0) {
+      part[((long)chunk * 2 + 0) * 64 + c] = za;
+      part[((long)chunk * 2 + 1) * 64 + c] = zb;
     }
-  }
-  // the four lane groups of a wave hold partial sums of the same 16 channels; wave w owns channels 16w..16w+15
-  za += __shfl_xor(za, 16); zb += __shfl_xor(zb, 16);
-  za += __shfl_xor(za, 32); zb += __shfl_xor(zb, 32);
-  if (g == 0) {
-    part[((long)blockIdx.x * 2 + 0) * 64 + c] = za;
-    part[((long)blockIdx.x * 2 + 1) * 64 + c] = zb;
   }
 }
 
@@ -567,221 +527,193 @@ __global__ __launch_bounds__(1024) void r3d_edge_reverse_kernel(const int* __res
 template <int RT>
 __global__ __launch_bounds__(256) void r3d_edgeconv_bwd2_kernel(
     const float* __restrict__ PQ, const float* __restrict__ s1, const float* __restrict__ mean1,
-    const float* __restrict__ invstd1, const float* __restrict__ bn1_sums /* [2][64] */, const float* __restrict__ DY1,
-    const float* __restrict__ BE, const int* __restrict__ rev_ptr, const int* __restrict__ rev, int e_off, long total_points,
-    float* __restrict__ dPQ /* (M,128), every entry written */) {
+    const float* __restrict__ invstd1, long bn_stride, const float* __restrict__ bn1_sums /* [seg][2][64] */,
+    const float* __restrict__ DY1, const float* __restrict__ BE, const int* __restrict__ rev_ptr, const int* __restrict__ rev,
+    int e_off, EcGeom gm, r3d_segmap cs /* clouds */, int n_chunks, float* __restrict__ dPQ /* (M,128), every entry written */) {
   // rev holds edge ids of the batch the reverse list was built for; this call's clouds start e_off edges into it
   constexpr int K = 4 * RT;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const double E = (double)total_points * K;
-  const float sc1 = s1[lane], mu1 = mean1[lane], is1 = invstd1[lane];
-  const float n1 = (float)((double)bn1_sums[lane] / E), n2 = (float)((double)bn1_sums[64 + lane] / E);
-  for (long pt = (long)blockIdx.x * 4 + w; pt < total_points; pt += (long)gridDim.x * 4) {
-    const int rb = rev_ptr[pt], re = rev_ptr[pt + 1];
-    const float pj = PQ[pt * 128 + lane];
-    const float bs = BE[pt * 128 + lane], es = BE[pt * 128 + 64 + lane];
-    float asum = 0.f, gsum = 0.f;
-    for (int e0 = rb; e0 < re; e0 += 16) {  // 16 incoming edges = 32 rows in flight per trip; adds in list order
-      const int my_e = rev[min(e0 + min(lane, 15), re - 1)];
-      float dv[16], qv[16];
+  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    int cloud, p0, p1;
+    gm.range(chunk, cloud, p0, p1);
+    const int seg = ec_seg(cs, cloud);
+    const long bo = (long)seg * bn_stride;
+    const double E = (double)cs.seg_rows(seg) * gm.N * K;
+    const float sc1 = s1[bo + lane], mu1 = mean1[bo + lane], is1 = invstd1[bo + lane];
+    const float n1 = (float)((double)bn1_sums[(long)seg * 128 + lane] / E), n2 = (float)((double)bn1_sums[(long)seg * 128 + 64 + lane] / E);
+    for (int pt_ = p0 + w; pt_ < p1; pt_ += 4) {
+      const long pt = pt_;
+      const int rb = rev_ptr[pt], re = rev_ptr[pt + 1];
+      const float pj = PQ[pt * 128 + lane];
+      const float bs = BE[pt * 128 + lane], es = BE[pt * 128 + 64 + lane];
+      float asum = 0.f, gsum = 0.f;
+      for (int e0 = rb; e0 < re; e0 += 16) {  // 16 incoming edges = 32 rows in flight per trip; adds in list order
+        const int my_e = rev[min(e0 + min(lane, 15), re - 1)];
+        float dv[16], qv[16];
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int e = __builtin_amdgcn_readlane(my_e, t) - e_off;
-        dv[t] = DY1[(long)e * 64 + lane];
-        qv[t] = PQ[(long)(e / K) * 128 + 64 + lane];
-      }
+        for (int t = 0; t < 16; ++t) {
+          const int e = __builtin_amdgcn_readlane(my_e, t) - e_off;
+          dv[t] = DY1[(long)e * 64 + lane];
+          qv[t] = PQ[(long)(e / K) * 128 + 64 + lane];
+        }
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const bool ok = e0 + t < re;
-        asum += r3d_keep(dv[t], ok);
-        gsum += r3d_keep(qv[t], ok);
+        for (int t = 0; t < 16; ++t) {
+          const bool ok = e0 + t < re;
+          asum += r3d_keep(dv[t], ok);
+          gsum += r3d_keep(qv[t], ok);
+        }
       }
+      const float cj = (float)(re - rb);
+      dPQ[pt * 128 + lane] = sc1 * (asum - cj * n1 - n2 * (is1 * (cj * (pj - mu1) + gsum)));
+      dPQ[pt * 128 + 64 + lane] = sc1 * (bs - (float)K * n1 - n2 * es);
     }
-    const float cj = (float)(re - rb);
-    dPQ[pt * 128 + lane] = sc1 * (asum - cj * n1 - n2 * (is1 * (cj * (pj - mu1) + gsum)));
-    dPQ[pt * 128 + 64 + lane] = sc1 * (bs - (float)K * n1 - n2 * es);
   }
 }
 
 // ===========================================================================
 // C ABI
 // ===========================================================================
-static int et_check(const char* fn, int B, int N, int K) {
-  if (B <= 0 || N <= 0 || N % ET_PTS != 0 || K < 4 || K > 32 || K % 4 != 0) {
-    r3d_set_error("%s: unsupported shape B=%d N=%d K=%d (N %% 8 == 0, K %% 4 == 0, 4..32)", fn, B, N, K);
+static int et_check(const char* fn, int B, int N, int K, int clouds_a, int clouds_b) {
+  if (B <= 0 || N <= 0 || N % E2_PTS != 0 || K < 4 || K > 32 || K % 4 != 0) {
+    r3d_set_error("%s: unsupported shape B=%d N=%d K=%d (N %% 4 == 0, K %% 4 == 0, 4..32)", fn, B, N, K);
+    return R3D_ERR_ARG;
+  }
+  const r3d_segmap cs{clouds_a, clouds_b};
+  if (!cs.covers(B)) {
+    r3d_set_error("%s: %d clouds are not whole segments of %d + %d clouds", fn, B, clouds_a, clouds_b);
+    return R3D_ERR_ARG;
+  }
+  if ((long)B * N * K >= 0x7fffffffL) {
+    r3d_set_error("%s: B*N*K = %ld edges exceed the 31-bit edge ids", fn, (long)B * N * K);
     return R3D_ERR_ARG;
   }
   return 0;
 }
-static int et_grid(long units) { return (int)(units < ET_MAXBLK ? units : ET_MAXBLK); }
-// dynamic LDS above 64 KB (K > 20) needs the attribute on every instance of the forward kernel
-static int et_fwd_lds_attr(size_t lds) {
-  static size_t done = 0;
-  if (lds <= done) return 0;
-  hipError_t e0 = hipFuncSetAttribute((const void*)r3d_edgeconv_train_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipError_t e1 = hipFuncSetAttribute((const void*)r3d_edgeconv_train_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e0 != hipSuccess || e1 != hipSuccess) {
-    r3d_set_error("r3d_edgeconv_train_fwd: cannot reserve %zu B of LDS", lds);
-    return R3D_ERR_LAUNCH;
-  }
-  done = lds;
-  return 0;
+static int et_chunks(int B, int N) { return B * EcGeom::make(N).cpc; }
+
+// floats of the scratch of the training-mode EdgeConv passes over B clouds of N points: one dW2 partial per workgroup
+// and one statistics partial per chunk
+extern "C" long r3d_edgeconv_train_ws_words(int B, int N) { return (long)ET_MAXBLK * 4096 + (long)et_chunks(B, N) * 128 + 64; }
+
+// launch the per-segment reduction of [chunk][2][64] partials -> out [seg][2][64]
+static void et_reduce_chunks(const float* part, int N, int clouds_a, int clouds_b, int n_seg, float* out, hipStream_t st) {
+  const int cpc = EcGeom::make(N).cpc;
+  hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(128 / 64, n_seg), dim3(1024), 0, st, part, clouds_a * cpc, clouds_b * cpc, 128,
+                     out, 128L, 128, (float*)nullptr, 0L);
 }
 
-extern "C" long r3d_edgeconv_train_ws_words(void) { return (long)(ET_MAXBLK + 1) * ET_PART + 64; }
-
-// sums_out [2][64] = (sum e1, sum e1^2) over all B*N*K edges
-extern "C" int r3d_edge_stats1(const float* PQ, const int32_t* idx, int B, int N, int K, float* sums_out, float* ws,
-                               void* stream) {
+// sums_out [seg][2][64] = (sum e1, sum e1^2) over the edges of every segment of clouds (clouds_a, clouds_b alternating;
+// clouds_b == 0: segments of clouds_a clouds)
+extern "C" int r3d_edge_stats1(const float* PQ, const int32_t* idx, int B, int N, int K, int clouds_a, int clouds_b,
+                               float* sums_out, float* ws, void* stream) {
   R3D_REQUIRE(PQ && idx && sums_out && ws, "r3d_edge_stats1: null pointer");
-  int rc = et_check("r3d_edge_stats1", B, N, K);
+  int rc = et_check("r3d_edge_stats1", B, N, K, clouds_a, clouds_b);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  const int grid = 1024;
+  const EcGeom gm = EcGeom::make(N);
+  const int n_chunks = et_chunks(B, N);
+  const int grid = (int)(n_chunks < 2048 ? n_chunks : 2048);
 #define E2_CASE(RT) \
-  case RT: hipLaunchKernelGGL(r3d_edge_stats1_kernel<RT>, dim3(grid), dim3(256), 0, st, PQ, idx, N, (long)B * N, ws); break
+  case RT: hipLaunchKernelGGL(r3d_edge_stats1_kernel<RT>, dim3(grid), dim3(256), 0, st, PQ, idx, gm, n_chunks, ws); break
   switch (K / 4) {
     E2_CASE(1); E2_CASE(2); E2_CASE(3); E2_CASE(4); E2_CASE(5); E2_CASE(6); E2_CASE(7); E2_CASE(8);
   }
 #undef E2_CASE
-  hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(128 / 64), dim3(1024), 0, st, ws, grid, 128, sums_out, 128, nullptr);
+  et_reduce_chunks(ws, N, clouds_a, clouds_b, r3d_segmap{clouds_a, clouds_b}.n_seg(B), sums_out, st);
   R3D_LAUNCH_CHECK("r3d_edge_stats1");
   return R3D_OK;
 }
 
-// mode 1: sums_out [2][64] = (sum z2, sum z2^2); mode 0: out (B*N, ldo), argmax (B*N,64) int32, zmax (B*N,64)
-extern "C" int r3d_edgeconv_train_fwd(const float* PQ, const int32_t* idx, const float* s1, const float* t1,
-                                      const float* W2, const float* s2, const float* t2, int mode, float* out, long ldo,
-                                      int B, int N, int K, int32_t* argmax_out, float* zmax_out, float* sums_out,
-                                      float* ws, void* stream) {
-  R3D_REQUIRE(PQ && idx && s1 && t1 && W2 && ws, "r3d_edgeconv_train_fwd: null pointer");
-  int rc = et_check("r3d_edgeconv_train_fwd", B, N, K);
-  if (rc) return rc;
-  const int waves = ET_PTS * K / 32;
-  const size_t lds = sizeof(float) * ((size_t)ET_PTS * K * ET_LD + 64 * ET_LD);
-  const long units = (long)B * N / ET_PTS;
-  const int grid = et_grid(units);
-  hipStream_t st = (hipStream_t)stream;
-  rc = et_fwd_lds_attr(lds);
-  if (rc) return rc;
-  if (mode == 1) {
-    R3D_REQUIRE(sums_out, "r3d_edgeconv_train_fwd: mode 1 needs sums_out");
-    hipLaunchKernelGGL(r3d_edgeconv_train_fwd_kernel<1>, dim3(grid), dim3(64 * waves), lds, st, PQ, idx, s1, t1, W2, s2, t2,
-                       out, ldo, N, K, (long)B * N, argmax_out, zmax_out, ws);
-    hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(128 / 64), dim3(1024), 0, st, ws, grid, 128, sums_out, 128, nullptr);
-  } else {
-    R3D_REQUIRE(out && s2 && t2 && ldo >= 64, "r3d_edgeconv_train_fwd: mode 0 needs out, s2, t2");
-    hipLaunchKernelGGL(r3d_edgeconv_train_fwd_kernel<0>, dim3(grid), dim3(64 * waves), lds, st, PQ, idx, s1, t1, W2, s2, t2,
-                       out, ldo, N, K, (long)B * N, argmax_out, zmax_out, ws);
-  }
-  R3D_LAUNCH_CHECK("r3d_edgeconv_train_fwd");
-  return R3D_OK;
-}
-
 template <int RT>
-static int fwd2_launch_rt(long units, hipStream_t st, const float* PQ, const int32_t* idx, const float* s1, const float* t1,
-                          const float* W2, int N, long total_points, int32_t* argmax, float* zmax, float* zmin,
-                          int32_t* argmin, float* ws, int* grid_out) {
+static int fwd2_launch_rt(int n_chunks, hipStream_t st, const float* PQ, const int32_t* idx, const float* s1, const float* t1,
+                          long bn_stride, const float* W2, EcGeom gm, r3d_segmap cs, int32_t* argmax, float* zmax, float* zmin,
+                          int32_t* argmin, float* ws) {
   const size_t lds = sizeof(float) * ((size_t)2 * 16 * RT * E2_LD);
   static int resident = 0;
   if (!resident) {
     resident = e2_resident_blocks(r3d_edgeconv_train_fwd2_kernel<RT>, lds, ET_MAXBLK);
     R3D_REQUIRE(resident > 0, "r3d_edgeconv_train_fwd_minmax: cannot reserve %zu B of LDS", lds);
   }
-  const int grid = (int)(units < resident ? units : resident);
-  hipLaunchKernelGGL(r3d_edgeconv_train_fwd2_kernel<RT>, dim3(grid), dim3(256), lds, st, PQ, idx, s1, t1, W2, N, total_points,
-                     argmax, zmax, zmin, argmin, ws);
-  *grid_out = grid;
+  const int grid = (int)(n_chunks < resident ? n_chunks : resident);
+  hipLaunchKernelGGL(r3d_edgeconv_train_fwd2_kernel<RT>, dim3(grid), dim3(256), lds, st, PQ, idx, s1, t1, bn_stride, W2, gm, cs,
+                     n_chunks, argmax, zmax, zmin, argmin, ws);
   return R3D_OK;
 }
-static int fwd2_launch(int K, long units, hipStream_t st, const float* PQ, const int32_t* idx, const float* s1, const float* t1,
-                       const float* W2, int N, long total_points, int32_t* argmax, float* zmax, float* zmin, int32_t* argmin,
-                       float* ws, int* grid_out) {
-#define E2_CASE(RT)                                                                                                       \
-  case RT:                                                                                                                \
-    return fwd2_launch_rt<RT>(units, st, PQ, idx, s1, t1, W2, N, total_points, argmax, zmax, zmin, argmin, ws, grid_out)
+
+// One-pass training forward (r3d_edgeconv_train_fwd2_kernel): sums_out [seg][2][64] = (sum z2, sum z2^2) over the edges of
+// every segment; zmax / zmin / argmax / argmin (B*N, 64) per point and channel.  s1 / t1 of segment s at + s * bn_stride.
+// Follow with r3d_bn_fold_seg and r3d_edge_select.
+extern "C" int r3d_edgeconv_train_fwd_minmax(const float* PQ, const int32_t* idx, const float* s1, const float* t1,
+                                             long bn_stride, const float* W2, int B, int N, int K, int clouds_a, int clouds_b,
+                                             float* zmax, float* zmin, int32_t* argmax, int32_t* argmin, float* sums_out,
+                                             float* ws, void* stream) {
+  R3D_REQUIRE(PQ && idx && s1 && t1 && W2 && zmax && zmin && argmax && argmin && sums_out && ws,
+              "r3d_edgeconv_train_fwd_minmax: null pointer");
+  int rc = et_check("r3d_edgeconv_train_fwd_minmax", B, N, K, clouds_a, clouds_b);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const EcGeom gm = EcGeom::make(N);
+  const r3d_segmap cs{clouds_a, clouds_b};
+  const int n_chunks = et_chunks(B, N);
+#define E2_CASE(RT)                                                                                                    \
+  case RT:                                                                                                             \
+    rc = fwd2_launch_rt<RT>(n_chunks, st, PQ, idx, s1, t1, bn_stride, W2, gm, cs, argmax, zmax, zmin, argmin, ws);      \
+    break
   switch (K / 4) {
     E2_CASE(1); E2_CASE(2); E2_CASE(3); E2_CASE(4); E2_CASE(5); E2_CASE(6); E2_CASE(7); E2_CASE(8);
   }
 #undef E2_CASE
-  r3d_set_error("r3d_edgeconv_train_fwd_minmax: unsupported K=%d", K);
-  return R3D_ERR_ARG;
-}
-
-// One-pass training forward (r3d_edgeconv_train_fwd2_kernel): sums_out [2][64] = (sum z2, sum z2^2) over all edges; zmax / zmin /
-// argmax / argmin (B*N, 64) per point and channel.  Follow with r3d_bn_fold and r3d_edge_select.
-extern "C" int r3d_edgeconv_train_fwd_minmax(const float* PQ, const int32_t* idx, const float* s1, const float* t1,
-                                             const float* W2, int B, int N, int K, float* zmax, float* zmin,
-                                             int32_t* argmax, int32_t* argmin, float* sums_out, float* ws, void* stream) {
-  R3D_REQUIRE(PQ && idx && s1 && t1 && W2 && zmax && zmin && argmax && argmin && sums_out && ws,
-              "r3d_edgeconv_train_fwd_minmax: null pointer");
-  int rc = et_check("r3d_edgeconv_train_fwd_minmax", B, N, K);
   if (rc) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  int grid = 0;
-  rc = fwd2_launch(K, (long)B * N / E2_PTS, st, PQ, idx, s1, t1, W2, N, (long)B * N, argmax, zmax, zmin, argmin, ws, &grid);
-  if (rc) return rc;
-  hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(128 / 64), dim3(1024), 0, st, ws, grid, 128, sums_out, 128, nullptr);
+  et_reduce_chunks(ws, N, clouds_a, clouds_b, cs.n_seg(B), sums_out, st);
   R3D_LAUNCH_CHECK("r3d_edgeconv_train_fwd_minmax");
   return R3D_OK;
 }
 
 // out[m][c] = lrelu(s2[c] * z + t2[c]) with z = zmax (s2[c] >= 0) or zmin (s2[c] < 0); IN PLACE zmax[m][c] := z and
 // argmax[m][c] := position of that edge (what the backward pass consumes).  Equal activations keep the
-// lowest edge position, like the reference's max over the K axis (dgcnn.py:78).
+// lowest edge position, like the reference's max over the K axis (dgcnn.py:78).  s2 / t2 of the row's segment.
 __global__ void r3d_edge_select_kernel(float* __restrict__ zmax, const float* __restrict__ zmin, int* __restrict__ argmax,
                                        const int* __restrict__ argmin, const float* __restrict__ s2,
-                                       const float* __restrict__ t2, long M, float* __restrict__ out, long ldo) {
+                                       const float* __restrict__ t2, long bn_stride, r3d_segmap sm /* rows */, long M,
+                                       float* __restrict__ out, long ldo) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M * 64) return;
   const int c = (int)(i & 63);
   const long m = i >> 6;
-  const float sc = s2[c];
+  const long bo = (long)sm.seg_of_row32((int)m) * bn_stride + c;
+  const float sc = s2[bo];
   const bool up = sc >= 0.f;
   const float z = up ? zmax[i] : zmin[i];
   if (!up) { zmax[i] = z; argmax[i] = argmin[i]; }
-  out[m * ldo + c] = lrelu(sc * z + t2[c]);
+  out[m * ldo + c] = lrelu(sc * z + t2[bo]);
 }
 extern "C" int r3d_edge_select(float* zmax, const float* zmin, int32_t* argmax, const int32_t* argmin, const float* s2,
-                               const float* t2, long M, float* out, long ldo, void* stream) {
+                               const float* t2, long bn_stride, long M, long rows_a, long rows_b, float* out, long ldo,
+                               void* stream) {
   R3D_REQUIRE(zmax && zmin && argmax && argmin && s2 && t2 && out && M > 0 && ldo >= 64, "r3d_edge_select: bad arguments");
+  const r3d_segmap sm{rows_a, rows_b};
+  R3D_REQUIRE(sm.covers(M), "r3d_edge_select: %ld rows are not whole segments of %ld + %ld rows", M, rows_a, rows_b);
   hipLaunchKernelGGL(r3d_edge_select_kernel, dim3(r3d_cdiv(M * 64, 256)), dim3(256), 0, (hipStream_t)stream, zmax, zmin,
-                     argmax, argmin, s2, t2, M, out, ldo);
+                     argmax, argmin, s2, t2, bn_stride, sm, M, out, ldo);
   R3D_LAUNCH_CHECK("r3d_edge_select");
   return R3D_OK;
 }
 
 template <int RT>
-static int bwd1_launch_rt(long units, hipStream_t st, const float* PQ, const int32_t* idx, const float* s1, const float* t1,
-                          const float* mean1, const float* invstd1, const float* W2, const float* s2, const float* t2,
-                          const float* mean2, const float* invstd2, const float* bn2_sums, const float* dout, long lddo,
-                          const int32_t* argmax, int N, long total_points, float* DY1, float* BE, float* ws, int* grid_out) {
-  const size_t lds = sizeof(float) * ((size_t)2 * 16 * RT * E2_LD + 2 * E2_PTS * 64);
-  static int resident = 0;  // workgroups the chip holds at once (persistent loop over the units)
+static int bwd1_launch_rt(int n_chunks, hipStream_t st, const float* PQ, const int32_t* idx, EcBn bn, const float* W2,
+                          const float* bn2_sums, const float* dout, long lddo, const int32_t* argmax, EcGeom gm, r3d_segmap cs,
+                          float* DY1, float* BE, float* part_dw, float* part_bn, int* grid_out) {
+  const size_t lds = sizeof(float) * ((size_t)2 * 16 * RT * E2_LD + 2 * E2_PTS * 64 + 6 * 64);
+  static int resident = 0;  // workgroups the chip holds at once (persistent loop over the chunks)
   if (!resident) {
     resident = e2_resident_blocks(r3d_edgeconv_bwd1_kernel<RT>, lds, ET_MAXBLK);
     R3D_REQUIRE(resident > 0, "r3d_edgeconv_bwd: cannot reserve %zu B of LDS", lds);
   }
-  const int grid = (int)(units < resident ? units : resident);
-  hipLaunchKernelGGL(r3d_edgeconv_bwd1_kernel<RT>, dim3(grid), dim3(256), lds, st, PQ, idx, s1, t1, mean1, invstd1, W2, s2, t2,
-                     mean2, invstd2, bn2_sums, dout, lddo, argmax, N, total_points, DY1, BE, ws);
+  const int grid = (int)(n_chunks < resident ? n_chunks : resident);
+  hipLaunchKernelGGL(r3d_edgeconv_bwd1_kernel<RT>, dim3(grid), dim3(256), lds, st, PQ, idx, bn, W2, bn2_sums, dout, lddo, argmax,
+                     gm, cs, n_chunks, DY1, BE, part_dw, part_bn);
   *grid_out = grid;
   return R3D_OK;
-}
-static int bwd1_launch(int K, long units, hipStream_t st, const float* PQ, const int32_t* idx, const float* s1, const float* t1,
-                       const float* mean1, const float* invstd1, const float* W2, const float* s2, const float* t2,
-                       const float* mean2, const float* invstd2, const float* bn2_sums, const float* dout, long lddo,
-                       const int32_t* argmax, int N, long total_points, float* DY1, float* BE, float* ws, int* grid_out) {
-#define E2_CASE(RT)                                                                                                       \
-  case RT:                                                                                                                \
-    return bwd1_launch_rt<RT>(units, st, PQ, idx, s1, t1, mean1, invstd1, W2, s2, t2, mean2, invstd2, bn2_sums, dout, lddo, \
-                              argmax, N, total_points, DY1, BE, ws, grid_out)
-  switch (K / 4) {
-    E2_CASE(1); E2_CASE(2); E2_CASE(3); E2_CASE(4); E2_CASE(5); E2_CASE(6); E2_CASE(7); E2_CASE(8);
-  }
-#undef E2_CASE
-  r3d_set_error("r3d_edgeconv_bwd: unsupported K=%d", K);
-  return R3D_ERR_ARG;
 }
 
 // Reverse neighbour list of a layer's kNN lists (used by r3d_edgeconv_bwd): rev_ws = B*N + 1 offsets followed by B*N*K
@@ -789,7 +721,8 @@ static int bwd1_launch(int K, long units, hipStream_t st, const float* PQ, const
 extern "C" long r3d_edge_reverse_ws_words(int B, int N, int K) { return (long)B * N + 1 + (long)B * N * K + 16; }
 extern "C" int r3d_edge_reverse(const int32_t* idx, int B, int N, int K, int32_t* rev_ws, long ws_words, void* stream) {
   R3D_REQUIRE(idx && rev_ws, "r3d_edge_reverse: null pointer");
-  R3D_REQUIRE(B > 0 && N > 0 && K > 0 && (long)B * N * K < 0x7fffffffL, "r3d_edge_reverse: bad shape B=%d N=%d K=%d", B, N, K);
+  R3D_REQUIRE(B > 0 && B <= 65535 && N > 0 && K > 0 && (long)B * N * K < 0x7fffffffL, "r3d_edge_reverse: bad shape B=%d N=%d K=%d",
+              B, N, K);
   R3D_REQUIRE(ws_words >= r3d_edge_reverse_ws_words(B, N, K), "r3d_edge_reverse: workspace of %ld words is shorter than "
               "r3d_edge_reverse_ws_words(%d, %d, %d)", ws_words, B, N, K);
   hipLaunchKernelGGL(r3d_edge_reverse_kernel, dim3(r3d_cdiv(N, RV_RANGE), B), dim3(1024), 0, (hipStream_t)stream, idx, N, K, B,
@@ -798,41 +731,50 @@ extern "C" int r3d_edge_reverse(const int32_t* idx, int B, int N, int K, int32_t
   return R3D_OK;
 }
 
-// Backward.  bn2_sums [2][64] = (sum dy2, sum dy2*zhat2) (from the point-level winners, computed by the
-// caller with r3d_colstats mode 1 on zmax).  Outputs: dW2 (64,64), bn1_sums [2][64] (sum dy1, sum dy1*ehat1),
-// dPQ (B*N,128) (every entry written).  Scratch: DY1 B*N*K*64 floats, BE B*N*128 floats; rev_ws from r3d_edge_reverse
-// on the same idx.
-// r3d_edgeconv_bwd_at: the same for clouds [b0, b0 + B) of a batch of B_total clouds whose reverse list rev_ws was built
-// in ONE r3d_edge_reverse call (every other pointer is this call's own clouds): the support and the query clouds of a
-// training episode have separate BatchNorm statistics, hence separate calls, but share the list build.
-extern "C" int r3d_edgeconv_bwd_at(const float* PQ, const int32_t* idx, const float* s1, const float* t1, const float* mean1,
-                                   const float* invstd1, const float* W2, const float* s2, const float* t2,
-                                   const float* mean2, const float* invstd2, const float* bn2_sums, const float* dout,
-                                   long lddo, const int32_t* argmax, int B, int N, int K, float* DY1, float* BE,
-                                   const int32_t* rev_ws, int B_total, int b0, float* dW2, float* bn1_sums, float* dPQ,
-                                   float* ws, void* stream) {
-  R3D_REQUIRE(b0 >= 0 && B > 0 && b0 + B <= B_total, "r3d_edgeconv_bwd_at: clouds [%d, %d) of %d", b0, b0 + B, B_total);
+// Backward over all B clouds of a batch.  The BatchNorm vectors of both edge layers (s1 .. invstd2) hold one set per
+// segment at + s * bn_stride; bn2_sums [seg][2][64] = (sum dy2, sum dy2*zhat2) of every segment (from the point-level
+// winners, computed by the caller with r3d_colstats_seg mode 1 on zmax).  Outputs: dW2 (64,64) summed over the WHOLE batch,
+// bn1_sums [seg][2][64] (sum dy1, sum dy1*ehat1), dPQ (B*N,128) (every entry written).  Scratch: DY1 B*N*K*64 floats, BE
+// B*N*128 floats, ws r3d_edgeconv_train_ws_words(B, N); rev_ws from r3d_edge_reverse on the same idx.
+extern "C" int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float* s1, const float* t1, const float* mean1,
+                                const float* invstd1, const float* W2, const float* s2, const float* t2, const float* mean2,
+                                const float* invstd2, long bn_stride, const float* bn2_sums, const float* dout, long lddo,
+                                const int32_t* argmax, int B, int N, int K, int clouds_a, int clouds_b, float* DY1, float* BE,
+                                const int32_t* rev_ws, float* dW2, float* bn1_sums, float* dPQ, float* ws, void* stream) {
   R3D_REQUIRE(PQ && idx && s1 && t1 && mean1 && invstd1 && W2 && s2 && t2 && mean2 && invstd2 && bn2_sums && dout &&
                   argmax && DY1 && BE && rev_ws && dW2 && bn1_sums && dPQ && ws,
               "r3d_edgeconv_bwd: null pointer");
-  int rc = et_check("r3d_edgeconv_bwd", B, N, K);
+  int rc = et_check("r3d_edgeconv_bwd", B, N, K, clouds_a, clouds_b);
   if (rc) return rc;
-  const long units = (long)B * N / E2_PTS;
+  const EcGeom gm = EcGeom::make(N);
+  const r3d_segmap cs{clouds_a, clouds_b};
+  const int n_chunks = et_chunks(B, N);
+  const int n_seg = cs.n_seg(B);
   hipStream_t st = (hipStream_t)stream;
+  float* part_dw = ws;
+  float* part_bn = ws + (long)ET_MAXBLK * 4096;
+  const EcBn bn{s1, t1, mean1, invstd1, s2, t2, mean2, invstd2, bn_stride};
   int grid = 0;
-  rc = bwd1_launch(K, units, st, PQ, idx, s1, t1, mean1, invstd1, W2, s2, t2, mean2, invstd2, bn2_sums, dout, lddo, argmax, N,
-                   (long)B * N, DY1, BE, ws, &grid);
+#define E2_CASE(RT)                                                                                                        \
+  case RT:                                                                                                                 \
+    rc = bwd1_launch_rt<RT>(n_chunks, st, PQ, idx, bn, W2, bn2_sums, dout, lddo, argmax, gm, cs, DY1, BE, part_dw, part_bn, \
+                            &grid);                                                                                        \
+    break
+  switch (K / 4) {
+    E2_CASE(1); E2_CASE(2); E2_CASE(3); E2_CASE(4); E2_CASE(5); E2_CASE(6); E2_CASE(7); E2_CASE(8);
+  }
+#undef E2_CASE
   if (rc) return rc;
-  // partial layout: dW2 (4096) | sum dy1 (64) | sum dy1*ehat1 (64)
-  hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(r3d_cdiv(ET_PART, 64)), dim3(1024), 0, st, ws, grid, ET_PART, dW2, 4096,
-                     bn1_sums);
-  const int32_t* rev_ptr = rev_ws + (long)b0 * N;
-  const int32_t* rev = rev_ws + (long)B_total * N + 1;
-  const int e_off = (int)((long)b0 * N * K);
-#define E2_CASE(RT)                                                                                                    \
-  case RT:                                                                                                             \
-    hipLaunchKernelGGL(r3d_edgeconv_bwd2_kernel<RT>, dim3(1024), dim3(256), 0, st, PQ, s1, mean1, invstd1, bn1_sums, DY1, BE, \
-                       rev_ptr, rev, e_off, (long)B * N, dPQ);                                                         \
+  hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(4096 / 64, 1), dim3(1024), 0, st, part_dw, grid, 0, 4096, dW2, 0L, 4096,
+                     (float*)nullptr, 0L);
+  et_reduce_chunks(part_bn, N, clouds_a, clouds_b, n_seg, bn1_sums, st);
+  const int32_t* rev_ptr = rev_ws;
+  const int32_t* rev = rev_ws + (long)B * N + 1;
+  const int grid2 = (int)(n_chunks < 4096 ? n_chunks : 4096);
+#define E2_CASE(RT)                                                                                                       \
+  case RT:                                                                                                                \
+    hipLaunchKernelGGL(r3d_edgeconv_bwd2_kernel<RT>, dim3(grid2), dim3(256), 0, st, PQ, s1, mean1, invstd1, bn_stride, bn1_sums, \
+                       DY1, BE, rev_ptr, rev, 0, gm, cs, n_chunks, dPQ);                                                  \
     break
   switch (K / 4) {
     E2_CASE(1); E2_CASE(2); E2_CASE(3); E2_CASE(4); E2_CASE(5); E2_CASE(6); E2_CASE(7); E2_CASE(8);
@@ -840,12 +782,4 @@ extern "C" int r3d_edgeconv_bwd_at(const float* PQ, const int32_t* idx, const fl
 #undef E2_CASE
   R3D_LAUNCH_CHECK("r3d_edgeconv_bwd");
   return R3D_OK;
-}
-extern "C" int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float* s1, const float* t1, const float* mean1,
-                                const float* invstd1, const float* W2, const float* s2, const float* t2,
-                                const float* mean2, const float* invstd2, const float* bn2_sums, const float* dout,
-                                long lddo, const int32_t* argmax, int B, int N, int K, float* DY1, float* BE,
-                                const int32_t* rev_ws, float* dW2, float* bn1_sums, float* dPQ, float* ws, void* stream) {
-  return r3d_edgeconv_bwd_at(PQ, idx, s1, t1, mean1, invstd1, W2, s2, t2, mean2, invstd2, bn2_sums, dout, lddo, argmax, B, N, K,
-                             DY1, BE, rev_ws, B, 0, dW2, bn1_sums, dPQ, ws, stream);
 }

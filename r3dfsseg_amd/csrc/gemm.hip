@@ -172,6 +172,23 @@ extern "C" int r3d_pointwise_conv_stats2(const float* X, long ldx, const float* 
   return r3d_colreduce(ws + (long)tiles_a * 2 * Co, r3d_cdiv(M, G_BM) - tiles_a, Co, sums_b, stream);
 }
 
+// ... and over the alternating segments of a batch of episodes (common.h: r3d_segmap; rows_a, rows_b multiples of the
+// 64-row tile, rows_b == 0: equal segments): ONE GEMM launch over all rows, sums_out [seg][2][Co] reduced per segment
+// from the tile partials.  A tile belongs to one segment and a segment's tiles are added relative to its first one, so
+// its statistics are bit for bit those of the episode running alone.
+extern "C" int r3d_colreduce_seg(const float* part, int count_a, int count_b, int n_seg, int C, float* sums_out, void* stream);
+extern "C" int r3d_pointwise_conv_stats_seg(const float* X, long ldx, const float* W, long M, int K, int Co, float* Out,
+                                            long ldo, long rows_a, long rows_b, float* sums_out, float* ws, void* stream) {
+  R3D_REQUIRE(sums_out && ws, "r3d_pointwise_conv_stats_seg: null pointer");
+  const r3d_segmap sm{rows_a, rows_b};
+  R3D_REQUIRE(sm.covers(M) && (sm.n_seg(M) == 1 || (rows_a % G_BM == 0 && rows_b % G_BM == 0)),
+              "r3d_pointwise_conv_stats_seg: %ld rows in segments of %ld + %ld rows (multiples of %d needed)", M, rows_a, rows_b,
+              G_BM);
+  int rc = pointwise_launch(X, ldx, W, M, K, Co, nullptr, nullptr, R3D_ACT_NONE, Out, ldo, 0, ws, stream);
+  if (rc) return rc;
+  return r3d_colreduce_seg(ws, r3d_cdiv(rows_a, G_BM), r3d_cdiv(rows_b, G_BM), sm.n_seg(M), Co, sums_out, stream);
+}
+
 // Out += act(scale * X W^T + shift): gradient accumulation into a (slice of a) wider buffer
 extern "C" int r3d_pointwise_conv_acc(const float* X, long ldx, const float* W, long M, int K, int Co,
                                       const float* scale, const float* shift, int act, float* Out,

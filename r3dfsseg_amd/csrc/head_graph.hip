@@ -23,12 +23,30 @@ typedef unsigned short hg_col_t; // CSR column ids: n_cap <= 32768 (checked at t
 #define HG_ROWS_PER_BLOCK_MIN 4 // CG SpMV: rows per 256-thread block (1 per wave; more when n_cap / 4 > HG_MAX_PART)
 #define HG_MAX_PART 2048        // max CG blocks
 
+// Batches of episodes (round 3): E label-propagation systems go through every launch of this file together --
+// blockIdx.y (or .z) is the system, its arrays sit `stride` further on than system 0's (HgEp: node / label / neighbour
+// ROWS, descriptor and status WORDS, and ONE stride in int32 words for everything carved out of the scratch).  The CG
+// iteration is then two launches for all E systems, each with its own convergence flag (a converged system's
+// workgroups return at once), and the SpMV streams E matrices: genuinely HBM bound instead of one 7 MB matrix that
+// sits in L2 while 18 workgroups wait on each other.
+struct HgEp {
+  long nodes, nbr, y, z, g, lam, dn;  // rows of nodes / nbr / Y / Z / G / lambda / dnodes between systems
+  long desc;                          // int32 words between the systems' (n_nodes, n_proto) descriptor words
+  long ws;                            // int32 words between the systems' scratch (a multiple of 4: float4 arrays inside)
+  long stats;                         // int32 words between the systems' {converged, iterations} pairs
+  long labels, logits, loss, pred;    // query labels (int64), logits (floats), loss (floats), predictions (int32) per system
+};
+#define HG_WS(p) p = (decltype(p))((const char*)(p) + (long)ep * st.ws * 4)
+#define HG_AT(p, stride) p += (long)ep * (stride)
+
 // ---------------------------------------------------------------------------
 // 2. bitmaps: outb[i] = { j : j in nbr(i) } ; sym[i] = outb[i] | { j : i in nbr(j) }
 // ---------------------------------------------------------------------------
 __global__ void r3d_graph_bits_kernel(const int* __restrict__ nbr, int kp1, const int* __restrict__ n_dev,
                                       int n_cap, int words, unsigned* __restrict__ outb,
-                                      unsigned* __restrict__ sym) {
+                                      unsigned* __restrict__ sym, HgEp st) {
+  const int ep = blockIdx.y;
+  nbr += (long)ep * st.nbr * kp1; HG_AT(n_dev, st.desc); HG_WS(outb); HG_WS(sym);
   const int n = min(*n_dev, n_cap);
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int k = kp1 - 1;
@@ -46,7 +64,9 @@ __global__ void r3d_graph_bits_kernel(const int* __restrict__ nbr, int kp1, cons
 // 3a. row lengths + exclusive scan (single workgroup; n_cap <= 32768)
 // ---------------------------------------------------------------------------
 __global__ void r3d_graph_rowlen_kernel(const unsigned* __restrict__ sym, int words,
-                                        const int* __restrict__ n_dev, int n_cap, int* __restrict__ row_len) {
+                                        const int* __restrict__ n_dev, int n_cap, int* __restrict__ row_len, HgEp st) {
+  const int ep = blockIdx.y;
+  HG_WS(sym); HG_AT(n_dev, st.desc); HG_WS(row_len);
   const int n = min(*n_dev, n_cap);
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -59,8 +79,10 @@ __global__ void r3d_graph_rowlen_kernel(const unsigned* __restrict__ sym, int wo
   if (lane == 0) row_len[row] = c;
 }
 
-__global__ __launch_bounds__(1024) void r3d_scan_kernel(const int* __restrict__ in, int n, int* __restrict__ out) {
-  // exclusive scan of in[0..n) -> out[0..n], out[n] = total.  One workgroup.
+__global__ __launch_bounds__(1024) void r3d_scan_kernel(const int* __restrict__ in, int n, int* __restrict__ out, HgEp st) {
+  // exclusive scan of in[0..n) -> out[0..n], out[n] = total.  One workgroup per system.
+  const int ep = blockIdx.x;
+  HG_WS(in); HG_WS(out);
   __shared__ int wave_tot[16];
   __shared__ int carry_s;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -97,7 +119,10 @@ __global__ __launch_bounds__(1024) void r3d_scan_kernel(const int* __restrict__ 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void r3d_graph_cols_kernel(const unsigned* __restrict__ sym, int words,
                                                              const int* __restrict__ n_dev, int n_cap,
-                                                             const int* __restrict__ row_ptr, hg_col_t* __restrict__ col) {
+                                                             const int* __restrict__ row_ptr, hg_col_t* __restrict__ col,
+                                                             HgEp st) {
+  const int ep = blockIdx.y;
+  HG_WS(sym); HG_AT(n_dev, st.desc); HG_WS(row_ptr); HG_WS(col);
   const int n = min(*n_dev, n_cap);
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -139,9 +164,12 @@ __global__ __launch_bounds__(256) void r3d_graph_cols_kernel(const unsigned* __r
 __global__ __launch_bounds__(256) void r3d_graph_weights_kernel(
     const float* __restrict__ nodes, long ldn, int D, const unsigned* __restrict__ outb, int words,
     const int* __restrict__ n_dev, int n_cap, const int* __restrict__ row_ptr, const hg_col_t* __restrict__ col,
-    float sigma, float* __restrict__ val, float* __restrict__ dinv, float* __restrict__ wdir /* [nnz][2] */) {
+    float sigma, float* __restrict__ val, float* __restrict__ dinv, float* __restrict__ wdir /* [nnz][2] */, HgEp st) {
   __shared__ __attribute__((aligned(16))) float xs[256];
   __shared__ float wsum[4];
+  const int ep = blockIdx.y;
+  nodes += (long)ep * st.nodes * ldn; HG_WS(outb); HG_AT(n_dev, st.desc); HG_WS(row_ptr); HG_WS(col); HG_WS(val); HG_WS(dinv);
+  HG_WS(wdir);
   const int n = min(*n_dev, n_cap);
   const int w = threadIdx.x >> 6;
   const int i = blockIdx.x;
@@ -209,7 +237,9 @@ __global__ __launch_bounds__(256) void r3d_graph_weights_kernel(
 // 4. S_ij = (dinv_i * A_ij) * dinv_j   (mpti.py:771-772: two diagonal matmuls)
 __global__ void r3d_graph_normalize_kernel(const int* __restrict__ row_ptr, const hg_col_t* __restrict__ col,
                                            const float* __restrict__ dinv, const int* __restrict__ n_dev,
-                                           int n_cap, float* __restrict__ val) {
+                                           int n_cap, float* __restrict__ val, HgEp st) {
+  const int ep = blockIdx.y;
+  HG_WS(row_ptr); HG_WS(col); HG_WS(dinv); HG_AT(n_dev, st.desc); HG_WS(val);
   const int n = min(*n_dev, n_cap);
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -309,8 +339,12 @@ static __device__ __forceinline__ float f4_get(const float4& v, int c) { return 
 #define HG_SEED_PITCH 257
 __global__ __launch_bounds__(256) void r3d_cg_aggregate_kernel(const float* __restrict__ nodes, long ldn, int D,
                                                                const int* __restrict__ n_dev, const int* __restrict__ n_proto_dev,
-                                                               int n_cap, int rows_per_wave, int* __restrict__ agg) {
+                                                               int n_cap, int rows_per_wave, int* __restrict__ agg, HgEp st) {
   extern __shared__ float smem[];           // seeds [HG_M][pitch] + 4 node rows [D]
+  {
+    const int ep = blockIdx.y;
+    nodes += (long)ep * st.nodes * ldn; HG_AT(n_dev, st.desc); HG_AT(n_proto_dev, st.desc); HG_WS(agg);
+  }
   const int pitch = D | 1;
   float* seeds = smem;
   float* xrow = smem + HG_M * pitch + (threadIdx.x >> 6) * D;
@@ -383,8 +417,12 @@ __global__ __launch_bounds__(256) void r3d_cg_aggregate_kernel(const float* __re
 __global__ __launch_bounds__(256) void r3d_cg_mw_kernel(const int* __restrict__ row_ptr, const hg_col_t* __restrict__ col,
                                                         const float* __restrict__ val, const float* __restrict__ dinv,
                                                         const int* __restrict__ agg, const int* __restrict__ n_dev, int n_cap,
-                                                        float alpha_lp, int rows_per_wave, float* __restrict__ MW) {
+                                                        float alpha_lp, int rows_per_wave, float* __restrict__ MW, HgEp st) {
   __shared__ float2 pairs[4][256];
+  {
+    const int ep = blockIdx.y;
+    HG_WS(row_ptr); HG_WS(col); HG_WS(val); HG_WS(dinv); HG_WS(agg); HG_AT(n_dev, st.desc); HG_WS(MW);
+  }
   const int n = min(*n_dev, n_cap);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int row0 = (blockIdx.x * 4 + w) * rows_per_wave;
@@ -427,8 +465,12 @@ __global__ __launch_bounds__(256) void r3d_cg_mw_kernel(const int* __restrict__ 
 // coefficient is then always zero).
 __global__ __launch_bounds__(128) void r3d_cg_epart_kernel(const float* __restrict__ MW, const float* __restrict__ dinv,
                                                            const int* __restrict__ agg, const int* __restrict__ n_dev, int n_cap,
-                                                           float* __restrict__ Epart /* [HG_EBLOCKS][HG_M][HG_M] */) {
+                                                           float* __restrict__ Epart /* [HG_EBLOCKS][HG_M][HG_M] */, HgEp st) {
   __shared__ float Ew[2][HG_M][HG_M];  // one accumulator matrix per wave (lane = column: conflict free), 32 KB
+  {
+    const int ep = blockIdx.y;
+    HG_WS(MW); HG_WS(dinv); HG_WS(agg); HG_AT(n_dev, st.desc); HG_WS(Epart);
+  }
   const int n = min(*n_dev, n_cap);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int a = 0; a < HG_M; ++a) Ew[w][a][lane] = 0.f;
@@ -457,8 +499,12 @@ __global__ __launch_bounds__(128) void r3d_cg_epart_kernel(const float* __restri
 // E^-1 in fp64 by Gauss-Jordan elimination on [E | I].  Thread (row = tid >> 4, column group = 4 * (tid & 15)) keeps its
 // 4 + 4 entries in registers for the whole elimination; per step the owners of pivot row k and of column k publish
 // them through double-buffered LDS, so a step costs ONE workgroup barrier.
-__global__ __launch_bounds__(1024) void r3d_cg_einv_kernel(const float* __restrict__ Epart, float* __restrict__ Einv) {
+__global__ __launch_bounds__(1024) void r3d_cg_einv_kernel(const float* __restrict__ Epart, float* __restrict__ Einv, HgEp st) {
   __shared__ double S0[HG_M][HG_M + 1];
+  {
+    const int ep = blockIdx.x;
+    HG_WS(Epart); HG_WS(Einv);
+  }
   __shared__ double prow[2][2 * HG_M];  // pivot row of [A | B], already scaled by 1 / pivot
   __shared__ double pcol[2][HG_M];      // column k of A
   const int tid = threadIdx.x;
@@ -687,7 +733,12 @@ __global__ __launch_bounds__(256) void r3d_cg_init_kernel(const float4* __restri
                                                           float4* __restrict__ x, float4* __restrict__ r,
                                                           float4* __restrict__ p, float4* __restrict__ q,
                                                           float* __restrict__ part, const float* __restrict__ Einv, float tol2,
-                                                          CgState* __restrict__ cg) {
+                                                          CgState* __restrict__ cg, HgEp st, long b_stride, long x_stride) {
+  {
+    const int ep = blockIdx.y;  // B, x: float4 rows (right-hand side and solution of the system)
+    HG_AT(B, b_stride); HG_WS(dinv); HG_WS(agg); HG_WS(MW); HG_AT(n_dev, st.desc); HG_AT(x, x_stride); HG_WS(r); HG_WS(p); HG_WS(q);
+    HG_WS(part); HG_WS(Einv); HG_WS(cg);
+  }
   __shared__ float4 sm[4];
   __shared__ float4 rs[HG_UROWS];
   __shared__ float us[HG_UROWS];
@@ -768,10 +819,16 @@ __global__ __launch_bounds__(256) void r3d_cg_spmv_kernel(
     const float* __restrict__ dinv, const int* __restrict__ agg, const float* __restrict__ MW,
     const int* __restrict__ n_dev, int n_cap, float alpha_lp, int it, int rows_per_block,
     const float4* __restrict__ r, float4* __restrict__ p, float4* __restrict__ q,
-    float4* __restrict__ part_pq, const CgState* __restrict__ cg) {
+    float4* __restrict__ part_pq, const CgState* __restrict__ cg, HgEp st) {
   __shared__ float4 mu_s[HG_M];
   __shared__ float4 wsum[4];
-  if (cg->done) return;
+  {
+    const int ep = blockIdx.y;
+    HG_WS(cg);
+    if (cg->done) return;  // this system has converged: the launch goes on for the others
+    HG_WS(row_ptr); HG_WS(col); HG_WS(val); HG_WS(dinv); HG_WS(agg); HG_WS(MW); HG_AT(n_dev, st.desc); HG_WS(r); HG_WS(p);
+    HG_WS(q); HG_WS(part_pq);
+  }
   const int n = min(*n_dev, n_cap);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (threadIdx.x < HG_M) mu_s[threadIdx.x] = reinterpret_cast<const float4*>(cg->mu)[threadIdx.x];
@@ -854,7 +911,7 @@ __global__ __launch_bounds__(256) void r3d_cg_update_kernel(
     const int* __restrict__ n_dev, int n_cap, int it, int nblk_pq, const float* __restrict__ dinv, const int* __restrict__ agg,
     const float* __restrict__ MW, const float4* __restrict__ p, const float4* __restrict__ q, float4* __restrict__ x,
     float4* __restrict__ r, const float4* __restrict__ part_pq, float* __restrict__ part, const float* __restrict__ Einv,
-    float tol2, CgState* __restrict__ cg) {
+    float tol2, CgState* __restrict__ cg, HgEp st, long x_stride) {
   __shared__ float4 sm[4];
   __shared__ float4 rs[HG_UROWS];
   __shared__ float us[HG_UROWS];
@@ -864,6 +921,11 @@ __global__ __launch_bounds__(256) void r3d_cg_update_kernel(
   __shared__ float t_s[HG_M * HG_NC];
   __shared__ float rr_s[HG_NC];
   __shared__ int last_s;
+  {
+    const int ep = blockIdx.y;
+    HG_AT(n_dev, st.desc); HG_WS(dinv); HG_WS(agg); HG_WS(MW); HG_WS(p); HG_WS(q); HG_AT(x, x_stride); HG_WS(r); HG_WS(part_pq);
+    HG_WS(part); HG_WS(Einv); HG_WS(cg);
+  }
   const int row0 = blockIdx.x * HG_UROWS;
   const int i = row0 + threadIdx.x;
   const int ic = min(i, n_cap - 1);
@@ -918,8 +980,15 @@ __global__ __launch_bounds__(1024) void r3d_logits_ce_kernel(const float4* __res
                                                              int n_q, int N, int n_classes,
                                                              const long long* __restrict__ labels,
                                                              float* __restrict__ logits /* (n_q, n_classes, N) */,
-                                                             float* __restrict__ loss_out, int* __restrict__ pred_out) {
+                                                             float* __restrict__ loss_out, int* __restrict__ pred_out, HgEp st) {
   __shared__ float red[16];
+  {
+    const int ep = blockIdx.x;
+    HG_AT(Z, st.z); HG_AT(desc_nproto, st.desc); HG_AT(logits, st.logits);
+    if (labels) HG_AT(labels, st.labels);
+    if (loss_out) HG_AT(loss_out, st.loss);
+    if (pred_out) HG_AT(pred_out, st.pred);
+  }
   const int n_proto = *desc_nproto;
   float acc = 0.f;
   for (int e = threadIdx.x; e < n_q * N; e += blockDim.x) {
@@ -1010,9 +1079,16 @@ extern "C" int r3d_lp_ws_offsets(int n_cap, int kp1, long* out6) {
   return R3D_OK;
 }
 
+// {converged, iterations} of every system -> stats_out (stride st.stats words)
+__global__ void r3d_cg_stats_kernel(const CgState* __restrict__ cg, int* __restrict__ stats_out, HgEp st) {
+  const int ep = blockIdx.x;
+  HG_WS(cg); HG_AT(stats_out, st.stats);
+  if (threadIdx.x == 0) { stats_out[0] = cg->done; stats_out[1] = cg->iters; }
+}
+
 // coarse space of the graph r3d_label_propagate built: aggregates, M W, E^-1 (shared by forward and adjoint solve)
 static int lp_coarse_space(const LpWs& L, const float* nodes, long ldn, int D, const int32_t* n_dev, const int32_t* n_proto_dev,
-                           int n_cap, float alpha, hipStream_t st) {
+                           int n_cap, float alpha, int n_ep, const HgEp& ep, hipStream_t st) {
   const int agg_rpw = 4;  // 16 nodes per workgroup: the 64 seed rows are staged once per workgroup
   const size_t agg_lds = ((size_t)HG_M * (D | 1) + 4 * D) * sizeof(float);
   static bool lds_opt_in = false;
@@ -1020,19 +1096,20 @@ static int lp_coarse_space(const LpWs& L, const float* nodes, long ldn, int D, c
     hipFuncSetAttribute((const void*)r3d_cg_aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     lds_opt_in = true;
   }
-  hipLaunchKernelGGL(r3d_cg_aggregate_kernel, dim3(r3d_cdiv(n_cap, 4 * agg_rpw)), dim3(256), agg_lds, st, nodes, ldn, D, n_dev,
-                     n_proto_dev, n_cap, agg_rpw, L.agg);
-  hipLaunchKernelGGL(r3d_cg_mw_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, L.row_ptr, L.col, L.val, L.dinv, L.agg, n_dev,
-                     n_cap, alpha, 1, L.MW);
-  const int nblk_v = (int)hg_vblocks(n_cap);
-  hipLaunchKernelGGL(r3d_cg_epart_kernel, dim3(HG_EBLOCKS), dim3(128), 0, st, L.MW, L.dinv, L.agg, n_dev, n_cap, L.Epart);
-  hipLaunchKernelGGL(r3d_cg_einv_kernel, dim3(1), dim3(1024), 0, st, L.Epart, L.Einv);
+  hipLaunchKernelGGL(r3d_cg_aggregate_kernel, dim3(r3d_cdiv(n_cap, 4 * agg_rpw), n_ep), dim3(256), agg_lds, st, nodes, ldn, D,
+                     n_dev, n_proto_dev, n_cap, agg_rpw, L.agg, ep);
+  hipLaunchKernelGGL(r3d_cg_mw_kernel, dim3(r3d_cdiv(n_cap, 4), n_ep), dim3(256), 0, st, L.row_ptr, L.col, L.val, L.dinv, L.agg,
+                     n_dev, n_cap, alpha, 1, L.MW, ep);
+  hipLaunchKernelGGL(r3d_cg_epart_kernel, dim3(HG_EBLOCKS, n_ep), dim3(128), 0, st, L.MW, L.dinv, L.agg, n_dev, n_cap, L.Epart,
+                     ep);
+  hipLaunchKernelGGL(r3d_cg_einv_kernel, dim3(n_ep), dim3(1024), 0, st, L.Epart, L.Einv, ep);
   return R3D_OK;
 }
 
-// two-level CG on the already built graph and coarse space: X = (I - alpha S)^-1 RHS
-static int lp_solve(const LpWs& L, const float* RHS, const int32_t* n_dev, int n_cap, float alpha, int max_iter, float tol,
-                    float* X, int32_t* stats_out, hipStream_t st) {
+// two-level CG on the already built graphs and coarse spaces: X = (I - alpha S)^-1 RHS for every system of the batch.
+// rhs_stride / x_stride: float4 rows between the systems' right-hand sides / solutions.
+static int lp_solve(const LpWs& L, const float* RHS, long rhs_stride, const int32_t* n_dev, int n_cap, float alpha, int max_iter,
+                    float tol, float* X, long x_stride, int32_t* stats_out, int n_ep, const HgEp& ep, hipStream_t st) {
   const int nblk_v = (int)hg_vblocks(n_cap);
   int rpb = HG_ROWS_PER_BLOCK_MIN;
   while (r3d_cdiv(n_cap, rpb) > HG_MAX_PART) rpb += 4;
@@ -1040,25 +1117,25 @@ static int lp_solve(const LpWs& L, const float* RHS, const int32_t* n_dev, int n
   R3D_REQUIRE(nblk_s <= HG_MAX_PART, "r3d_label_propagate: n_cap too large");
   float4* x = (float4*)X;
   const float tol2 = tol * tol;
-  r3d_zero_words(&L.cg->ticket, 1, st);
+  r3d_fill_words_ep(&L.cg->ticket, 0u, 1, n_ep, ep.ws, st);
   // partials of b -> (last workgroup) c0 = E^-1 W^T b ; x0 = W c0, r0 = b - (M W) c0 -> (last workgroup) mu, rz of iteration 0
   for (int mode = 0; mode < 2; ++mode)
-    hipLaunchKernelGGL(r3d_cg_init_kernel, dim3(nblk_v), dim3(256), 0, st, (const float4*)RHS, L.dinv, L.agg, L.MW, n_dev, n_cap,
-                       mode, x, L.r, L.p, L.q, L.part, L.Einv, tol2, L.cg);
+    hipLaunchKernelGGL(r3d_cg_init_kernel, dim3(nblk_v, n_ep), dim3(256), 0, st, (const float4*)RHS, L.dinv, L.agg, L.MW, n_dev,
+                       n_cap, mode, x, L.r, L.p, L.q, L.part, L.Einv, tol2, L.cg, ep, rhs_stride, x_stride);
   for (int it = 0; it < max_iter; ++it) {
-    hipLaunchKernelGGL(r3d_cg_spmv_kernel, dim3(nblk_s), dim3(256), 0, st, L.row_ptr, L.col, L.val, L.dinv, L.agg, L.MW, n_dev,
-                       n_cap, alpha, it, rpb, L.r, L.p, L.q, L.part_pq, L.cg);
-    hipLaunchKernelGGL(r3d_cg_update_kernel, dim3(nblk_v), dim3(256), 0, st, n_dev, n_cap, it, nblk_s, L.dinv, L.agg, L.MW, L.p,
-                       L.q, x, L.r, L.part_pq, L.part, L.Einv, tol2, L.cg);
+    hipLaunchKernelGGL(r3d_cg_spmv_kernel, dim3(nblk_s, n_ep), dim3(256), 0, st, L.row_ptr, L.col, L.val, L.dinv, L.agg, L.MW,
+                       n_dev, n_cap, alpha, it, rpb, L.r, L.p, L.q, L.part_pq, L.cg, ep);
+    hipLaunchKernelGGL(r3d_cg_update_kernel, dim3(nblk_v, n_ep), dim3(256), 0, st, n_dev, n_cap, it, nblk_s, L.dinv, L.agg, L.MW,
+                       L.p, L.q, x, L.r, L.part_pq, L.part, L.Einv, tol2, L.cg, ep, x_stride);
   }
-  if (stats_out) r3d_copy_words(stats_out, &L.cg->done, 2, st);
+  if (stats_out) hipLaunchKernelGGL(r3d_cg_stats_kernel, dim3(n_ep), dim3(64), 0, st, L.cg, stats_out, ep);
   return R3D_OK;
 }
 
-extern "C" int r3d_label_propagate(const float* nodes, long ldn, int D, const int32_t* nbr, int kp1,
-                                   const float* Y, const int32_t* n_dev, const int32_t* n_proto_dev, int n_cap, float sigma,
-                                   float alpha, int max_iter, float tol, float* Z, int32_t* ws, long ws_words,
-                                   int32_t* stats_out, void* stream) {
+static int label_propagate_impl(int n_ep, const HgEp& ep, const float* nodes, long ldn, int D, const int32_t* nbr, int kp1,
+                                const float* Y, const int32_t* n_dev, const int32_t* n_proto_dev, int n_cap, float sigma,
+                                float alpha, int max_iter, float tol, float* Z, int32_t* ws, long ws_words, int32_t* stats_out,
+                                void* stream) {
   R3D_REQUIRE(nodes && nbr && Y && n_dev && n_proto_dev && Z && ws, "r3d_label_propagate: null pointer");
   R3D_REQUIRE(n_cap > 0 && kp1 >= 2 && ws_words >= r3d_lp_ws_words(n_cap, kp1),
               "r3d_label_propagate: workspace of %ld words, r3d_lp_ws_words(%d, %d) = %ld needed", ws_words, n_cap, kp1,
@@ -1070,28 +1147,54 @@ extern "C" int r3d_label_propagate(const float* nodes, long ldn, int D, const in
   R3D_REQUIRE(max_iter > 0 && max_iter <= HG_MAX_ITER && sigma > 0.f, "r3d_label_propagate: bad solver parameters");
   R3D_REQUIRE(((uintptr_t)ws & 15) == 0 && ((uintptr_t)Y & 15) == 0 && ((uintptr_t)Z & 15) == 0,
               "r3d_label_propagate: ws, Y and Z must be 16-byte aligned");
+  R3D_REQUIRE(n_ep >= 1 && n_ep <= 4096 && (n_ep == 1 || ((ep.ws & 3) == 0 && ep.ws >= ws_words)),
+              "r3d_label_propagate: %d systems need a scratch stride that is a multiple of 4 words and >= the scratch size", n_ep);
   hipStream_t st = (hipStream_t)stream;
   const LpWs L = lp_carve(ws, n_cap, kp1);
   const long words = L.words;
-  r3d_zero_words(L.outb, 2L * n_cap * words, st);
+  r3d_fill_words_ep(L.outb, 0u, 2L * n_cap * words, n_ep, ep.ws, st);
   const long edges = (long)n_cap * (kp1 - 1);
-  hipLaunchKernelGGL(r3d_graph_bits_kernel, dim3(r3d_cdiv(edges, 256)), dim3(256), 0, st, nbr, kp1, n_dev, n_cap,
-                     (int)words, L.outb, L.sym);
-  hipLaunchKernelGGL(r3d_graph_rowlen_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, L.sym, (int)words, n_dev,
-                     n_cap, L.row_len);
-  hipLaunchKernelGGL(r3d_scan_kernel, dim3(1), dim3(1024), 0, st, L.row_len, n_cap, L.row_ptr);
-  hipLaunchKernelGGL(r3d_graph_cols_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, L.sym, (int)words, n_dev,
-                     n_cap, L.row_ptr, L.col);
-  hipLaunchKernelGGL(r3d_graph_weights_kernel, dim3(n_cap), dim3(256), 0, st, nodes, ldn, D, L.outb,
-                     (int)words, n_dev, n_cap, L.row_ptr, L.col, sigma, L.val, L.dinv, L.wdir);
-  hipLaunchKernelGGL(r3d_graph_normalize_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, L.row_ptr, L.col, L.dinv,
-                     n_dev, n_cap, L.val);
-  int rc = lp_coarse_space(L, nodes, ldn, D, n_dev, n_proto_dev, n_cap, alpha, st);
+  hipLaunchKernelGGL(r3d_graph_bits_kernel, dim3(r3d_cdiv(edges, 256), n_ep), dim3(256), 0, st, nbr, kp1, n_dev, n_cap,
+                     (int)words, L.outb, L.sym, ep);
+  hipLaunchKernelGGL(r3d_graph_rowlen_kernel, dim3(r3d_cdiv(n_cap, 4), n_ep), dim3(256), 0, st, L.sym, (int)words, n_dev,
+                     n_cap, L.row_len, ep);
+  hipLaunchKernelGGL(r3d_scan_kernel, dim3(n_ep), dim3(1024), 0, st, L.row_len, n_cap, L.row_ptr, ep);
+  hipLaunchKernelGGL(r3d_graph_cols_kernel, dim3(r3d_cdiv(n_cap, 4), n_ep), dim3(256), 0, st, L.sym, (int)words, n_dev,
+                     n_cap, L.row_ptr, L.col, ep);
+  hipLaunchKernelGGL(r3d_graph_weights_kernel, dim3(n_cap, n_ep), dim3(256), 0, st, nodes, ldn, D, L.outb,
+                     (int)words, n_dev, n_cap, L.row_ptr, L.col, sigma, L.val, L.dinv, L.wdir, ep);
+  hipLaunchKernelGGL(r3d_graph_normalize_kernel, dim3(r3d_cdiv(n_cap, 4), n_ep), dim3(256), 0, st, L.row_ptr, L.col, L.dinv,
+                     n_dev, n_cap, L.val, ep);
+  int rc = lp_coarse_space(L, nodes, ldn, D, n_dev, n_proto_dev, n_cap, alpha, n_ep, ep, st);
   if (rc) return rc;
-  rc = lp_solve(L, Y, n_dev, n_cap, alpha, max_iter, tol, Z, stats_out, st);
+  rc = lp_solve(L, Y, ep.y, n_dev, n_cap, alpha, max_iter, tol, Z, ep.z, stats_out, n_ep, ep, st);
   if (rc) return rc;
   R3D_LAUNCH_CHECK("r3d_label_propagate");
   return R3D_OK;
+}
+
+extern "C" int r3d_label_propagate(const float* nodes, long ldn, int D, const int32_t* nbr, int kp1,
+                                   const float* Y, const int32_t* n_dev, const int32_t* n_proto_dev, int n_cap, float sigma,
+                                   float alpha, int max_iter, float tol, float* Z, int32_t* ws, long ws_words,
+                                   int32_t* stats_out, void* stream) {
+  const HgEp one{};
+  return label_propagate_impl(1, one, nodes, ldn, D, nbr, kp1, Y, n_dev, n_proto_dev, n_cap, sigma, alpha, max_iter, tol, Z, ws,
+                              ws_words, stats_out, stream);
+}
+
+// n_ep systems at once.  System e: nodes / nbr / Y / Z rows [e * n_cap, (e + 1) * n_cap) of the batch arrays, its node and
+// prototype counts at n_dev[e * desc_stride] / n_proto_dev[e * desc_stride], scratch ws + e * ws_stride (a multiple of 4
+// words, >= r3d_lp_ws_words), {converged, iterations} at stats_out + e * stats_stride.  Every CG launch serves all systems;
+// max_iter launches are issued, a system that converged earlier idles through the rest.
+extern "C" int r3d_label_propagate_batched(int n_ep, const float* nodes, long ldn, int D, const int32_t* nbr, int kp1,
+                                           const float* Y, const int32_t* n_dev, const int32_t* n_proto_dev, long desc_stride,
+                                           int n_cap, float sigma, float alpha, int max_iter, float tol, float* Z, int32_t* ws,
+                                           long ws_words, long ws_stride, int32_t* stats_out, long stats_stride, void* stream) {
+  HgEp ep{};
+  ep.nodes = ep.nbr = ep.y = ep.z = n_cap;
+  ep.desc = desc_stride; ep.ws = ws_stride; ep.stats = stats_stride;
+  return label_propagate_impl(n_ep, ep, nodes, ldn, D, nbr, kp1, Y, n_dev, n_proto_dev, n_cap, sigma, alpha, max_iter, tol, Z, ws,
+                              ws_words, stats_out, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -1108,7 +1211,9 @@ __global__ __launch_bounds__(256) void r3d_lp_bwd_dd_kernel(const int* __restric
                                                             const float* __restrict__ val, const float* __restrict__ dinv,
                                                             const int* __restrict__ n_dev, int n_cap, float alpha,
                                                             const float4* __restrict__ lam, const float4* __restrict__ Z,
-                                                            float* __restrict__ dD) {
+                                                            float* __restrict__ dD, HgEp st) {
+  const int ep = blockIdx.y;
+  HG_WS(row_ptr); HG_WS(col); HG_WS(val); HG_WS(dinv); HG_AT(n_dev, st.desc); HG_AT(lam, st.lam); HG_AT(Z, st.z); HG_WS(dD);
   const int n = min(*n_dev, n_cap);
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -1133,7 +1238,12 @@ __global__ __launch_bounds__(256) void r3d_lp_bwd_dx_kernel(
     const float* __restrict__ nodes, long ldn, int D, const float* __restrict__ wdir,
     const int* __restrict__ row_ptr, const hg_col_t* __restrict__ col, const float* __restrict__ dinv,
     const int* __restrict__ n_dev, int n_cap, float sigma, float alpha, const float4* __restrict__ lam,
-    const float4* __restrict__ Z, const float* __restrict__ dD, float* __restrict__ dnodes, long ldd) {
+    const float4* __restrict__ Z, const float* __restrict__ dD, float* __restrict__ dnodes, long ldd, HgEp st) {
+  {
+    const int ep = blockIdx.y;
+    nodes += (long)ep * st.nodes * ldn; HG_WS(wdir); HG_WS(row_ptr); HG_WS(col); HG_WS(dinv); HG_AT(n_dev, st.desc);
+    HG_AT(lam, st.lam); HG_AT(Z, st.z); HG_WS(dD); dnodes += (long)ep * st.dn * ldd;
+  }
   // one WORKGROUP per row, its four waves take every fourth chunk of 64 entries (a wave's work is a chain of
   // column-index -> neighbour-row round trips; one wave per row walked five chunks: 185 us at S)
   __shared__ float acc_s[4][256];
@@ -1205,7 +1315,11 @@ __global__ __launch_bounds__(256) void r3d_lp_bwd_dx_kernel(
 // dL/dZ of the mean cross entropy over the query rows (mpti.py:778-781), scaled by *gscale
 __global__ void r3d_ce_grad_kernel(const float4* __restrict__ Z, const int* __restrict__ n_proto_dev, int n_cap, int n_qpts,
                                    int n_classes, const long long* __restrict__ labels, const float* __restrict__ gscale,
-                                   float4* __restrict__ G) {
+                                   float4* __restrict__ G, HgEp st) {
+  {
+    const int ep = blockIdx.y;
+    HG_AT(Z, st.z); HG_AT(n_proto_dev, st.desc); HG_AT(labels, st.labels); HG_AT(G, st.g);
+  }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_cap) return;
   const int n_proto = *n_proto_dev;
@@ -1227,10 +1341,10 @@ __global__ void r3d_ce_grad_kernel(const float4* __restrict__ Z, const int* __re
 
 // Backward through label propagation + affinity.  Requires ws exactly as r3d_label_propagate left it.
 // G (n_cap,4) = dL/dZ (from r3d_ce_grad); lam scratch (n_cap,4); dnodes (n_cap, ldd) out.
-extern "C" int r3d_label_propagate_bwd(const float* nodes, long ldn, int D, int kp1, const float* Z, const float* G,
-                                       const int32_t* n_dev, int n_cap, float sigma, float alpha, int max_iter, float tol,
-                                       float* lam, float* dnodes, long ldd, int32_t* ws, long ws_words, int32_t* stats_out,
-                                       void* stream) {
+static int label_propagate_bwd_impl(int n_ep, const HgEp& ep, const float* nodes, long ldn, int D, int kp1, const float* Z,
+                                    const float* G, const int32_t* n_dev, int n_cap, float sigma, float alpha, int max_iter,
+                                    float tol, float* lam, float* dnodes, long ldd, int32_t* ws, long ws_words,
+                                    int32_t* stats_out, void* stream) {
   R3D_REQUIRE(nodes && Z && G && n_dev && lam && dnodes && ws, "r3d_label_propagate_bwd: null pointer");
   R3D_REQUIRE(n_cap > 0 && kp1 >= 2 && ws_words >= r3d_lp_ws_words(n_cap, kp1),
               "r3d_label_propagate_bwd: workspace of %ld words is shorter than r3d_lp_ws_words(%d, %d)", ws_words, n_cap, kp1);
@@ -1239,39 +1353,79 @@ extern "C" int r3d_label_propagate_bwd(const float* nodes, long ldn, int D, int 
               "r3d_label_propagate_bwd: ldn must be a multiple of 4; nodes, ws, Z, G, lam 16-byte aligned");
   R3D_REQUIRE(n_cap > 0 && n_cap <= 32768 && D > 0 && D <= 256 && max_iter > 0 && max_iter <= HG_MAX_ITER,
               "r3d_label_propagate_bwd: bad arguments");
+  R3D_REQUIRE(n_ep >= 1 && n_ep <= 4096 && (n_ep == 1 || ((ep.ws & 3) == 0 && ep.ws >= ws_words)),
+              "r3d_label_propagate_bwd: %d systems need a scratch stride that is a multiple of 4 words and >= the scratch size", n_ep);
   hipStream_t st = (hipStream_t)stream;
   const LpWs L = lp_carve(ws, n_cap, kp1);
-  int rc = lp_solve(L, G, n_dev, n_cap, alpha, max_iter, tol, lam, stats_out, st);
+  int rc = lp_solve(L, G, ep.g, n_dev, n_cap, alpha, max_iter, tol, lam, ep.lam, stats_out, n_ep, ep, st);
   if (rc) return rc;
   float* dD = (float*)L.q;  // the CG vectors are free again after the solve
-  hipLaunchKernelGGL(r3d_lp_bwd_dd_kernel, dim3(r3d_cdiv(n_cap, 4)), dim3(256), 0, st, L.row_ptr, L.col, L.val, L.dinv, n_dev,
-                     n_cap, alpha, (const float4*)lam, (const float4*)Z, dD);
-  hipLaunchKernelGGL(r3d_lp_bwd_dx_kernel, dim3(n_cap), dim3(256), 0, st, nodes, ldn, D, L.wdir,
+  hipLaunchKernelGGL(r3d_lp_bwd_dd_kernel, dim3(r3d_cdiv(n_cap, 4), n_ep), dim3(256), 0, st, L.row_ptr, L.col, L.val, L.dinv, n_dev,
+                     n_cap, alpha, (const float4*)lam, (const float4*)Z, dD, ep);
+  hipLaunchKernelGGL(r3d_lp_bwd_dx_kernel, dim3(n_cap, n_ep), dim3(256), 0, st, nodes, ldn, D, L.wdir,
                      L.row_ptr, L.col, L.dinv, n_dev, n_cap, sigma, alpha, (const float4*)lam, (const float4*)Z, dD, dnodes,
-                     ldd);
+                     ldd, ep);
   R3D_LAUNCH_CHECK("r3d_label_propagate_bwd");
   return R3D_OK;
 }
+extern "C" int r3d_label_propagate_bwd(const float* nodes, long ldn, int D, int kp1, const float* Z, const float* G,
+                                       const int32_t* n_dev, int n_cap, float sigma, float alpha, int max_iter, float tol,
+                                       float* lam, float* dnodes, long ldd, int32_t* ws, long ws_words, int32_t* stats_out,
+                                       void* stream) {
+  const HgEp one{};
+  return label_propagate_bwd_impl(1, one, nodes, ldn, D, kp1, Z, G, n_dev, n_cap, sigma, alpha, max_iter, tol, lam, dnodes, ldd,
+                                  ws, ws_words, stats_out, stream);
+}
+// n_ep systems at once (layout as r3d_label_propagate_batched; G, lam, dnodes: n_cap rows per system)
+extern "C" int r3d_label_propagate_bwd_batched(int n_ep, const float* nodes, long ldn, int D, int kp1, const float* Z,
+                                               const float* G, const int32_t* n_dev, long desc_stride, int n_cap, float sigma,
+                                               float alpha, int max_iter, float tol, float* lam, float* dnodes, long ldd,
+                                               int32_t* ws, long ws_words, long ws_stride, int32_t* stats_out,
+                                               long stats_stride, void* stream) {
+  HgEp ep{};
+  ep.nodes = ep.z = ep.g = ep.lam = ep.dn = n_cap;
+  ep.desc = desc_stride; ep.ws = ws_stride; ep.stats = stats_stride;
+  return label_propagate_bwd_impl(n_ep, ep, nodes, ldn, D, kp1, Z, G, n_dev, n_cap, sigma, alpha, max_iter, tol, lam, dnodes, ldd,
+                                  ws, ws_words, stats_out, stream);
+}
 
-extern "C" int r3d_ce_grad(const float* Z, const int32_t* n_proto_dev, int n_cap, int n_query_pts, int n_classes,
-                           const int64_t* labels, const float* gscale_dev, float* G, void* stream) {
-  R3D_REQUIRE(Z && n_proto_dev && labels && gscale_dev && G, "r3d_ce_grad: null pointer");
-  hipLaunchKernelGGL(r3d_ce_grad_kernel, dim3(r3d_cdiv(n_cap, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)Z,
-                     n_proto_dev, n_cap, n_query_pts, n_classes, (const long long*)labels, gscale_dev, (float4*)G);
+// G = dL/dZ of n_ep systems (n_ep == 1: the ABI-version-2 call).  labels: n_query_pts int64 per system; *gscale_dev scales
+// every system alike (the step's loss is the SUM of the episodes' losses).
+extern "C" int r3d_ce_grad_batched(int n_ep, const float* Z, const int32_t* n_proto_dev, long desc_stride, int n_cap,
+                                   int n_query_pts, int n_classes, const int64_t* labels, const float* gscale_dev, float* G,
+                                   void* stream) {
+  R3D_REQUIRE(Z && n_proto_dev && labels && gscale_dev && G && n_ep >= 1 && n_ep <= 65535, "r3d_ce_grad: bad arguments");
+  HgEp ep{};
+  ep.z = ep.g = n_cap; ep.desc = desc_stride; ep.labels = n_query_pts;
+  hipLaunchKernelGGL(r3d_ce_grad_kernel, dim3(r3d_cdiv(n_cap, 256), n_ep), dim3(256), 0, (hipStream_t)stream, (const float4*)Z,
+                     n_proto_dev, n_cap, n_query_pts, n_classes, (const long long*)labels, gscale_dev, (float4*)G, ep);
   R3D_LAUNCH_CHECK("r3d_ce_grad");
   return R3D_OK;
 }
+extern "C" int r3d_ce_grad(const float* Z, const int32_t* n_proto_dev, int n_cap, int n_query_pts, int n_classes,
+                           const int64_t* labels, const float* gscale_dev, float* G, void* stream) {
+  return r3d_ce_grad_batched(1, Z, n_proto_dev, 0, n_cap, n_query_pts, n_classes, labels, gscale_dev, G, stream);
+}
 
-// logits (n_q, n_classes, N) fp32, loss (1) fp32, pred (n_q*N) int32 (argmax), labels int64
+// logits (n_q, n_classes, N) fp32, loss (1) fp32, pred (n_q*N) int32 (argmax), labels int64 -- per system; system e reads
+// Z rows [e * z_ep_rows, ...) and writes logits / loss / pred number e of the batch arrays
+extern "C" int r3d_query_logits_ce_batched(int n_ep, const float* Z, long z_ep_rows, const int32_t* n_proto_dev, long desc_stride,
+                                           int n_q, int N, int n_classes, const int64_t* labels, float* logits, float* loss_out,
+                                           int32_t* pred_out, void* stream) {
+  R3D_REQUIRE(Z && n_proto_dev && logits, "r3d_query_logits_ce: null pointer");
+  R3D_REQUIRE(n_q > 0 && N > 0 && n_classes >= 2 && n_classes <= HG_NC && n_ep >= 1, "r3d_query_logits_ce: bad shape");
+  HgEp ep{};
+  ep.z = z_ep_rows; ep.desc = desc_stride; ep.labels = (long)n_q * N; ep.logits = (long)n_q * n_classes * N; ep.loss = 1;
+  ep.pred = (long)n_q * N;
+  hipLaunchKernelGGL(r3d_logits_ce_kernel, dim3(n_ep), dim3(1024), 0, (hipStream_t)stream, (const float4*)Z,
+                     n_proto_dev, n_q, N, n_classes, (const long long*)labels, logits, loss_out, pred_out, ep);
+  R3D_LAUNCH_CHECK("r3d_query_logits_ce");
+  return R3D_OK;
+}
 extern "C" int r3d_query_logits_ce(const float* Z, const int32_t* n_proto_dev, int n_q, int N, int n_classes,
                                    const int64_t* labels, float* logits, float* loss_out, int32_t* pred_out,
                                    void* stream) {
-  R3D_REQUIRE(Z && n_proto_dev && logits, "r3d_query_logits_ce: null pointer");
-  R3D_REQUIRE(n_q > 0 && N > 0 && n_classes >= 2 && n_classes <= HG_NC, "r3d_query_logits_ce: bad shape");
-  hipLaunchKernelGGL(r3d_logits_ce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float4*)Z,
-                     n_proto_dev, n_q, N, n_classes, (const long long*)labels, logits, loss_out, pred_out);
-  R3D_LAUNCH_CHECK("r3d_query_logits_ce");
-  return R3D_OK;
+  return r3d_query_logits_ce_batched(1, Z, 0, n_proto_dev, 0, n_q, N, n_classes, labels, logits, loss_out, pred_out, stream);
 }
 
 // ---------------------------------------------------------------------------

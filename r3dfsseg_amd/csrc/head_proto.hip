@@ -31,6 +31,15 @@ enum {
   HD_WORDS = 3 * HP_MAXSEG + 8
 };
 
+// Batches of episodes (round 3): every kernel below takes the episode from a grid dimension and shifts its per-episode
+// pointers by the strides of HpEp (elements of each array between consecutive episodes; all capacity sized, so episode e
+// of a batch lives at base + e * stride).  One episode = strides unused = the ABI-version-2 entry points.
+struct HpEp {
+  long sy, keep, feat, qfeat;                   // support_y, shot_keep, support feature ROWS, query feature ROWS
+  long nodes, labels, desc, assign, ccount, ws;  // node rows, label rows, descriptor words, assign words, counts, scratch words
+};
+#define HP_SHIFT(p, stride) (p) += (long)ep * (stride)
+
 struct SegGeom {
   int n_way, k_shot, N;
   __host__ __device__ int nseg() const { return n_way + 1; }
@@ -65,10 +74,12 @@ struct SegGeom {
 __global__ __launch_bounds__(1024) void r3d_head_compact_kernel(const int* __restrict__ support_y,
                                                                 const int* __restrict__ shot_keep,
                                                                 SegGeom g, int* __restrict__ comp,
-                                                                int* __restrict__ desc) {
+                                                                int* __restrict__ desc, HpEp st) {
   __shared__ int wave_tot[16];
   __shared__ int base_s;
-  const int seg = blockIdx.x;
+  const int seg = blockIdx.x, ep = blockIdx.y;
+  HP_SHIFT(support_y, st.sy); HP_SHIFT(comp, st.ws); HP_SHIFT(desc, st.desc);
+  if (shot_keep) HP_SHIFT(shot_keep, st.keep);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const long first = seg == 0 ? 0 : (long)(seg - 1) * g.k_shot * g.N;
   const long count = g.cap(seg);
@@ -117,8 +128,10 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_head_gather_kernel(const float* 
                                                                    long ldf, int D, SegGeom g,
                                                                    const int* __restrict__ comp,
                                                                    const int* __restrict__ desc,
-                                                                   float* __restrict__ featC, long pitch) {
+                                                                   float* __restrict__ featC, long pitch, HpEp st) {
   __shared__ float t[64][65];
+  const int ep = blockIdx.y;
+  feat += (long)ep * st.feat * ldf; HP_SHIFT(comp, st.ws); HP_SHIFT(desc, st.desc); HP_SHIFT(featC, st.ws);
   int blk0;
   const int seg = g.seg_of_block(blockIdx.x, &blk0);
   const int count = desc[HD_SEG_COUNT + seg];
@@ -166,8 +179,14 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_fps_round_kernel(
     const float* __restrict__ featC /* (D, pitch) compacted channel-major */, long pitch, int D, SegGeom g,
     const int* __restrict__ desc, int k, int round,
     float* __restrict__ mind, const Cand* __restrict__ cand_prev, Cand* __restrict__ cand_next,
-    int* __restrict__ sel /* [nseg][HP_MAXK] */) {
+    int* __restrict__ sel /* [nseg][HP_MAXK] */, HpEp st) {
   __shared__ float seedf[DP];
+  {
+    const int ep = blockIdx.y;  // Cand = 2 words
+    HP_SHIFT(featC, st.ws); HP_SHIFT(desc, st.desc); HP_SHIFT(mind, st.ws); HP_SHIFT(sel, st.ws);
+    cand_prev = (const Cand*)((const int*)cand_prev + (long)ep * st.ws);
+    cand_next = (Cand*)((int*)cand_next + (long)ep * st.ws);
+  }
   __shared__ float red_v[4];
   __shared__ int red_p[4];
   __shared__ int seed_pos_s;
@@ -275,8 +294,13 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_fps_round_kernel(
 template <int DP>
 __global__ __launch_bounds__(HP_BLOCK) void r3d_fps_persistent_kernel(
     const float* __restrict__ featC, long pitch, int D, SegGeom g, int* __restrict__ desc, int k,
-    unsigned long long* __restrict__ xch /* [k][total_blocks] */, int total_blocks, int* __restrict__ sel) {
+    unsigned long long* __restrict__ xch /* [k][total_blocks] */, int total_blocks, int* __restrict__ sel, HpEp st, int ep0) {
   __shared__ float seedf[DP];
+  {
+    const int ep = ep0 + blockIdx.y;  // the launch holds episodes ep0 .. ep0 + gridDim.y - 1 (co-resident together)
+    HP_SHIFT(featC, st.ws); HP_SHIFT(desc, st.desc); HP_SHIFT(sel, st.ws);
+    xch = (unsigned long long*)((int*)xch + (long)ep * st.ws);  // st.ws is even: 8-byte alignment is kept
+  }
   __shared__ float red_v[4];
   __shared__ int red_p[4];
   __shared__ int seed_pos_s;
@@ -371,7 +395,9 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_fps_persistent_kernel(
 __global__ __launch_bounds__(HP_MAXK) void r3d_fps_finalize_kernel(SegGeom g, int k, int n_query_pts,
                                                                    const int* __restrict__ sel,
                                                                    int* __restrict__ seeds /*[nseg][HP_MAXK]*/,
-                                                                   int* __restrict__ desc) {
+                                                                   int* __restrict__ desc, HpEp st) {
+  const int ep = blockIdx.x;
+  HP_SHIFT(sel, st.ws); HP_SHIFT(seeds, st.ws); HP_SHIFT(desc, st.desc);
   __shared__ int a[HP_MAXK];
   __shared__ int m_s[HP_MAXSEG];
   const int tid = threadIdx.x;
@@ -436,8 +462,13 @@ __global__ __launch_bounds__(HP_MAXK) void r3d_fps_finalize_kernel(SegGeom g, in
 __global__ __launch_bounds__(HP_BLOCK) void r3d_assign_kernel(const float* __restrict__ featC, long pitch, int D,
                                                               SegGeom g, const int* __restrict__ desc,
                                                               const int* __restrict__ seeds,
-                                                              unsigned long long* __restrict__ best_packed) {
+                                                              unsigned long long* __restrict__ best_packed, HpEp st) {
   __shared__ float sf[256 * AS_TILE];  // [c][AS_TILE], D <= 256
+  {
+    const int ep = blockIdx.z;
+    HP_SHIFT(featC, st.ws); HP_SHIFT(desc, st.desc); HP_SHIFT(seeds, st.ws);
+    best_packed = (unsigned long long*)((int*)best_packed + (long)ep * st.ws);
+  }
   int blk0;
   const int seg = g.seg_of_block(blockIdx.x, &blk0);
   const int tid = threadIdx.x;
@@ -493,7 +524,11 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_assign_kernel(const float* __res
   }
   atomicMin(&best_packed[g.off(seg) + pos], ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)besti);
 }
-__global__ void r3d_assign_unpack_kernel(const unsigned long long* __restrict__ best_packed, long n, int* __restrict__ assign) {
+__global__ void r3d_assign_unpack_kernel(const unsigned long long* __restrict__ best_packed, long n, int* __restrict__ assign,
+                                         HpEp st) {
+  const int ep = blockIdx.y;
+  best_packed = (const unsigned long long*)((const int*)best_packed + (long)ep * st.ws);
+  HP_SHIFT(assign, st.assign);
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) assign[i] = (int)(unsigned)(best_packed[i] & 0xffffffffull);
 }
@@ -509,10 +544,13 @@ __global__ void r3d_assign_unpack_kernel(const unsigned long long* __restrict__ 
 __global__ __launch_bounds__(HP_BLOCK) void r3d_cluster_partial_kernel(
     const float* __restrict__ feat /* (S*N, ldf) point-major */, long ldf, int D, SegGeom g,
     const int* __restrict__ comp, const int* __restrict__ desc, const int* __restrict__ assign, int max_chunks,
-    float* __restrict__ part /* [nseg][HP_MAXK][max_chunks][256] */, int* __restrict__ part_cnt) {
+    float* __restrict__ part /* [nseg][HP_MAXK][max_chunks][256] */, int* __restrict__ part_cnt, HpEp st) {
   __shared__ float psum[4][256];
   __shared__ int cnt_s[4];
-  const int seg = blockIdx.z, s = blockIdx.x, chunk = blockIdx.y;
+  const int ep = blockIdx.z / g.nseg();
+  const int seg = blockIdx.z - ep * g.nseg(), s = blockIdx.x, chunk = blockIdx.y;
+  feat += (long)ep * st.feat * ldf; HP_SHIFT(comp, st.ws); HP_SHIFT(desc, st.desc); HP_SHIFT(assign, st.assign);
+  HP_SHIFT(part, st.ws); HP_SHIFT(part_cnt, st.ws);
   const int m = desc[HD_SEG_M + seg];
   const int count = desc[HD_SEG_COUNT + seg];
   if (s >= m || (long)chunk * CM_CHUNK >= count) return;
@@ -564,8 +602,11 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_cluster_partial_kernel(
 __global__ __launch_bounds__(HP_BLOCK) void r3d_cluster_reduce_kernel(
     int D, const int* __restrict__ desc, int max_chunks, const float* __restrict__ part,
     const int* __restrict__ part_cnt, float* __restrict__ nodes /* (n_cap, ldn) */, long ldn,
-    float* __restrict__ node_labels /* (n_cap, 4) */, int* __restrict__ cluster_count) {
-  const int seg = blockIdx.y, s = blockIdx.x;
+    float* __restrict__ node_labels /* (n_cap, 4) */, int* __restrict__ cluster_count, HpEp st) {
+  const int seg = blockIdx.y, s = blockIdx.x, ep = blockIdx.z;
+  HP_SHIFT(desc, st.desc); HP_SHIFT(part, st.ws); HP_SHIFT(part_cnt, st.ws);
+  nodes += (long)ep * st.nodes * ldn; node_labels += (long)ep * st.labels * 4;
+  if (cluster_count) HP_SHIFT(cluster_count, st.ccount);
   const int m = desc[HD_SEG_M + seg];
   if (s >= m) return;
   const int count = desc[HD_SEG_COUNT + seg];
@@ -589,7 +630,10 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_cluster_reduce_kernel(
 // ---------------------------------------------------------------------------
 __global__ void r3d_nodes_append_query_kernel(const float* __restrict__ qfeat, long ldq, int D, int nq_pts,
                                               const int* __restrict__ desc, float* __restrict__ nodes,
-                                              long ldn, float* __restrict__ node_labels) {
+                                              long ldn, float* __restrict__ node_labels, HpEp st) {
+  const int ep = blockIdx.y;
+  qfeat += (long)ep * st.qfeat * ldq; HP_SHIFT(desc, st.desc);
+  nodes += (long)ep * st.nodes * ldn; node_labels += (long)ep * st.labels * 4;
   const int n_proto = desc[HD_N_PROTO];
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)nq_pts * D) return;
@@ -630,32 +674,39 @@ extern "C" long r3d_head_proto_ws_words(int n_way, int k_shot, int N) {
          2L * cap + 2;                                                      // ... + 64-bit (distance, seed) minimum per point
 }
 
-// Builds prototypes into node rows [0, n_proto) and appends the query rows.
+// Builds prototypes into node rows [0, n_proto) and appends the query rows, for n_ep episodes at once.
 //   support_y : (n_way*k_shot, N) int32 {0,1}
 //   shot_keep : optional (n_way*k_shot) int32, 0 drops a shot's foreground (clean-shot detection)
-//   feat      : (S*N, ldf) point-major support features;  featT: (S, D, N) channel-major copy
-//   qfeat     : (n_q*N, ldq) point-major query features
+//   feat      : (S*N, ldf) point-major support features;  qfeat: (n_q*N, ldq) point-major query features
 //   nodes     : (n_cap, ldn) out, n_cap = (n_way+1)*k + n_q*N;  node_labels: (n_cap, 4) one-hot Y
 //   desc      : device descriptor (r3d_head_desc_words int32);  ws: scratch words
-extern "C" int r3d_head_prototypes(const int32_t* support_y, const int32_t* shot_keep, const float* feat,
-                                   long ldf, const float* featT, const float* qfeat, long ldq, int n_way,
-                                   int k_shot, int N, int D, int n_query_pts, int k, float* nodes, long ldn,
-                                   float* node_labels, int32_t* desc, int32_t* assign_out,
-                                   int32_t* cluster_count, int32_t* ws, long ws_words, int flags, void* stream) {
-  R3D_REQUIRE(support_y && feat && featT && qfeat && nodes && node_labels && desc && ws,
-              "r3d_head_prototypes: null pointer");
+// Every pointer addresses episode 0; episode e sits ep->... elements further on (HpEp; feature strides in ROWS).
+// fps_group: episodes whose farthest-point samplings share ONE persistent launch (flags & R3D_HEAD_FPS_ONE_LAUNCH): all
+// their workgroups that hold points must be co-resident, so the caller sizes it to the chip (~500 workgroup slots at
+// D <= 192, 250 above; an episode needs ceil(S N / 256) + n_way + 1); the batch takes ceil(n_ep / fps_group) such launches.
+static int head_prototypes_impl(int n_ep, const HpEp& ep, int fps_group, const int32_t* support_y, const int32_t* shot_keep,
+                                const float* feat, long ldf, const float* qfeat, long ldq, int n_way, int k_shot, int N, int D,
+                                int n_query_pts, int k, float* nodes, long ldn, float* node_labels, int32_t* desc,
+                                int32_t* assign_out, int32_t* cluster_count, int32_t* ws, long ws_words, int flags,
+                                void* stream) {
+  R3D_REQUIRE(support_y && feat && qfeat && nodes && node_labels && desc && ws, "r3d_head_prototypes: null pointer");
   int rc = check_geom("r3d_head_prototypes", n_way, k_shot, N, D);
   if (rc) return rc;
   R3D_REQUIRE(ws_words >= r3d_head_proto_ws_words(n_way, k_shot, N),
               "r3d_head_prototypes: workspace of %ld words, r3d_head_proto_ws_words = %ld needed", ws_words,
               r3d_head_proto_ws_words(n_way, k_shot, N));
   R3D_REQUIRE(k >= 1 && k <= HP_MAXK, "r3d_head_prototypes: k=%d unsupported (1..%d)", k, HP_MAXK);
+  R3D_REQUIRE(n_ep >= 1 && n_ep <= 4096 && fps_group >= 1, "r3d_head_prototypes: %d episodes, %d per FPS launch", n_ep, fps_group);
+  R3D_REQUIRE(n_ep == 1 || (assign_out && (ep.ws & 1) == 0 && ep.ws >= ws_words),
+              "r3d_head_prototypes: a batch needs assign_out and an even scratch stride >= the scratch size");
   hipStream_t st = (hipStream_t)stream;
   SegGeom g{n_way, k_shot, N};
   const long cap = g.total_cap();
   int* comp = ws;
   float* mind = (float*)(ws + cap);
   int* assign = assign_out ? assign_out : ws + 2 * cap;
+  HpEp e2 = ep;
+  if (!assign_out) e2.assign = ep.ws;  // (single episode only)
   Cand* cand0 = (Cand*)(ws + 3 * cap);
   Cand* cand1 = cand0 + g.total_blocks();
   int* sel = ws + 3 * cap + 4L * g.total_blocks();
@@ -669,26 +720,28 @@ extern "C" int r3d_head_prototypes(const int32_t* support_y, const int32_t* shot
   xoff += xoff & 1;
   unsigned long long* xch = (unsigned long long*)(ws + xoff);
   unsigned long long* best_packed = xch + (long)HP_MAXK * g.total_blocks() + 1;  // behind the exchange words
-  hipLaunchKernelGGL(r3d_head_compact_kernel, dim3(g.nseg()), dim3(1024), 0, st, support_y, shot_keep, g,
-                     comp, desc);
-  hipLaunchKernelGGL(r3d_head_gather_kernel, dim3(g.total_blocks()), dim3(HP_BLOCK), 0, st, feat, ldf, D, g, comp,
-                     desc, featC, pitch);
+  const int tb = g.total_blocks();
+  hipLaunchKernelGGL(r3d_head_compact_kernel, dim3(g.nseg(), n_ep), dim3(1024), 0, st, support_y, shot_keep, g, comp, desc, e2);
+  hipLaunchKernelGGL(r3d_head_gather_kernel, dim3(tb, n_ep), dim3(HP_BLOCK), 0, st, feat, ldf, D, g, comp, desc, featC, pitch,
+                     e2);
   if (flags & 1 /* R3D_HEAD_FPS_ONE_LAUNCH */) {
-    const int tb = g.total_blocks();
-    r3d_zero_words(xch, 2L * k * tb, st);
-#define FPS_ONE(DPAD)                                                                                                 \
-    hipLaunchKernelGGL(r3d_fps_persistent_kernel<DPAD>, dim3(tb), dim3(HP_BLOCK), 0, st, featC, pitch, D, g, desc, k, \
-                       xch, tb, sel)
-    if (D <= 64) FPS_ONE(64);
-    else if (D <= 128) FPS_ONE(128);
-    else if (D <= 192) FPS_ONE(192);
-    else FPS_ONE(256);
+    r3d_fill_words_ep(xch, 0u, 2L * k * tb, n_ep, e2.ws, st);
+    for (int e0 = 0; e0 < n_ep; e0 += fps_group) {
+      const int ne = n_ep - e0 < fps_group ? n_ep - e0 : fps_group;
+#define FPS_ONE(DPAD)                                                                                                   \
+      hipLaunchKernelGGL(r3d_fps_persistent_kernel<DPAD>, dim3(tb, ne), dim3(HP_BLOCK), 0, st, featC, pitch, D, g, desc, k, \
+                         xch, tb, sel, e2, e0)
+      if (D <= 64) FPS_ONE(64);
+      else if (D <= 128) FPS_ONE(128);
+      else if (D <= 192) FPS_ONE(192);
+      else FPS_ONE(256);
 #undef FPS_ONE
+    }
   } else {
     for (int t = 0; t < k; ++t) {
   #define FPS_LAUNCH(DPAD)                                                                                          \
-      hipLaunchKernelGGL(r3d_fps_round_kernel<DPAD>, dim3(g.total_blocks()), dim3(HP_BLOCK), 0, st, featC, pitch, D, g, \
-                         desc, k, t, mind, (t & 1) ? cand0 : cand1, (t & 1) ? cand1 : cand0, sel)
+      hipLaunchKernelGGL(r3d_fps_round_kernel<DPAD>, dim3(tb, n_ep), dim3(HP_BLOCK), 0, st, featC, pitch, D, g,      \
+                         desc, k, t, mind, (t & 1) ? cand0 : cand1, (t & 1) ? cand1 : cand0, sel, e2)
       if (D <= 64) FPS_LAUNCH(64);
       else if (D <= 128) FPS_LAUNCH(128);
       else if (D <= 192) FPS_LAUNCH(192);
@@ -696,21 +749,48 @@ extern "C" int r3d_head_prototypes(const int32_t* support_y, const int32_t* shot
   #undef FPS_LAUNCH
     }
   }
-  hipLaunchKernelGGL(r3d_fps_finalize_kernel, dim3(1), dim3(HP_MAXK), 0, st, g, k, n_query_pts, sel, seeds,
-                     desc);
-  hipLaunchKernelGGL(r3d_fill_words_kernel, dim3(r3d_cdiv(2 * cap, 256)), dim3(256), 0, st, (unsigned*)best_packed, 0xffffffffu,
-                     2 * cap);
-  hipLaunchKernelGGL(r3d_assign_kernel, dim3(g.total_blocks(), r3d_cdiv(k, AS_TILE)), dim3(HP_BLOCK), 0, st, featC, pitch, D, g,
-                     desc, seeds, best_packed);
-  hipLaunchKernelGGL(r3d_assign_unpack_kernel, dim3(r3d_cdiv(cap, 256)), dim3(256), 0, st, best_packed, cap, assign);
-  hipLaunchKernelGGL(r3d_cluster_partial_kernel, dim3(k, max_chunks, g.nseg()), dim3(HP_BLOCK), 0, st, feat, ldf, D,
-                     g, comp, desc, assign, max_chunks, part, part_cnt);
-  hipLaunchKernelGGL(r3d_cluster_reduce_kernel, dim3(k, g.nseg()), dim3(HP_BLOCK), 0, st, D, desc, max_chunks, part,
-                     part_cnt, nodes, ldn, node_labels, cluster_count);
-  hipLaunchKernelGGL(r3d_nodes_append_query_kernel, dim3(r3d_cdiv((long)n_query_pts * D, 256)), dim3(256), 0, st,
-                     qfeat, ldq, D, n_query_pts, desc, nodes, ldn, node_labels);
+  hipLaunchKernelGGL(r3d_fps_finalize_kernel, dim3(n_ep), dim3(HP_MAXK), 0, st, g, k, n_query_pts, sel, seeds, desc, e2);
+  r3d_fill_words_ep(best_packed, 0xffffffffu, 2 * cap, n_ep, e2.ws, st);
+  hipLaunchKernelGGL(r3d_assign_kernel, dim3(tb, r3d_cdiv(k, AS_TILE), n_ep), dim3(HP_BLOCK), 0, st, featC, pitch, D, g, desc,
+                     seeds, best_packed, e2);
+  hipLaunchKernelGGL(r3d_assign_unpack_kernel, dim3(r3d_cdiv(cap, 256), n_ep), dim3(256), 0, st, best_packed, cap, assign, e2);
+  hipLaunchKernelGGL(r3d_cluster_partial_kernel, dim3(k, max_chunks, g.nseg() * n_ep), dim3(HP_BLOCK), 0, st, feat, ldf, D, g,
+                     comp, desc, assign, max_chunks, part, part_cnt, e2);
+  hipLaunchKernelGGL(r3d_cluster_reduce_kernel, dim3(k, g.nseg(), n_ep), dim3(HP_BLOCK), 0, st, D, desc, max_chunks, part,
+                     part_cnt, nodes, ldn, node_labels, cluster_count, e2);
+  hipLaunchKernelGGL(r3d_nodes_append_query_kernel, dim3(r3d_cdiv((long)n_query_pts * D, 256), n_ep), dim3(256), 0, st, qfeat,
+                     ldq, D, n_query_pts, desc, nodes, ldn, node_labels, e2);
   R3D_LAUNCH_CHECK("r3d_head_prototypes");
   return R3D_OK;
+}
+
+extern "C" int r3d_head_prototypes(const int32_t* support_y, const int32_t* shot_keep, const float* feat,
+                                   long ldf, const float* featT, const float* qfeat, long ldq, int n_way,
+                                   int k_shot, int N, int D, int n_query_pts, int k, float* nodes, long ldn,
+                                   float* node_labels, int32_t* desc, int32_t* assign_out,
+                                   int32_t* cluster_count, int32_t* ws, long ws_words, int flags, void* stream) {
+  (void)featT;  // (ABI version 2 took a channel-major copy; the compacted copy is built here)
+  const HpEp one{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  return head_prototypes_impl(1, one, 1, support_y, shot_keep, feat, ldf, qfeat, ldq, n_way, k_shot, N, D, n_query_pts, k, nodes,
+                              ldn, node_labels, desc, assign_out, cluster_count, ws, ws_words, flags, stream);
+}
+
+// n_ep episodes in one launch sequence.  Per-episode strides: support_y / shot_keep in int32 words, feat / qfeat in ROWS
+// (episode e's support rows start feat_ep_rows rows after episode e - 1's), nodes / node_labels in rows, desc / assign /
+// cluster_count / ws in int32 words (ws stride even and >= r3d_head_proto_ws_words).
+extern "C" int r3d_head_prototypes_batched(int n_ep, int fps_group, const int32_t* support_y, long sy_stride,
+                                           const int32_t* shot_keep, long keep_stride, const float* feat, long ldf,
+                                           long feat_ep_rows, const float* qfeat, long ldq, long qfeat_ep_rows, int n_way,
+                                           int k_shot, int N, int D, int n_query_pts, int k, float* nodes, long ldn,
+                                           long nodes_ep_rows, float* node_labels, int32_t* desc, long desc_stride,
+                                           int32_t* assign_out, long assign_stride, int32_t* cluster_count,
+                                           long ccount_stride, int32_t* ws, long ws_words, long ws_stride, int flags,
+                                           void* stream) {
+  const HpEp ep{sy_stride, keep_stride, feat_ep_rows, qfeat_ep_rows, nodes_ep_rows, nodes_ep_rows, desc_stride, assign_stride,
+                ccount_stride, ws_stride};
+  return head_prototypes_impl(n_ep, ep, fps_group, support_y, shot_keep, feat, ldf, qfeat, ldq, n_way, k_shot, N, D,
+                              n_query_pts, k, nodes, ldn, node_labels, desc, assign_out, cluster_count, ws, ws_words, flags,
+                              stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -721,7 +801,10 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_proto_bwd_kernel(const float* __
                                                                  const int* __restrict__ comp, const int* __restrict__ desc,
                                                                  const int* __restrict__ assign,
                                                                  const int* __restrict__ cluster_count,
-                                                                 float* __restrict__ dsfeat, long lds_) {
+                                                                 float* __restrict__ dsfeat, long lds_, HpEp st) {
+  const int ep = blockIdx.y;
+  dnodes += (long)ep * st.nodes * ldd; HP_SHIFT(comp, st.ws); HP_SHIFT(desc, st.desc); HP_SHIFT(assign, st.assign);
+  HP_SHIFT(cluster_count, st.ccount); dsfeat += (long)ep * st.feat * lds_;
   int blk0;
   const int seg = g.seg_of_block(blockIdx.x, &blk0);
   const int count = desc[HD_SEG_COUNT + seg];
@@ -738,7 +821,9 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_proto_bwd_kernel(const float* __
 }
 
 __global__ void r3d_query_bwd_kernel(const float* __restrict__ dnodes, long ldd, int D, int nq_pts,
-                                     const int* __restrict__ desc, float* __restrict__ dqfeat, long ldq) {
+                                     const int* __restrict__ desc, float* __restrict__ dqfeat, long ldq, HpEp st) {
+  const int ep = blockIdx.y;
+  dnodes += (long)ep * st.nodes * ldd; HP_SHIFT(desc, st.desc); dqfeat += (long)ep * st.qfeat * ldq;
   const int n_proto = desc[HD_N_PROTO];
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)nq_pts * D) return;
@@ -748,20 +833,39 @@ __global__ void r3d_query_bwd_kernel(const float* __restrict__ dnodes, long ldd,
 }
 
 // dsfeat (S*N, lds) must be zero-initialised by the caller (points in no list keep a zero gradient)
-extern "C" int r3d_head_prototypes_bwd(const float* dnodes, long ldd, int n_way, int k_shot, int N, int D, int n_query_pts,
-                                       const int32_t* desc, const int32_t* assign, const int32_t* cluster_count,
-                                       const int32_t* ws, float* dsfeat, long lds_, float* dqfeat, long ldq, void* stream) {
+static int head_prototypes_bwd_impl(int n_ep, const HpEp& ep, const float* dnodes, long ldd, int n_way, int k_shot, int N, int D,
+                                    int n_query_pts, const int32_t* desc, const int32_t* assign, const int32_t* cluster_count,
+                                    const int32_t* ws, float* dsfeat, long lds_, float* dqfeat, long ldq, void* stream) {
   R3D_REQUIRE(dnodes && desc && assign && cluster_count && ws && dsfeat && dqfeat, "r3d_head_prototypes_bwd: null pointer");
   int rc = check_geom("r3d_head_prototypes_bwd", n_way, k_shot, N, D);
   if (rc) return rc;
+  R3D_REQUIRE(n_ep >= 1 && n_ep <= 4096, "r3d_head_prototypes_bwd: %d episodes", n_ep);
   SegGeom g{n_way, k_shot, N};
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(r3d_proto_bwd_kernel, dim3(g.total_blocks()), dim3(HP_BLOCK), 0, st, dnodes, ldd, D, g, ws /* comp */,
-                     desc, assign, cluster_count, dsfeat, lds_);
-  hipLaunchKernelGGL(r3d_query_bwd_kernel, dim3(r3d_cdiv((long)n_query_pts * D, 256)), dim3(256), 0, st, dnodes, ldd, D,
-                     n_query_pts, desc, dqfeat, ldq);
+  hipLaunchKernelGGL(r3d_proto_bwd_kernel, dim3(g.total_blocks(), n_ep), dim3(HP_BLOCK), 0, st, dnodes, ldd, D, g, ws /* comp */,
+                     desc, assign, cluster_count, dsfeat, lds_, ep);
+  hipLaunchKernelGGL(r3d_query_bwd_kernel, dim3(r3d_cdiv((long)n_query_pts * D, 256), n_ep), dim3(256), 0, st, dnodes, ldd, D,
+                     n_query_pts, desc, dqfeat, ldq, ep);
   R3D_LAUNCH_CHECK("r3d_head_prototypes_bwd");
   return R3D_OK;
+}
+extern "C" int r3d_head_prototypes_bwd(const float* dnodes, long ldd, int n_way, int k_shot, int N, int D, int n_query_pts,
+                                       const int32_t* desc, const int32_t* assign, const int32_t* cluster_count, const int32_t* ws,
+                                       float* dsfeat, long lds_, float* dqfeat, long ldq, void* stream) {
+  const HpEp one{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  return head_prototypes_bwd_impl(1, one, dnodes, ldd, n_way, k_shot, N, D, n_query_pts, desc, assign, cluster_count, ws, dsfeat,
+                                  lds_, dqfeat, ldq, stream);
+}
+// strides as r3d_head_prototypes_batched (dsfeat / dqfeat: rows of the gradient buffers between episodes)
+extern "C" int r3d_head_prototypes_bwd_batched(int n_ep, const float* dnodes, long ldd, long nodes_ep_rows, int n_way, int k_shot,
+                                               int N, int D, int n_query_pts, const int32_t* desc, long desc_stride,
+                                               const int32_t* assign, long assign_stride, const int32_t* cluster_count,
+                                               long ccount_stride, const int32_t* ws, long ws_stride, float* dsfeat, long lds_,
+                                               long dsfeat_ep_rows, float* dqfeat, long ldq, long dqfeat_ep_rows, void* stream) {
+  const HpEp ep{0, 0, dsfeat_ep_rows, dqfeat_ep_rows, nodes_ep_rows, nodes_ep_rows, desc_stride, assign_stride, ccount_stride,
+                ws_stride};
+  return head_prototypes_bwd_impl(n_ep, ep, dnodes, ldd, n_way, k_shot, N, D, n_query_pts, desc, assign, cluster_count, ws,
+                                  dsfeat, lds_, dqfeat, ldq, stream);
 }
 
 // Word offsets of the scratch sub-arrays inside ws (for tests that inspect the

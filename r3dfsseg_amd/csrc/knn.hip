@@ -99,12 +99,12 @@ static __device__ __forceinline__ void list_insert(TopList<R>& L, float val, int
 template <int R>
 __global__ __launch_bounds__(256) void r3d_knn_topk_kernel(
     const float* __restrict__ x, long ldx, int N, int C, int k, int mode,
-    const int* __restrict__ n_dev, const float* __restrict__ nrm, int* __restrict__ idx_out,
+    const int* __restrict__ n_dev, int n_dev_stride, const float* __restrict__ nrm, int* __restrict__ idx_out,
     float* __restrict__ score_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.y;
   const int q0 = blockIdx.x * KNN_Q;
-  const int n = n_dev ? min(*n_dev, N) : N;  // valid rows of this batch
+  const int n = n_dev ? min(n_dev[(long)b * n_dev_stride], N) : N;  // valid rows of this batch
   if (q0 >= n) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int Cp = (C + 1) & ~1;
@@ -285,14 +285,14 @@ __device__ unsigned long long g_knn_dbg[16];
 
 template <int KS>
 __global__ __launch_bounds__(256) void r3d_knn_small_kernel(
-    const float* __restrict__ xT, long ldT, int N, int C, int k, int mode, const int* __restrict__ n_dev,
+    const float* __restrict__ xT, long ldT, int N, int C, int k, int mode, const int* __restrict__ n_dev, int n_dev_stride,
     const float* __restrict__ nrm, int* __restrict__ idx_out, float* __restrict__ score_out,
     const int* __restrict__ tile_flags /* optional: only 32-row tiles with a non-zero flag are computed */) {
   if (tile_flags && !tile_flags[(long)blockIdx.y * gridDim.x + blockIdx.x]) return;
   __shared__ float smem[32 * 129 > 2 * 32 * 128 ? 32 * 129 : 2 * 32 * 128];
   __shared__ float tau_s[32];
   const int b = blockIdx.y;
-  const int n = n_dev ? min(*n_dev, N) : N;
+  const int n = n_dev ? min(n_dev[(long)b * n_dev_stride], N) : N;
   const int q0 = blockIdx.x * 32;
   if (q0 >= n) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -552,7 +552,7 @@ template <int KB_WAVES, int KB_CAP, int KB_TOP, int KCH /* k-pairs per channel c
                        competes with the MFMAs for issue slots, 8 instructions per element with both forms computed */>
 __global__ __launch_bounds__(64 * KB_WAVES) __attribute__((amdgpu_waves_per_eu(KB_WAVES == 4 && (FULLC || KCH < 32) ? 3 : 2)))
 void r3d_knn_append_kernel(
-    const float* __restrict__ xT, long ldT, int N, int C, int k, int mode, const int* __restrict__ n_dev,
+    const float* __restrict__ xT, long ldT, int N, int C, int k, int mode, const int* __restrict__ n_dev, int n_dev_stride,
     const float* __restrict__ nrm, int* __restrict__ idx_out, float* __restrict__ score_out,
     int* __restrict__ status, int* __restrict__ tile_flags, int nsplit, int* __restrict__ idx_tmp,
     float* __restrict__ sc_tmp) {
@@ -566,7 +566,7 @@ void r3d_knn_append_kernel(
   __shared__ int cnt_s[32];
   __shared__ float tau_s[32];
   const int b = blockIdx.y;
-  const int n = n_dev ? min(*n_dev, N) : N;
+  const int n = n_dev ? min(n_dev[(long)b * n_dev_stride], N) : N;
   const int q0 = blockIdx.x * 32;
   if (q0 >= n) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -844,13 +844,13 @@ void r3d_knn_append_kernel(
 // hold disjoint candidates, so keys never tie across lists).  One wave per row, lists in LDS.  Keys as in the rank
 // phase: (order-preserving score bits, complemented index), larger = better.
 __global__ __launch_bounds__(256) void r3d_knn_merge_kernel(const int* __restrict__ idx_tmp, const float* __restrict__ sc_tmp,
-                                                            int nsplit, long rows, int k, const int* __restrict__ n_dev, int N,
+                                                            int nsplit, long rows, int k, const int* __restrict__ n_dev, int n_dev_stride, int N,
                                                             int* __restrict__ idx_out, float* __restrict__ score_out) {
   __shared__ unsigned long long keys[4][2][256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long row = (long)blockIdx.x * 4 + w;
   if (row >= rows) return;
-  if (n_dev && (int)(row % N) >= min(*n_dev, N)) return;  // rows beyond n are not queried
+  if (n_dev && (int)(row % N) >= min(n_dev[(row / N) * n_dev_stride], N)) return;  // rows beyond n are not queried
   // nsplit == 2 (the only configuration launched)
   for (int p = 0; p < 2; ++p)
     for (int t = lane; t < k; t += 64) {
@@ -907,7 +907,7 @@ static size_t knn_lds_bytes(int C) {
 // launch one instance of the append-and-rank kernel (raising its dynamic-LDS limit once per instance)
 template <int WAVES, int CAP, int TOP, int KCH, int SAMPLE, bool FULLC, int SMODE>
 static int knn_append_launch_mode(dim3 grid, size_t lds, hipStream_t st, const float* xT, long ldT, int N, int C, int k,
-                                  const int* n_valid_dev, const float* nrm, int* idx_out, float* score_out, int* status,
+                                  const int* n_valid_dev, int n_valid_stride, const float* nrm, int* idx_out, float* score_out, int* status,
                                   int* tile_flags, int nsplit = 1, int* idx_tmp = nullptr, float* sc_tmp = nullptr) {
   static size_t attr = 0;
   if (lds > attr) {
@@ -917,18 +917,18 @@ static int knn_append_launch_mode(dim3 grid, size_t lds, hipStream_t st, const f
     attr = lds;
   }
   hipLaunchKernelGGL((r3d_knn_append_kernel<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, SMODE>), grid, dim3(64 * WAVES), lds, st, xT, ldT,
-                     N, C, k, SMODE, n_valid_dev, nrm, idx_out, score_out, status, tile_flags, nsplit, idx_tmp, sc_tmp);
+                     N, C, k, SMODE, n_valid_dev, n_valid_stride, nrm, idx_out, score_out, status, tile_flags, nsplit, idx_tmp, sc_tmp);
   return R3D_OK;
 }
 template <int WAVES, int CAP, int TOP, int KCH, int SAMPLE, bool FULLC>
 static int knn_append_launch(dim3 grid, size_t lds, hipStream_t st, const float* xT, long ldT, int N, int C, int k, int mode,
-                             const int* n_valid_dev, const float* nrm, int* idx_out, float* score_out, int* status,
+                             const int* n_valid_dev, int n_valid_stride, const float* nrm, int* idx_out, float* score_out, int* status,
                              int* tile_flags, int nsplit = 1, int* idx_tmp = nullptr, float* sc_tmp = nullptr) {
   return mode == R3D_SCORE_DGCNN
-             ? knn_append_launch_mode<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, R3D_SCORE_DGCNN>(grid, lds, st, xT, ldT, N, C, k, n_valid_dev,
+             ? knn_append_launch_mode<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, R3D_SCORE_DGCNN>(grid, lds, st, xT, ldT, N, C, k, n_valid_dev, n_valid_stride,
                                                                                             nrm, idx_out, score_out, status, tile_flags,
                                                                                             nsplit, idx_tmp, sc_tmp)
-             : knn_append_launch_mode<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, R3D_SCORE_L2>(grid, lds, st, xT, ldT, N, C, k, n_valid_dev, nrm,
+             : knn_append_launch_mode<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, R3D_SCORE_L2>(grid, lds, st, xT, ldT, N, C, k, n_valid_dev, n_valid_stride, nrm,
                                                                                          idx_out, score_out, status, tile_flags, nsplit,
                                                                                          idx_tmp, sc_tmp);
 }
@@ -961,15 +961,15 @@ extern "C" long r3d_knn_norm_ws_words(int B, int N) { return (long)B * N + (long
 // floats of split_ws for r3d_knn_topk_split (two partial top-k lists per row: indices and scores)
 extern "C" long r3d_knn_split_ws_words(int B, int N, int k) { return 4L * B * N * k + 64; }
 
-extern "C" int r3d_knn_topk_split(const float* x, long ldx, const float* x_cm, int B, int N, int C, int k, int mode,
-                                  const int* n_valid_dev, float* norm_ws, float* cm_ws, int32_t* idx_out,
-                                  float* score_out, int32_t* status, float* split_ws, long split_ws_words, void* stream);
+static int knn_topk_impl(const float* x, long ldx, const float* x_cm, int B, int N, int C, int k, int mode,
+                         const int* n_valid_dev, int n_valid_stride, float* norm_ws, float* cm_ws, int32_t* idx_out,
+                         float* score_out, int32_t* status, float* split_ws, long split_ws_words, void* stream);
 
 extern "C" int r3d_knn_topk(const float* x, long ldx, const float* x_cm, int B, int N, int C, int k, int mode,
                             const int* n_valid_dev, float* norm_ws, float* cm_ws, int32_t* idx_out,
                             float* score_out, int32_t* status, void* stream) {
-  return r3d_knn_topk_split(x, ldx, x_cm, B, N, C, k, mode, n_valid_dev, norm_ws, cm_ws, idx_out, score_out, status, nullptr, 0,
-                            stream);
+  return knn_topk_impl(x, ldx, x_cm, B, N, C, k, mode, n_valid_dev, 0, norm_ws, cm_ws, idx_out, score_out, status, nullptr, 0,
+                       stream);
 }
 
 // r3d_knn_topk with an optional scratch for the large-k streamed kernel: when the query tiles alone cannot fill the
@@ -978,6 +978,25 @@ extern "C" int r3d_knn_topk(const float* x, long ldx, const float* x_cm, int B, 
 extern "C" int r3d_knn_topk_split(const float* x, long ldx, const float* x_cm, int B, int N, int C, int k, int mode,
                                   const int* n_valid_dev, float* norm_ws, float* cm_ws, int32_t* idx_out,
                                   float* score_out, int32_t* status, float* split_ws, long split_ws_words, void* stream) {
+  return knn_topk_impl(x, ldx, x_cm, B, N, C, k, mode, n_valid_dev, 0, norm_ws, cm_ws, idx_out, score_out, status, split_ws,
+                       split_ws_words, stream);
+}
+
+// The same over a batch of B point sets with their OWN valid counts: set b has n_valid_dev[b * n_valid_stride] rows (the
+// graph nodes of B episodes' label-propagation systems, each at its capacity N).  status: ONE word for the batch (bit 0:
+// some set's survivor buffer overflowed).
+extern "C" int r3d_knn_topk_batched(const float* x, long ldx, const float* x_cm, int B, int N, int C, int k, int mode,
+                                    const int* n_valid_dev, int n_valid_stride, float* norm_ws, float* cm_ws,
+                                    int32_t* idx_out, float* score_out, int32_t* status, float* split_ws,
+                                    long split_ws_words, void* stream) {
+  R3D_REQUIRE(n_valid_stride >= 0, "r3d_knn_topk_batched: negative stride");
+  return knn_topk_impl(x, ldx, x_cm, B, N, C, k, mode, n_valid_dev, n_valid_stride, norm_ws, cm_ws, idx_out, score_out, status,
+                       split_ws, split_ws_words, stream);
+}
+
+static int knn_topk_impl(const float* x, long ldx, const float* x_cm, int B, int N, int C, int k, int mode,
+                         const int* n_valid_dev, int n_valid_stride, float* norm_ws, float* cm_ws, int32_t* idx_out,
+                         float* score_out, int32_t* status, float* split_ws, long split_ws_words, void* stream) {
   R3D_REQUIRE((x || x_cm) && norm_ws && idx_out, "r3d_knn_topk: null pointer");
   R3D_REQUIRE(B > 0 && N > 0 && C > 0 && (!x || ldx >= C), "r3d_knn_topk: bad shape B=%d N=%d C=%d ldx=%ld", B, N, C, ldx);
   R3D_REQUIRE(k > 0 && k <= N && k <= 256, "r3d_knn_topk: unsupported k=%d (need 1..min(N,256))", k);
@@ -999,10 +1018,10 @@ extern "C" int r3d_knn_topk_split(const float* x, long ldx, const float* x_cm, i
     int* tile_flags = (int*)(norm_ws + (long)B * N);  // r3d_knn_norm_ws_words reserves B * ceil(N/32) words here
     if (two_pass_only) {
       if (C <= 16)
-        hipLaunchKernelGGL(r3d_knn_small_kernel<8>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, norm_ws,
+        hipLaunchKernelGGL(r3d_knn_small_kernel<8>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, n_valid_stride, norm_ws,
                            idx_out, score_out, (const int*)nullptr);
       else
-        hipLaunchKernelGGL(r3d_knn_small_kernel<32>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, norm_ws,
+        hipLaunchKernelGGL(r3d_knn_small_kernel<32>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, n_valid_stride, norm_ws,
                            idx_out, score_out, (const int*)nullptr);
     } else {
       // append-and-rank (mid configuration); tiles whose survivor buffer overflowed are redone by the exact
@@ -1014,18 +1033,18 @@ extern "C" int r3d_knn_topk_split(const float* x, long ldx, const float* x_cm, i
       const size_t lds = knn_append_lds_bytes(C, few ? 8 : KM_WAVES, KM_CAP, KM_TOP, C <= 16 ? 8 : 32);
       int rc;
 #define KM_LAUNCH(WAVES, KCH, FULLC)                                                                                       \
-  knn_append_launch<WAVES, KM_CAP, KM_TOP, KCH, KM_SAMPLE, FULLC>(g2, lds, st, xT, ldT, N, C, k, mode, n_valid_dev, norm_ws, \
+  knn_append_launch<WAVES, KM_CAP, KM_TOP, KCH, KM_SAMPLE, FULLC>(g2, lds, st, xT, ldT, N, C, k, mode, n_valid_dev, n_valid_stride, norm_ws, \
                                                                   idx_out, score_out, nullptr, tile_flags)
       if (C <= 16) {
         rc = few ? KM_LAUNCH(8, 8, false) : KM_LAUNCH(KM_WAVES, 8, false);
         if (rc) return rc;
-        hipLaunchKernelGGL(r3d_knn_small_kernel<8>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, norm_ws,
+        hipLaunchKernelGGL(r3d_knn_small_kernel<8>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, n_valid_stride, norm_ws,
                            idx_out, score_out, (const int*)tile_flags);
       } else {
         if (C % 64 == 0) rc = few ? KM_LAUNCH(8, 32, true) : KM_LAUNCH(KM_WAVES, 32, true);
         else rc = few ? KM_LAUNCH(8, 32, false) : KM_LAUNCH(KM_WAVES, 32, false);
         if (rc) return rc;
-        hipLaunchKernelGGL(r3d_knn_small_kernel<32>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, norm_ws,
+        hipLaunchKernelGGL(r3d_knn_small_kernel<32>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, n_valid_stride, norm_ws,
                            idx_out, score_out, (const int*)tile_flags);
       }
 #undef KM_LAUNCH
@@ -1058,14 +1077,14 @@ extern "C" int r3d_knn_topk_split(const float* x, long ldx, const float* x_cm, i
       int* idx_tmp = (int*)split_ws;
       float* sc_tmp = split_ws ? split_ws + 2L * B * N * k : nullptr;
       const int rc = C % 64 == 0
-                         ? knn_append_launch<8, 384, 2, 32, 1, true>(gb, knn_big_lds_bytes(C), st, xT, ldT, N, C, k, mode, n_valid_dev,
+                         ? knn_append_launch<8, 384, 2, 32, 1, true>(gb, knn_big_lds_bytes(C), st, xT, ldT, N, C, k, mode, n_valid_dev, n_valid_stride,
                                                                      norm_ws, idx_out, score_out, status, nullptr, nsplit, idx_tmp, sc_tmp)
-                         : knn_append_launch<8, 384, 2, 32, 1, false>(gb, knn_big_lds_bytes(C), st, xT, ldT, N, C, k, mode, n_valid_dev,
+                         : knn_append_launch<8, 384, 2, 32, 1, false>(gb, knn_big_lds_bytes(C), st, xT, ldT, N, C, k, mode, n_valid_dev, n_valid_stride,
                                                                       norm_ws, idx_out, score_out, status, nullptr, nsplit, idx_tmp, sc_tmp);
       if (rc) return rc;
       if (split)
         hipLaunchKernelGGL(r3d_knn_merge_kernel, dim3(r3d_cdiv((long)B * N, 4)), dim3(256), 0, st, idx_tmp, sc_tmp, 2,
-                           (long)B * N, k, n_valid_dev, N, idx_out, score_out);
+                           (long)B * N, k, n_valid_dev, n_valid_stride, N, idx_out, score_out);
     }
     R3D_LAUNCH_CHECK("r3d_knn_topk(big)");
     return R3D_OK;
@@ -1085,7 +1104,7 @@ extern "C" int r3d_knn_topk_split(const float* x, long ldx, const float* x_cm, i
       attr_set = true;                                                                           \
     }                                                                                            \
     hipLaunchKernelGGL(r3d_knn_topk_kernel<RR>, grid, block, lds, st, x, ldx, N, C, k, mode,     \
-                       n_valid_dev, norm_ws, idx_out, score_out);                                \
+                       n_valid_dev, n_valid_stride, norm_ws, idx_out, score_out);                \
   } while (0)
   if (k <= 64) KNN_LAUNCH(1);
   else if (k <= 128) KNN_LAUNCH(2);

@@ -10,6 +10,14 @@
 // r3d_affine_act (y = act(scale z + shift)).  Backward:  r3d_bn_bwd_stats (sum du, sum du zhat) ->
 // r3d_bn_bwd_apply (dz) -> r3d_pointwise_conv(dz, W^T) for dX and r3d_gemm_tn(dz, X) for dW.
 // All reductions run in a fixed order (partials per row chunk, chunks added ascending, in fp64).
+//
+// SEGMENTS.  A batch of E training episodes goes through ONE launch sequence, but BatchNorm keeps the statistics of
+// every getFeatures call apart (models/mpti.py:434,436: the S support clouds, then the Q query clouds of an episode).
+// Rows are laid out episode after episode, [support rows | query rows] each, so the segment of a row follows from two
+// numbers (common.h: r3d_segmap): rows_a = S N, rows_b = Q N; segment 2 e + p is call p of episode e -- the order in
+// which the reference updates the running statistics.  Every reduction below is per segment with a partition that
+// depends on the segment's size alone, so a segment's statistics are bit for bit the same whether its episode runs
+// alone or inside a batch.  The single-segment entry points of ABI version 2 are the case rows_b = 0, rows_a = M.
 #include "common.h"
 
 #define TS_ROWS 512      // rows per partial
@@ -20,18 +28,28 @@
 // mode 0: (x, x*x)                                             -- forward statistics
 // mode 1: (du, du * zhat), du = dy * act'(s z + t), zhat = (z - mean) * invstd   -- BN backward
 __global__ __launch_bounds__(256) void r3d_colpartial_kernel(
-    const float* __restrict__ X, long ldx, const float* __restrict__ DY, long lddy, long M, int C, int mode,
+    const float* __restrict__ X, long ldx, const float* __restrict__ DY, long lddy, r3d_segmap sm, int C, int mode,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ invstd, int act, int rows_per_chunk, float* __restrict__ part /* [chunks][2][C] */) {
+    const float* __restrict__ invstd, long bn_stride, int act, int rows_per_chunk_a, int rows_per_chunk_b, int cmax,
+    float* __restrict__ part /* [seg][cmax][2][C] */) {
   __shared__ float sa[4][64], sb[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
-  const long r0 = (long)blockIdx.y * rows_per_chunk;
-  const long r1 = min(M, r0 + rows_per_chunk);
+  const int seg = blockIdx.z;
+  const long srows = sm.seg_rows(seg);
+  const int rows_per_chunk = sm.odd(seg) ? rows_per_chunk_b : rows_per_chunk_a;
+  const long s0 = (long)blockIdx.y * rows_per_chunk;
+  if (s0 >= srows) return;  // uniform: this segment has fewer chunks than the longest one
+  const long base = sm.seg_row0(seg);
+  const long r0 = base + s0;
+  const long r1 = base + min(srows, s0 + rows_per_chunk);
   float a = 0.f, b = 0.f;
   if (c < C) {
     float sc = 1.f, sh = 0.f, mu = 0.f, is = 1.f;
-    if (mode == 1) { sc = scale[c]; sh = shift[c]; mu = mean[c]; is = invstd[c]; }
+    if (mode == 1) {
+      const long o = (long)seg * bn_stride + c;
+      sc = scale[o]; sh = shift[o]; mu = mean[o]; is = invstd[o];
+    }
     // 8 rows in flight per step (unconditional loads on clamped rows, masked afterwards: common.h r3d_keep); the
     // row order of the sums is unchanged
     for (long rb = r0 + w; rb < r1; rb += 32) {
@@ -65,18 +83,30 @@ __global__ __launch_bounds__(256) void r3d_colpartial_kernel(
   sb[w][lane] = b;
   __syncthreads();
   if (w == 0 && c < C) {
-    part[((long)blockIdx.y * 2 + 0) * C + c] = ((sa[0][lane] + sa[1][lane]) + sa[2][lane]) + sa[3][lane];
-    part[((long)blockIdx.y * 2 + 1) * C + c] = ((sb[0][lane] + sb[1][lane]) + sb[2][lane]) + sb[3][lane];
+    const long slot = (long)seg * cmax + blockIdx.y;
+    part[(slot * 2 + 0) * C + c] = ((sa[0][lane] + sa[1][lane]) + sa[2][lane]) + sa[3][lane];
+    part[(slot * 2 + 1) * C + c] = ((sb[0][lane] + sb[1][lane]) + sb[2][lane]) + sb[3][lane];
   }
 }
 
 // 64 columns per workgroup; the chunk axis is split over the 4 waves (chunks q, q+4, ...), each adding in
 // ascending order in fp64, and the four wave totals are combined in a fixed order: deterministic for any count.
-__global__ __launch_bounds__(256) void r3d_colreduce_kernel(const float* __restrict__ part, int chunks, int C,
-                                                            float* __restrict__ out /* [2][C] */) {
+// blockIdx.y = segment.  Its chunks are rows [first, first + count) of `part`: cmax > 0: first = seg * cmax (the
+// layout r3d_colpartial_kernel writes); cmax == 0: the chunks of all segments follow each other (one partial per
+// 64-row tile of a GEMM, gemm.hip), count_a / count_b of them alternating.  Chunk indices are relative to the
+// segment's first chunk, so a segment's sums do not depend on where it sits in the batch.
+__global__ __launch_bounds__(256) void r3d_colreduce_kernel(const float* __restrict__ part, int count_a, int count_b,
+                                                            int cmax, int C, float* __restrict__ out /* [seg][2][C] */) {
   __shared__ double sa[4][64], sb[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
+  const int seg = blockIdx.y;
+  const bool odd = count_b > 0 && (seg & 1);
+  const int chunks = odd ? count_b : count_a;
+  const long first = cmax > 0 ? (long)seg * cmax
+                              : (count_b > 0 ? (long)(seg >> 1) * (count_a + count_b) + (odd ? count_a : 0) : (long)seg * count_a);
+  part += first * 2 * C;
+  out += (long)seg * 2 * C;
   double a = 0.0, b = 0.0;
   if (c < C) {
     int k = w;
@@ -107,31 +137,57 @@ __global__ __launch_bounds__(256) void r3d_colreduce_kernel(const float* __restr
 // ---- batch statistics -> affine, running statistics update ------------------------------------
 // sums [2][C] (sum, sumsq over `count` elements per channel).  Writes mean, invstd, scale = gamma*invstd,
 // shift = beta - mean*scale; running_mean/var updated in place (momentum 0.1, unbiased variance).
-__global__ void r3d_bn_fold_kernel(const float* __restrict__ sums, double count, int C, const float* __restrict__ gamma,
+// One thread per channel walks the segments IN ORDER (segment 2 e + p = call p of episode e): the running statistics
+// see the batches one after the other exactly as the reference's one-episode-at-a-time schedule applies them.
+__global__ void r3d_bn_fold_kernel(const float* __restrict__ sums /* [seg][2][C] */, int n_seg, double count_a,
+                                   double count_b, int C, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, float momentum,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
-                                   float* __restrict__ shift, float* __restrict__ rec, const int* __restrict__ rec_index,
-                                   long rec_stride) {
+                                   float* __restrict__ shift, long bn_stride, float* __restrict__ rec,
+                                   const int* __restrict__ rec_index, long rec_stride) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double m = (double)sums[c] / count;
-  double var = (double)sums[C + c] / count - m * m;
-  if (var < 0.0) var = 0.0;
-  const float is = (float)(1.0 / sqrt(var + (double)eps));
-  mean[c] = (float)m;
-  invstd[c] = is;
-  const float sc = gamma[c] * is;
-  scale[c] = sc;
-  shift[c] = beta[c] - (float)m * sc;
-  const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-  if (rec) {  // captured episodes: the batch statistics are recorded, r3d_bn_running_update applies them in episode order
-    float* r = rec + (long)(rec_index ? *rec_index : 0) * rec_stride;
-    r[c] = (float)m;
-    r[C + c] = (float)unb;
-  } else if (running_mean) {
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  const float g = gamma[c], bt = beta[c];
+  float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+  const long rec0 = rec_index ? *rec_index : 0;
+  for (int s0 = 0; s0 < n_seg; s0 += 8) {  // 16 loads in flight; the update order stays the segment order
+    float sv[8], qv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long o = (long)min(s0 + u, n_seg - 1) * 2 * C;
+      sv[u] = sums[o + c];
+      qv[u] = sums[o + C + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int seg = s0 + u;
+      if (seg >= n_seg) break;
+      const double count = (count_b > 0.0 && (seg & 1)) ? count_b : count_a;
+      const double m = (double)sv[u] / count;
+      double var = (double)qv[u] / count - m * m;
+      if (var < 0.0) var = 0.0;
+      const float is = (float)(1.0 / sqrt(var + (double)eps));
+      const long o = (long)seg * bn_stride + c;
+      mean[o] = (float)m;
+      invstd[o] = is;
+      const float sc = g * is;
+      scale[o] = sc;
+      shift[o] = bt - (float)m * sc;
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      if (rec) {  // captured episodes: the batch statistics are recorded, r3d_bn_running_update applies them in episode order
+        float* r = rec + (rec0 + seg) * rec_stride;
+        r[c] = (float)m;
+        r[C + c] = (float)unb;
+      } else if (running_mean) {
+        rm = (1.f - momentum) * rm + momentum * (float)m;
+        rv = (1.f - momentum) * rv + momentum * (float)unb;
+      }
+    }
+  }
+  if (!rec && running_mean) {
+    running_mean[c] = rm;
+    running_var[c] = rv;
   }
 }
 
@@ -167,38 +223,88 @@ __global__ void r3d_bn_running_update_kernel(const float* __restrict__ rec, int 
 }
 
 
-// ---- y = act(scale * z + shift), elementwise over (M, C) ---------------------------------------
-__global__ void r3d_affine_act_kernel(const float* __restrict__ Z, long ldz, long M, int C,
-                                      const float* __restrict__ scale, const float* __restrict__ shift, int act,
-                                      float* __restrict__ Y, long ldy) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= M * C) return;
-  const long r = i / C;
-  const int c = (int)(i - r * C);
-  float v = scale[c] * Z[r * ldz + c] + shift[c];
-  if (act == 1) v = fmaxf(v, 0.f);
-  else if (act == 2) v = v > 0.f ? v : 0.2f * v;
-  Y[r * ldy + c] = v;
+// ---- y = act(scale * z + shift), elementwise over (M, C); scale / shift of the row's segment -------
+// One workgroup = EW_ROWS rows, wave w takes rows w, w + 4, ... with the lanes along the columns: no division per
+// element (a 64-bit i / C and a segment lookup per element are ~250 VALU instructions against 8 bytes of traffic: the
+// kernel was instruction bound), the row's segment once per row, eight rows of loads in flight per wave.
+#define EW_ROWS 32
+__global__ __launch_bounds__(256) void r3d_affine_act_kernel(const float* __restrict__ Z, long ldz, int M, int C, r3d_segmap sm,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             long bn_stride, int act, float* __restrict__ Y, long ldy) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * EW_ROWS + w;
+  long zo[EW_ROWS / 4], yo[EW_ROWS / 4], bo[EW_ROWS / 4];
+#pragma unroll
+  for (int u = 0; u < EW_ROWS / 4; ++u) {
+    const int r = min(r0 + 4 * u, M - 1);
+    zo[u] = (long)r * ldz; yo[u] = (long)r * ldy;
+    bo[u] = (long)sm.seg_of_row32(r) * bn_stride;
+  }
+  for (int c = lane; c < C; c += 64) {
+    float zv[EW_ROWS / 4], sc[EW_ROWS / 4], sh[EW_ROWS / 4];
+#pragma unroll
+    for (int u = 0; u < EW_ROWS / 4; ++u) { zv[u] = Z[zo[u] + c]; sc[u] = scale[bo[u] + c]; sh[u] = shift[bo[u] + c]; }
+#pragma unroll
+    for (int u = 0; u < EW_ROWS / 4; ++u) {
+      float v = sc[u] * zv[u] + sh[u];
+      if (act == 1) v = fmaxf(v, 0.f);
+      else if (act == 2) v = v > 0.f ? v : 0.2f * v;
+      if (r0 + 4 * u < M) Y[yo[u] + c] = v;
+    }
+  }
 }
 
-// ---- BN backward, apply: dz = scale * (du - sum_du / n - zhat * sum_du_zhat / n) ----------------
-__global__ void r3d_bn_bwd_apply_kernel(const float* __restrict__ Z, long ldz, const float* __restrict__ DY, long lddy,
-                                        long M, int C, const float* __restrict__ scale, const float* __restrict__ shift,
-                                        const float* __restrict__ mean, const float* __restrict__ invstd, int act,
-                                        const float* __restrict__ sums /* [2][C]: sum du, sum du*zhat */, double count,
-                                        float* __restrict__ DZ, long lddz) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= M * C) return;
-  const long r = i / C;
-  const int c = (int)(i - r * C);
-  const float z = Z[r * ldz + c];
-  const float u = scale[c] * z + shift[c];
-  float g = DY[r * lddy + c];
-  if (act == 1) g = u > 0.f ? g : 0.f;
-  else if (act == 2) g = u > 0.f ? g : 0.2f * g;
-  const float zh = (z - mean[c]) * invstd[c];
-  const float m1 = (float)((double)sums[c] / count), m2 = (float)((double)sums[C + c] / count);
-  DZ[r * lddz + c] = scale[c] * (g - m1 - zh * m2);
+// ---- BN backward, apply: dz = scale * (du - sum_du / n - zhat * sum_du_zhat / n), per segment ----
+__global__ __launch_bounds__(256) void r3d_bn_bwd_apply_kernel(
+    const float* __restrict__ Z, long ldz, const float* __restrict__ DY, long lddy, int M, int C, r3d_segmap sm,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, long bn_stride, int act, const float* __restrict__ sums /* [seg][2][C]: sum du, sum du*zhat */,
+    double count_a, double count_b, float* __restrict__ DZ, long lddz) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * EW_ROWS + w;
+  constexpr int U = 4;  // rows in flight per trip (each brings two row loads and six vector loads)
+  for (int rr = 0; rr < EW_ROWS / 4; rr += U) {
+    long zo[U], go[U], oo[U], bo[U], so[U];
+    double cnt[U];
+    bool same = true;  // the usual case: the trip's rows lie in one segment -> one pair of fp64 divisions per column
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = min(r0 + 4 * (rr + u), M - 1);
+      const int seg = sm.seg_of_row32(r);
+      zo[u] = (long)r * ldz; go[u] = (long)r * lddy; oo[u] = (long)r * lddz;
+      bo[u] = (long)seg * bn_stride; so[u] = (long)seg * 2 * C;
+      cnt[u] = sm.odd(seg) ? count_b : count_a;
+      same = same && so[u] == so[0];
+    }
+    for (int c = lane; c < C; c += 64) {
+      float z[U], g[U], sc[U], sh[U], mu[U], is[U], m1[U], m2[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        z[u] = Z[zo[u] + c]; g[u] = DY[go[u] + c];
+        sc[u] = scale[bo[u] + c]; sh[u] = shift[bo[u] + c]; mu[u] = mean[bo[u] + c]; is[u] = invstd[bo[u] + c];
+      }
+      if (same) {  // wave-uniform
+        const float a1 = (float)((double)sums[so[0] + c] / cnt[0]), a2 = (float)((double)sums[so[0] + C + c] / cnt[0]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) { m1[u] = a1; m2[u] = a2; }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          m1[u] = (float)((double)sums[so[u] + c] / cnt[u]);
+          m2[u] = (float)((double)sums[so[u] + C + c] / cnt[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float uu = sc[u] * z[u] + sh[u];
+        float gg = g[u];
+        if (act == 1) gg = uu > 0.f ? gg : 0.f;
+        else if (act == 2) gg = uu > 0.f ? gg : 0.2f * gg;
+        const float zh = (z[u] - mu[u]) * is[u];
+        if (r0 + 4 * (rr + u) < M) DZ[oo[u] + c] = sc[u] * (gg - m1[u] - zh * m2[u]);
+      }
+    }
+  }
 }
 
 // ---- C = A^T B over the row axis: out[i][j] = sum_m A[m][i] * B[m][j] ---------------------------
@@ -331,46 +437,77 @@ static int ts_rows(long M, int C) {
   if (rows > TS_ROWS) rows = TS_ROWS;
   return (int)rows;
 }
-extern "C" long r3d_colstats_ws_words(long M, int C) {
-  const int rows = ts_rows(M, C);
-  return ((M + rows - 1) / rows) * 2L * C + 16;
+static int ts_chunks(long rows, int C) { return rows > 0 ? r3d_cdiv(rows, ts_rows(rows, C)) : 0; }
+extern "C" long r3d_colstats_seg_ws_words(long M, int C, long rows_a, long rows_b) {
+  const r3d_segmap sm{rows_a, rows_b};
+  if (!sm.covers(M)) return 0;
+  const int ca = ts_chunks(rows_a, C), cb = ts_chunks(rows_b, C);
+  return (long)sm.n_seg(M) * (ca > cb ? ca : cb) * 2L * C + 16;
 }
+extern "C" long r3d_colstats_ws_words(long M, int C) { return r3d_colstats_seg_ws_words(M, C, M, 0); }
 
-// sums_out [2][C]: mode 0 (sum x, sum x^2); mode 1 (sum du, sum du*zhat) -- see kernel comment
-extern "C" int r3d_colstats(const float* X, long ldx, const float* DY, long lddy, long M, int C, int mode,
-                            const float* scale, const float* shift, const float* mean, const float* invstd, int act,
-                            float* sums_out, float* ws, void* stream) {
+// sums_out [seg][2][C]: mode 0 (sum x, sum x^2); mode 1 (sum du, sum du*zhat) -- see kernel comment.  The BatchNorm
+// vectors of segment s are read at scale + s * bn_stride, ...
+extern "C" int r3d_colstats_seg(const float* X, long ldx, const float* DY, long lddy, long M, int C, long rows_a,
+                                long rows_b, int mode, const float* scale, const float* shift, const float* mean,
+                                const float* invstd, long bn_stride, int act, float* sums_out, float* ws, void* stream) {
   R3D_REQUIRE(X && sums_out && ws && M > 0 && C > 0 && C <= TS_MAXC, "r3d_colstats: bad arguments");
   R3D_REQUIRE(mode == 0 || (DY && scale && shift && mean && invstd), "r3d_colstats: mode 1 needs dy and the BN vectors");
-  const int rows = ts_rows(M, C);
-  const int chunks = r3d_cdiv(M, rows);
+  const r3d_segmap sm{rows_a, rows_b};
+  R3D_REQUIRE(sm.covers(M), "r3d_colstats: %ld rows are not whole segments of %ld + %ld rows", M, rows_a, rows_b);
+  const int ra = ts_rows(rows_a, C), rb = rows_b > 0 ? ts_rows(rows_b, C) : ra;
+  const int ca = ts_chunks(rows_a, C), cb = ts_chunks(rows_b, C);
+  const int cmax = ca > cb ? ca : cb, n_seg = sm.n_seg(M);
+  R3D_REQUIRE(n_seg <= 65535 && cmax <= 65535, "r3d_colstats: too many segments");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(r3d_colpartial_kernel, dim3(r3d_cdiv(C, 64), chunks), dim3(256), 0, st, X, ldx, DY, lddy, M, C, mode,
-                     scale, shift, mean, invstd, act, rows, ws);
-  hipLaunchKernelGGL(r3d_colreduce_kernel, dim3(r3d_cdiv(C, 64)), dim3(256), 0, st, ws, chunks, C, sums_out);
+  hipLaunchKernelGGL(r3d_colpartial_kernel, dim3(r3d_cdiv(C, 64), cmax, n_seg), dim3(256), 0, st, X, ldx, DY, lddy, sm, C, mode,
+                     scale, shift, mean, invstd, bn_stride, act, ra, rb, cmax, ws);
+  hipLaunchKernelGGL(r3d_colreduce_kernel, dim3(r3d_cdiv(C, 64), n_seg), dim3(256), 0, st, ws, ca, cb, cmax, C, sums_out);
   R3D_LAUNCH_CHECK("r3d_colstats");
   return R3D_OK;
 }
+extern "C" int r3d_colstats(const float* X, long ldx, const float* DY, long lddy, long M, int C, int mode,
+                            const float* scale, const float* shift, const float* mean, const float* invstd, int act,
+                            float* sums_out, float* ws, void* stream) {
+  return r3d_colstats_seg(X, ldx, DY, lddy, M, C, M, 0, mode, scale, shift, mean, invstd, 0, act, sums_out, ws, stream);
+}
 
-// [chunks][2][C] partial column sums -> sums_out [2][C] (shared with the GEMM-epilogue statistics of gemm.hip)
-extern "C" int r3d_colreduce(const float* part, int chunks, int C, float* sums_out, void* stream) {
-  R3D_REQUIRE(part && sums_out && chunks > 0 && C > 0, "r3d_colreduce: bad arguments");
-  hipLaunchKernelGGL(r3d_colreduce_kernel, dim3(r3d_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, part, chunks, C,
-                     sums_out);
+// [chunks][2][C] partial column sums -> sums_out [seg][2][C] (shared with the GEMM-epilogue statistics of gemm.hip): the
+// chunks of the segments follow each other, count_a / count_b of them alternating (count_b == 0: count_a each)
+extern "C" int r3d_colreduce_seg(const float* part, int count_a, int count_b, int n_seg, int C, float* sums_out, void* stream) {
+  R3D_REQUIRE(part && sums_out && count_a > 0 && count_b >= 0 && n_seg > 0 && n_seg <= 65535 && C > 0,
+              "r3d_colreduce: bad arguments");
+  hipLaunchKernelGGL(r3d_colreduce_kernel, dim3(r3d_cdiv(C, 64), n_seg), dim3(256), 0, (hipStream_t)stream, part, count_a, count_b,
+                     0, C, sums_out);
   R3D_LAUNCH_CHECK("r3d_colreduce");
   return R3D_OK;
 }
+extern "C" int r3d_colreduce(const float* part, int chunks, int C, float* sums_out, void* stream) {
+  return r3d_colreduce_seg(part, chunks, 0, 1, C, sums_out, stream);
+}
 
+// sums [seg][2][C] -> mean / invstd / scale / shift of segment s at (pointer + s * bn_stride).  Running statistics (or
+// the records, rec + (*rec_index_dev + s) * rec_stride) are updated in segment order.
+extern "C" int r3d_bn_fold_seg(const float* sums, int n_seg, double count_a, double count_b, int C, const float* gamma,
+                               const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                               float* mean, float* invstd, float* scale, float* shift, long bn_stride, float* rec,
+                               const int32_t* rec_index_dev, long rec_stride, void* stream) {
+  R3D_REQUIRE(sums && gamma && beta && mean && invstd && scale && shift && C > 0 && count_a > 0 && count_b >= 0 && n_seg > 0,
+              "r3d_bn_fold: bad arguments");
+  R3D_REQUIRE(n_seg == 1 || bn_stride >= C, "r3d_bn_fold: %d segments need a vector stride of at least C", n_seg);
+  R3D_REQUIRE(!rec || rec_stride >= 2L * C, "r3d_bn_fold: a record holds 2 C floats");
+  hipLaunchKernelGGL(r3d_bn_fold_kernel, dim3(r3d_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, sums, n_seg, count_a, count_b,
+                     C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, bn_stride, rec,
+                     rec_index_dev, rec_stride);
+  R3D_LAUNCH_CHECK("r3d_bn_fold");
+  return R3D_OK;
+}
 extern "C" int r3d_bn_fold(const float* sums, double count, int C, const float* gamma, const float* beta, float eps,
                            float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
                            float* scale, float* shift, float* rec, const int32_t* rec_index_dev, long rec_stride,
                            void* stream) {
-  R3D_REQUIRE(sums && gamma && beta && mean && invstd && scale && shift && C > 0 && count > 0, "r3d_bn_fold: bad arguments");
-  R3D_REQUIRE(!rec || rec_stride >= 2L * C, "r3d_bn_fold: a record holds 2 C floats");
-  hipLaunchKernelGGL(r3d_bn_fold_kernel, dim3(r3d_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, count, C, gamma,
-                     beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, rec, rec_index_dev, rec_stride);
-  R3D_LAUNCH_CHECK("r3d_bn_fold");
-  return R3D_OK;
+  return r3d_bn_fold_seg(sums, 1, count, 0.0, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale,
+                         shift, 0, rec, rec_index_dev, rec_stride, stream);
 }
 
 extern "C" int r3d_bn_running_update(const float* rec, int n_records, long rec_stride, int C, float momentum, const float* bias,
@@ -383,23 +520,39 @@ extern "C" int r3d_bn_running_update(const float* rec, int n_records, long rec_s
   return R3D_OK;
 }
 
-extern "C" int r3d_affine_act(const float* Z, long ldz, long M, int C, const float* scale, const float* shift, int act,
-                              float* Y, long ldy, void* stream) {
+extern "C" int r3d_affine_act_seg(const float* Z, long ldz, long M, int C, long rows_a, long rows_b, const float* scale,
+                                  const float* shift, long bn_stride, int act, float* Y, long ldy, void* stream) {
   R3D_REQUIRE(Z && Y && scale && shift && M > 0 && C > 0, "r3d_affine_act: bad arguments");
-  hipLaunchKernelGGL(r3d_affine_act_kernel, dim3(r3d_cdiv(M * C, 256)), dim3(256), 0, (hipStream_t)stream, Z, ldz, M, C,
-                     scale, shift, act, Y, ldy);
+  const r3d_segmap sm{rows_a, rows_b};
+  R3D_REQUIRE(sm.covers(M), "r3d_affine_act: %ld rows are not whole segments of %ld + %ld rows", M, rows_a, rows_b);
+  hipLaunchKernelGGL(r3d_affine_act_kernel, dim3(r3d_cdiv(M, EW_ROWS)), dim3(256), 0, (hipStream_t)stream, Z, ldz, (int)M, C, sm,
+                     scale, shift, bn_stride, act, Y, ldy);
   R3D_LAUNCH_CHECK("r3d_affine_act");
   return R3D_OK;
 }
+extern "C" int r3d_affine_act(const float* Z, long ldz, long M, int C, const float* scale, const float* shift, int act,
+                              float* Y, long ldy, void* stream) {
+  return r3d_affine_act_seg(Z, ldz, M, C, M, 0, scale, shift, 0, act, Y, ldy, stream);
+}
 
+extern "C" int r3d_bn_bwd_apply_seg(const float* Z, long ldz, const float* DY, long lddy, long M, int C, long rows_a,
+                                    long rows_b, const float* scale, const float* shift, const float* mean,
+                                    const float* invstd, long bn_stride, int act, const float* sums, double count_a,
+                                    double count_b, float* DZ, long lddz, void* stream) {
+  R3D_REQUIRE(Z && DY && DZ && scale && shift && mean && invstd && sums, "r3d_bn_bwd_apply: null pointer");
+  const r3d_segmap sm{rows_a, rows_b};
+  R3D_REQUIRE(sm.covers(M) && count_a > 0, "r3d_bn_bwd_apply: %ld rows are not whole segments of %ld + %ld rows", M, rows_a,
+              rows_b);
+  hipLaunchKernelGGL(r3d_bn_bwd_apply_kernel, dim3(r3d_cdiv(M, EW_ROWS)), dim3(256), 0, (hipStream_t)stream, Z, ldz, DY,
+                     lddy, (int)M, C, sm, scale, shift, mean, invstd, bn_stride, act, sums, count_a, count_b, DZ, lddz);
+  R3D_LAUNCH_CHECK("r3d_bn_bwd_apply");
+  return R3D_OK;
+}
 extern "C" int r3d_bn_bwd_apply(const float* Z, long ldz, const float* DY, long lddy, long M, int C, const float* scale,
                                 const float* shift, const float* mean, const float* invstd, int act, const float* sums,
                                 double count, float* DZ, long lddz, void* stream) {
-  R3D_REQUIRE(Z && DY && DZ && scale && shift && mean && invstd && sums, "r3d_bn_bwd_apply: null pointer");
-  hipLaunchKernelGGL(r3d_bn_bwd_apply_kernel, dim3(r3d_cdiv(M * C, 256)), dim3(256), 0, (hipStream_t)stream, Z, ldz, DY,
-                     lddy, M, C, scale, shift, mean, invstd, act, sums, count, DZ, lddz);
-  R3D_LAUNCH_CHECK("r3d_bn_bwd_apply");
-  return R3D_OK;
+  return r3d_bn_bwd_apply_seg(Z, ldz, DY, lddy, M, C, M, 0, scale, shift, mean, invstd, 0, act, sums, count, 0.0, DZ, lddz,
+                              stream);
 }
 
 extern "C" long r3d_gemm_tn_ws_words(long M, int Ca, int Cb) {

@@ -185,12 +185,13 @@ class SelfAttention(nn.Module):
         self._folded = (key, f)
         return self._folded[1]
 
-    def forward_pm(self, x_pm, B, N, out):
+    def forward_pm(self, x_pm, B, N, out, group=0):
+        """group > 0: the B clouds are a batch of episodes of `group` clouds each (ops.attention)."""
         if self.training:
             raise NotImplementedError("training-mode forward goes through r3dfsseg_amd.train_ops")
         W, scale = self._fold()
         qkv = ops.pointwise_conv(x_pm, W, scale, None, ops.ACT_NONE)
-        ops.attention(qkv, B, N, out)
+        ops.attention(qkv, B, N, out, group=group)
         return out
 
     def forward(self, x):

@@ -10,17 +10,26 @@ from . import dist as D
 
 
 class DPTrainer:
-    def __init__(self, learner, n_slots=0, example=None, lp_budget=None):
-        """n_slots > 0: the local episodes of a step are replayed as captured hipGraphs, n_slots in flight on
-        separate HIP streams (episode_graph.EpisodeGraphs; `example` = one episode fixing the shapes); every
-        slot accumulates into its own gradient row and the rows are summed into the bucket before the
-        all-reduce.  n_slots == 0: eager launches, one episode after the other."""
+    def __init__(self, learner, n_slots=0, example=None, lp_budget=None, batch_size=0):
+        """batch_size > 0 (the throughput path, batched.py): the local episodes of a step go through ONE launch sequence
+        per batch of up to batch_size episodes -- every kernel works on the whole batch, the weight gradients are summed
+        inside the dW GEMMs straight into the bucket.
+        n_slots > 0 (round 2's schedule, kept for the single-episode learner): the episodes are replayed as captured
+        hipGraphs, n_slots in flight on separate HIP streams (episode_graph.EpisodeGraphs; `example` = one episode fixing
+        the shapes); every slot accumulates into its own gradient row and the rows are summed into the bucket.
+        Neither: eager launches, one episode after the other (the reference's schedule)."""
         self.learner = learner
         self.model = learner.model
         self.bucket = D.FlatGradBucket(self.model.parameters())
         self.graphs = None
+        self.runner = None
+        self.batch_size = batch_size
         self.redone = False   # did the last step fall back to the conservative schedule?
         self.n_redone = 0     # ... and how many steps did so far
+        self.last_status = (0, 0, 0, 0)
+        if batch_size:
+            from .batched import EpisodeBatchRunner
+            self.runner = EpisodeBatchRunner(self.model)
         if n_slots:
             from .episode_graph import EpisodeGraphs
             self.rows = torch.zeros(n_slots, self.bucket.store.numel(), device=self.bucket.store.device)
@@ -38,6 +47,29 @@ class DPTrainer:
         all-reduce is always an exact gradient, so no agreement between ranks is needed."""
         self.model.train()
         self.redone = False
+        if self.runner is not None:
+            from .batch import EpisodeBatch
+            from .batched import collate
+            batches = episodes if (episodes and isinstance(episodes[0], EpisodeBatch)) else collate(episodes, self.batch_size)
+            n_local = sum(b.E for b in batches)
+            self.bucket.zero_()
+            self.runner.begin_step()
+            total = None
+            for b in batches:
+                loss = self.runner.train_batch(b, [p.grad for p in self.bucket.params])[0].sum()
+                total = loss if total is None else total + loss
+            self.last_status = self.runner.step_status()
+            if self.last_status[0] or self.last_status[1]:
+                eps = [b.episode(e) for b in batches for e in range(b.E)]
+                total = self._eager_pass(eps, logger, conservative=True)  # updates the running statistics itself
+                self.redone = True
+                self.n_redone += 1
+            else:
+                self.runner.apply_running_stats()
+            self.bucket.all_reduce_mean(n_local)
+            self.learner.optimizer.step()
+            self.learner.lr_scheduler.step()
+            return total / max(n_local, 1)
         if self.graphs is not None:
             total = self.graphs.run(episodes, apply_bn=False)
             bad, overflow, _, _ = self.graphs.step_status()

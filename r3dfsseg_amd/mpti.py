@@ -70,8 +70,9 @@ class MPTI_SelfAtten(nn.Module):
         self._trace = None
 
     # ------------------------------------------------------------------ features (mpti.py:579-595)
-    def getFeatures_pm(self, x):
-        """x (B, C_in, N) -> point-major features (B*N, feat_dim): [level1 | att | base]."""
+    def getFeatures_pm(self, x, group=0):
+        """x (B, C_in, N) -> point-major features (B*N, feat_dim): [level1 | att | base].  group > 0: x is a batch of episodes
+        of `group` clouds each (the attention then splits its key axis as for one episode: batch-independent bits)."""
         B, _, N = x.shape
         x = x.contiguous().float()
         self.encoder.trace = [] if self._trace is not None else None
@@ -84,7 +85,7 @@ class MPTI_SelfAtten(nn.Module):
         feat = torch.empty(B * N, self.feat_dim, device=x.device, dtype=torch.float32)
         ops.copy_cols(cat[:, :d1], feat[:, :d1])
         if self.use_attention:
-            self.att_learner.forward_pm(level2, B, N, feat[:, d1:d1 + 64])
+            self.att_learner.forward_pm(level2, B, N, feat[:, d1:d1 + 64], group=group)
         else:
             W = self.linear_mapper.weight.reshape(64, -1).contiguous()
             ops.pointwise_conv(level2, W, None, None, ops.ACT_NONE, out=feat[:, d1:d1 + 64])
@@ -101,12 +102,15 @@ class MPTI_SelfAtten(nn.Module):
     def _head(self):
         return self._slot.last
 
-    def _head_buffers(self, n_q, device):
-        key = (n_q, str(device))
+    def _head_buffers(self, n_q, device, E=1):
+        """The head buffers of E episodes (one set per (shape, batch size) and slot, kept between calls)."""
+        key = (n_q, str(device), E)
         slot = self._slot
         if key not in slot.heads:
-            slot.heads = {key: ops.HeadBuffers(self.n_way, self.k_shot, self.n_points, n_q * self.n_points,
-                                               self.n_subprototypes, self.k_connect, self.feat_dim, device)}
+            keep = {k: v for k, v in slot.heads.items() if k[2] != E}  # one single-episode and one batched set stay
+            keep[key] = ops.HeadBuffers(self.n_way, self.k_shot, self.n_points, n_q * self.n_points,
+                                        self.n_subprototypes, self.k_connect, self.feat_dim, device, E=E)
+            slot.heads = keep
         slot.heads[key].fps_one_launch = slot.fps_one_launch
         slot.last = (key, slot.heads[key])
         return slot.heads[key]
@@ -119,7 +123,8 @@ class MPTI_SelfAtten(nn.Module):
         if self._lp_probe is not None:
             host, ev = self._lp_probe
             if ev.query():
-                conv, iters = int(host[0]), int(host[1])
+                h = host.view(-1, 2)  # one {converged, iterations} pair per system of the batch
+                conv, iters = int(h[:, 0].min()), int(h[:, 1].max())
                 if conv:
                     self._lp_budget = min(self.lp_max_iter, max(12, iters + iters // 3 + 4))
                 else:
@@ -131,8 +136,8 @@ class MPTI_SelfAtten(nn.Module):
         if self._slot.fixed_budget is not None:  # frozen launch sequence: convergence is checked by the graph owner
             return
         if self._lp_probe is None:
-            host = torch.empty(2, dtype=torch.int32, pin_memory=True)
-            host.copy_(hb.stats, non_blocking=True)
+            host = torch.empty(hb.stats.numel(), dtype=torch.int32, pin_memory=True)
+            host.copy_(hb.stats.view(-1), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
             self._lp_probe = (host, ev)
@@ -143,11 +148,13 @@ class MPTI_SelfAtten(nn.Module):
         forward again with lp_iters=self.lp_max_iter (which also selects the always-exact insertion kNN kernel).
         backward=True: the adjoint solve of the last backward pass must have converged as well."""
         hb = self._head[1]
-        words = [hb.stats[:1], hb.knn_status, hb.desc[ops.HD_FPS_TIMEOUT:ops.HD_FPS_TIMEOUT + 1]]
+        E = hb.E
+        words = [hb.stats.view(E, 2)[:, 0], hb.knn_status, hb.desc.view(E, 32)[:, ops.HD_FPS_TIMEOUT]]
         if backward:
-            words.append(hb.stats_bwd[:1])
+            words.append(hb.stats_bwd.view(E, 2)[:, 0])
         w = torch.cat(words).tolist()  # one device-to-host copy
-        return w[0] != 0 and w[1] == 0 and w[2] == 0 and (not backward or w[3] != 0)
+        ok = all(v != 0 for v in w[:E]) and w[E] == 0 and all(v == 0 for v in w[E + 1:2 * E + 1])
+        return ok and (not backward or all(v != 0 for v in w[2 * E + 1:]))
 
     # ------------------------------------------------------------------ forward (mpti.py:414-577)
     def forward(self, support_x, support_y, query_x, query_y, gt_support_y=None, gt_query_y=None, train=False,
@@ -166,34 +173,52 @@ class MPTI_SelfAtten(nn.Module):
             raise NotImplementedError("train=False on a model in .train() mode (batch-statistics BatchNorm in an "
                                       "inference forward) is not built; call model.eval() first as "
                                       "models/mpti_learner.py:93 does")
+        logits, loss = self._forward_eval(support_x[None], support_y[None], query_x[None],
+                                          query_y[None] if query_y is not None else None, eval, lp_iters)
+        return logits[0], loss[0]
+
+    def forward_episodes(self, batch, eval=False, lp_iters=None):
+        """Inference forward of the E episodes of `batch` (batch.EpisodeBatch) in ONE launch sequence -> (logits
+        (E, n_q, n_way + 1, N), loss (E,)): per episode what forward(..., eval=eval) returns for it (a capability of this
+        build; the reference evaluates one episode per call, eval_noise.py:85-91).  lp_converged() then speaks for every
+        system of the batch."""
+        if self.training:
+            raise NotImplementedError("forward_episodes is the inference path; training batches go through "
+                                      "batched.EpisodeBatchRunner / head_train.explicit_train_batch")
+        self._lp_force = bool(lp_iters)
+        return self._forward_eval(batch.support_x, batch.support_y, batch.query_x, batch.query_y, eval, lp_iters)
+
+    def _forward_eval(self, support_x, support_y, query_x, query_y, eval, lp_iters):
+        """support_x (E, n_way, k_shot, C, N), support_y (E, n_way, k_shot, N), query_x (E, n_q, C, N), query_y (E, n_q, N)."""
+        E = support_x.shape[0]
         S = self.n_way * self.k_shot
         N = self.n_points
-        n_q = query_x.shape[0]
-        sx = support_x.reshape(S, self.in_channels, N)
-        # eval-mode BatchNorm uses running statistics, so support and query clouds share one pass
-        feat = self.getFeatures_pm(torch.cat((sx, query_x), 0))
-        sfeat, qfeat = feat[:S * N], feat[S * N:]
-        sfeatT = ops.pm_to_cm(sfeat, S, N)
+        n_q = query_x.shape[1]
+        sx = support_x.reshape(E, S, self.in_channels, N)
+        # eval-mode BatchNorm uses running statistics, so all clouds of all episodes share one pass; rows per episode:
+        # its S support clouds, then its n_q query clouds
+        feat = self.getFeatures_pm(torch.cat((sx, query_x), 1).reshape(E * (S + n_q), self.in_channels, N), group=S + n_q)
+        ep_rows = (S + n_q) * N
+        sfeat, qfeat = feat, feat[S * N:]
         shot_keep = None
         if eval:
             # clean-shot detection (mpti.py:87-223, 316-371, called at :440-442), eval only: 0 = the shot's foreground
             # points are ignored when the class prototypes are built (the reference's pl_support_y, which is
             # constant within a shot)
-            shot_keep = ops.clean_shot_detect(sfeat, support_x, support_y, self.n_way, self.k_shot, N)
-        hb = self._head_buffers(n_q, feat.device)
+            shot_keep = ops.clean_shot_detect(sfeat, support_x, support_y, self.n_way, self.k_shot, N, E=E,
+                                              feat_ep_rows=ep_rows)
+        hb = self._head_buffers(n_q, feat.device, E)
         if lp_iters:  # the conservative re-run: one FPS launch per round as well
             hb.fps_one_launch = False
-        sy = support_y.reshape(S, N).to(torch.int32).contiguous()
-        ops.head_prototypes(hb, sy, shot_keep, sfeat, sfeatT, qfeat)
-        nbr = ops.knn(hb.nodes, 1, hb.n_cap, hb.kp1, mode=ops.SCORE_L2, n_valid=hb.desc[ops.HD_N_NODES:],
-                      status=None if lp_iters else hb.knn_status)
-        if lp_iters:
-            hb.knn_status.zero_()
+        sy = support_y.reshape(E, S, N).to(torch.int32).contiguous()
+        ops.head_prototypes(hb, sy, shot_keep, sfeat, qfeat, ep_rows)
+        nbr = ops.knn_nodes(hb, exact=bool(lp_iters))
         ops.label_propagate(hb, nbr, self.sigma, 0.99, lp_iters or self._lp_next_budget(), self.lp_tol)
         self._lp_post(hb)
-        labels = query_y.to(torch.int64).contiguous() if query_y is not None else None
+        labels = query_y.reshape(E, n_q, N).to(torch.int64).contiguous() if query_y is not None else None
         logits, loss, _ = ops.query_logits_ce(hb, n_q, self.n_classes, labels)
-        self.num_prototypes_dev = hb.desc[ops.HD_N_PROTO]
+        logits, loss = logits.reshape(E, n_q, self.n_classes, N), loss.reshape(E)
+        self.num_prototypes_dev = hb.desc.view(E, 32)[:, ops.HD_N_PROTO]
         if self._trace is not None:
-            self._trace.update(sfeat=sfeat, qfeat=qfeat, shot_keep=shot_keep, nbr=nbr)
+            self._trace.update(sfeat=feat[:S * N], qfeat=feat[S * N:ep_rows], feat=feat, shot_keep=shot_keep, nbr=nbr)
         return logits, loss

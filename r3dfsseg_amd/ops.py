@@ -19,6 +19,30 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+class SegLayout:
+    """Row layout of a batch of E episodes in the encoder (include/r3d.h, "BATCHES OF EPISODES"): the clouds of the
+    batch are the rows of one matrix, episode after episode, [S support clouds | Q query clouds] each.  Segment
+    2 e + p is getFeatures call p of episode e (models/mpti.py:434,436: support, then query) -- the unit of the
+    BatchNorm batch statistics and the order in which the running statistics see them.  Q == 0: E equal segments
+    of S clouds (a plain getFeatures call is E = 1, S = B)."""
+
+    def __init__(self, E, S, Q, N):
+        self.E, self.S, self.Q, self.N = E, S, Q, N
+        self.clouds = S + Q                    # clouds per episode
+        self.B = E * (S + Q)                   # clouds of the batch
+        self.M = self.B * N                    # rows of the batch
+        self.rows_a, self.rows_b = S * N, Q * N
+        self.n_seg = E * (2 if Q else 1)
+        self.ep_rows = (S + Q) * N             # rows between consecutive episodes
+
+    def counts(self, per_row=1):
+        """(count_a, count_b) of the BatchNorm statistics: elements per channel in a support / query segment."""
+        return float(self.rows_a * per_row), float(self.rows_b * per_row)
+
+    def aligned(self, tile=64):
+        return self.rows_a % tile == 0 and self.rows_b % tile == 0
+
+
 class KernelTimer:
     """HIP-event timing of selected entry points on the stream they are launched on
     (bench.py's roofline leg).  Disabled (None) by default: zero overhead.
@@ -126,9 +150,10 @@ def copy_cols(src, dst):
     return dst
 
 
-def knn(x_pm, B, N, k, mode=SCORE_DGCNN, n_valid=None, return_scores=False, x_cm=None, status=None):
+def knn(x_pm, B, N, k, mode=SCORE_DGCNN, n_valid=None, return_scores=False, x_cm=None, status=None, n_valid_stride=0):
     """x_pm (B*N, C) -> idx (B, N, k) int32, best first.  x_cm: optional (B, C, N) channel-major
-    copy of the same points (saves the internal transpose of the streamed k <= 32 kernel)."""
+    copy of the same points (saves the internal transpose of the streamed k <= 32 kernel).
+    n_valid (device int32) with n_valid_stride > 0: set b has n_valid[b * n_valid_stride] valid rows."""
     M, ld = _rows(x_pm)
     C = x_pm.shape[1]
     assert M == B * N
@@ -154,8 +179,8 @@ def knn(x_pm, B, N, k, mode=SCORE_DGCNN, n_valid=None, return_scores=False, x_cm
         split_words = lib.r3d_knn_split_ws_words(B, N, k)
         split_ws = torch.empty(split_words, device=dev, dtype=torch.float32)
     with _timed("knn_topk_l2" if mode == SCORE_L2 else "knn_topk"):
-        _lib.check(lib.r3d_knn_topk_split(_p(x_pm), ld, _p(x_cm), B, N, C, k, mode, _p(n_valid), _p(norm), _p(cm_ws),
-                                          _p(idx), _p(sc), _p(status), _p(split_ws), split_words, _st()))
+        _lib.check(lib.r3d_knn_topk_batched(_p(x_pm), ld, _p(x_cm), B, N, C, k, mode, _p(n_valid), n_valid_stride, _p(norm),
+                                            _p(cm_ws), _p(idx), _p(sc), _p(status), _p(split_ws), split_words, _st()))
     return (idx, sc) if return_scores else idx
 
 
@@ -188,111 +213,159 @@ def edgeconv(PQ, idx, W2, s2, t2, out, B, N, want_argmax=False):
     return am
 
 
-def attention(qkv, B, N, out, want_lse=False):
+def attention(qkv, B, N, out, want_lse=False, group=0):
+    """Inference attention of B clouds.  group > 0: the clouds are a batch of episodes of `group` clouds each; the
+    key-axis split (and with it every output bit) is then the one of a single episode."""
     M, ld = _rows(qkv)
     M2, ldo = _rows(out)
     assert M == B * N and M2 == M and qkv.shape[1] == 192 and out.shape[1] == 64
-    lse = torch.empty(M, device=qkv.device, dtype=torch.float32) if want_lse else None
     lib = _lib.load()
-    ws = torch.empty(lib.r3d_attention_ws_words(B, N), device=qkv.device, dtype=torch.float32)
+    lse = torch.empty(M, device=qkv.device, dtype=torch.float32)
+    ws = torch.empty(lib.r3d_attention_ws_words_ep(B, N, group), device=qkv.device, dtype=torch.float32)
     with _timed("attention"):
-        _lib.check(lib.r3d_attention_fwd(_p(qkv), ld, B, N, _p(out), ldo, _p(lse), _p(ws), _st()))
-    return lse
+        _lib.check(lib.r3d_attention_fwd_train_ep(_p(qkv), ld, B, N, _p(out), ldo, _p(lse), 0.0, ctypes.c_uint(0), None, group,
+                                                  _p(ws), _st()))
+    return lse if want_lse else None
 
 
 class HeadBuffers:
-    """Device buffers of one episode's transductive head (capacity sized, no host sync)."""
+    """Device buffers of the transductive heads of E episodes (capacity sized, no host sync).  E > 1: every array has a
+    leading episode axis, episode e's system lives at [e] (nodes / Y / Z: rows [e n_cap, (e + 1) n_cap)).  E = 1, the
+    single-episode head of the reference's schedule, keeps the plain shapes (desc (32,), stats (2,), ...)."""
 
-    def __init__(self, n_way, k_shot, N, n_q_pts, k_sub, k_connect, D, device):
+    def __init__(self, n_way, k_shot, N, n_q_pts, k_sub, k_connect, D, device, E=1):
         lib = _lib.load()
+        self.E = E
         self.n_way, self.k_shot, self.N, self.n_q_pts, self.k_sub, self.kp1, self.D = \
             n_way, k_shot, N, n_q_pts, k_sub, k_connect + 1, D
         self.n_cap = (n_way + 1) * k_sub + n_q_pts
         assert lib.r3d_head_desc_words() == 32
         i32 = dict(device=device, dtype=torch.int32)
         f32 = dict(device=device, dtype=torch.float32)
-        self.desc = torch.zeros(32, **i32)
-        self.nodes = torch.empty(self.n_cap, D, **f32)
-        self.Y = torch.empty(self.n_cap, 4, **f32)
-        self.Z = torch.empty(self.n_cap, 4, **f32)
-        self.proto_ws = torch.empty(lib.r3d_head_proto_ws_words(n_way, k_shot, N), **i32)
-        self.lp_ws = torch.empty(lib.r3d_lp_ws_words(self.n_cap, self.kp1), **i32)
-        self.assign = torch.empty(2 * n_way * k_shot * N, **i32)
-        self.cluster_count = torch.zeros(self.n_cap, **i32)
-        self.stats = torch.zeros(2, **i32)
-        self.knn_status = torch.zeros(1, **i32)
-        self.stats_bwd = torch.zeros(2, **i32)
-        # all FPS rounds in one persistent launch: safe while (episodes in flight) x fps_blocks workgroups stay
-        # co-resident (~384 of the chip's 512 slots for this kernel); episode_graph.EpisodeGraphs decides per slot
+        one = (lambda t: t[0]) if E == 1 else (lambda t: t)
+        self.desc = one(torch.zeros(E, 32, **i32))
+        self.nodes = torch.empty(E * self.n_cap, D, **f32)
+        self.Y = torch.empty(E * self.n_cap, 4, **f32)
+        self.Z = torch.empty(E * self.n_cap, 4, **f32)
+        self.proto_words = lib.r3d_head_proto_ws_words(n_way, k_shot, N)
+        self.proto_stride = (self.proto_words + 3) // 4 * 4      # even (64-bit words inside), 16-byte rows
+        self.proto_ws = one(torch.empty(E, self.proto_stride, **i32))
+        self.lp_words = lib.r3d_lp_ws_words(self.n_cap, self.kp1)
+        self.lp_stride = (self.lp_words + 3) // 4 * 4             # float4 arrays inside
+        self.lp_ws = one(torch.empty(E, self.lp_stride, **i32))
+        self.assign = one(torch.empty(E, 2 * n_way * k_shot * N, **i32))
+        self.cluster_count = one(torch.zeros(E, self.n_cap, **i32))
+        self.stats = one(torch.zeros(E, 2, **i32))                # per system: {converged, CG iterations}
+        self.knn_status = torch.zeros(1, **i32)                   # ONE word for the batch (bit 0: survivor overflow)
+        self.stats_bwd = one(torch.zeros(E, 2, **i32))
+        # all FPS rounds in one persistent launch: its workgroups that hold points must be co-resident (~500 slots of
+        # this kernel at D <= 192, 250 above); fps_group episodes share a launch, fps_slots caps what may be resident
         self.fps_one_launch = True
         self.fps_blocks = (n_way * k_shot * N + 255) // 256 + n_way + 1
+        self.fps_slots = 500 if D <= 192 else 250
         off = (ctypes.c_long * 6)()
         lib.r3d_head_proto_ws_offsets(n_way, k_shot, N, off)
         self.ws_off = list(off)
         lib.r3d_lp_ws_offsets(self.n_cap, self.kp1, off)
         self.lp_off = dict(zip(("row_ptr", "col", "val", "dinv", "agg", "cg"), off))
 
-    def csr(self):
+    @property
+    def fps_group(self):
+        return max(1, self.fps_slots // self.fps_blocks)
+
+    def n_nodes_ptr(self):
+        return self.desc.view(-1)[HD_N_NODES:]   # episode e's count 32 words further on
+
+    def n_proto_ptr(self):
+        return self.desc.view(-1)[HD_N_PROTO:]
+
+    def csr(self, e=0):
         """(n, row_ptr (n+1) int64, col (nnz) int64, val (nnz) fp32) of the normalised graph S the last
-        r3d_label_propagate left in the workspace (synchronises; tests, tools and bench.py's byte counts)."""
-        n = int(self.desc[HD_N_NODES].item())
+        r3d_label_propagate left in episode e's workspace (synchronises; tests, tools and bench.py's byte counts)."""
+        n = int(self.desc.view(-1, 32)[e, HD_N_NODES].item())
         o = self.lp_off
-        row_ptr = self.lp_ws[o["row_ptr"]:o["row_ptr"] + n + 1].to(torch.int64)
+        ws = self.lp_ws.view(-1, self.lp_stride)[e]
+        row_ptr = ws[o["row_ptr"]:o["row_ptr"] + n + 1].to(torch.int64)
         nnz = int(row_ptr[-1].item())
-        col = self.lp_ws[o["col"]:o["col"] + (nnz + 1) // 2].view(torch.int16)[:nnz].to(torch.int64) & 0xffff
-        val = self.lp_ws[o["val"]:o["val"] + nnz].view(torch.float32)
+        col = ws[o["col"]:o["col"] + (nnz + 1) // 2].view(torch.int16)[:nnz].to(torch.int64) & 0xffff
+        val = ws[o["val"]:o["val"] + nnz].view(torch.float32)
         return n, row_ptr, col, val
 
 
-def head_prototypes(hb, support_y, shot_keep, sfeat_pm, sfeatT, qfeat_pm):
+def head_prototypes(hb, support_y, shot_keep, sfeat_pm, qfeat_pm, feat_ep_rows=0):
+    """Prototypes + node matrices of hb.E episodes.  sfeat_pm / qfeat_pm: the support / query rows of episode 0 inside
+    the batch's feature matrix; episode e's rows start feat_ep_rows rows further on.  support_y (E, S, N) int32,
+    shot_keep optional (E, S) int32."""
     S = hb.n_way * hb.k_shot
-    M, ldf = _rows(sfeat_pm)
-    Mq, ldq = _rows(qfeat_pm)
-    assert M == S * hb.N and Mq == hb.n_q_pts and sfeatT.is_contiguous() and sfeatT.shape == (S, hb.D, hb.N)
-    assert support_y.dtype == torch.int32 and support_y.is_contiguous() and support_y.numel() == S * hb.N
+    E = hb.E
+    ldf, ldq = sfeat_pm.stride(0), qfeat_pm.stride(0)
+    assert sfeat_pm.dtype == torch.float32 and qfeat_pm.dtype == torch.float32 and sfeat_pm.stride(1) == 1
+    assert E == 1 or feat_ep_rows >= S * hb.N
+    assert support_y.dtype == torch.int32 and support_y.is_contiguous() and support_y.numel() == E * S * hb.N
+    assert shot_keep is None or (shot_keep.dtype == torch.int32 and shot_keep.numel() == E * S)
     with _timed("head_prototypes"):
-        _lib.check(_lib.load().r3d_head_prototypes(
-            _p(support_y), _p(shot_keep), _p(sfeat_pm), ldf, _p(sfeatT), _p(qfeat_pm), ldq, hb.n_way, hb.k_shot,
-            hb.N, hb.D, hb.n_q_pts, hb.k_sub, _p(hb.nodes), hb.nodes.stride(0), _p(hb.Y), _p(hb.desc),
-            _p(hb.assign), _p(hb.cluster_count), _p(hb.proto_ws), hb.proto_ws.numel(),
-            HEAD_FPS_ONE_LAUNCH if hb.fps_one_launch else 0, _st()))
+        _lib.check(_lib.load().r3d_head_prototypes_batched(
+            E, hb.fps_group, _p(support_y), S * hb.N, _p(shot_keep), S, _p(sfeat_pm), ldf, feat_ep_rows, _p(qfeat_pm), ldq,
+            feat_ep_rows, hb.n_way, hb.k_shot, hb.N, hb.D, hb.n_q_pts, hb.k_sub, _p(hb.nodes), hb.nodes.stride(0), hb.n_cap,
+            _p(hb.Y), _p(hb.desc), 32, _p(hb.assign), 2 * S * hb.N, _p(hb.cluster_count), hb.n_cap, _p(hb.proto_ws),
+            hb.proto_words, hb.proto_stride, HEAD_FPS_ONE_LAUNCH if hb.fps_one_launch else 0, _st()))
+
+
+def knn_nodes(hb, exact=False):
+    """201-NN lists (E, n_cap, kp1) of every episode's graph nodes (mpti.py:731-736).  exact: the insertion kernel
+    (always exact); otherwise the append-and-rank kernel, whose survivor-buffer overflow sets hb.knn_status."""
+    nbr = knn(hb.nodes, hb.E, hb.n_cap, hb.kp1, mode=SCORE_L2, n_valid=hb.n_nodes_ptr(), n_valid_stride=32,
+              status=None if exact else hb.knn_status)
+    if exact:
+        hb.knn_status.zero_()
+    return nbr
 
 
 def label_propagate(hb, nbr, sigma, alpha=0.99, max_iter=200, tol=1e-6):
-    assert nbr.shape == (1, hb.n_cap, hb.kp1) or nbr.shape == (hb.n_cap, hb.kp1)
+    assert nbr.numel() == hb.E * hb.n_cap * hb.kp1 and nbr.is_contiguous()
     with _timed("label_propagate"):
-        _lib.check(_lib.load().r3d_label_propagate(
-            _p(hb.nodes), hb.nodes.stride(0), hb.D, _p(nbr), hb.kp1, _p(hb.Y), _p(hb.desc[HD_N_NODES:]),
-            _p(hb.desc[HD_N_PROTO:]), hb.n_cap, float(sigma), float(alpha), int(max_iter), float(tol), _p(hb.Z),
-            _p(hb.lp_ws), hb.lp_ws.numel(), _p(hb.stats), _st()))
+        _lib.check(_lib.load().r3d_label_propagate_batched(
+            hb.E, _p(hb.nodes), hb.nodes.stride(0), hb.D, _p(nbr), hb.kp1, _p(hb.Y), _p(hb.n_nodes_ptr()),
+            _p(hb.n_proto_ptr()), 32, hb.n_cap, float(sigma), float(alpha), int(max_iter), float(tol), _p(hb.Z), _p(hb.lp_ws),
+            hb.lp_words, hb.lp_stride, _p(hb.stats), 2, _st()))
     return hb.Z
 
 
 def query_logits_ce(hb, n_q, n_classes, labels):
+    """labels (E, n_q, N) int64 or None -> logits (E, n_q, n_classes, N), loss (E,), pred (E, n_q, N) int32 (E = 1: without
+    the episode axis)."""
     dev = hb.Z.device
-    logits = torch.empty(n_q, n_classes, hb.N, device=dev, dtype=torch.float32)
-    loss = torch.empty((), device=dev, dtype=torch.float32)
-    pred = torch.empty(n_q, hb.N, device=dev, dtype=torch.int32)
+    E = hb.E
+    logits = torch.empty(E, n_q, n_classes, hb.N, device=dev, dtype=torch.float32)
+    loss = torch.empty(E, device=dev, dtype=torch.float32)
+    pred = torch.empty(E, n_q, hb.N, device=dev, dtype=torch.int32)
     if labels is not None:
-        assert labels.dtype == torch.int64 and labels.is_contiguous()
-    _lib.check(_lib.load().r3d_query_logits_ce(_p(hb.Z), _p(hb.desc[HD_N_PROTO:]), n_q, hb.N, n_classes,
-                                               _p(labels), _p(logits), _p(loss), _p(pred), _st()))
+        assert labels.dtype == torch.int64 and labels.is_contiguous() and labels.numel() == E * n_q * hb.N
+    _lib.check(_lib.load().r3d_query_logits_ce_batched(E, _p(hb.Z), hb.n_cap, _p(hb.n_proto_ptr()), 32, n_q, hb.N, n_classes,
+                                                       _p(labels), _p(logits), _p(loss), _p(pred), _st()))
+    if E == 1:  # the single-episode shapes: (n_q, n_classes, N), 0-d, (n_q, N)
+        return logits[0], loss[0], pred[0]
     return logits, loss, pred
 
 
-def clean_shot_detect(sfeat_pm, support_x, support_y, n_way, k_shot, N, want_debug=False):
-    """shot_keep (n_way*k_shot) int32 of the eval-only clean-shot detection (mpti.py:178-223)."""
-    M, ldf = _rows(sfeat_pm)
+def clean_shot_detect(sfeat_pm, support_x, support_y, n_way, k_shot, N, want_debug=False, E=1, feat_ep_rows=0):
+    """shot_keep (E, n_way*k_shot) int32 of the eval-only clean-shot detection (mpti.py:178-223).  sfeat_pm: support rows
+    of episode 0 inside the batch's feature matrix, episode e feat_ep_rows rows further on; support_x (E, S, Cin, N)."""
+    ldf = sfeat_pm.stride(0)
     S = n_way * k_shot
-    assert M == S * N
-    sx = support_x.reshape(S, -1, N).contiguous().float()
-    sy = support_y.reshape(S, N).to(torch.int32).contiguous()
+    sx = support_x.reshape(E * S, -1, N).contiguous().float()
+    sy = support_y.reshape(E * S, N).to(torch.int32).contiguous()
     dev = sfeat_pm.device
-    keep = torch.empty(S, device=dev, dtype=torch.int32)
-    dbg = torch.zeros(n_way, 2, 4 * k_shot, device=dev, dtype=torch.float32) if want_debug else None
-    ws = torch.empty(_lib.load().r3d_clean_ws_words(n_way, k_shot), device=dev, dtype=torch.int32)
-    _lib.check(_lib.load().r3d_clean_shot_detect(_p(sfeat_pm), ldf, sfeat_pm.shape[1], _p(sx), sx.shape[1], _p(sy),
-                                                 n_way, k_shot, N, _p(keep), _p(dbg), _p(ws), _st()))
+    keep = torch.empty(E, S, device=dev, dtype=torch.int32)
+    dbg = torch.zeros(E, n_way, 2, 4 * k_shot, device=dev, dtype=torch.float32) if want_debug else None
+    words = _lib.load().r3d_clean_ws_words(n_way, k_shot)
+    ws = torch.empty(E, words, device=dev, dtype=torch.int32)
+    _lib.check(_lib.load().r3d_clean_shot_detect_batched(E, _p(sfeat_pm), ldf, feat_ep_rows, sfeat_pm.shape[1], _p(sx),
+                                                         sx.shape[1], _p(sy), n_way, k_shot, N, _p(keep), _p(dbg), _p(ws),
+                                                         words, _st()))
+    if E == 1:
+        keep = keep[0]
+        dbg = dbg[0] if dbg is not None else None
     return (keep, dbg) if want_debug else keep
 
 

@@ -47,9 +47,8 @@ def test_prototypes_bitexact_indices(ops, n_way, k_shot, N, k_sub, seed):
     qfeat = torch.from_numpy((rs.randn(n_q * N, D) * 0.1).astype(np.float32))
     hb = ops.HeadBuffers(n_way, k_shot, N, n_q * N, k_sub, 200, D, "cuda")
     sfeat = feat.cuda()
-    sfeatT = ops.pm_to_cm(sfeat, Sx, N)
     sy = support_y.reshape(Sx, N).to(torch.int32).contiguous().cuda()
-    ops.head_prototypes(hb, sy, None, sfeat, sfeatT, qfeat.cuda())
+    ops.head_prototypes(hb, sy, None, sfeat, qfeat.cuda())
     torch.cuda.synchronize()
     desc = hb.desc.cpu().numpy()
     ws = hb.proto_ws.cpu().numpy()

@@ -250,37 +250,48 @@ def test_learner_train_step_runs_and_descends():
 
 
 @pytest.mark.parametrize("N", [512, 40])
-def test_shared_launch_sequence_equals_two_sequences(N):
-    """mpti.py:434,436 call getFeatures twice; the training path runs both calls through one launch sequence when the
-    support block ends on a 64-row tile (N = 512) and falls back to two sequences otherwise (N = 40).  Either way the
-    result must be the reference's: same losses, running statistics bit for bit, gradients equal up to LeakyReLU kinks."""
-    from r3dfsseg_amd import train_ops as T
+def test_one_launch_sequence_equals_two_getfeatures_calls(N):
+    """mpti.py:434,436 call getFeatures twice; the training path runs both calls through ONE launch sequence with the
+    BatchNorm statistics of the two calls kept apart (segments).  Against two separate calls (support clouds alone, query
+    clouds alone): features of every BatchNorm-only path and the running statistics bit for bit (a segment's reductions
+    do not depend on what it is batched with; N = 40: segments that do not end on the GEMM tiles), losses to rounding,
+    gradients equal up to LeakyReLU kinks."""
+    from r3dfsseg_amd import contrast, head_train, train_ops as T
     from r3dfsseg_amd.mpti import MPTI_SelfAtten
     cfg = S.make_cfg(n_way=2, k_shot=2, pc_npts=N)
     data, _ = S.make_episode(cfg, seed=11, noise_ratio=0.5, train=True)
     ep = [t.cuda() for t in data]
+    Sn = cfg["n_way"] * cfg["k_shot"]
     res = {}
-    before = T.SHARED_LAUNCHES
-    try:
-        for shared in (False, True):
-            T.SHARED_LAUNCHES = shared
-            m = MPTI_SelfAtten(SimpleNamespace(**cfg))
-            m.load_state_dict(S.make_state_dict(cfg, 123))
-            m.cuda().train()
-            m.att_learner.dropout.p = 0.0
-            assert T.shared_launches_ok(m, cfg["n_way"] * cfg["k_shot"]) == (shared and N == 512)
+    for joint in (False, True):
+        m = MPTI_SelfAtten(SimpleNamespace(**cfg))
+        m.load_state_dict(S.make_state_dict(cfg, 123))
+        m.cuda().train()
+        m.att_learner.dropout.p = 0.0
+        m._trace = {}
+        if joint:
             out = m(ep[0], ep[1], ep[2], ep[3], gt_support_y=ep[6], gt_query_y=ep[7], train=True, support_flag=ep[10],
                     lp_iters=m.lp_max_iter)
-            (out[1] + 0.1 * out[2]).backward()
-            assert m.lp_converged(backward=True)
-            res[shared] = dict(lp=out[1].item(), cl=out[2].item(),
-                               grads={n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None},
-                               stats={n: b.clone() for n, b in m.named_buffers()})
-    finally:
-        T.SHARED_LAUNCHES = before
+            lp, cl = out[1], out[2]
+            sfeat, qfeat = m._trace["sfeat"], m._trace["qfeat"]
+        else:
+            m._lp_force = True
+            sfeat = T.get_features_train(m, ep[0].reshape(Sn, cfg["pc_in_dim"], N), seed=2)
+            qfeat = T.get_features_train(m, ep[2], seed=3)
+            cl = contrast.per_way_contrast_loss(m, sfeat, ep[1], ep[10])
+            lp = head_train.HeadLPFn.apply(sfeat, qfeat, m, ep[1], ep[3])
+        (lp + 0.1 * cl).backward()
+        assert m.lp_converged(backward=True)
+        res[joint] = dict(lp=lp.item(), cl=cl.item(), sfeat=sfeat.detach().clone(), qfeat=qfeat.detach().clone(),
+                          grads={n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None},
+                          stats={n: b.clone() for n, b in m.named_buffers()})
     a, b = res[False], res[True]
-    assert abs(a["lp"] - b["lp"]) <= 1e-5 * max(1.0, abs(a["lp"])) and abs(a["cl"] - b["cl"]) <= 1e-5 * max(1.0, abs(a["cl"]))
     for n_ in a["stats"]:
         assert torch.equal(a["stats"][n_], b["stats"][n_]), n_
+    for f in ("sfeat", "qfeat"):  # level-1 and BaseLearner columns see BatchNorm only; the attention columns depend on the
+        # key-axis split, which follows the number of clouds in the launch
+        assert torch.equal(a[f][:, :64], b[f][:, :64]) and torch.equal(a[f][:, 128:], b[f][:, 128:]), f
+        assert (a[f][:, 64:128] - b[f][:, 64:128]).abs().max().item() < 1e-5
+    assert abs(a["lp"] - b["lp"]) <= 1e-5 * max(1.0, abs(a["lp"])) and abs(a["cl"] - b["cl"]) <= 1e-5 * max(1.0, abs(a["cl"]))
     for n_ in a["grads"]:
         assert _rel(b["grads"][n_], a["grads"][n_]) <= 2e-3, (n_, _rel(b["grads"][n_], a["grads"][n_]))

@@ -18,7 +18,7 @@ m.cuda().train()
 m.att_learner.dropout.p = 0.0
 Sn, N = cfg["n_way"] * cfg["k_shot"], cfg["pc_npts"]
 with torch.no_grad():
-    T.SHARED_LAUNCHES = False
+    pass
     c = SimpleNamespace(param_list=T.encoder_params(m))
     sf = T.EncoderTrainFn.forward(c, ep[0].reshape(Sn, -1, N), m, 0).clone()
     c = SimpleNamespace(param_list=T.encoder_params(m))
