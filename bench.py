@@ -9,22 +9,26 @@ BASELINE.json configs[4]'s 256-episode batch over 8 GPUs; each episode is config
   --mode train (default): E x (forward + backward) + ONE flat-bucket RCCL gradient all-reduce + Adam.  With
                           E = 1 this is the reference's MPTILearner_V3.train step (models/mpti_learner.py:60-72).
   --mode eval           : forward only, MPTILearner_V3.test without its host sync.
-  --slots G (6 / 4)     : episodes in flight per GPU -- every slot is a captured hipGraph replayed on its own HIP
-                          stream (r3dfsseg_amd/episode_graph.py); --slots 0 = eager launches, one episode at a time.
+  --batch B (default E) : episodes per launch sequence -- the E episodes of a step go through the kernels TOGETHER
+                          (r3dfsseg_amd/batched.py: one launch sequence per batch of B episodes); --batch 0 = eager
+                          launches, one episode at a time (the reference's schedule).
 Episodes are independent: ranks take disjoint episodes (weak scaling); the only collective is
-the 1.5 MB gradient all-reduce of train mode.  ONE JSON line on rank 0, with
-  roofline     -- the entry point taking most device time in a live pass of single-episode EAGER steps (one episode
-                  in flight, so launches do not overlap), named by its main kernel and priced with its ALGORITHMIC
-                  work over its HIP-event time (events on the launch stream).  When that entry
-                  point is the label propagation, the CG iteration (its three kernels) is measured on its own.
-  rooflines    -- every entry point against both ceilings; these are WARM-CACHE figures (each region is launched
-                  again 8 times back to back on the same buffers between one event pair)
-  cpu_baseline -- the CPU oracle (a port of the reference path) on this box's host cores, EVAL FORWARD: compare it
-                  with eval_forward_episodes_per_sec, not with the train-step headline
-  steady_state -- the same timed step again after --steady-steps optimiser steps (the label-propagation systems get
-                  harder as the encoder separates the classes; the first steps after initialisation flatter)
-Extra fields: single_episode_eager_step_episodes_per_sec (E = 1, eager: the reference's own schedule) and
-eval_forward_episodes_per_sec.
+the 1.5 MB gradient all-reduce of train mode.  ONE JSON line on rank 0.
+  value        -- STEADY STATE: K timed steps after --steady-steps optimiser steps from the synthetic initial weights
+                  (the label-propagation systems get harder as the encoder separates the classes: CG iterations
+                  roughly double within 150 steps; the reference trains 40 000 episodes, mpti_train_noise.py:182).
+                  `fresh_weights` is the same measurement over the first K steps after W warm-up steps.
+  roofline     -- the kernel with the most device time in a live batched step, timed with HIP events on the launch
+                  stream (one event pair per entry-point call; batched launches do not overlap) and priced with its
+                  ALGORITHMIC work.  When that entry point is the label propagation, the CG
+                  iteration (its two kernels, all systems of the batch per launch) is measured on its own.
+  rooflines    -- every entry point of the batched step against both ceilings, same timing
+  cpu_baseline -- the CPU oracle (a port of the reference path) on this box's host cores: EVAL FORWARD (1 warm-up,
+                  min / median of 5) to be compared with eval_forward_episodes_per_sec, and a TRAIN STEP (forward,
+                  backward through the dense inverse, Adam; 1 warm-up, median of 3) to be compared with
+                  single_episode_eager_step_episodes_per_sec (same schedule) or `value`
+Extra fields: single_episode_eager_step_episodes_per_sec (E = 1, eager: the reference's own schedule),
+single_episode_graph_step_episodes_per_sec (the same as one captured hipGraph) and eval_forward_episodes_per_sec.
 """
 import argparse
 import json
@@ -44,12 +48,13 @@ BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no spar
 
 OPS = ["knn_topk", "knn_topk_l2", "pointwise_conv", "edgeconv", "attention", "head_prototypes", "label_propagate",
        "gemm_tn", "edgeconv_bwd", "attention_bwd", "bn_stats", "label_propagate_bwd"]
+FETCH_SIZE_WIDE_READ_FACTOR = 2.0  # MI355X_MICROARCH.md: on gfx950 FETCH_SIZE counts half of wide coalesced reads
 
 
 def algorithmic_work(op, cfg, n_nodes, cg_iters, train):
-    """ALGORITHMIC (flops, bytes, bound, launches) of ONE step's calls of an entry point (DESIGN.md section 4;
-    per-unit figures from SURVEY.md 8d).  bytes = every input read once + every output written once (fp32 /
-    int32).  In train mode getFeatures runs twice (support clouds, query clouds) with the same totals."""
+    """ALGORITHMIC (flops, bytes, bound, launches) of ONE EPISODE's share of an entry point (DESIGN.md section 4;
+    per-unit figures from SURVEY.md 8d); a batched step's launches carry E times this.  bytes = every input read once
+    + every output written once (fp32 / int32)."""
     n_way, k_shot, N = cfg["n_way"], cfg["k_shot"], cfg["pc_npts"]
     S_ = n_way * k_shot
     n_q = n_way * cfg.get("n_queries", 1)
@@ -161,16 +166,14 @@ def main():
     ap.add_argument("--mode", default="train", choices=["eval", "train"])
     ap.add_argument("--episodes-per-rank", type=int, default=32,
                     help="episodes of one step on every rank (BASELINE configs[4]: 256-episode batch / 8 GPUs)")
-    ap.add_argument("--slots", type=int, default=None,
-                    help="episodes in flight per GPU (hipGraphs on HIP streams); 0 = eager; default 6, "
-                         "the measured optimum on MI355X for both modes")
-    ap.add_argument("--eval-slots", type=int, default=6, help="slots of the eval-forward leg of train mode")
-    ap.add_argument("--lp-budget", type=int, default=None, help="CG launches frozen into each episode graph")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="episodes per launch sequence (default: all of the rank's episodes; 0 = one episode at a time, eager)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-episode and eval legs (profiling runs)")
     ap.add_argument("--roofline-kernel", default="auto", help="entry point to price (auto = the one taking most time)")
     ap.add_argument("--steady-steps", type=int, default=150,
-                    help="train mode: optimiser steps before the steady-state leg is timed (0 = skip that leg)")
+                    help="train mode: optimiser steps from the initial weights before the headline is timed (0 = headline on fresh weights)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,6 +196,9 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from r3dfsseg_amd import ops, synthetic as S
+    from r3dfsseg_amd.batch import EpisodeBatch
+    from r3dfsseg_amd.batched import EpisodeBatchRunner
+    from r3dfsseg_amd.dp_train import DPTrainer
     from r3dfsseg_amd.mpti import MPTI_SelfAtten
 
     cfg = S.workload_cfg(args.workload)
@@ -200,18 +206,20 @@ def main():
     model.load_state_dict(S.make_state_dict(cfg, 123))
     model.to(dev)
 
-    if args.slots is None:
-        args.slots = 6
-    E, G = args.episodes_per_rank, args.slots
-    n_pool = max(8, min(E, 32))  # distinct episodes per rank, resident in HBM before timing starts
+    E = args.episodes_per_rank
+    Bsz = E if args.batch is None else args.batch
+    batched = Bsz > 0
+    # the synthetic pool: 2 E distinct episodes per rank, resident in HBM (and already collated into batches of Bsz
+    # episodes) before any timing starts; consecutive steps alternate between the two halves
+    n_pool = 2 * E
     pool = []
     for e in range(n_pool):
         data, _ = S.make_episode(cfg, seed=1000 * rank + e, noise_ratio=0.2, train=True)
         pool.append([t.to(dev) for t in data])
+    halves = [pool[:E], pool[E:]]
+    pool_batches = [[EpisodeBatch.from_episodes(h[i:i + Bsz]) for i in range(0, E, Bsz)] for h in halves] if batched else None
     torch.cuda.synchronize()
 
-    from r3dfsseg_amd.dp_train import DPTrainer
-    from r3dfsseg_amd.episode_graph import EpisodeGraphs
     learner = SimpleNamespace(model=model)
     learner.optimizer = torch.optim.Adam(
         [{'params': model.encoder.parameters(), 'lr': 0.0001}, {'params': model.base_learner.parameters()},
@@ -219,36 +227,42 @@ def main():
     learner.lr_scheduler = torch.optim.lr_scheduler.StepLR(learner.optimizer, step_size=5000, gamma=0.5)
     train = args.mode == "train"
     model.train(train)
-    trainer = DPTrainer(learner, n_slots=G if train else 0, example=pool[0], lp_budget=args.lp_budget) if train else None
-    G_eval = (args.eval_slots if train else G) if G else 0
-    eval_graphs = EpisodeGraphs(model, pool[0][:4], n_slots=G_eval, train=False, lp_budget=args.lp_budget) if G else None
+    trainer = DPTrainer(learner, batch_size=Bsz) if train else None
+    runner = trainer.runner if (train and batched) else (EpisodeBatchRunner(model) if batched else None)
     lp_flags = []
-
-    def batch(i, n):
-        return [pool[(i * n + j) % n_pool] for j in range(n)]
+    cg_acc = [0, 0, 0]    # CG iterations of the forward solves: sum, systems, max
+    invalid = []          # reasons why a timed leg does not count (every episode must have a converged, exact head)
+    redone_notes = []
 
     def head_flags():
         hb = model._head[1]
-        return torch.cat((hb.stats, hb.knn_status))  # (CG converged, CG iterations, kNN overflow)
+        return torch.cat((hb.stats.view(-1)[:2], hb.knn_status))  # (CG converged, CG iterations, kNN overflow)
 
-    def train_step(i):  # E episodes in flight as hipGraphs -> gradient rows -> ONE all-reduce -> Adam
-        trainer.step(batch(i, E))
+    def train_step(i):  # E episodes through the batched launch sequences -> ONE all-reduce -> Adam
+        trainer.step(pool_batches[i & 1] if batched else halves[i & 1])
+        if batched:
+            bad, ovf, its, mx = trainer.last_status
+            cg_acc[0] += its; cg_acc[1] += E; cg_acc[2] = max(cg_acc[2], mx)
 
     def train_step_eager(i):  # the reference's schedule: one episode, eager launches, all-reduce, Adam
-        saved, trainer.graphs = trainer.graphs, None
-        trainer.step(batch(i, 1))
-        trainer.graphs = saved
+        saved = trainer.runner, trainer.graphs
+        trainer.runner, trainer.graphs = None, None
+        trainer.step([pool[i % n_pool]])
+        trainer.runner, trainer.graphs = saved
         hb = model._head[1]
         f = head_flags()
-        f[0] = f[0] * hb.stats_bwd[0].clamp(max=1)  # forward AND adjoint solve converged
+        f[0] = f[0] * hb.stats_bwd.view(-1)[0].clamp(max=1)  # forward AND adjoint solve converged
         lp_flags.append(f)
-
-    def train_step_single_graph(i):  # the reference's schedule (one episode per optimiser step) as ONE hipGraph replay
-        trainer.step(batch(i, 1))
 
     def eval_step(i):
         model.eval()
-        eval_graphs.run([ep[:4] for ep in batch(i, E)])
+        runner.begin_step()
+        for b in pool_batches[i & 1]:
+            runner.eval_batch(b)
+        bad, ovf, its, mx = runner.step_status()
+        cg_acc[0] += its; cg_acc[1] += E; cg_acc[2] = max(cg_acc[2], mx)
+        if bad or ovf:
+            invalid.append("eval step %d: %d system(s) did not converge / timed out, %d batch(es) with 201-NN overflow" % (i, bad, ovf))
 
     def eval_step_eager(i):
         model.eval()
@@ -257,22 +271,18 @@ def main():
             model(sx, sy, qx, qy)
         lp_flags.append(head_flags())
 
-    invalid = []  # reasons why a timed leg does not count (every episode must have a converged, exact head)
-    redone_notes = []
-    lp_budget_info = {}
-
-    def timed(step_fn, steps, warmup, graphs=None):
+    def timed(step_fn, steps, warmup):
         for i in range(warmup):
             step_fn(i)
         del lp_flags[:]
-        if graphs is not None:
-            graphs.check()
+        cg_acc[:] = [0, 0, 0]
+        redone0 = trainer.n_redone if trainer is not None else 0
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            step_fn(i)
+            step_fn(warmup + i)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -281,77 +291,79 @@ def main():
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = t.item()
-        if graphs is not None:
-            lp_budget_info[step_fn.__name__] = {"captured": graphs.lp_budget, "enabled_at_end": graphs.active_budget}
-            enabled = graphs.active_budget
-            bad, it_sum, it_max = graphs.check()
-            if bad:  # recorded, not fatal: an abort on one rank would leave the others in the next barrier
-                msg = ("%s: %d episode(s) with unconverged label propagation / FPS time-out (CG max %d of budget %d), "
-                       "%d with 201-NN survivor overflow" % (step_fn.__name__, graphs.last_unconverged, it_max, enabled,
-                                                             graphs.last_knn_overflow))
-                if step_fn in (train_step, train_step_single_graph):  # DPTrainer.step fails closed: it redid those steps exactly, inside the timed region
-                    redone_notes.append(msg + " -- redone on the conservative schedule before the optimiser step")
-                else:
-                    invalid.append(msg)
-            return el, (it_sum / (steps * E), it_max)
-        lp = torch.stack(lp_flags).cpu()
-        if int(lp[:, 2].max()) != 0:
-            invalid.append("%s: 201-NN survivor buffer overflowed" % step_fn.__name__)
-        if int(lp[:, 0].min()) != 1:
-            invalid.append("%s: label propagation did not converge in %d episode(s)" % (step_fn.__name__, int((lp[:, 0] != 1).sum())))
-        return el, (float(lp[:, 1].float().mean()), int(lp[:, 1].max()))
+        if trainer is not None and trainer.n_redone > redone0:  # DPTrainer.step fails closed: redone exactly, inside the timed region
+            redone_notes.append("%s: %d step(s) redone on the conservative schedule" % (step_fn.__name__, trainer.n_redone - redone0))
+        if lp_flags:
+            lp = torch.stack(lp_flags).cpu()
+            if int(lp[:, 2].max()) != 0:
+                invalid.append("%s: 201-NN survivor buffer overflowed" % step_fn.__name__)
+            if int(lp[:, 0].min()) != 1:
+                invalid.append("%s: label propagation did not converge in %d episode(s)" % (step_fn.__name__, int((lp[:, 0] != 1).sum())))
+            return el, (float(lp[:, 1].float().mean()), int(lp[:, 1].max()))
+        return el, (cg_acc[0] / max(cg_acc[1], 1), cg_acc[2])
 
     extra = {}
+    steps_done = 0
     if train:
-        if G:
-            elapsed, cg = timed(train_step, args.steps, args.warmup, trainer.graphs)
-            n_e = max(args.steps * E // 4, 8)
+        main_step = train_step if batched else train_step_eager
+        el_f, cg_f = timed(main_step, args.steps, args.warmup)
+        steps_done = args.steps + args.warmup
+        Eeff = E if batched else 1
+        fresh = {"value": args.steps * Eeff * world / el_f, "unit": "episodes/s", "ms_per_step": el_f / args.steps * 1e3,
+                 "lp_cg_iterations": {"mean": cg_f[0], "max": cg_f[1]}, "optimiser_steps_before": args.warmup}
+        if batched and args.steady_steps > steps_done:
+            for i in range(args.steady_steps - steps_done):  # conditioning: train on (all ranks, untimed)
+                train_step(steps_done + i)
+            steps_done = args.steady_steps
+            elapsed, cg = timed(train_step, args.steps, 0)
+            steps_done += args.steps
+            extra["fresh_weights"] = fresh
+        else:
+            elapsed, cg = el_f, cg_f
+        E = Eeff
+        if batched and not args.no_extras:
+            n_e = max(args.steps, 16)
             el1, _ = timed(train_step_eager, n_e, 3)
             extra["single_episode_eager_step_episodes_per_sec"] = n_e * world / el1
-            el1g, _ = timed(train_step_single_graph, n_e, 3, trainer.graphs)  # what MPTILearner_V3.train does with episode_graphs on
-            extra["single_episode_graph_step_episodes_per_sec"] = n_e * world / el1g
-        else:
-            E = 1
-            elapsed, cg = timed(train_step_eager, args.steps, args.warmup)
-        step_fn = train_step_eager
+            saved_runner = trainer.runner
+            try:  # the same schedule as ONE captured hipGraph per episode (episode_graph.py, MPTILearner_V3's episode_graphs switch)
+                from r3dfsseg_amd.episode_graph import EpisodeGraphs
+                rows = torch.zeros(1, trainer.bucket.store.numel(), device=dev)
+                trainer.graphs = EpisodeGraphs(model, pool[0], 1, train=True, grad_rows=rows)
+                trainer.rows = rows
+                trainer.runner = None
+
+                def train_step_single_graph(i):
+                    trainer.step([pool[i % n_pool]])
+                el1g, _ = timed(train_step_single_graph, n_e, 3)
+                extra["single_episode_graph_step_episodes_per_sec"] = n_e * world / el1g
+            except Exception as exc:  # an extra, never the headline
+                extra["single_episode_graph_step_error"] = repr(exc)[:200]
+            trainer.runner, trainer.graphs = saved_runner, None
+            n_ev = max(args.steps // 2, 2)
+            el_ev, cg_ev = timed(eval_step, n_ev, 2)
+            extra["eval_forward_episodes_per_sec"] = n_ev * E * world / el_ev
+            extra["eval_forward_lp_cg_iterations"] = {"mean": cg_ev[0], "max": cg_ev[1]}
+            model.train()
     else:
-        if G:
-            elapsed, cg = timed(eval_step, args.steps, args.warmup, eval_graphs)
+        if batched:
+            elapsed, cg = timed(eval_step, args.steps, args.warmup)
         else:
             E = 1
             elapsed, cg = timed(eval_step_eager, args.steps, args.warmup)
-        step_fn = eval_step_eager
-    if train and G:
-        n_ev = max(args.steps // 2, 1)
-        el_ev, cg_ev = timed(eval_step, n_ev, 3, eval_graphs)
-        extra["eval_forward_episodes_per_sec"] = n_ev * E * world / el_ev
-        extra["eval_forward_lp_cg_iterations"] = {"mean": cg_ev[0], "max": cg_ev[1]}
-        model.train()
+    cg_mean, cg_max = cg
 
-    # roofline leg: single-episode EAGER steps; every entry point's library calls are launched again 8 times back
-    # to back between one HIP event pair (recorded on the launch stream = torch's current stream), so the
-    # per-launch time is device time, free of event packets and host launch gaps; outside the timed region above
-    n_roof = 10
-    timer = ops.KernelTimer(OPS, repeat=8)
+    # roofline leg: ONE more step of the headline kind with a HIP event pair (torch's current stream = the launch stream)
+    # around every entry-point call; batched launches run one after the other, so the pairs do not overlap
+    step_fn = (train_step if batched else train_step_eager) if train else (eval_step if batched else eval_step_eager)
+    n_roof = 2
+    timer = ops.KernelTimer(OPS, repeat=0)
     ops.set_timer(timer)
     for i in range(n_roof):
         step_fn(i)
     ops.set_timer(None)
     timer.close()
     ksum_all = timer.summary()
-    cg_mean, cg_max = cg
-
-    # steady-state leg (all ranks): train on, then time the same step again.  The first steps after initialisation
-    # solve easy label-propagation systems; once the encoder separates the classes the graph splits into clusters
-    # and the solves take more iterations.  Outside the headline's timed region.
-    if train and G and args.steady_steps > 0:
-        for i in range(max(0, args.steady_steps - args.steps - args.warmup)):
-            train_step(i)
-        el_ss, cg_ss = timed(train_step, args.steps, 1, trainer.graphs)
-        extra["steady_state"] = {"value": args.steps * E * world / el_ss, "unit": "episodes/s",
-                                 "optimiser_steps_before": args.steady_steps, "ms_per_step": el_ss / args.steps * 1e3,
-                                 "lp_cg_iterations": {"mean": cg_ss[0], "max": cg_ss[1]},
-                                 "redone_steps": getattr(trainer, "n_redone", 0)}
 
     n_invalid = torch.tensor([float(len(invalid))], device=dev)
     if dist is not None:
@@ -363,23 +375,25 @@ def main():
 
     N = cfg["pc_npts"]
     B = cfg["n_way"] * cfg["k_shot"] + cfg["n_way"] * cfg.get("n_queries", 1)
-    n_nodes = int(model._head[1].desc[ops.HD_N_NODES].item())
+    hb = model._head[1]
+    n_nodes = int(hb.desc.view(-1, 32)[0, ops.HD_N_NODES].item())
     per_step_ms = {k: v["total_ms"] / n_roof for k, v in ksum_all.items() if v["launches"]}
+    calls_per_step = {k: v["launches"] / n_roof for k, v in ksum_all.items() if v["launches"]}
     mode_name = "train" if train else "eval"
     prof, prof_name = committed_profile(args.workload, mode_name)
     pmc, pmc_name = committed_traffic(args.workload, mode_name)
     kern = args.roofline_kernel
-    if kern == "auto":  # the entry point with the most device time in the live eager pass above
+    if kern == "auto":  # the entry point with the most device time in the live step above
         kern = max(per_step_ms, key=per_step_ms.get)
     roof = None
-    if kern in ("label_propagate", "label_propagate_bwd"):
-        # The label propagation is graph build + CG; its dominant kernels are the two of one CG iteration.  Their time
-        # is measured live: the same solve with 8 and with 40 forced iterations (tol = 0), HIP events on the launch
-        # stream, difference / 32.
-        hb = model._head[1]
-        nbr = ops.knn(hb.nodes, 1, hb.n_cap, hb.kp1, mode=ops.SCORE_L2, n_valid=hb.desc[ops.HD_N_NODES:], status=hb.knn_status)
+    cg_roof = None
+    if True:
+        # The label propagation is graph build + CG; its dominant kernels are the two of one CG iteration, which serve
+        # every system of the batch.  Their time is measured live: the same solves with 8 and with 40 forced iterations
+        # (tol = 0), HIP events on the launch stream, difference / 32.
+        nbr = ops.knn_nodes(hb)
 
-        def solve_ms(iters, reps=6):
+        def solve_ms(iters, reps=4):
             ops.label_propagate(hb, nbr, model.sigma, 0.99, iters, 0.0)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
@@ -389,55 +403,68 @@ def main():
             torch.cuda.synchronize()
             return a.elapsed_time(b) / reps
         t_iter = (solve_ms(40) - solve_ms(8)) / 32.0 * 1e-3
-        _, row_ptr, _, _ = hb.csr()
-        nnz = int(row_ptr[-1].item())
-        by = cg_iteration_bytes(nnz, n_nodes)
-        fl = nnz * 2.0 * 4 + n_nodes * 4 * (12.0 + 4 * CG_M)
+        nnz = sum(int(hb.csr(e)[1][-1].item()) for e in range(hb.E))
+        nodes_tot = int(hb.desc.view(-1, 32)[:, ops.HD_N_NODES].sum().item())
+        by = cg_iteration_bytes(nnz, nodes_tot)
+        fl = nnz * 2.0 * 4 + nodes_tot * 4 * (12.0 + 4 * CG_M)
         cg_names = ("r3d_cg_spmv_kernel", "r3d_cg_update_kernel")
         traffic = rocprof_us = None
         if pmc is not None and all(k in pmc for k in cg_names):
-            traffic = 1024.0 * sum(pmc[k]["fetch_kb_per_launch"] + pmc[k]["write_kb_per_launch"] for k in cg_names)
+            traffic = 1024.0 * sum(FETCH_SIZE_WIDE_READ_FACTOR * pmc[k]["fetch_kb_per_launch"] + pmc[k]["write_kb_per_launch"]
+                                   for k in cg_names)
         if prof is not None:
             us = [v[2] for k, v in prof.items() if k.split("(")[0] in cg_names]
             rocprof_us = sum(us) if len(us) == 2 else None
-        roof = dict(kernel="r3d_cg_spmv_kernel + r3d_cg_update_kernel (one iteration of the two-level CG of the label "
-                           "propagation; entry point %s)" % kern,
+        cg_roof = dict(kernel="r3d_cg_spmv_kernel + r3d_cg_update_kernel (one iteration of the two-level CG of the label "
+                           "propagation, %d systems per launch; entry points label_propagate / label_propagate_bwd)" % hb.E,
                     bound="hbm", achieved=by / t_iter / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t_iter / 1e9 / HBM_PEAK_GBS,
                     traffic=traffic, avg_launch_ms=t_iter * 1e3, algorithmic_mb_per_launch=by / 1e6,
-                    algorithmic_gflop_per_launch=fl / 1e9, csr_nnz=nnz, nodes=n_nodes,
+                    algorithmic_gflop_per_launch=fl / 1e9, csr_nnz=nnz, nodes=nodes_tot, systems_per_launch=hb.E,
                     iterations_per_episode=cg_mean * (2 if train else 1), rocprofv3_kernel_us=rocprof_us,
                     frac_kernel_time_only=(by / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rocprof_us else None,
                     rocprofv3_summary=prof_name, pmc_summary=pmc_name,
-                    lp_solve_ms_per_episode=cg_mean * (2 if train else 1) * t_iter * 1e3,
-                    note=("avg_launch_ms is event-measured over back-to-back DEPENDENT launches, so it contains the two "
-                          "launch gaps of an iteration; rocprofv3_kernel_us is the pair's in-kernel time from the committed "
-                          "--kernel-trace summary of this workload (null when none is committed; that average includes the "
-                          "launches past convergence, which return at once); traffic = FETCH_SIZE + "
-                          "WRITE_SIZE of the pair from the committed PMC passes of this workload (raw counters); the matrix "
-                          "(%.1f MB) is L2 / Infinity-Cache resident between launches" % (nnz * 6 / 1e6)))
+                    note=("avg_launch_ms is event-measured over back-to-back launches (pair of kernels); rocprofv3_kernel_us is "
+                          "the pair's in-kernel time from the committed --kernel-trace summary of this workload (null when none "
+                          "is committed); traffic = %.0f x FETCH_SIZE + WRITE_SIZE of the pair from the committed PMC passes "
+                          "(the guide's gfx950 correction for wide coalesced reads)" % FETCH_SIZE_WIDE_READ_FACTOR))
+    if kern in ("label_propagate", "label_propagate_bwd"):
+        roof = cg_roof
     if roof is None:
         fl, by, bound, launches = algorithmic_work(kern, cfg, n_nodes, cg_mean, train)
-        t_launch = per_step_ms[kern] * 1e-3 / launches
+        fl, by = fl * E, by * E                       # the step's work of this entry point
+        calls = calls_per_step[kern]
+        t_launch = per_step_ms[kern] * 1e-3 / calls
         if bound == "mfma":
-            ach, peak, unit = fl / launches / t_launch / 1e12, F32_MFMA_PEAK_TF, "TFLOP/s"
+            ach, peak, unit = fl / calls / t_launch / 1e12, F32_MFMA_PEAK_TF, "TFLOP/s"
         else:
-            ach, peak, unit = by / launches / t_launch / 1e9, HBM_PEAK_GBS, "GB/s"
-        roof = dict(kernel="%s (entry point %s)" % (MAIN_KERNEL.get(kern, kern), kern), bound=bound, achieved=ach, peak=peak,
-                    unit=unit, frac=ach / peak, traffic=None, avg_launch_ms=t_launch * 1e3, launches_per_step=launches,
-                    algorithmic_gflop_per_launch=fl / launches / 1e9, algorithmic_mb_per_launch=by / launches / 1e6,
-                    hbm_gbs=by / launches / t_launch / 1e9, fp32_tflops=fl / launches / t_launch / 1e12,
-                    rocprofv3_summary=prof_name, pmc_summary=pmc_name,
-                    note="warm-cache repeat timing: the entry point's launches are issued again 8 times back to back on the "
-                         "same buffers between one HIP event pair on the launch stream (inputs L2 / Infinity-Cache warm)")
+            ach, peak, unit = by / calls / t_launch / 1e9, HBM_PEAK_GBS, "GB/s"
+        traffic = rocprof_us = None
+        main = MAIN_KERNEL.get(kern, kern)
+        if pmc is not None:
+            hit = [v for k, v in pmc.items() if k.split("(")[0].split("<")[0] in main]
+            if hit:
+                traffic = 1024.0 * max(FETCH_SIZE_WIDE_READ_FACTOR * v["fetch_kb_per_launch"] + v["write_kb_per_launch"] for v in hit)
+        if prof is not None:
+            us = [v[2] for k, v in prof.items() if k.split("(")[0].split("<")[0] in main]
+            rocprof_us = max(us) if us else None
+        roof = dict(kernel="%s (entry point %s, %d episodes per launch)" % (main, kern, E), bound=bound, achieved=ach, peak=peak,
+                    unit=unit, frac=ach / peak, traffic=traffic, avg_launch_ms=t_launch * 1e3, launches_per_step=calls,
+                    algorithmic_gflop_per_launch=fl / calls / 1e9, algorithmic_mb_per_launch=by / calls / 1e6,
+                    hbm_gbs=by / calls / t_launch / 1e9, fp32_tflops=fl / calls / t_launch / 1e12,
+                    rocprofv3_kernel_us=rocprof_us, rocprofv3_summary=prof_name, pmc_summary=pmc_name,
+                    note="one HIP event pair per entry-point call on the launch stream (launches of the batched step do not "
+                         "overlap; the pair includes the entry point's small helper kernels); traffic = %.0f x FETCH_SIZE + "
+                         "WRITE_SIZE of the main kernel from the committed PMC passes" % FETCH_SIZE_WIDE_READ_FACTOR)
     # every entry point against both ceilings (north_star: HBM GB/s for kNN / EdgeConv, MFMA utilisation for attention)
     from r3dfsseg_amd import _lib as _l0
     bx3_attention = _l0.load().r3d_get_matrix_arith() == 1
-    rooflines = {"_note": "warm-cache repeat timings (8 back-to-back relaunches per region on identical buffers): "
-                          "hbm_gbs is algorithmic bytes / device time, not HBM traffic"}
+    rooflines = {"_note": "HIP event pairs around every entry-point call of a live step (%d episodes per launch): hbm_gbs is "
+                          "algorithmic bytes / device time, not HBM traffic" % E}
     for op, ms in per_step_ms.items():
-        f_, b_, bnd, calls = algorithmic_work(op, cfg, n_nodes, cg_mean, train)
+        f_, b_, bnd, _ = algorithmic_work(op, cfg, n_nodes, cg_mean, train)
+        f_, b_ = f_ * E, b_ * E
         sec = ms * 1e-3
-        rooflines[op] = dict(bound=bnd, ms_per_step=round(ms, 4), calls_per_step=calls,
+        rooflines[op] = dict(bound=bnd, ms_per_step=round(ms, 4), calls_per_step=calls_per_step[op],
                              hbm_gbs=round(b_ / sec / 1e9, 1), frac_hbm=round(b_ / sec / 1e9 / HBM_PEAK_GBS, 4),
                              fp32_tflops=round(f_ / sec / 1e12, 2), frac_mfma=round(f_ / sec / 1e12 / F32_MFMA_PEAK_TF, 4))
         if op in ("attention", "attention_bwd") and bx3_attention:
@@ -450,28 +477,7 @@ def main():
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:
-        # the GPU box hands one GPU a 16-core CPU share (os.cpu_count() reports the whole host)
-        ncores = min(os.cpu_count() or 1, int(os.environ.get("R3D_CPU_THREADS", "16")))
-        os.environ["OMP_NUM_THREADS"] = str(ncores)
-        from oracle import r3d_oracle as O
-        torch.set_num_threads(ncores)
-        sd = S.make_state_dict(cfg, 123)
-        data, _ = S.make_episode(cfg, seed=0)
-        sx, sy, qx, qy = data[:4]
-        O.knn(qx[:1, :, :256], 4)  # load + warm the C library
-        c0 = time.perf_counter()
-        n_cpu = 0
-        while True:
-            O.mpti_forward(sd, cfg, sx, sy, qx, qy)
-            n_cpu += 1
-            if time.perf_counter() - c0 > 10.0 or n_cpu >= 3:
-                break
-        c1 = time.perf_counter()
-        cpu = dict(value=n_cpu / (c1 - c0), unit="episodes/s", cores=ncores, kind="port",
-                   sample="%d full %s episode(s), EVAL FORWARD only, CPU oracle (C + torch-CPU, %d threads)" % (n_cpu, args.workload, ncores),
-                   compare_with="eval_forward_episodes_per_sec" if (train and G) else "value",
-                   gpu_eval_forward_over_cpu=(extra.get("eval_forward_episodes_per_sec", args.steps * E * world / elapsed)
-                                              / (n_cpu / (c1 - c0))))
+        cpu = cpu_baseline(S, cfg, args.workload, extra, train, batched)
 
     eps = args.steps * E * world / elapsed
     from r3dfsseg_amd import _lib as _l
@@ -489,13 +495,13 @@ def main():
         "vs_baseline": None, "dtype": dtype_str, "matrix_arith": matrix_arith, "data": "synthetic",
         "config": {"workload": "%s: %d-way %d-shot %d pts, %d clouds/episode, %d episode(s)/step/rank (%s), mode=%s" % (
             args.workload, cfg["n_way"], cfg["k_shot"], N, B, E,
-            "%d in flight as hipGraphs on HIP streams" % G if G else "eager launches", args.mode),
-            "episodes_per_step": E * world, "episodes_per_rank": E, "slots": G},
+            "%d per launch sequence (episode-batched kernels)" % Bsz if batched else "eager launches, one at a time", args.mode),
+            "episodes_per_step": E * world, "episodes_per_rank": E, "episodes_per_launch_sequence": Bsz,
+            "optimiser_steps_before_timing": (steps_done - args.steps) if train else 0},
         "valid": int(n_invalid.item()) == 0, "invalid": invalid,
-        "roofline": roof, "rooflines": rooflines, "cpu_baseline": cpu,
+        "roofline": roof, "roofline_cg_iteration": cg_roof, "rooflines": rooflines, "cpu_baseline": cpu,
         "entry_point_ms_per_step": breakdown,
         "lp_cg_iterations": {"mean": cg_mean, "max": cg_max},
-        "lp_cg_launch_budget": lp_budget_info,  # CG iterations captured per graph / kept enabled (episode_graph.py)
         "train_steps_redone": {"count": getattr(trainer, "n_redone", 0) if trainer is not None else 0, "notes": redone_notes},
     }
     out.update(extra)
@@ -504,6 +510,58 @@ def main():
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def cpu_baseline(S, cfg, workload, extra, train, batched):
+    """The CPU oracle (kind "port": C + torch-CPU restatement of the reference path, oracle/) on this box's host cores,
+    on a bounded sample of the same workload: eval forward (1 warm-up, 5 timed) and one-episode training steps (forward,
+    backward through the dense closed-form label propagation, Adam; 1 warm-up, 3 timed)."""
+    # the GPU box hands one GPU a 16-core CPU share (os.cpu_count() reports the whole host)
+    ncores = min(os.cpu_count() or 1, int(os.environ.get("R3D_CPU_THREADS", "16")))
+    os.environ["OMP_NUM_THREADS"] = str(ncores)
+    from oracle import r3d_oracle as O
+    torch.set_num_threads(ncores)
+    sd = S.make_state_dict(cfg, 123)
+    data, _ = S.make_episode(cfg, seed=0, noise_ratio=0.2, train=True)
+    sx, sy, qx, qy = data[:4]
+    O.knn(qx[:1, :, :256], 4)  # load + warm the C library
+    times = []
+    for i in range(6):
+        c0 = time.perf_counter()
+        with torch.no_grad():
+            O.mpti_forward(sd, cfg, sx, sy, qx, qy)
+        if i:
+            times.append(time.perf_counter() - c0)
+    times.sort()
+    ev_min, ev_med = times[0], times[len(times) // 2]
+    # training step of the reference's schedule (mpti_learner.py:60-72): one episode, loss = lp + 0.1 contrast, Adam
+    params = {k: v.clone().requires_grad_() for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+    sdt = dict(sd)
+    sdt.update(params)
+    opt = torch.optim.Adam(list(params.values()), lr=1e-3)
+    ttimes = []
+    for i in range(4):
+        c0 = time.perf_counter()
+        out = O.mpti_forward(sdt, cfg, sx, sy, qx, qy, gt_support_y=data[6], gt_query_y=data[7], train=True,
+                             support_flag=data[10], new_stats={})
+        loss = out[1] + 0.1 * out[2]
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if i:
+            ttimes.append(time.perf_counter() - c0)
+    ttimes.sort()
+    tr_med = ttimes[len(ttimes) // 2]
+    gpu_eval = extra.get("eval_forward_episodes_per_sec")
+    gpu_single = extra.get("single_episode_eager_step_episodes_per_sec")
+    return dict(value=1.0 / ev_med, unit="episodes/s", cores=ncores, kind="port",
+                sample="%s episodes on the CPU oracle (C + torch-CPU, %d threads): EVAL FORWARD 1 warm-up + 5 timed (value = 1 / median), "
+                       "TRAIN STEP (forward + backward + Adam, dropout off) 1 warm-up + 3 timed" % (workload, ncores),
+                eval_forward={"episodes_per_sec_median": 1.0 / ev_med, "episodes_per_sec_best": 1.0 / ev_min, "timed": 5, "warmup": 1},
+                train_step={"episodes_per_sec_median": 1.0 / tr_med, "timed": 3, "warmup": 1},
+                compare_with={"eval_forward": "eval_forward_episodes_per_sec", "train_step": "single_episode_eager_step_episodes_per_sec (same schedule) / value"},
+                gpu_eval_forward_over_cpu=(gpu_eval * ev_med) if gpu_eval else None,
+                gpu_single_episode_train_step_over_cpu=(gpu_single * tr_med) if gpu_single else None)
 
 
 if __name__ == "__main__":

@@ -19,6 +19,7 @@
 #define HP_MAXSEG 8
 #define HP_BLOCK 256
 #define HP_MAXK 128
+#define HP_DP 256      // row pitch (floats) of the compacted point-major copy
 
 // int32 words of the device-side descriptor
 enum {
@@ -128,10 +129,12 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_head_gather_kernel(const float* 
                                                                    long ldf, int D, SegGeom g,
                                                                    const int* __restrict__ comp,
                                                                    const int* __restrict__ desc,
-                                                                   float* __restrict__ featC, long pitch, HpEp st) {
+                                                                   float* __restrict__ featC, long pitch,
+                                                                   float* __restrict__ featP /* [pos][HP_DP] */, HpEp st) {
   __shared__ float t[64][65];
   const int ep = blockIdx.y;
   feat += (long)ep * st.feat * ldf; HP_SHIFT(comp, st.ws); HP_SHIFT(desc, st.desc); HP_SHIFT(featC, st.ws);
+  HP_SHIFT(featP, st.ws);
   int blk0;
   const int seg = g.seg_of_block(blockIdx.x, &blk0);
   const int count = desc[HD_SEG_COUNT + seg];
@@ -160,6 +163,12 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_head_gather_kernel(const float* 
         const int c = c0 + r;
         const int pos = posb + lane;
         if (c < D && pos < count) featC[(long)c * pitch + g.off(seg) + pos] = t[lane][r];
+      }
+      // ... and the same rows compacted but still point-major: the FPS seed of a round is ONE row, read by every
+      // workgroup of its segment (6 cache lines here against one line per channel from the channel-major copy)
+      for (int r = w; r < 64; r += 4) {
+        const int pos = posb + r;
+        if (c0 + lane < D && pos < count) featP[(g.off(seg) + pos) * HP_DP + c0 + lane] = t[r][lane];
       }
     }
   }
@@ -279,39 +288,86 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_fps_round_kernel(
 // 2b. the same sampling as ONE launch: every workgroup keeps its 256 points (all channels) in registers for
 //     all k rounds instead of re-reading them every round (the per-round launches above fetch the whole
 //     compacted feature matrix from the memory side each round: 100 x 16 MB per episode on the S workload).
-//     Per round a workgroup publishes its best candidate as ONE 64-bit word (score bits << 32 | position + 1;
-//     0 = not yet written; the slot array is zeroed before the launch) with a relaxed agent-scope atomic
-//     store and reads the words of its segment's workgroups with atomic loads: the words are the only data
-//     exchanged, so no fence / cache write-back is needed (cf. profiles/r01_experiments.md: a fenced grid
-//     barrier costs 3-13 us, this exchange ~1-2 us).
+//     Election of a round, per segment: every workgroup publishes its best candidate as ONE 64-bit word -- key =
+//     distance bits (non-negative floats order like their bits) above the complemented position, so the largest key is
+//     the largest distance and, among equal distances, the lowest position: exactly the scan order of the oracle; 0 =
+//     not yet written (the words are zeroed before the launch) -- with a relaxed agent-scope atomic store.  The
+//     segment's FIRST workgroup (the leader) reads the words of all its workgroups, takes the maximum and publishes it
+//     as the round's result word; the other workgroups wait for that ONE word (one lane polling).  The words are the
+//     only data exchanged and the accesses are performed at the memory side, so no fence / cache write-back is needed
+//     (cf. profiles/r01_experiments.md: a fenced grid barrier costs 3-13 us).  Measured with tools/probe/fps_exchange.hip
+//     (us per round, exchange only, 1 segment of 66 workgroups -> 6 segments of 66 resident together): every workgroup
+//     reads all words (round 2) 2.4 -> 3.2; atomic maximum into one word + arrival counter 2.5 -> 6.6 (same-address
+//     atomics serialise at the memory side); leader 2.0 -> 2.1.
+//     The seed's feature row comes from the compacted point-major copy (6 cache lines, not 192).
 //     Co-residency: all workgroups of a grid that hold points must be resident together (one workgroup waits
 //     for its peers).  A workgroup needs ~200 VGPRs, i.e. 2 workgroups fit a CU, 512 on the chip; the caller
-//     selects this kernel only when (episodes in flight) x (support points / 256) stays below that
-//     (flags & R3D_HEAD_FPS_ONE_LAUNCH).  A waiter that sees nothing for ~2 s sets desc[HD_FPS_TIMEOUT] and
-//     proceeds, so a mis-sized launch ends with an error flag instead of a hung GPU.
+//     groups the episodes of a batch into launches that stay below that (fps_group).  A waiter that sees
+//     nothing for ~2 s sets desc[HD_FPS_TIMEOUT] and proceeds, so a mis-sized launch ends with an error flag
+//     instead of a hung GPU.
 // ---------------------------------------------------------------------------
 #define FPS_SPIN_LIMIT (1 << 22)
-template <int DP>
-__global__ __launch_bounds__(HP_BLOCK) void r3d_fps_persistent_kernel(
-    const float* __restrict__ featC, long pitch, int D, SegGeom g, int* __restrict__ desc, int k,
-    unsigned long long* __restrict__ xch /* [k][total_blocks] */, int total_blocks, int* __restrict__ sel, HpEp st, int ep0) {
-  __shared__ float seedf[DP];
-  {
-    const int ep = ep0 + blockIdx.y;  // the launch holds episodes ep0 .. ep0 + gridDim.y - 1 (co-resident together)
-    HP_SHIFT(featC, st.ws); HP_SHIFT(desc, st.desc); HP_SHIFT(sel, st.ws);
-    xch = (unsigned long long*)((int*)xch + (long)ep * st.ws);  // st.ws is even: 8-byte alignment is kept
+#ifdef FPS_STAMPS  // residency probe of the persistent kernel (tools/fps_stamps.py; never in the product build)
+__device__ unsigned long long g_fps_dbg[8192 * 4];
+extern "C" int r3d_fps_debug_read(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fps_dbg), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 1;
+}
+#define FSTAMP_BEGIN()                                                                                       \
+  unsigned long long fs_t0 = 0;                                                                              \
+  unsigned fs_hw = 0, fs_xcc = 0;                                                                            \
+  if (threadIdx.x == 0) {                                                                                    \
+    fs_t0 = __builtin_amdgcn_s_memtime();                                                                    \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(fs_hw));                                      \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(fs_xcc));                                    \
   }
+#define FSTAMP_END(active)                                                                                   \
+  if (threadIdx.x == 0) {                                                                                    \
+    const long fs_i = ((long)blockIdx.y * gridDim.x + blockIdx.x) & 8191;                                    \
+    g_fps_dbg[4 * fs_i + 0] = fs_t0;                                                                         \
+    g_fps_dbg[4 * fs_i + 1] = __builtin_amdgcn_s_memtime();                                                  \
+    g_fps_dbg[4 * fs_i + 2] = ((unsigned long long)fs_xcc << 32) | fs_hw;                                    \
+    g_fps_dbg[4 * fs_i + 3] = (active);                                                                      \
+  }
+#else
+#define FSTAMP_BEGIN()
+#define FSTAMP_END(active)
+#endif
+// FULL: D == DP.  With a run-time D < DP the unrolled channel loop carries a uniform `c < D` test per channel, which the
+// compiler turns into 192 precomputed lane masks parked in a VGPR: two v_readlane, a wait state and a v_cndmask per
+// channel beside the sub and the fma -- 3.5 times the VALU work of the round (5 of its 8 us with two workgroups per CU).
+template <int DP, bool FULL>
+__global__ __launch_bounds__(HP_BLOCK) void r3d_fps_persistent_kernel(
+    const float* __restrict__ featC, long pitch, const float* __restrict__ featP, int D, SegGeom g, int* __restrict__ desc,
+    int k, unsigned long long* __restrict__ xch /* [k][tb_dense] candidates, then [nseg][HP_MAXK] results */, int tb_dense,
+    int* __restrict__ sel, HpEp st, int ep0) {
+  __shared__ float seedf[DP];
   __shared__ float red_v[4];
   __shared__ int red_p[4];
   __shared__ int seed_pos_s;
-  int blk0;
-  const int seg = g.seg_of_block(blockIdx.x, &blk0);
+  {
+    const int ep = ep0 + blockIdx.y;  // the launch holds episodes ep0 .. ep0 + gridDim.y - 1 (co-resident together)
+    HP_SHIFT(featC, st.ws); HP_SHIFT(featP, st.ws); HP_SHIFT(desc, st.desc); HP_SHIFT(sel, st.ws);
+    xch = (unsigned long long*)((int*)xch + (long)ep * st.ws);  // st.ws is a multiple of 4 words: 8-byte alignment is kept
+  }
+  FSTAMP_BEGIN();
+  // DENSE block -> (segment, block in segment) map: the grid has just the ceil(S N / 256) + nseg workgroups an episode
+  // can need, and the ones that hold points are the first of them.  Workgroups go to the XCDs round robin in launch
+  // order, so a dense range spreads evenly; the capacity-sized grid of the other kernels (blocks(seg) per segment, most
+  // of them exiting at once) left the XCDs up to 71 : 55 unbalanced, a segment's last workgroups then waited for
+  // another segment's to END, and a launch of six episodes took 2.6 times one episode's time (tools/fps_stamps.py).
+  int seg = -1, bis = 0, count = 0, blk0 = 0;
+  {
+    int first = 0;
+    for (int s = 0; s < g.nseg(); ++s) {
+      const int cnt = desc[HD_SEG_COUNT + s];
+      const int nb = cnt > k ? (cnt + HP_BLOCK - 1) / HP_BLOCK : 0;  // count <= k: identity case (mpti.py:631-634), no sampling
+      if (seg < 0 && (int)blockIdx.x < first + nb) { seg = s; bis = blockIdx.x - first; count = cnt; blk0 = first; }
+      first += nb;
+    }
+  }
+  if (seg < 0) { FSTAMP_END(0); return; }
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int count = desc[HD_SEG_COUNT + seg];
-  if (count <= k) return;  // identity case (mpti.py:631-634): no sampling
-  const int bis = blockIdx.x - blk0;
-  if ((long)bis * HP_BLOCK >= count) return;
-  const int nblk = (count + HP_BLOCK - 1) / HP_BLOCK;
+  const unsigned nblk = (unsigned)((count + HP_BLOCK - 1) / HP_BLOCK);
   const int pos = bis * HP_BLOCK + tid;
   const bool have = pos < count;
   float xv[DP];
@@ -320,18 +376,20 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_fps_persistent_kernel(
 #pragma unroll
     for (int c = 0; c < DP; ++c) xv[c] = fp[(long)min(c, D - 1) * pitch];
   }
+  const float* rows = featP + g.off(seg) * HP_DP;
+  unsigned long long* res = xch + (long)k * tb_dense + (long)seg * HP_MAXK;  // the segment's result word of every round
   float md = INFINITY;
   int seed_pos = 0;
   for (int round = 0; round < k; ++round) {
     if (bis == 0 && tid == 0) sel[seg * HP_MAXK + round] = seed_pos;
     if (round == k - 1) break;
     __syncthreads();  // seedf / red_* of the previous round are no longer read
-    for (int c = tid; c < D; c += HP_BLOCK) seedf[c] = featC[(long)c * pitch + g.off(seg) + seed_pos];
+    for (int c = tid; c < D; c += HP_BLOCK) seedf[c] = rows[(long)seed_pos * HP_DP + c];
     __syncthreads();
     float acc = 0.f;
 #pragma unroll
     for (int c = 0; c < DP; ++c) {
-      if (c < D) {
+      if (FULL || c < D) {
         const float df = xv[c] - seedf[c];
         acc = __builtin_fmaf(df, df, acc);
       }
@@ -347,45 +405,60 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_fps_persistent_kernel(
     }
     if (lane == 0) { red_v[w] = v; red_p[w] = p; }
     __syncthreads();
+    unsigned long long* cw = xch + (long)round * tb_dense + blk0;  // the candidate words of the segment's workgroups
     if (tid == 0) {
       for (int i = 1; i < 4; ++i) cand_better(v, p, red_v[i], red_p[i]);
-      const unsigned long long word = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(p + 1);
-      __hip_atomic_store(&xch[(long)round * total_blocks + blockIdx.x], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (a workgroup that holds points has a candidate with v >= 0; anything else must not win: key 1, never 0)
+      const unsigned long long key =
+          (v >= 0.f && (unsigned)p < (unsigned)count) ? (((unsigned long long)__float_as_uint(v) << 32) | (0xffffffffu - (unsigned)p)) : 1ull;
+      __hip_atomic_store(&cw[bis], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // gather the segment's candidates (every workgroup reads all of them: same election everywhere)
-    v = -INFINITY;
-    p = 0x7fffffff;
-    for (int i = tid; i < nblk; i += HP_BLOCK) {
-      const unsigned long long* src = &xch[(long)round * total_blocks + blk0 + i];
-      unsigned long long word = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long win = 0ull;
+    if (bis == 0) {  // leader: the maximum of the segment's candidate words -> the round's result word
+      for (unsigned i = tid; i < nblk; i += HP_BLOCK) {
+        unsigned long long word = __hip_atomic_load(&cw[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (word == 0ull && spins < FPS_SPIN_LIMIT) {
+          __builtin_amdgcn_s_sleep(1);
+          word = __hip_atomic_load(&cw[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ++spins;
+        }
+        if (word == 0ull) desc[HD_FPS_TIMEOUT] = 1;
+        win = word > win ? word : win;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long y = __shfl_xor(win, o);
+        win = y > win ? y : win;
+      }
+      __syncthreads();  // red_* reuse
+      if (lane == 0) { red_v[w] = __uint_as_float((unsigned)(win >> 32)); red_p[w] = (int)(unsigned)(win & 0xffffffffull); }
+      __syncthreads();
+      if (tid == 0) {
+        for (int i = 1; i < 4; ++i) {
+          const unsigned long long y = ((unsigned long long)__float_as_uint(red_v[i]) << 32) | (unsigned)red_p[i];
+          win = y > win ? y : win;
+        }
+        __hip_atomic_store(&res[round], win | 1ull << 63, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // bit 63: written (distances are >= 0: the sign bit is free)
+      }
+    } else if (tid == 0) {
+      win = __hip_atomic_load(&res[round], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int spins = 0;
-      while (word == 0ull && spins < FPS_SPIN_LIMIT) {
-        __builtin_amdgcn_s_sleep(2);
-        word = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (win == 0ull && spins < FPS_SPIN_LIMIT) {
+        __builtin_amdgcn_s_sleep(1);
+        win = __hip_atomic_load(&res[round], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ++spins;
       }
-      if (word == 0ull) {
-        desc[HD_FPS_TIMEOUT] = 1;
-      } else {
-        cand_better(v, p, __uint_as_float((unsigned)(word >> 32)), (int)(unsigned)(word & 0xffffffffull) - 1);
-      }
+      if (win == 0ull) desc[HD_FPS_TIMEOUT] = 1;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float v2 = __shfl_xor(v, o);
-      const int p2 = __shfl_xor(p, o);
-      cand_better(v, p, v2, p2);
-    }
-    __syncthreads();  // red_* reuse
-    if (lane == 0) { red_v[w] = v; red_p[w] = p; }
-    __syncthreads();
     if (tid == 0) {
-      for (int i = 1; i < 4; ++i) cand_better(v, p, red_v[i], red_p[i]);
-      seed_pos_s = (p >= 0 && p < count) ? p : 0;  // stays a valid position even after a timeout
+      const unsigned wp = 0xffffffffu - (unsigned)(win & 0xffffffffull);
+      seed_pos_s = (win != 0ull && wp < (unsigned)count) ? (int)wp : 0;  // stays a valid position even after a timeout
     }
     __syncthreads();
     seed_pos = seed_pos_s;
   }
+  FSTAMP_END(1);
 }
 
 // ---------------------------------------------------------------------------
@@ -662,17 +735,37 @@ static int check_geom(const char* fn, int n_way, int k_shot, int N, int D) {
 extern "C" int r3d_head_desc_words(void) { return HD_WORDS; }
 extern "C" int r3d_head_max_k(void) { return HP_MAXK; }
 
-// Scratch sizes (in 4-byte words) the caller must provide for r3d_head_prototypes.
-extern "C" long r3d_head_proto_ws_words(int n_way, int k_shot, int N) {
-  SegGeom g{n_way, k_shot, N};
+// Scratch layout (4-byte words) of r3d_head_prototypes.
+struct HpWs {
+  long comp, mind, assign, cand, sel, seeds, part, part_cnt, featC, xch, best, featP, total;
+  long pitch;
+  int max_chunks;
+};
+static HpWs hp_carve(const SegGeom& g) {
+  HpWs L;
   const long cap = g.total_cap();
-  // comp + mind + assign + cand(2 x blocks x 2 words) + sel + seeds + cluster partial sums
-  const long max_chunks = (g.cap(0) + CM_CHUNK - 1) / CM_CHUNK;
-  return cap * 3 + 4L * g.total_blocks() + 2L * HP_MAXSEG * HP_MAXK + 64 +
-         (long)g.nseg() * HP_MAXK * max_chunks * 257 + 256L * (cap + 64) +  // ... + featC (D <= 256 rows)
-         2L * HP_MAXK * g.total_blocks() + 8 +                              // ... + one-launch FPS exchange words
-         2L * cap + 2;                                                      // ... + 64-bit (distance, seed) minimum per point
+  L.max_chunks = (int)((g.cap(0) + CM_CHUNK - 1) / CM_CHUNK);
+  L.pitch = cap + 32;
+  long o = 0;
+  L.comp = o; o += cap;
+  L.mind = o; o += cap;
+  L.assign = o; o += cap;
+  L.cand = o; o += 4L * g.total_blocks();                          // 2 x blocks x (value, position)
+  L.sel = o; o += (long)HP_MAXSEG * HP_MAXK;
+  L.seeds = o; o += (long)HP_MAXSEG * HP_MAXK + 64;
+  L.part = o; o += (long)g.nseg() * HP_MAXK * L.max_chunks * 256;  // cluster partial sums
+  L.part_cnt = o; o += (long)g.nseg() * HP_MAXK * L.max_chunks;
+  L.featC = o; o += 256L * (cap + 64);                             // compacted channel-major copy (D <= 256 rows)
+  o = (o + 3) & ~3L;
+  // one-launch FPS: a candidate word per (round, workgroup) and a result word per (segment, round), 64 bit each
+  L.xch = o; o += 2L * HP_MAXK * ((g.cap(0) + HP_BLOCK - 1) / HP_BLOCK + g.nseg()) + 2L * HP_MAXSEG * HP_MAXK;
+  L.best = o; o += 2L * cap + 2;                                   // 64-bit (distance, seed) minimum per point
+  o = (o + 3) & ~3L;
+  L.featP = o; o += cap * HP_DP;                                   // compacted point-major copy
+  L.total = o + 8;
+  return L;
 }
+extern "C" long r3d_head_proto_ws_words(int n_way, int k_shot, int N) { return hp_carve(SegGeom{n_way, k_shot, N}).total; }
 
 // Builds prototypes into node rows [0, n_proto) and appends the query rows, for n_ep episodes at once.
 //   support_y : (n_way*k_shot, N) int32 {0,1}
@@ -697,40 +790,48 @@ static int head_prototypes_impl(int n_ep, const HpEp& ep, int fps_group, const i
               r3d_head_proto_ws_words(n_way, k_shot, N));
   R3D_REQUIRE(k >= 1 && k <= HP_MAXK, "r3d_head_prototypes: k=%d unsupported (1..%d)", k, HP_MAXK);
   R3D_REQUIRE(n_ep >= 1 && n_ep <= 4096 && fps_group >= 1, "r3d_head_prototypes: %d episodes, %d per FPS launch", n_ep, fps_group);
-  R3D_REQUIRE(n_ep == 1 || (assign_out && (ep.ws & 1) == 0 && ep.ws >= ws_words),
-              "r3d_head_prototypes: a batch needs assign_out and an even scratch stride >= the scratch size");
+  R3D_REQUIRE(((uintptr_t)ws & 15) == 0, "r3d_head_prototypes: ws must be 16-byte aligned");
+  R3D_REQUIRE(n_ep == 1 || (assign_out && (ep.ws & 3) == 0 && ep.ws >= ws_words),
+              "r3d_head_prototypes: a batch needs assign_out and a scratch stride that is a multiple of 4 words >= the scratch size");
   hipStream_t st = (hipStream_t)stream;
   SegGeom g{n_way, k_shot, N};
   const long cap = g.total_cap();
-  int* comp = ws;
-  float* mind = (float*)(ws + cap);
-  int* assign = assign_out ? assign_out : ws + 2 * cap;
+  const HpWs L = hp_carve(g);
+  int* comp = ws + L.comp;
+  float* mind = (float*)(ws + L.mind);
+  int* assign = assign_out ? assign_out : ws + L.assign;
   HpEp e2 = ep;
   if (!assign_out) e2.assign = ep.ws;  // (single episode only)
-  Cand* cand0 = (Cand*)(ws + 3 * cap);
+  Cand* cand0 = (Cand*)(ws + L.cand);
   Cand* cand1 = cand0 + g.total_blocks();
-  int* sel = ws + 3 * cap + 4L * g.total_blocks();
-  int* seeds = sel + HP_MAXSEG * HP_MAXK;
-  const int max_chunks = (int)((g.cap(0) + CM_CHUNK - 1) / CM_CHUNK);
-  float* part = (float*)(seeds + HP_MAXSEG * HP_MAXK + 64);
-  int* part_cnt = (int*)(part + (long)g.nseg() * HP_MAXK * max_chunks * 256);
-  float* featC = (float*)(part_cnt + (long)g.nseg() * HP_MAXK * max_chunks);
-  const long pitch = cap + 32;
-  long xoff = (featC + 256L * (cap + 64)) - (float*)ws;  // exchange words of the one-launch FPS, 8-byte aligned
-  xoff += xoff & 1;
-  unsigned long long* xch = (unsigned long long*)(ws + xoff);
-  unsigned long long* best_packed = xch + (long)HP_MAXK * g.total_blocks() + 1;  // behind the exchange words
+  int* sel = ws + L.sel;
+  int* seeds = ws + L.seeds;
+  const int max_chunks = L.max_chunks;
+  float* part = (float*)(ws + L.part);
+  int* part_cnt = ws + L.part_cnt;
+  float* featC = (float*)(ws + L.featC);
+  const long pitch = L.pitch;
+  unsigned long long* xch = (unsigned long long*)(ws + L.xch);
+  unsigned long long* best_packed = (unsigned long long*)(ws + L.best);
+  float* featP = (float*)(ws + L.featP);
   const int tb = g.total_blocks();
   hipLaunchKernelGGL(r3d_head_compact_kernel, dim3(g.nseg(), n_ep), dim3(1024), 0, st, support_y, shot_keep, g, comp, desc, e2);
   hipLaunchKernelGGL(r3d_head_gather_kernel, dim3(tb, n_ep), dim3(HP_BLOCK), 0, st, feat, ldf, D, g, comp, desc, featC, pitch,
-                     e2);
+                     featP, e2);
   if (flags & 1 /* R3D_HEAD_FPS_ONE_LAUNCH */) {
-    r3d_fill_words_ep(xch, 0u, 2L * k * tb, n_ep, e2.ws, st);
+    const int tb_dense = (int)((g.cap(0) + HP_BLOCK - 1) / HP_BLOCK) + g.nseg();  // the segments' counts add up to cap(0)
+    r3d_fill_words_ep(xch, 0u, 2L * k * tb_dense + 2L * HP_MAXSEG * HP_MAXK, n_ep, e2.ws, st);
     for (int e0 = 0; e0 < n_ep; e0 += fps_group) {
       const int ne = n_ep - e0 < fps_group ? n_ep - e0 : fps_group;
 #define FPS_ONE(DPAD)                                                                                                   \
-      hipLaunchKernelGGL(r3d_fps_persistent_kernel<DPAD>, dim3(tb, ne), dim3(HP_BLOCK), 0, st, featC, pitch, D, g, desc, k, \
-                         xch, tb, sel, e2, e0)
+      do {                                                                                                              \
+        if (D == DPAD)                                                                                                  \
+          hipLaunchKernelGGL((r3d_fps_persistent_kernel<DPAD, true>), dim3(tb_dense, ne), dim3(HP_BLOCK), 0, st, featC, pitch, \
+                             featP, D, g, desc, k, xch, tb_dense, sel, e2, e0);                                         \
+        else                                                                                                            \
+          hipLaunchKernelGGL((r3d_fps_persistent_kernel<DPAD, false>), dim3(tb_dense, ne), dim3(HP_BLOCK), 0, st, featC, pitch, \
+                             featP, D, g, desc, k, xch, tb_dense, sel, e2, e0);                                         \
+      } while (0)
       if (D <= 64) FPS_ONE(64);
       else if (D <= 128) FPS_ONE(128);
       else if (D <= 192) FPS_ONE(192);
@@ -871,13 +972,7 @@ extern "C" int r3d_head_prototypes_bwd_batched(int n_ep, const float* dnodes, lo
 // Word offsets of the scratch sub-arrays inside ws (for tests that inspect the
 // intermediate index results): comp, mind, assign, cand, sel, seeds.
 extern "C" int r3d_head_proto_ws_offsets(int n_way, int k_shot, int N, long* out6) {
-  SegGeom g{n_way, k_shot, N};
-  const long cap = g.total_cap();
-  out6[0] = 0;
-  out6[1] = cap;
-  out6[2] = 2 * cap;
-  out6[3] = 3 * cap;
-  out6[4] = 3 * cap + 4L * g.total_blocks();
-  out6[5] = out6[4] + HP_MAXSEG * HP_MAXK;
+  const HpWs L = hp_carve(SegGeom{n_way, k_shot, N});
+  out6[0] = L.comp; out6[1] = L.mind; out6[2] = L.assign; out6[3] = L.cand; out6[4] = L.sel; out6[5] = L.seeds;
   return R3D_OK;
 }
