@@ -46,6 +46,9 @@ int r3d_abi_version(void);
  * points use mode 1 only when they are given a workspace (the packed operands live there). */
 /* test utility: fills the chip's LDS with `pattern` (no result of this library may depend on stale LDS contents) */
 int r3d_debug_poison_lds(unsigned pattern, unsigned* sink /* 1 device word */, void* stream);
+/* test / A-B utility: the CG's SpMV runs on its LDS-resident form when the launch holds at least min_blocks 128-row
+ * workgroups (default 256; 0 = always, INT_MAX = never); both forms give the same bits.  Returns the previous value. */
+int r3d_debug_set_cg_spmv_lds_min_blocks(int min_blocks);
 int r3d_set_matrix_arith(int mode);
 int r3d_get_matrix_arith(void);
 

@@ -38,6 +38,7 @@ _SIGS = {
     "r3d_attention_fwd": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_f, c_f]),
     "r3d_head_desc_words": (c_i, []),
     "r3d_debug_poison_lds": (c_i, [c_u, c_f, c_f]),
+    "r3d_debug_set_cg_spmv_lds_min_blocks": (c_i, [c_i]),
     "r3d_set_matrix_arith": (c_i, [c_i]),
     "r3d_get_matrix_arith": (c_i, []),
     "r3d_head_max_k": (c_i, []),

@@ -893,6 +893,196 @@ __global__ __launch_bounds__(256) void r3d_cg_spmv_kernel(
   }
 }
 
+// S with the residual of the system in LDS (n x float4 <= SL_MAX_LDS).  Once a batch of systems streams its matrices
+// from HBM, what is left in the way is the gather: every matrix entry fetches a 16-byte row of r through a 64-byte L2
+// sector (4 x the traffic, ~14 TB/s of sector reads per iteration for 32 systems of workload S) -- the launch was bound
+// by L2 -> CU bandwidth at 1.6 TB/s of algorithmic bytes.  Here a workgroup of 8 waves takes SL_ROWS consecutive rows of
+// ONE system, stages that system's r in LDS once (70 KB at S: coalesced, 12 % of what the gathers read) and gathers
+// from there; a wave walks 16 rows with the next row's column / value loads in flight behind the current row's
+// gather, and the 16 row tails (p, q updates) run lane-parallel with coalesced loads and stores.  The arithmetic is
+// that of r3d_cg_spmv_kernel bit for bit, INCLUDING the <p, q> partials (one per 4 rows, added in row order): which of
+// the two kernels a solve runs on -- a matter of how many systems the launch holds -- changes no bit of its result.
+#define SL_ROWS 128
+#define SL_WAVES 8
+#define SL_RPW (SL_ROWS / SL_WAVES)
+#define SL_MAX_LDS (144 * 1024)
+__global__ __launch_bounds__(64 * SL_WAVES) void r3d_cg_spmv_lds_kernel(
+    const int* __restrict__ row_ptr, const hg_col_t* __restrict__ col, const float* __restrict__ val,
+    const float* __restrict__ dinv, const int* __restrict__ agg, const float* __restrict__ MW,
+    const int* __restrict__ n_dev, int n_cap, float alpha_lp, int it, int rows_per_block,
+    const float4* __restrict__ r, float4* __restrict__ p, float4* __restrict__ q,
+    float4* __restrict__ part_pq /* [ceil(n_cap / 4)] */, const CgState* __restrict__ cg, HgEp st) {
+  extern __shared__ __attribute__((aligned(16))) float4 rs[];  // [n] the system's residual
+  __shared__ float4 mu_s[HG_M];
+  {
+    const int ep = blockIdx.y;
+    HG_WS(cg);
+    if (cg->done) return;  // this system has converged: the launch goes on for the others
+    HG_WS(row_ptr); HG_WS(col); HG_WS(val); HG_WS(dinv); HG_WS(agg); HG_WS(MW); HG_AT(n_dev, st.desc); HG_WS(r); HG_WS(p);
+    HG_WS(q); HG_WS(part_pq);
+  }
+  const int n = min(*n_dev, n_cap);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int row0 = blockIdx.x * SL_ROWS + w * SL_RPW;
+  const int n_part = (n_cap + 3) / 4;  // partials of <p, q>: one per 4 rows, as r3d_cg_spmv_kernel with rows_per_block = 4
+  if (blockIdx.x * SL_ROWS >= n) {  // uniform: a workgroup beyond the system's rows
+    if (tid < SL_ROWS / 4 && blockIdx.x * (SL_ROWS / 4) + tid < n_part) part_pq[blockIdx.x * (SL_ROWS / 4) + tid] = f4_zero();
+    return;
+  }
+  // this wave's row bounds: one coalesced load (lane k holds row_ptr[row0 + k], k <= SL_RPW)
+  const int my_ptr = row_ptr[min(row0 + min(lane, SL_RPW), n)];
+  // stage r: 4 float4 per thread in flight
+  for (int i0 = tid; i0 < n; i0 += 4 * 64 * SL_WAVES) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = r[min(i0 + u * 64 * SL_WAVES, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u * 64 * SL_WAVES < n) rs[i0 + u * 64 * SL_WAVES] = v[u];
+  }
+  if (tid < HG_M) mu_s[tid] = reinterpret_cast<const float4*>(cg->mu)[tid];
+  const float4 beta = *reinterpret_cast<const float4*>(cg->beta);
+  __syncthreads();
+  const float4 mul = mu_s[lane];
+  const int nrows = min(SL_RPW, n - row0);  // uniform over the wave (may be <= 0)
+  int jv[6], jn[6];
+  float av[6], an[6];
+  float mw = 0.f, mwn = 0.f;
+  auto issue = [&](int k, int (&jj)[6], float (&aa)[6], float& mm) {
+    const int rb = __builtin_amdgcn_readlane(my_ptr, k), re = __builtin_amdgcn_readlane(my_ptr, k + 1);
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int e = rb + lane + 64 * u;
+      const int ec = max(min(e, re - 1), 0);
+      jj[u] = col[ec];
+      aa[u] = r3d_keep(val[ec], e < re);
+    }
+    mm = MW[(long)(row0 + k) * HG_M + lane];
+  };
+  // Rows go in two groups of 8.  A lane keeps its partial sums of the group's rows in registers and the 64 lanes'
+  // partials meet in ONE transposed butterfly per group: the xor-32 step halves the rows a lane is responsible for (it
+  // sends the other half to its partner), xor-16 and xor-8 halve again, and the last three steps run on the one row
+  // left -- lanes 8 g .. 8 g + 7 end up with the total of row g.  Every row still sees the pairs (l, l ^ 32), (l, l ^ 16),
+  // ... (l, l ^ 1) in this order, i.e. the additions of the plain butterfly of r3d_cg_spmv_kernel (x + y = y + x bit for
+  // bit), at 5 cross-lane moves per row and column instead of 24: the moves go through the LDS crossbar, which the
+  // gathers need (the first version of this kernel was bound by exactly that: 153 us per launch, as slow as gathering
+  // from L2).
+  float4 tot[2] = {f4_zero(), f4_zero()};  // lanes 8 g ..: row 8 h + g of this wave (h = group)
+  if (nrows > 0) issue(0, jv, av, mw);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float4 acc[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int k = 8 * h + kk;
+      acc[kk] = f4_zero();
+      if (k < nrows) {  // uniform
+        if (k + 1 < nrows) issue(k + 1, jn, an, mwn);
+        const int rb = __builtin_amdgcn_readlane(my_ptr, k), re = __builtin_amdgcn_readlane(my_ptr, k + 1);
+        float4 s = f4_zero();
+        {
+          float4 rj[6];
+#pragma unroll
+          for (int u = 0; u < 6; ++u) rj[u] = rs[jv[u]];
+#pragma unroll
+          for (int u = 0; u < 6; ++u) {
+            s.x = __builtin_fmaf(av[u], rj[u].x, s.x); s.y = __builtin_fmaf(av[u], rj[u].y, s.y);
+            s.z = __builtin_fmaf(av[u], rj[u].z, s.z); s.w = __builtin_fmaf(av[u], rj[u].w, s.w);
+          }
+        }
+        for (int e0 = rb + 384; e0 < re; e0 += 384) {  // rows with more than 384 entries (uniform trip count)
+          int j2[6];
+          float a2[6];
+#pragma unroll
+          for (int u = 0; u < 6; ++u) {
+            const int e = e0 + lane + 64 * u;
+            const int ec = min(e, re - 1);
+            j2[u] = col[ec];
+            a2[u] = r3d_keep(val[ec], e < re);
+          }
+#pragma unroll
+          for (int u = 0; u < 6; ++u) {
+            const float4 rj = rs[j2[u]];
+            s.x = __builtin_fmaf(a2[u], rj.x, s.x); s.y = __builtin_fmaf(a2[u], rj.y, s.y);
+            s.z = __builtin_fmaf(a2[u], rj.z, s.z); s.w = __builtin_fmaf(a2[u], rj.w, s.w);
+          }
+        }
+        // (M W) mu rides the same butterfly: per lane -alpha s + MW[i][lane] mu[lane]
+        s.x = __builtin_fmaf(mw, mul.x, -alpha_lp * s.x); s.y = __builtin_fmaf(mw, mul.y, -alpha_lp * s.y);
+        s.z = __builtin_fmaf(mw, mul.z, -alpha_lp * s.z); s.w = __builtin_fmaf(mw, mul.w, -alpha_lp * s.w);
+        acc[kk] = s;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) { jv[u] = jn[u]; av[u] = an[u]; }
+        mw = mwn;
+      }
+    }
+    // transposed butterfly: 8 rows -> 4 -> 2 -> 1 row per lane, then the plain steps
+    float4 a4[4], a2[2], a1;
+    {
+      const bool hi = (lane & 32) != 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float4 keepv = hi ? acc[4 + t] : acc[t], sendv = hi ? acc[t] : acc[4 + t];
+        a4[t].x = keepv.x + __shfl_xor(sendv.x, 32); a4[t].y = keepv.y + __shfl_xor(sendv.y, 32);
+        a4[t].z = keepv.z + __shfl_xor(sendv.z, 32); a4[t].w = keepv.w + __shfl_xor(sendv.w, 32);
+      }
+    }
+    {
+      const bool hi = (lane & 16) != 0;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float4 keepv = hi ? a4[2 + t] : a4[t], sendv = hi ? a4[t] : a4[2 + t];
+        a2[t].x = keepv.x + __shfl_xor(sendv.x, 16); a2[t].y = keepv.y + __shfl_xor(sendv.y, 16);
+        a2[t].z = keepv.z + __shfl_xor(sendv.z, 16); a2[t].w = keepv.w + __shfl_xor(sendv.w, 16);
+      }
+    }
+    {
+      const bool hi = (lane & 8) != 0;
+      const float4 keepv = hi ? a2[1] : a2[0], sendv = hi ? a2[0] : a2[1];
+      a1.x = keepv.x + __shfl_xor(sendv.x, 8); a1.y = keepv.y + __shfl_xor(sendv.y, 8);
+      a1.z = keepv.z + __shfl_xor(sendv.z, 8); a1.w = keepv.w + __shfl_xor(sendv.w, 8);
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+      a1.x += __shfl_xor(a1.x, o); a1.y += __shfl_xor(a1.y, o);
+      a1.z += __shfl_xor(a1.z, o); a1.w += __shfl_xor(a1.w, o);
+    }
+    tot[h] = a1;
+  }
+  // the wave's row tails: lane 8 g + h takes row 8 h + g (16 lanes busy; rows of a group sit 8 lanes apart)
+  float4 acc_pq = f4_zero();
+  const int trow = 8 * (lane & 7) + (lane >> 3);  // (meaningful for lane & 7 < 2)
+  if ((lane & 7) < 2 && trow < nrows) {
+    const float4 keep = (lane & 1) ? tot[1] : tot[0];
+    const int i = row0 + trow;
+    const float4 ri = rs[i], pi = p[i], qi = q[i];
+    const float u = 1.f / dinv[i];
+    const float4 m = mu_s[agg[i]];
+    const float4 pn = make_float4((ri.x + u * m.x) + beta.x * pi.x, (ri.y + u * m.y) + beta.y * pi.y,
+                                  (ri.z + u * m.z) + beta.z * pi.z, (ri.w + u * m.w) + beta.w * pi.w);
+    const float4 qn = make_float4((ri.x + keep.x) + beta.x * qi.x, (ri.y + keep.y) + beta.y * qi.y,
+                                  (ri.z + keep.z) + beta.z * qi.z, (ri.w + keep.w) + beta.w * qi.w);
+    p[i] = pn;
+    q[i] = qn;
+    acc_pq = make_float4(pn.x * qn.x, pn.y * qn.y, pn.z * qn.z, pn.w * qn.w);
+  }
+  // one partial per 4 rows, ((r0 + r1) + r2) + r3: the order in which r3d_cg_spmv_kernel adds its four waves.  Row r of
+  // the wave sits in lane 8 (r & 7) + (r >> 3); lane c < 4 gathers the four rows 4 c .. 4 c + 3.
+  {
+    float4 t = f4_zero();
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int r_ = 4 * (lane & 3) + d;
+      const int src = 8 * (r_ & 7) + (r_ >> 3);
+      const float x = __shfl(acc_pq.x, src), y = __shfl(acc_pq.y, src), z = __shfl(acc_pq.z, src), w_ = __shfl(acc_pq.w, src);
+      if (d == 0) t = make_float4(x, y, z, w_);
+      else { t.x += x; t.y += y; t.z += z; t.w += w_; }
+    }
+    const int gidx = (row0 >> 2) + lane;
+    if (lane < SL_RPW / 4 && gidx < n_part) part_pq[gidx] = t;
+  }
+}
+
 #ifdef CG_STAMPS  // phase stamps of the update kernel (tools/cg_stamps.py; never in the product build)
 __device__ unsigned long long g_cg_dbg[32];
 #define CSTAMP(i) do { if (it == 3 && threadIdx.x == 0 && blockIdx.x == 0) g_cg_dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -1106,6 +1296,14 @@ static int lp_coarse_space(const LpWs& L, const float* nodes, long ldn, int D, c
   return R3D_OK;
 }
 
+// workgroups a launch must hold for the LDS-resident SpMV to be chosen (test / A-B utility: 0 = always, a huge value = never)
+static int g_cg_lds_min_blocks = 256;
+extern "C" int r3d_debug_set_cg_spmv_lds_min_blocks(int min_blocks) {
+  const int old = g_cg_lds_min_blocks;
+  g_cg_lds_min_blocks = min_blocks;
+  return old;
+}
+
 // two-level CG on the already built graphs and coarse spaces: X = (I - alpha S)^-1 RHS for every system of the batch.
 // rhs_stride / x_stride: float4 rows between the systems' right-hand sides / solutions.
 static int lp_solve(const LpWs& L, const float* RHS, long rhs_stride, const int32_t* n_dev, int n_cap, float alpha, int max_iter,
@@ -1122,10 +1320,29 @@ static int lp_solve(const LpWs& L, const float* RHS, long rhs_stride, const int3
   for (int mode = 0; mode < 2; ++mode)
     hipLaunchKernelGGL(r3d_cg_init_kernel, dim3(nblk_v, n_ep), dim3(256), 0, st, (const float4*)RHS, L.dinv, L.agg, L.MW, n_dev,
                        n_cap, mode, x, L.r, L.p, L.q, L.part, L.Einv, tol2, L.cg, ep, rhs_stride, x_stride);
+  // the SpMV with the residual in LDS when it fits and the launch holds enough systems to fill the chip with 128-row
+  // workgroups (a single system is 35 of them at workload S: there the one-row-per-wave kernel, 1099 workgroups, is the
+  // faster one); same bits either way
+  const size_t lds_r = (size_t)n_cap * sizeof(float4);
+  const bool use_lds = lds_r <= SL_MAX_LDS && rpb == HG_ROWS_PER_BLOCK_MIN && (long)n_ep * r3d_cdiv(n_cap, SL_ROWS) >= g_cg_lds_min_blocks;
+  if (use_lds) {
+    static size_t attr = 0;
+    if (lds_r > attr) {
+      hipError_t e = hipFuncSetAttribute((const void*)r3d_cg_spmv_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+      R3D_REQUIRE(e == hipSuccess, "r3d_label_propagate: cannot reserve %zu B of LDS: %s", lds_r, hipGetErrorString(e));
+      attr = lds_r;
+    }
+  }
+  const int nblk_l = r3d_cdiv(n_cap, SL_ROWS);
+  const int nblk_pq = nblk_s;  // (the LDS kernel writes the same 4-row partials)
   for (int it = 0; it < max_iter; ++it) {
-    hipLaunchKernelGGL(r3d_cg_spmv_kernel, dim3(nblk_s, n_ep), dim3(256), 0, st, L.row_ptr, L.col, L.val, L.dinv, L.agg, L.MW,
-                       n_dev, n_cap, alpha, it, rpb, L.r, L.p, L.q, L.part_pq, L.cg, ep);
-    hipLaunchKernelGGL(r3d_cg_update_kernel, dim3(nblk_v, n_ep), dim3(256), 0, st, n_dev, n_cap, it, nblk_s, L.dinv, L.agg, L.MW,
+    if (use_lds)
+      hipLaunchKernelGGL(r3d_cg_spmv_lds_kernel, dim3(nblk_l, n_ep), dim3(64 * SL_WAVES), lds_r, st, L.row_ptr, L.col, L.val, L.dinv,
+                         L.agg, L.MW, n_dev, n_cap, alpha, it, SL_ROWS, L.r, L.p, L.q, L.part_pq, L.cg, ep);
+    else
+      hipLaunchKernelGGL(r3d_cg_spmv_kernel, dim3(nblk_s, n_ep), dim3(256), 0, st, L.row_ptr, L.col, L.val, L.dinv, L.agg, L.MW,
+                         n_dev, n_cap, alpha, it, rpb, L.r, L.p, L.q, L.part_pq, L.cg, ep);
+    hipLaunchKernelGGL(r3d_cg_update_kernel, dim3(nblk_v, n_ep), dim3(256), 0, st, n_dev, n_cap, it, nblk_pq, L.dinv, L.agg, L.MW,
                        L.p, L.q, x, L.r, L.part_pq, L.part, L.Einv, tol2, L.cg, ep, x_stride);
   }
   if (stats_out) hipLaunchKernelGGL(r3d_cg_stats_kernel, dim3(n_ep), dim3(64), 0, st, L.cg, stats_out, ep);
@@ -1454,7 +1671,7 @@ extern "C" int r3d_graph_set_lp_budget(void* graph, void* graph_exec, int budget
     hipKernelNodeParams kp;
     if (hipGraphKernelNodeGetParams(nodes[i], &kp) != hipSuccess) { rc = R3D_ERR_LAUNCH; break; }
     int it, on;
-    if (kp.func == (void*)r3d_cg_spmv_kernel) { it = *(const int*)kp.kernelParams[9]; on = it < budget; }
+    if (kp.func == (void*)r3d_cg_spmv_kernel || kp.func == (void*)r3d_cg_spmv_lds_kernel) { it = *(const int*)kp.kernelParams[9]; on = it < budget; }
     else if (kp.func == (void*)r3d_cg_update_kernel) { it = *(const int*)kp.kernelParams[2]; on = it < budget; }
     else continue;
     ++found;

@@ -195,3 +195,34 @@ def test_dptrainer_batched_step_equals_eager_step():
     assert perr < 2e-5, perr
     for k in a[3]:
         np.testing.assert_allclose(a[3][k].float().cpu().numpy(), b[3][k].float().cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_lds_resident_spmv_gives_the_same_bits():
+    """The CG's SpMV has two forms (one matrix row per wave gathering r from L2; 128-row workgroups with r staged in LDS,
+    chosen when a launch holds enough systems): same arithmetic, same <p, q> partials -> bit-identical solves, forward
+    and adjoint."""
+    from r3dfsseg_amd import _lib
+    from r3dfsseg_amd.batch import EpisodeBatch
+    from r3dfsseg_amd.batched import EpisodeBatchRunner
+    from r3dfsseg_amd.dist import FlatGradBucket
+    lib = _lib.load()
+    cfg = S.make_cfg(n_way=2, k_shot=2, pc_npts=512)
+    eps = _episodes(cfg, 3)
+    batch = EpisodeBatch.from_episodes(eps)
+    res = {}
+    old = lib.r3d_debug_set_cg_spmv_lds_min_blocks(256)
+    try:
+        for mode, min_blocks in (("global", 1 << 30), ("lds", 0)):
+            lib.r3d_debug_set_cg_spmv_lds_min_blocks(min_blocks)
+            m = _model(cfg, True, 0.0)
+            bucket = FlatGradBucket(m.parameters())
+            run = EpisodeBatchRunner(m)
+            run.begin_step()
+            loss, logits, metrics, lp, cl = run.train_batch(batch, [p.grad for p in bucket.params])
+            assert run.step_status()[:2] == (0, 0)
+            hb = m._head[1]
+            res[mode] = (logits.clone(), hb.Z.clone(), bucket.flat.clone(), hb.stats.clone(), hb.stats_bwd.clone())
+    finally:
+        lib.r3d_debug_set_cg_spmv_lds_min_blocks(old)
+    for a, b in zip(res["global"], res["lds"]):
+        assert torch.equal(a, b)
