@@ -31,14 +31,15 @@ def shard_episodes(n_episodes, rank, world):
 
 class FlatGradBucket:
     """All trainable parameters' gradients viewed through ONE contiguous fp32 buffer, so a step
-    needs a single all-reduce (SUM) followed by a division by the global episode count."""
+    needs a single all-reduce (SUM) followed by a division by the global episode count.  Two extra slots travel with the
+    gradients: the episode count (the divisor) and a failure flag -- a rank whose episodes could not be solved exactly
+    raises only AFTER the collective, together with every other rank (nobody is left waiting in an all-reduce)."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        # one extra slot carries the episode count, so gradients AND their divisor travel in one all-reduce
-        self.store = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        self.store = torch.zeros(n + 2, dtype=torch.float32, device=dev)
         self.flat = self.store[:n]
         off = 0
         for p in self.params:  # p.grad becomes a view into the bucket
@@ -48,14 +49,42 @@ class FlatGradBucket:
     def zero_(self):
         self.flat.zero_()
 
-    def all_reduce_mean(self, n_local_episodes):
-        """Sum gradients over ranks and divide by the total number of episodes of the step."""
-        total = self.store[-1:]
-        total.fill_(float(n_local_episodes))  # a fill kernel: no host->device copy, no host sync
+    def all_reduce_mean(self, n_local_episodes, failed=False):
+        """Sum gradients over ranks and divide by the total number of episodes of the step.  `failed`: this rank has no
+        exact gradient to contribute; returns the number of ranks that said so (a host read only when distributed)."""
+        tail = self.store[-2:]
+        tail[0].fill_(float(n_local_episodes))  # fill kernels: no host->device copy, no host sync
+        tail[1].fill_(1.0 if failed else 0.0)
+        n_failed = 1 if failed else 0
         if dist.is_initialized():  # also with one rank (cheap, and it keeps the single-rank path identical)
             dist.all_reduce(self.store, op=dist.ReduceOp.SUM)
-        self.flat.div_(total)
-        return self.flat
+            if dist.get_world_size() > 1:
+                n_failed = int(tail[1].item())
+        self.flat.div_(tail[0])
+        return n_failed
+
+
+def sync_running_stats(model):
+    """Average the BatchNorm running statistics over the ranks (ONE all-reduce of ~2.6 k floats).  Ranks train on disjoint
+    episodes, so their running statistics drift apart while their weights stay identical; call this before an evaluation
+    sweep or a checkpoint so that every rank evaluates / saves the same model.  The reference is single-process
+    (models/mpti_learner.py:24 is a commented-out DataParallel): there is no precedent to follow, the mean is the
+    estimate that uses every rank's episodes."""
+    bufs = [b for n, b in model.named_buffers() if n.endswith("running_mean") or n.endswith("running_var")]
+    if not bufs or not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    flat = torch.cat([b.reshape(-1).float() for b in bufs])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(dist.get_world_size())
+    off = 0
+    with torch.no_grad():
+        for b in bufs:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+    for mod in model.modules():  # BatchNorm-folded weights are derived data
+        if hasattr(mod, "_folded") and mod._folded is not None:
+            mod._folded = (None, mod._folded[1])
+    return flat.numel()
 
 
 def all_reduce_histogram(hist):

@@ -2,8 +2,8 @@
 forward + backward of its own episodes into ONE flat fp32 gradient bucket, a single RCCL all-reduce
 (SUM) over xGMI follows and every rank applies the same Adam step.  The reference itself steps Adam
 after every single episode (mpti_train_noise.py:57,98); with world_size 1 and one episode per step
-this class does exactly that.  BatchNorm running statistics stay per rank (rank 0's are the ones
-checkpointed), as documented in DESIGN.md."""
+this class does exactly that.  BatchNorm running statistics are per rank during training (ranks see disjoint
+episodes) and are averaged over the ranks by DPTrainer.sync_running_stats() before evaluation / checkpoints."""
 import torch
 
 from . import dist as D
@@ -43,8 +43,9 @@ class DPTrainer:
         out of launch budget, whose 201-NN survivor buffer overflowed or whose one-launch FPS timed out.  The status
         words are read after the local episodes and BEFORE the all-reduce (one host wait per step, ~0.3 % of a
         32-episode step); a miss makes this rank redo its episodes of the step on the conservative schedule (full
-        budget, exact kernels) and raises if that fails too.  Ranks decide locally: a rank's contribution to the
-        all-reduce is always an exact gradient, so no agreement between ranks is needed."""
+        budget, exact kernels).  Ranks decide locally: a rank's contribution to the all-reduce is an exact gradient or
+        nothing -- if the conservative schedule fails too, the rank says so in the bucket's failure slot, takes part in
+        the collective like everybody else, and EVERY rank raises after it (no rank is left blocked in an all-reduce)."""
         self.model.train()
         self.redone = False
         if self.runner is not None:
@@ -59,52 +60,79 @@ class DPTrainer:
                 loss = self.runner.train_batch(b, [p.grad for p in self.bucket.params])[0].sum()
                 total = loss if total is None else total + loss
             self.last_status = self.runner.step_status()
+            failed = None
             if self.last_status[0] or self.last_status[1]:
                 eps = [b.episode(e) for b in batches for e in range(b.E)]
-                total = self._eager_pass(eps, logger, conservative=True)  # updates the running statistics itself
+                try:
+                    total = self._eager_pass(eps, logger, conservative=True)  # updates the running statistics itself
+                except RuntimeError as exc:
+                    failed = exc
                 self.redone = True
                 self.n_redone += 1
             else:
                 self.runner.apply_running_stats()
-            self.bucket.all_reduce_mean(n_local)
-            self.learner.optimizer.step()
-            self.learner.lr_scheduler.step()
+            self._reduce_and_step(n_local, failed)
             return total / max(n_local, 1)
-        if self.graphs is not None:
-            total = self.graphs.run(episodes, apply_bn=False)
-            bad, overflow, _, _ = self.graphs.step_status()
-            if bad or overflow:
-                total = self._eager_pass(episodes, logger, conservative=True)  # updates the running statistics itself
-                self.redone = True
-                self.n_redone += 1
+        failed = None
+        try:
+            if self.graphs is not None:
+                total = self.graphs.run(episodes, apply_bn=False)
+                bad, overflow, _, _ = self.graphs.step_status()
+                if bad or overflow:
+                    self.redone = True
+                    self.n_redone += 1
+                    total = self._eager_pass(episodes, logger, conservative=True)  # updates the running statistics itself
+                else:
+                    self.graphs.apply_running_stats(len(episodes))
+                    torch.sum(self.rows, 0, out=self.bucket.store)
             else:
-                self.graphs.apply_running_stats(len(episodes))
-                torch.sum(self.rows, 0, out=self.bucket.store)
-        else:
-            total = self._eager_pass(episodes, logger, conservative=False)
-        self.bucket.all_reduce_mean(len(episodes))
-        self.learner.optimizer.step()
-        self.learner.lr_scheduler.step()
+                total = self._eager_pass(episodes, logger, conservative=False)
+        except RuntimeError as exc:
+            failed, total = exc, torch.zeros((), device=self.bucket.store.device)
+        self._reduce_and_step(len(episodes), failed)
         return total / max(len(episodes), 1)
 
+    def _reduce_and_step(self, n_local, failed):
+        """The step's ONE collective (gradients + episode count + failure flag), then Adam -- or, if any rank could not
+        produce an exact gradient, the same error on every rank."""
+        n_failed = self.bucket.all_reduce_mean(n_local, failed=failed is not None)
+        if n_failed:
+            raise RuntimeError("training step abandoned on all ranks: %d rank(s) could not solve their episodes exactly%s" % (
+                n_failed, (" (this rank: %s)" % failed) if failed is not None else ""))
+        self.learner.optimizer.step()
+        self.learner.lr_scheduler.step()
+
+    def sync_running_stats(self):
+        """Average the BatchNorm running statistics over the ranks (dist.sync_running_stats): call before an evaluation
+        sweep or a checkpoint, so that every rank evaluates / saves the same model."""
+        return D.sync_running_stats(self.model)
+
     def _eager_pass(self, episodes, logger, conservative):
-        """Forward + backward of every episode into the bucket (parameter .grad tensors are views into it)."""
+        """Forward + backward of every episode into the bucket (parameter .grad tensors are views into it).  An attempt
+        on the adaptive schedule that misses (CG budget, 201-NN overflow, FPS time-out) is discarded -- its gradient AND
+        its BatchNorm statistics -- and the episode is redone on the conservative schedule."""
+        from . import train_ops as T
         self.bucket.zero_()
         total = None
         for data in episodes:
             (support_x, support_y, query_x, query_y, support_c, query_c, gt_support_y, gt_query_y, bg_pcd_x, bg_pcd_y,
              support_flag) = data
             for lp_iters in ((self.model.lp_max_iter,) if conservative else (None, self.model.lp_max_iter)):
-                keep = self.bucket.store.clone() if lp_iters is None else None
-                out = self.model(support_x, support_y, query_x, query_y, gt_support_y=gt_support_y,
-                                 gt_query_y=gt_query_y, train=True, logger=logger, support_flag=support_flag,
-                                 lp_iters=lp_iters)
-                loss = out[1] + 0.1 * out[2]  # mpti_learner.py:66
-                loss.backward()               # accumulates into the bucket views
+                keep = self.bucket.flat.clone() if lp_iters is None and total is not None else None
+                with T.deferred_running_stats(self.model) as rec:
+                    out = self.model(support_x, support_y, query_x, query_y, gt_support_y=gt_support_y,
+                                     gt_query_y=gt_query_y, train=True, logger=logger, support_flag=support_flag,
+                                     lp_iters=lp_iters)
+                    loss = out[1] + 0.1 * out[2]  # mpti_learner.py:66
+                    loss.backward()               # accumulates into the bucket views
                 if self.model.lp_converged(backward=True):
+                    rec.apply(1)
                     break
-                if keep is not None:          # drop the inexact gradient again, then the conservative schedule
-                    self.bucket.store.copy_(keep)
+                if lp_iters is None:              # drop the inexact gradient again, then the conservative schedule
+                    if keep is not None:
+                        self.bucket.flat.copy_(keep)
+                    else:
+                        self.bucket.zero_()       # (first episode of the step: nothing to keep)
             else:
                 raise RuntimeError("label propagation did not converge in %d CG iterations" % self.model.lp_max_iter)
             total = loss.detach() if total is None else total + loss.detach()

@@ -97,21 +97,26 @@ class MPTILearner_V3(object):
         [support_x, support_y, query_x, query_y, support_c, query_c, gt_support_y, gt_query_y, bg_pcd_x, bg_pcd_y,
          support_flag] = data
         self.model.train()
+        from . import train_ops as T
         for lp_iters in (None, self.model.lp_max_iter):
-            (query_logits, lp_loss, contrastive_loss, query_acc_LP, query_acc_original, clean_ratio_LP_avg,
-             original_clean_ratio) = self.model(support_x, support_y, query_x, query_y, gt_support_y=gt_support_y,
-                                                gt_query_y=gt_query_y, train=True, logger=logger, bg_pcd_x=bg_pcd_x,
-                                                bg_pcd_y=bg_pcd_y, support_c=support_c, support_flag=support_flag,
-                                                lp_iters=lp_iters)
-            loss = lp_loss + 0.1 * contrastive_loss
-            # (once a gradient bucket exists the parameters' .grad tensors are views into it: zero them in place)
-            self.optimizer.zero_grad(set_to_none=self._trainer is None)
-            loss.backward()
+            # an attempt's BatchNorm statistics are recorded and only the attempt that is kept updates the running
+            # statistics (a discarded attempt would otherwise count the episode twice)
+            with T.deferred_running_stats(self.model) as rec:
+                (query_logits, lp_loss, contrastive_loss, query_acc_LP, query_acc_original, clean_ratio_LP_avg,
+                 original_clean_ratio) = self.model(support_x, support_y, query_x, query_y, gt_support_y=gt_support_y,
+                                                    gt_query_y=gt_query_y, train=True, logger=logger, bg_pcd_x=bg_pcd_x,
+                                                    bg_pcd_y=bg_pcd_y, support_c=support_c, support_flag=support_flag,
+                                                    lp_iters=lp_iters)
+                loss = lp_loss + 0.1 * contrastive_loss
+                # (once a gradient bucket exists the parameters' .grad tensors are views into it: zero them in place)
+                self.optimizer.zero_grad(set_to_none=self._trainer is None)
+                loss.backward()
             # the CG solves (forward and adjoint) run on a launch budget and the 201-NN / FPS fast paths can report
             # overflow / time-out: never step Adam on an inexact gradient.  One host read per step, where the
             # reference synchronises anyway (`.item()` below, mpti_learner.py:75); a miss is redone once on the
             # conservative schedule (full budget, exact kernels).
             if self.model.lp_converged(backward=True):
+                rec.apply(1)
                 break
         else:
             raise RuntimeError("label propagation did not converge in %d CG iterations (forward or adjoint solve)"

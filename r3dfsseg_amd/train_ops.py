@@ -58,6 +58,29 @@ class BNRecorder:
 bn_recorder = None  # set by the owner of a deferred sequence (episode_graph.EpisodeGraphs, batched.EpisodeBatchRunner)
 
 
+class deferred_running_stats:
+    """``with deferred_running_stats(model) as rec: <training forward of ONE episode>`` records the episode's BatchNorm batch
+    statistics instead of updating the running statistics; ``rec.apply(1)`` afterwards folds them in.  The eager
+    one-episode schedule runs an attempt that may be discarded (CG launch budget, 201-NN overflow, FPS time-out) and
+    redone on the conservative schedule: only the attempt that is kept may count in the running statistics."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def __enter__(self):
+        global bn_recorder
+        rec = self.model.__dict__.get("_bn_rec1")
+        if rec is None:
+            rec = self.model.__dict__["_bn_rec1"] = BNRecorder(1, next(self.model.parameters()).device)
+        self.saved, bn_recorder = bn_recorder, rec
+        return rec
+
+    def __exit__(self, *exc):
+        global bn_recorder
+        bn_recorder = self.saved
+        return False
+
+
 def _f(n, dev):
     return torch.empty(n, device=dev, dtype=torch.float32)
 

@@ -28,9 +28,19 @@ def _worker(rank, world, port, out):
     for e in episodes:  # gradient of a per-episode loss, accumulated into the flat bucket
         x = torch.full((2, 7), float(e + 1))
         lin(x).sum().backward()
-    flat = bucket.all_reduce_mean(len(episodes)).clone()
+    n_failed = bucket.all_reduce_mean(len(episodes))
+    flat = bucket.flat.clone()
     hist = D.all_reduce_histogram(torch.tensor([[rank + 1, 2, 3]], dtype=torch.int64))
-    out[rank] = (episodes, flat, hist, [p.grad.data_ptr() for p in lin.parameters()], bucket.flat.data_ptr())
+    # the failure flag travels with the gradients: one rank without an exact gradient is seen by every rank
+    n_failed2 = bucket.all_reduce_mean(len(episodes), failed=(rank == 1))
+    # BatchNorm running statistics: per rank during training, averaged over the ranks on request
+    bn = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.BatchNorm1d(4))
+    with torch.no_grad():
+        bn[1].running_mean.fill_(float(rank))
+        bn[1].running_var.fill_(1.0 + 2.0 * rank)
+    n_sync = D.sync_running_stats(bn)
+    out[rank] = (episodes, flat, hist, [p.grad.data_ptr() for p in lin.parameters()], bucket.flat.data_ptr(),
+                 (n_failed, n_failed2), (n_sync, bn[1].running_mean.clone(), bn[1].running_var.clone()))
     dist.destroy_process_group()
 
 
@@ -51,3 +61,7 @@ def test_two_rank_flat_bucket_allreduce():
     assert torch.allclose(out[0][1], want, rtol=1e-6, atol=1e-6)
     assert out[0][2].tolist() == [[3, 4, 6]]
     assert out[0][3][0] == out[0][4]  # gradients are views into the one bucket
+    assert out[0][5] == (0, 1) and out[1][5] == (0, 1)
+    for r in (0, 1):
+        n_sync, rm, rv = out[r][6]
+        assert n_sync == 8 and torch.equal(rm, torch.full((4,), 0.5)) and torch.equal(rv, torch.full((4,), 2.0))

@@ -105,3 +105,75 @@ def test_attention_results_do_not_depend_on_other_streams():
         for b in bs:
             for name in ("out", "lse", "dqkv"):
                 assert torch.equal(b[name], ref[name]), (rep, name)
+
+
+def test_training_kernels_are_not_disturbed_by_attention_on_another_stream():
+    """The wider net around the packed-fp32 hazard (build rule): the kernels of a training episode's
+    encoder pass and contrastive loss -- both kNN forms, EdgeConv training forward / backward, the point-wise and
+    weight-gradient GEMMs, the BatchNorm reductions, the contrast kernels -- run on one stream while the attention kernels
+    (bf16 x 3, then fp32) keep another stream busy: every feature and every gradient must equal the run alone, bit for
+    bit.  (The batched trainer runs on ONE stream, so nothing executes beside the attention there; the multi-slot graph
+    path of episode_graph.py does.)"""
+    from types import SimpleNamespace
+    from r3dfsseg_amd import _lib, contrast, synthetic as S, train_ops as T
+    from r3dfsseg_amd.mpti import MPTI_SelfAtten
+    from r3dfsseg_amd.ops import SegLayout, _p
+    lib = _lib.load()
+    cfg = S.workload_cfg("S")
+    m = MPTI_SelfAtten(SimpleNamespace(**cfg))
+    m.load_state_dict(S.make_state_dict(cfg, 123))
+    m.cuda().train()
+    m.att_learner.dropout.p = 0.1
+    data, _ = S.make_episode(cfg, seed=3, noise_ratio=0.2, train=True)
+    ep = [t.cuda() for t in data]
+    Sn, N = cfg["n_way"] * cfg["k_shot"], cfg["pc_npts"]
+    x_all = torch.cat((ep[0].reshape(Sn, -1, N), ep[2]), 0).contiguous()
+    B = x_all.shape[0]
+    R = torch.randn(B * N, 192, device="cuda")
+    qkv = torch.randn(B * N, 192, device="cuda")
+    dO = torch.randn(B * N, 64, device="cuda")
+    aws = torch.empty(lib.r3d_attention_ws_words(B, N), device="cuda")
+    out = torch.empty(B * N, 64, device="cuda")
+    lse = torch.empty(B * N, device="cuda")
+    dqkv = torch.empty(B * N, 192, device="cuda")
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+
+    def victim():
+        with torch.cuda.stream(sa), torch.no_grad():
+            c = SimpleNamespace(param_list=T.encoder_params(m), seg=SegLayout(1, Sn, B - Sn, N))
+            feat = T.EncoderTrainFn.forward(c, x_all, m, 11)
+            cc = SimpleNamespace()
+            closs = contrast.ContrastFn.forward(cc, feat[:Sn * N], m.proj.weight, m.proj.bias, m, ep[1], ep[10])
+            dc = contrast.ContrastFn.backward(cc, torch.ones((), device="cuda"))[:3]
+            grads = T.EncoderTrainFn.backward(c, R)[3:]
+            res = [feat.clone(), closs.clone()] + [g.clone() for g in dc] + [g.clone() for g in grads if g is not None]
+        return res
+
+    def attention(k):
+        with torch.cuda.stream(sb):
+            for _ in range(k):
+                _lib.check(lib.r3d_attention_fwd_train(_p(qkv), 192, B, N, _p(out), 64, _p(lse), 0.1, 7, None, _p(aws),
+                                                       sb.cuda_stream))
+                _lib.check(lib.r3d_attention_bwd_ws(_p(qkv), 192, B, N, _p(out), 64, _p(dO), 64, _p(lse), 0.1, 7, None, 0.125,
+                                                    _p(dqkv), 192, _p(aws), 1, sb.cuda_stream))
+
+    T.update_running_stats = False
+    before = lib.r3d_get_matrix_arith()
+    try:
+        for mode in (1, 0):
+            _lib.check(lib.r3d_set_matrix_arith(mode))
+            ref = victim()
+            torch.cuda.synchronize()
+            again = victim()
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(ref, again))  # (alone: reproducible)
+            for rep in range(3):
+                attention(60)
+                got = victim()
+                torch.cuda.synchronize()
+                bad = [i for i, (a, b) in enumerate(zip(ref, got)) if not torch.equal(a, b)]
+                assert not bad, (mode, rep, bad)
+    finally:
+        T.update_running_stats = True
+        _lib.check(lib.r3d_set_matrix_arith(before))

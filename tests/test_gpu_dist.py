@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _setup(slots):
+def _setup(slots, batch=0):
     from r3dfsseg_amd import synthetic as S
     from r3dfsseg_amd.dp_train import DPTrainer
     from r3dfsseg_amd.mpti import MPTI_SelfAtten
@@ -41,7 +41,7 @@ def _setup(slots):
         [{'params': model.encoder.parameters(), 'lr': 0.0001}, {'params': model.base_learner.parameters()},
          {'params': model.att_learner.parameters()}, {'params': model.proj.parameters()}], lr=1e-3)
     learner.lr_scheduler = torch.optim.lr_scheduler.StepLR(learner.optimizer, step_size=5000, gamma=0.5)
-    trainer = DPTrainer(learner, n_slots=slots, example=eps[0])
+    trainer = DPTrainer(learner, n_slots=slots, example=eps[0], batch_size=batch)
     return cfg, model, eps, trainer
 
 
@@ -57,26 +57,43 @@ def _hist(model, eps, ids):
     return acc
 
 
-def _worker(rank, world, port, slots, out):
+def _worker(rank, world, port, slots, out, batch=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0")
     from r3dfsseg_amd import dist as D
     assert D.init("gloo") == world
     torch.cuda.set_device(0)
-    cfg, model, eps, trainer = _setup(slots)
+    cfg, model, eps, trainer = _setup(slots, batch)
     ids = D.shard_episodes(N_EPISODES, rank, world)
     acc = _hist(model, eps, ids)      # before the step: both ranks hold the same weights
     acc.reduce()
     loss = trainer.step([eps[e] for e in ids])
     torch.cuda.synchronize()
+    # ranks saw disjoint episodes: their BatchNorm running statistics differ until they are averaged
+    own = model.encoder.conv.layer[1].running_mean.clone()
+    n_synced = trainer.sync_running_stats()
     out[rank] = dict(ids=ids, grad=trainer.bucket.flat.cpu(), loss=float(loss), redone=trainer.redone,
                      params=torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu(),
-                     hist=acc.hist.cpu())
+                     hist=acc.hist.cpu(), own_stat=own.cpu(), n_synced=n_synced,
+                     stats={k: v.cpu() for k, v in model.named_buffers() if "running" in k})
+    # a rank that cannot solve its episodes: every rank raises after the collective, nobody hangs in it
+    if batch:
+        if rank == 0:  # the conservative schedule cannot converge in one CG iteration; rank 1 stays healthy
+            model.lp_max_iter = 1
+            model._lp_budget = 1
+            model._lp_probe = None
+        try:
+            trainer.step([eps[e] for e in ids])
+            out[str(rank) + "_raised"] = False
+        except RuntimeError as exc:
+            out[str(rank) + "_raised"] = "abandoned on all ranks" in str(exc)
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("slots", [0, 2])
-def test_two_ranks_of_dptrainer_equal_one_rank(slots):
+
+@pytest.mark.parametrize("slots,batch", [(0, 0), (2, 0), (0, 2)])
+def test_two_ranks_of_dptrainer_equal_one_rank(slots, batch):
+    # slots / batch: the ranks run eager launches, two captured hipGraph slots, or the episode-batched launch sequence
     # one process, all episodes, eager launches: the reference value
     cfg, model, eps, trainer = _setup(0)
     want_hist = _hist(model, eps, range(N_EPISODES)).hist.cpu()
@@ -89,7 +106,7 @@ def test_two_ranks_of_dptrainer_equal_one_rank(slots):
     world, port = 2, _free_port()
     with mp.Manager() as mgr:
         out = mgr.dict()
-        mp.spawn(_worker, args=(world, port, slots, out), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, slots, out, batch), nprocs=world, join=True)
         out = dict(out)
     assert sorted(out[0]["ids"] + out[1]["ids"]) == list(range(N_EPISODES))
     assert not out[0]["redone"] and not out[1]["redone"]
@@ -104,3 +121,43 @@ def test_two_ranks_of_dptrainer_equal_one_rank(slots):
     assert perr <= 2e-3, perr  # one Adam step of lr 1e-3: sign-level agreement of the update
     assert abs(0.5 * (out[0]["loss"] + out[1]["loss"]) - float(loss)) <= 1e-4 * max(1.0, abs(float(loss)))
     assert torch.equal(out[0]["hist"], want_hist) and torch.equal(out[1]["hist"], want_hist)
+    # running statistics: different per rank after the step, identical (their mean) after sync_running_stats()
+    assert not torch.equal(out[0]["own_stat"], out[1]["own_stat"]) and out[0]["n_synced"] > 2000
+    for k in out[0]["stats"]:
+        assert torch.equal(out[0]["stats"][k], out[1]["stats"][k]), k
+    mean = 0.5 * (out[0]["own_stat"] + out[1]["own_stat"])
+    np.testing.assert_allclose(out[0]["stats"]["encoder.conv.layer.1.running_mean"].numpy(), mean.numpy(), rtol=1e-6, atol=1e-7)
+    if batch:
+        assert out["0_raised"] is True and out["1_raised"] is True
+
+
+def _rccl_worker(rank, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    cfg, model, eps, trainer = _setup(0, batch=2)
+    loss = trainer.step(eps)
+    torch.cuda.synchronize()
+    out["loss"] = float(loss)
+    out["grad"] = trainer.bucket.flat.cpu()
+    out["backend"] = torch.distributed.get_backend()
+    torch.distributed.destroy_process_group()
+
+
+def test_rccl_all_reduce_executes_with_one_rank():
+    """The nccl (= RCCL) backend of the training step: one rank, so the flat-bucket all-reduce, the division by the
+    episode count and the failure flag run through RCCL at least once on this box (the 8-GPU node is the driver's)."""
+    cfg, model, eps, trainer = _setup(0, batch=2)
+    want_loss = float(trainer.step(eps))
+    torch.cuda.synchronize()
+    want = trainer.bucket.flat.cpu()
+    del trainer, model
+    torch.cuda.empty_cache()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_rccl_worker, args=(_free_port(), out), nprocs=1, join=True)
+        out = dict(out)
+    assert out["backend"] == "nccl"
+    assert torch.equal(out["grad"], want) and abs(out["loss"] - want_loss) < 1e-6
+

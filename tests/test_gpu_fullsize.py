@@ -62,16 +62,21 @@ def test_full_size_S_against_oracle():
     m = _model(cfg)
     data, _ = S.make_episode(cfg, seed=78, noise_ratio=0.4)
     sx, sy, qx, qy = data[:4]
+    m._trace = {}
     with torch.no_grad():
-        logits, loss = m(sx.cuda(), sy.cuda(), qx.cuda(), qy.cuda())
+        logits, loss = m(sx.cuda(), sy.cuda(), qx.cuda(), qy.cuda(), lp_iters=m.lp_max_iter)
+    assert m.lp_converged()
+    from custody import head_custody
+    head_custody(m, cfg, sd, data, logits, loss)   # every logit within 1e-4 given the (bit-exact) index decisions
+    m._trace = None
+    # end to end on the oracle's own features and decisions: near-ties of a neighbour choice in layers 2 / 3 move a
+    # fraction of the points (quantified by tests/test_gpu_parity_full.py)
     want_logits, want_loss = O.mpti_forward(sd, cfg, sx, sy, qx, qy)
     agree = (logits.cpu().argmax(1) == want_logits.argmax(1)).float().mean().item()
     assert agree >= 0.99, agree
     assert abs(loss.item() - want_loss.item()) < 5e-3
-    # logits are O(1..3): 1e-4 relative to max(1, |value|).  Measured: median 1.4e-5, 99 % below 5e-5 relative; the
-    # tail (max 2e-3) sits behind fp32 near-ties of a neighbour choice in layers 2 / 3
     d = (logits.cpu() - want_logits).abs() / want_logits.abs().clamp(min=1.0)
-    assert (d < 1e-4).float().mean().item() >= 0.99 and d.max().item() < 1e-2, (d.max().item(),)
+    assert (d < 1e-4).float().mean().item() >= 0.99
 
 
 def test_full_size_graph_slots_match_eager():
