@@ -131,7 +131,7 @@ def committed_profile(workload, mode):
     --kernel-trace summary of THIS workload and mode
     (profiles/rNN_*_rocprofv3_kernel_stats_<mode>_eager_<workload>.txt, written by tools/prof_summary.py), or (None, None)."""
     import glob
-    names = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_kernel_stats_%s_eager_%s.txt" % (mode, workload))))
+    names = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_kernel_stats_%s_batched_%s.txt" % (mode, workload))))
     if not names:
         return None, None
     rows = {}

@@ -35,13 +35,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void r
     const float* __restrict__ qkv, long ld, int N, float* __restrict__ out, long ldo,
     float* __restrict__ lse_out, float p_drop, unsigned seed, const unsigned* __restrict__ seed_dev, int seed_group,
     int tiles_per_split, float* __restrict__ part /* split > 1: [split][M][AT_PROW] = unnormalised o | m | l */) {
+  // (plain block order.  An XCD-aware order -- common.h: r3d_xcd_swizzle, the workgroups sharing an L2 on the same clouds --
+  // was measured and lost 3-8 % on these kernels: an XCD then holds 4 clouds' K / V pieces at a time, 6 MB against its 4 MB
+  // L2, while in plain order the operands come out of the Infinity Cache: profiles/r03_experiments.md)
+  const int bid_x = blockIdx.x, bid_y = blockIdx.y, bid_z = blockIdx.z;
   if (seed_dev) seed += *seed_dev;  // per-replay seed of a captured hipGraph lives in device memory
   const unsigned thresh = p_drop > 0.f ? (unsigned)(p_drop * 4294967296.0) : 0u;
   const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   __shared__ float Ks[2][32 * AT_LD];
   __shared__ float Vs[2][32 * AT_LD];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int b = blockIdx.y;
+  const int b = bid_y;
   const long base = (long)b * N;
   unsigned hbase = (unsigned)base;  // row id the dropout hash sees
   if (seed_group > 0) {             // batch of episodes: every group of seed_group clouds is one episode with its own seed
@@ -49,7 +53,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void r
     seed += 2u * (unsigned)ep_;
     hbase = (unsigned)((b - ep_ * seed_group) * N);
   }
-  const int q_row = blockIdx.x * 128 + 32 * w + (lane & 31);
+  const int q_row = bid_x * 128 + 32 * w + (lane & 31);
   const bool q_ok = q_row < N;
   // Q^T fragments: B[k = ch][j = query]
   float bq[32];
@@ -89,8 +93,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void r
     }
   };
 
-  // key tiles [t_beg, t_end) of this workgroup (blockIdx.z = split of the key axis: more workgroups for small grids)
-  const int t_beg = blockIdx.z * tiles_per_split;
+  // key tiles [t_beg, t_end) of this workgroup (bid_z = split of the key axis: more workgroups for small grids)
+  const int t_beg = bid_z * tiles_per_split;
   const int ntiles = min((N + 31) / 32, t_beg + tiles_per_split);
   load_tile(32 * t_beg);
   store_tile(t_beg & 1);
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void r
   }
   if (!q_ok) return;
   if (part) {  // partial (o, m, l) of this key range; r3d_attention_combine_kernel merges the splits
-    float* prow = part + ((long)blockIdx.z * gridDim.y * N + base + q_row) * AT_PROW;
+    float* prow = part + ((long)bid_z * gridDim.y * N + base + q_row) * AT_PROW;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {  // registers 4g .. 4g+3 are 4 consecutive channels: 16-byte stores
       const int ch = 8 * g + 4 * (lane >> 5);
@@ -335,13 +339,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
     const unsigned short* __restrict__ Qp, const unsigned short* __restrict__ Kp, const unsigned short* __restrict__ Vp,
     int N, float* __restrict__ out, long ldo, float* __restrict__ lse_out, float p_drop, unsigned seed,
     const unsigned* __restrict__ seed_dev, int seed_group, int tiles_per_split, float* __restrict__ part) {
+  // (plain block order.  An XCD-aware order -- common.h: r3d_xcd_swizzle, the workgroups sharing an L2 on the same clouds --
+  // was measured and lost 3-8 % on these kernels: an XCD then holds 4 clouds' K / V pieces at a time, 6 MB against its 4 MB
+  // L2, while in plain order the operands come out of the Infinity Cache: profiles/r03_experiments.md)
+  const int bid_x = blockIdx.x, bid_y = blockIdx.y, bid_z = blockIdx.z;
   if (seed_dev) seed += *seed_dev;
   const unsigned thresh = DROP ? (unsigned)(p_drop * 4294967296.0) : 0u;
   const float keep_scale = DROP ? 1.f / (1.f - p_drop) : 1.f;
   __shared__ __attribute__((aligned(16))) unsigned short Ks[2][AG_TILE];
   __shared__ __attribute__((aligned(16))) unsigned short Vs[2][AG_TILE];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
-  const int b = blockIdx.y;
+  const int b = bid_y;
   const long base = (long)b * N;
   unsigned hbase = (unsigned)base;  // row id the dropout hash sees
   if (seed_group > 0) {             // batch of episodes: every group of seed_group clouds is one episode with its own seed
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
     seed += 2u * (unsigned)ep_;
     hbase = (unsigned)((b - ep_ * seed_group) * N);
   }
-  const int q_row = blockIdx.x * 128 + 32 * w + (lane & 31);
+  const int q_row = bid_x * 128 + 32 * w + (lane & 31);
   const bool q_ok = q_row < N;
   r3d_bx3 bq[4];
   ab_load_row_frags(Qp + (base + min(q_row, N - 1)) * AB_ROW, half, q_ok, bq);
@@ -358,7 +366,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; s_a[r] = 0.f; }
   const float LOG2E = 1.4426950408889634f;
   float m_run = -INFINITY, l_run = 0.f;  // m_run in the log2 domain: max of s * log2(e)
-  const int t_beg = blockIdx.z * tiles_per_split;
+  const int t_beg = bid_z * tiles_per_split;
   const int ntiles = min((N + 31) / 32, t_beg + tiles_per_split);
   const ag_offs offs = ag_make_offs(lane);
   auto s_tile = [&](int t, f32x16& s) {  // S^T = K Q^T of tile t
@@ -450,7 +458,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   else step(t, s_a, s_b, F_{}, F_{}, F_{});
 
 #ifdef ATT_STAMPS
-  if (tid == 0 && blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0) {
+  if (tid == 0 && bid_x == 1 && bid_y == 1 && bid_z == 0) {
     for (int i = 0; i < 6; ++i) g_att_dbg[i] = dbg_acc[i];
     g_att_dbg[6] = __builtin_amdgcn_s_memtime() - dbg_t0;
     g_att_dbg[7] = __builtin_amdgcn_s_memrealtime() - dbg_r0;
@@ -460,7 +468,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   if (!q_ok) return;
   const float LN2 = 0.6931471805599453f;
   if (part) {
-    float* prow = part + ((long)blockIdx.z * gridDim.y * N + base + q_row) * AT_PROW;
+    float* prow = part + ((long)bid_z * gridDim.y * N + base + q_row) * AT_PROW;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {  // registers 4g .. 4g+3 are 4 consecutive channels: 16-byte stores
       const int ch = 8 * g + 4 * (lane >> 5);
@@ -624,6 +632,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
     const float* __restrict__ qkv, long ld, int N, const float* __restrict__ dO, long lddo, const float* __restrict__ lse,
     const float* __restrict__ Dv, float* __restrict__ dqkv, long ldd, float p_drop, unsigned seed,
     const unsigned* __restrict__ seed_dev, int seed_group, int tiles_per_split, float* __restrict__ part /* [split][M][128] or NULL */) {
+  // (plain block order.  An XCD-aware order -- common.h: r3d_xcd_swizzle, the workgroups sharing an L2 on the same clouds --
+  // was measured and lost 3-8 % on these kernels: an XCD then holds 4 clouds' K / V pieces at a time, 6 MB against its 4 MB
+  // L2, while in plain order the operands come out of the Infinity Cache: profiles/r03_experiments.md)
+  const int bid_x = blockIdx.x, bid_y = blockIdx.y, bid_z = blockIdx.z;
   if (seed_dev) seed += *seed_dev;
   __shared__ float Qs[2][32 * AT_LD];
   __shared__ float Gs[2][32 * AT_LD];  // dO tile
@@ -632,7 +644,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, j = lane & 31;
-  const int b = blockIdx.y;
+  const int b = bid_y;
   const long base = (long)b * N;
   unsigned hbase = (unsigned)base;  // row id the dropout hash sees
   if (seed_group > 0) {             // batch of episodes: every group of seed_group clouds is one episode with its own seed
@@ -640,7 +652,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
     seed += 2u * (unsigned)ep_;
     hbase = (unsigned)((b - ep_ * seed_group) * N);
   }
-  const int key = blockIdx.x * 128 + 32 * w + j;  // this lane's key column
+  const int key = bid_x * 128 + 32 * w + j;  // this lane's key column
   const bool key_ok = key < N;
   float bk[32], bv[32];  // B[k = ch][j = key] fragments of K and V
 #pragma unroll
@@ -682,7 +694,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
     }
     if (tid < 32) { Ls[buf][tid] = lreg; Ds[buf][tid] = dreg; }
   };
-  const int t_beg = blockIdx.z * tiles_per_split;
+  const int t_beg = bid_z * tiles_per_split;
   const int ntiles = min((N + 31) / 32, t_beg + tiles_per_split);
   load_tile(32 * t_beg);
   store_tile(t_beg & 1);
@@ -731,7 +743,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
     __syncthreads();
   }
   if (!key_ok) return;
-  float* drow = part ? part + ((long)blockIdx.z * gridDim.y * N + base + key) * 128 - 64 : dqkv + (base + key) * ldd;
+  float* drow = part ? part + ((long)bid_z * gridDim.y * N + base + key) * 128 - 64 : dqkv + (base + key) * ldd;
   if (part) {  // 16-byte rows: registers 4g .. 4g+3 are 4 consecutive channels
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -770,6 +782,10 @@ __global__ __launch_bounds__(256) void r3d_attention_bwd_q_kernel(
     const float* __restrict__ Dv, float* __restrict__ dqkv, long ldd, float p_drop, unsigned seed,
     const unsigned* __restrict__ seed_dev, int seed_group, float q_scale, int tiles_per_split,
     float* __restrict__ part /* [split][M][64] unscaled, or NULL */) {
+  // (plain block order.  An XCD-aware order -- common.h: r3d_xcd_swizzle, the workgroups sharing an L2 on the same clouds --
+  // was measured and lost 3-8 % on these kernels: an XCD then holds 4 clouds' K / V pieces at a time, 6 MB against its 4 MB
+  // L2, while in plain order the operands come out of the Infinity Cache: profiles/r03_experiments.md)
+  const int bid_x = blockIdx.x, bid_y = blockIdx.y, bid_z = blockIdx.z;
   if (seed_dev) seed += *seed_dev;
   __shared__ float Ks[2][32 * AT_LD];
   __shared__ float Vs[2][32 * AT_LD];
@@ -777,7 +793,7 @@ __global__ __launch_bounds__(256) void r3d_attention_bwd_q_kernel(
   const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, j = lane & 31;
-  const int b = blockIdx.y;
+  const int b = bid_y;
   const long base = (long)b * N;
   unsigned hbase = (unsigned)base;  // row id the dropout hash sees
   if (seed_group > 0) {             // batch of episodes: every group of seed_group clouds is one episode with its own seed
@@ -785,7 +801,7 @@ __global__ __launch_bounds__(256) void r3d_attention_bwd_q_kernel(
     seed += 2u * (unsigned)ep_;
     hbase = (unsigned)((b - ep_ * seed_group) * N);
   }
-  const int q_row = blockIdx.x * 128 + 32 * w + j;
+  const int q_row = bid_x * 128 + 32 * w + j;
   const bool q_ok = q_row < N;
   float bq[32], bg[32];  // B[k = ch][j = query] fragments of Q' and dO
 #pragma unroll
@@ -822,7 +838,7 @@ __global__ __launch_bounds__(256) void r3d_attention_bwd_q_kernel(
       vd[0] = vreg[i].x; vd[1] = vreg[i].y; vd[2] = vreg[i].z; vd[3] = vreg[i].w;
     }
   };
-  const int t_beg = blockIdx.z * tiles_per_split;
+  const int t_beg = bid_z * tiles_per_split;
   const int ntiles = min((N + 31) / 32, t_beg + tiles_per_split);
   load_tile(32 * t_beg);
   store_tile(t_beg & 1);
@@ -865,7 +881,7 @@ __global__ __launch_bounds__(256) void r3d_attention_bwd_q_kernel(
     __syncthreads();
   }
   if (!q_ok) return;
-  float* drow = part ? part + ((long)blockIdx.z * gridDim.y * N + base + q_row) * 64 : dqkv + (base + q_row) * ldd;
+  float* drow = part ? part + ((long)bid_z * gridDim.y * N + base + q_row) * 64 : dqkv + (base + q_row) * ldd;
   const float osc = part ? 1.f : q_scale;  // partials stay unscaled; r3d_attention_sum_kernel applies q_scale
   if (part) {
 #pragma unroll
@@ -896,6 +912,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
     const unsigned short* __restrict__ Gp /* dO */, int N, const float* __restrict__ lse, const float* __restrict__ Dv,
     float* __restrict__ dqkv, long ldd, float p_drop, unsigned seed, const unsigned* __restrict__ seed_dev, int seed_group,
     int tiles_per_split, float* __restrict__ part) {
+  // (plain block order.  An XCD-aware order -- common.h: r3d_xcd_swizzle, the workgroups sharing an L2 on the same clouds --
+  // was measured and lost 3-8 % on these kernels: an XCD then holds 4 clouds' K / V pieces at a time, 6 MB against its 4 MB
+  // L2, while in plain order the operands come out of the Infinity Cache: profiles/r03_experiments.md)
+  const int bid_x = blockIdx.x, bid_y = blockIdx.y, bid_z = blockIdx.z;
   if (seed_dev) seed += *seed_dev;
   __shared__ __attribute__((aligned(16))) unsigned short Qs[2][AG_TILE];
   __shared__ __attribute__((aligned(16))) unsigned short Gs[2][AG_TILE];
@@ -905,7 +925,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   const float LOG2E = 1.4426950408889634f;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, j = lane & 31;
-  const int b = blockIdx.y;
+  const int b = bid_y;
   const long base = (long)b * N;
   unsigned hbase = (unsigned)base;  // row id the dropout hash sees
   if (seed_group > 0) {             // batch of episodes: every group of seed_group clouds is one episode with its own seed
@@ -913,7 +933,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
     seed += 2u * (unsigned)ep_;
     hbase = (unsigned)((b - ep_ * seed_group) * N);
   }
-  const int key = blockIdx.x * 128 + 32 * w + j;  // this lane's key column
+  const int key = bid_x * 128 + 32 * w + j;  // this lane's key column
   const bool key_ok = key < N;
   r3d_bx3 bk[4], bv[4];  // B[k = ch][j = key] fragments of K and V
   ab_load_row_frags(Kp + (base + min(key, N - 1)) * AB_ROW, h, key_ok, bk);
@@ -923,7 +943,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
   const ag_offs offs = ag_make_offs(lane);
   const unsigned doff = ag_dma_off(w, lane);
-  const int t_beg = blockIdx.z * tiles_per_split;
+  const int t_beg = bid_z * tiles_per_split;
   const int ntiles = min((N + 31) / 32, t_beg + tiles_per_split);
   float lreg = 0.f, dreg = 0.f;
   auto load_rows = [&](int q0) {
@@ -982,7 +1002,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
     __syncthreads();
   }
   if (!key_ok) return;
-  float* drow = part ? part + ((long)blockIdx.z * gridDim.y * N + base + key) * 128 - 64 : dqkv + (base + key) * ldd;
+  float* drow = part ? part + ((long)bid_z * gridDim.y * N + base + key) * 128 - 64 : dqkv + (base + key) * ldd;
   if (part) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -1010,6 +1030,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
     const unsigned short* __restrict__ Gp /* dO */, int N, const float* __restrict__ lse, const float* __restrict__ Dv,
     float* __restrict__ dqkv, long ldd, float p_drop, unsigned seed, const unsigned* __restrict__ seed_dev, int seed_group, float q_scale,
     int tiles_per_split, float* __restrict__ part) {
+  // (plain block order.  An XCD-aware order -- common.h: r3d_xcd_swizzle, the workgroups sharing an L2 on the same clouds --
+  // was measured and lost 3-8 % on these kernels: an XCD then holds 4 clouds' K / V pieces at a time, 6 MB against its 4 MB
+  // L2, while in plain order the operands come out of the Infinity Cache: profiles/r03_experiments.md)
+  const int bid_x = blockIdx.x, bid_y = blockIdx.y, bid_z = blockIdx.z;
   if (seed_dev) seed += *seed_dev;
   __shared__ __attribute__((aligned(16))) unsigned short Ks[2][AG_TILE];
   __shared__ __attribute__((aligned(16))) unsigned short Vs[2][AG_TILE];
@@ -1018,7 +1042,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   const float LOG2E = 1.4426950408889634f;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, j = lane & 31;
-  const int b = blockIdx.y;
+  const int b = bid_y;
   const long base = (long)b * N;
   unsigned hbase = (unsigned)base;  // row id the dropout hash sees
   if (seed_group > 0) {             // batch of episodes: every group of seed_group clouds is one episode with its own seed
@@ -1026,7 +1050,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
     seed += 2u * (unsigned)ep_;
     hbase = (unsigned)((b - ep_ * seed_group) * N);
   }
-  const int q_row = blockIdx.x * 128 + 32 * w + j;
+  const int q_row = bid_x * 128 + 32 * w + j;
   const bool q_ok = q_row < N;
   r3d_bx3 bq[4], bg[4];  // B[k = ch][j = query] fragments of Q' and dO
   ab_load_row_frags(Qp + (base + min(q_row, N - 1)) * AB_ROW, h, q_ok, bq);
@@ -1038,7 +1062,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
   const ag_offs offs = ag_make_offs(lane);
   const unsigned doff = ag_dma_off(w, lane);
-  const int t_beg = blockIdx.z * tiles_per_split;
+  const int t_beg = bid_z * tiles_per_split;
   const int ntiles = min((N + 31) / 32, t_beg + tiles_per_split);
   ag_dma_tile(Kp, base, 32 * t_beg, N, Ks[t_beg & 1], w, lane, doff);
   ag_dma_tile(Vp, base, 32 * t_beg, N, Vs[t_beg & 1], w, lane, doff);
@@ -1080,7 +1104,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
     __syncthreads();
   }
   if (!q_ok) return;
-  float* drow = part ? part + ((long)blockIdx.z * gridDim.y * N + base + q_row) * 64 : dqkv + (base + q_row) * ldd;
+  float* drow = part ? part + ((long)bid_z * gridDim.y * N + base + q_row) * 64 : dqkv + (base + q_row) * ldd;
   if (part) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {

@@ -133,6 +133,16 @@ static __device__ __forceinline__ f32x16 r3d_bx3_mma(const r3d_bx3& a, const r3d
 
 static inline int r3d_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// XCD-aware work order (cdna_hip_programming.md 5.5, T1).  Workgroups are dealt to the 8 XCDs round robin in launch
+// order, so blocks b and b + 8 share an XCD (and its L2); the remap hands every such group a CONTIGUOUS range of the
+// work items -- the tiles of one cloud, the chunks of one cloud -- so that what they re-read or gather (a cloud's K / V,
+// its PQ rows) is fetched into ONE L2 instead of all eight.  Bijective for any item count; a speed hint only: results
+// never depend on it (every item is processed exactly once whatever the placement).
+static __device__ __forceinline__ int r3d_xcd_swizzle(int id, int n) {
+  const int q = n >> 3, r = n & 7, x = id & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+}
+
 // Row (or cloud) segments of a batch of episodes: segments of `a` and `b` units alternate, [a | b | a | b | ...]
 // (a = support part, b = query part of one episode; b == 0: every segment has `a` units).  Segment 2 e + p is part p of
 // episode e.  BatchNorm statistics, dropout seeds and every per-episode quantity of the training path are keyed by it.

@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256) void r3d_edgeconv_kernel(
   for (int s = 0; s < 16; ++s) Bz[s] = W2[c * 64 + 16 * g + s];  // z2[e][c] = sum_k h1[e][k] W2[c][k]
   const float s2c = s2[c], t2c = t2[c];
   const long units = total_points / E2_PTS;
-  for (long u = blockIdx.x; u < units; u += gridDim.x) {
+  for (long item = blockIdx.x; item < units; item += gridDim.x) {
+    const long u = r3d_xcd_swizzle((int)item, (int)units);  // workgroups sharing an L2 walk the units of the same clouds
     const long pt0 = u * E2_PTS;        // first point of the unit (global row)
     const long cloud0 = (pt0 / N) * N;  // first row of its cloud
     {
@@ -89,7 +90,7 @@ static int edgeconv_launch_rt(const float* PQ, const int32_t* idx, const float* 
     R3D_REQUIRE(resident > 0, "r3d_edgeconv_fwd: cannot reserve %zu B of LDS", lds);
   }
   const long units = total_points / E2_PTS;
-  const int grid = (int)(units < resident ? units : resident);
+  const int grid = (int)(units <= resident ? units : (resident & ~7));  // several units per workgroup: keep their XCD label
   hipLaunchKernelGGL(r3d_edgeconv_kernel<RT>, dim3(grid), dim3(256), lds, st, PQ, idx, W2, s2, t2, out, ldo, N, total_points,
                      argmax_out);
   return R3D_OK;

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void r3d_edge_stats1_kernel(const float* __res
   __shared__ float sa[4][64], sb[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int N = gm.N;
-  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+  for (int item = blockIdx.x; item < n_chunks; item += gridDim.x) {
+    const int chunk = r3d_xcd_swizzle(item, n_chunks);  // workgroups sharing an L2 walk the chunks of the same clouds
     int cloud, p0, p1;
     gm.range(chunk, cloud, p0, p1);
     const long cloud0 = (long)cloud * N;
@@ -163,7 +164,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT <= 5 ? 3
   f32x4 dw[4];  // dW2 rows 16w + 4g + i, columns 4n + tj
 #pragma unroll
   for (int tj = 0; tj < 4; ++tj) dw[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+  for (int item = blockIdx.x; item < n_chunks; item += gridDim.x) {
+    const int chunk = r3d_xcd_swizzle(item, n_chunks);  // workgroups sharing an L2 walk the chunks of the same clouds
     int cloud, p0, p1;
     gm.range(chunk, cloud, p0, p1);
     const long cloud0 = (long)cloud * N;
@@ -321,7 +323,8 @@ __global__ __launch_bounds__(256) void r3d_edgeconv_train_fwd2_kernel(
   float Bz[16];
 #pragma unroll
   for (int s = 0; s < 16; ++s) Bz[s] = W2[c * 64 + 16 * g + s];  // z2[e][c] = sum_k h1[e][k] W2[c][k]
-  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+  for (int item = blockIdx.x; item < n_chunks; item += gridDim.x) {
+    const int chunk = r3d_xcd_swizzle(item, n_chunks);  // workgroups sharing an L2 walk the chunks of the same clouds
     int cloud, p0, p1;
     gm.range(chunk, cloud, p0, p1);
     const long cloud0 = (long)cloud * N;
@@ -533,7 +536,8 @@ __global__ __launch_bounds__(256) void r3d_edgeconv_bwd2_kernel(
   // rev holds edge ids of the batch the reverse list was built for; this call's clouds start e_off edges into it
   constexpr int K = 4 * RT;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+  for (int item = blockIdx.x; item < n_chunks; item += gridDim.x) {
+    const int chunk = r3d_xcd_swizzle(item, n_chunks);  // workgroups sharing an L2 walk the chunks of the same clouds
     int cloud, p0, p1;
     gm.range(chunk, cloud, p0, p1);
     const int seg = ec_seg(cs, cloud);
@@ -590,6 +594,9 @@ static int et_check(const char* fn, int B, int N, int K, int clouds_a, int cloud
   return 0;
 }
 static int et_chunks(int B, int N) { return B * EcGeom::make(N).cpc; }
+// grid of a persistent chunk loop: all chunks, or -- when workgroups take several -- a multiple of 8 below the cap, so that
+// a workgroup's chunks keep its XCD label (r3d_xcd_swizzle)
+static int et_grid8(int n_chunks, int cap) { return n_chunks <= cap ? n_chunks : (cap >= 8 ? cap & ~7 : cap); }
 
 // floats of the scratch of the training-mode EdgeConv passes over B clouds of N points: one dW2 partial per workgroup
 // and one statistics partial per chunk
@@ -612,7 +619,7 @@ extern "C" int r3d_edge_stats1(const float* PQ, const int32_t* idx, int B, int N
   hipStream_t st = (hipStream_t)stream;
   const EcGeom gm = EcGeom::make(N);
   const int n_chunks = et_chunks(B, N);
-  const int grid = (int)(n_chunks < 2048 ? n_chunks : 2048);
+  const int grid = et_grid8(n_chunks, 2048);
 #define E2_CASE(RT) \
   case RT: hipLaunchKernelGGL(r3d_edge_stats1_kernel<RT>, dim3(grid), dim3(256), 0, st, PQ, idx, gm, n_chunks, ws); break
   switch (K / 4) {
@@ -634,7 +641,7 @@ static int fwd2_launch_rt(int n_chunks, hipStream_t st, const float* PQ, const i
     resident = e2_resident_blocks(r3d_edgeconv_train_fwd2_kernel<RT>, lds, ET_MAXBLK);
     R3D_REQUIRE(resident > 0, "r3d_edgeconv_train_fwd_minmax: cannot reserve %zu B of LDS", lds);
   }
-  const int grid = (int)(n_chunks < resident ? n_chunks : resident);
+  const int grid = et_grid8(n_chunks, resident);
   hipLaunchKernelGGL(r3d_edgeconv_train_fwd2_kernel<RT>, dim3(grid), dim3(256), lds, st, PQ, idx, s1, t1, bn_stride, W2, gm, cs,
                      n_chunks, argmax, zmax, zmin, argmin, ws);
   return R3D_OK;
@@ -709,7 +716,7 @@ static int bwd1_launch_rt(int n_chunks, hipStream_t st, const float* PQ, const i
     resident = e2_resident_blocks(r3d_edgeconv_bwd1_kernel<RT>, lds, ET_MAXBLK);
     R3D_REQUIRE(resident > 0, "r3d_edgeconv_bwd: cannot reserve %zu B of LDS", lds);
   }
-  const int grid = (int)(n_chunks < resident ? n_chunks : resident);
+  const int grid = et_grid8(n_chunks, resident);
   hipLaunchKernelGGL(r3d_edgeconv_bwd1_kernel<RT>, dim3(grid), dim3(256), lds, st, PQ, idx, bn, W2, bn2_sums, dout, lddo, argmax,
                      gm, cs, n_chunks, DY1, BE, part_dw, part_bn);
   *grid_out = grid;
@@ -770,7 +777,7 @@ extern "C" int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float
   et_reduce_chunks(part_bn, N, clouds_a, clouds_b, n_seg, bn1_sums, st);
   const int32_t* rev_ptr = rev_ws;
   const int32_t* rev = rev_ws + (long)B * N + 1;
-  const int grid2 = (int)(n_chunks < 4096 ? n_chunks : 4096);
+  const int grid2 = et_grid8(n_chunks, 4096);
 #define E2_CASE(RT)                                                                                                       \
   case RT:                                                                                                                \
     hipLaunchKernelGGL(r3d_edgeconv_bwd2_kernel<RT>, dim3(grid2), dim3(256), 0, st, PQ, s1, mean1, invstd1, bn_stride, bn1_sums, \
