@@ -32,8 +32,16 @@ __global__ __launch_bounds__(256) void r3d_pointwise_gemm_kernel(
   __shared__ float Ws[2][G_BN * G_LD];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
-  const long m0 = (long)blockIdx.x * G_BM;
-  const int n0 = blockIdx.y * G_BN;
+  // Tile order: a 1-D grid, XCD-aware (common.h: r3d_xcd_swizzle), the column tiles of one row tile next to each other.
+  // The workgroups that share an L2 then work on the SAME 64 rows of X, which is fetched into that L2 once and re-read
+  // there by the other column tiles; with the row tile as the fast grid axis every column tile of a row block ran ~12 000
+  // workgroups later and on another XCD, and X (the large operand: M = 786 432 rows for 32 episodes) came from HBM once
+  // per column tile (Co = 512: 8 times).
+  const int tiles_n = (Co + G_BN - 1) / G_BN;
+  const int tile = r3d_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+  const int tile_m = tile / tiles_n;
+  const long m0 = (long)tile_m * G_BM;
+  const int n0 = (tile - tile_m * tiles_n) * G_BN;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(256) void r3d_pointwise_gemm_kernel(
       const int which = tid >> 6, cc = tid & 63, wn2 = cc >> 5, l2 = cc & 31;
       const int jj = n0 + cc;
       if (jj < Co)
-        stats_part[((long)blockIdx.x * 2 + which) * Co + jj] =
+        stats_part[((long)tile_m * 2 + which) * Co + jj] =
             red[((0 * 2 + wn2) * 2 + which) * 32 + l2] + red[((1 * 2 + wn2) * 2 + which) * 32 + l2];
     }
   }
@@ -203,7 +211,9 @@ static int pointwise_launch(const float* X, long ldx, const float* W, long M, in
   R3D_REQUIRE(M > 0 && K > 0 && Co > 0 && ldx >= K && ldo >= Co,
               "r3d_pointwise_conv: bad shape M=%ld K=%d Co=%d ldx=%ld ldo=%ld", M, K, Co, ldx, ldo);
   R3D_REQUIRE(act >= 0 && act <= 2, "r3d_pointwise_conv: unknown activation %d", act);
-  dim3 grid(r3d_cdiv(M, G_BM), r3d_cdiv(Co, G_BN));
+  const long tiles = (long)r3d_cdiv(M, G_BM) * r3d_cdiv(Co, G_BN);
+  R3D_REQUIRE(tiles < 0x7fffffffL, "r3d_pointwise_conv: too many tiles");
+  dim3 grid((unsigned)tiles);
   hipLaunchKernelGGL(r3d_pointwise_gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, W,
                      (int)M, K, Co, scale, shift, act, Out, ldo, accumulate, stats_part);
   R3D_LAUNCH_CHECK("r3d_pointwise_conv");

@@ -331,8 +331,13 @@ __global__ __launch_bounds__(256) void r3d_gemm_tn_kernel(const float* __restric
   __shared__ float Bs[2][32 * 65];  // [buffer][m][j]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wi = w >> 1, wj = w & 1;
-  const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
-  const long m_beg = (long)blockIdx.z * TN_ROWS, m_end = min(M, m_beg + TN_ROWS);
+  // 1-D grid in XCD-aware order (common.h: r3d_xcd_swizzle): the output tiles of one row chunk sit next to each other, so
+  // the workgroups sharing an L2 read the same rows of A and B
+  const int nti = (Ca + 63) / 64, ntj = (Cb + 63) / 64;
+  const int tile = r3d_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+  const int chunk = tile / (nti * ntj), tij = tile - chunk * (nti * ntj);
+  const int i0 = (tij % nti) * 64, j0 = (tij / nti) * 64;
+  const long m_beg = (long)chunk * TN_ROWS, m_end = min(M, m_beg + TN_ROWS);
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(256) void r3d_gemm_tn_kernel(const float* __restric
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int i = i0 + 32 * wi + r3d_acc_row(r, lane);
-    if (i < Ca && j < Cb) part[((long)blockIdx.z * Ca + i) * Cb + j] = acc[r];
+    if (i < Ca && j < Cb) part[((long)chunk * Ca + i) * Cb + j] = acc[r];
   }
 }
 
@@ -567,7 +572,7 @@ extern "C" int r3d_gemm_tn(const float* A, long lda, const float* B, long ldb, l
   const int rows = tn_rows(M, Ca, Cb);
   const int chunks = r3d_cdiv(M, rows);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(r3d_gemm_tn_kernel, dim3(r3d_cdiv(Ca, 64), r3d_cdiv(Cb, 64), chunks), dim3(256), 0, st, A, lda, B, ldb,
+  hipLaunchKernelGGL(r3d_gemm_tn_kernel, dim3(r3d_cdiv(Ca, 64) * r3d_cdiv(Cb, 64) * chunks), dim3(256), 0, st, A, lda, B, ldb,
                      M, Ca, Cb, rows, ws);
   hipLaunchKernelGGL(r3d_chunk_reduce_kernel, dim3(r3d_cdiv((long)Ca * Cb, 256)), dim3(256), 0, st, ws, chunks,
                      (long)Ca * Cb, alpha, out, accumulate);
