@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libr3d_hip.so")
-SOURCES = ["error.hip", "knn.hip", "gemm.hip", "edgeconv.hip", "attention.hip", "head_proto.hip",
+SOURCES = ["error.hip", "knn.hip", "gemm.hip", "gemm_bx3.hip", "edgeconv.hip", "attention.hip", "head_proto.hip",
            "head_graph.hip", "aux_heads.hip", "train_ops.hip", "edgeconv_train.hip", "contrast.hip"]
 # No packed fp32 vector arithmetic (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32), neither from the SLP vectoriser nor from
 # float2 / float4 source arithmetic: measured on MI355X (profiles/r02_experiments.md, section 9), a wave executing them

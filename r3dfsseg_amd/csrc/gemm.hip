@@ -141,7 +141,11 @@ __global__ __launch_bounds__(256) void r3d_pointwise_gemm_kernel(
 static int pointwise_launch(const float* X, long ldx, const float* W, long M, int K, int Co, const float* scale,
                             const float* shift, int act, float* Out, long ldo, int accumulate, float* stats_part,
                             void* stream);
-
+// gemm_bx3.hip: the same GEMM on the bf16 matrix core in three-piece arithmetic
+bool r3d_pointwise_bx3_ok(const float* X, long ldx, const float* W, long M, int K, int Co);
+int r3d_pointwise_bx3_launch(const float* X, long ldx, const float* W, long M, int K, int Co, const float* scale,
+                             const float* shift, int act, float* Out, long ldo, int accumulate, float* stats_part,
+                             hipStream_t st);
 
 extern "C" int r3d_pointwise_conv(const float* X, long ldx, const float* W, long M, int K, int Co,
                                   const float* scale, const float* shift, int act, float* Out,
@@ -211,6 +215,13 @@ static int pointwise_launch(const float* X, long ldx, const float* W, long M, in
   R3D_REQUIRE(M > 0 && K > 0 && Co > 0 && ldx >= K && ldo >= Co,
               "r3d_pointwise_conv: bad shape M=%ld K=%d Co=%d ldx=%ld ldo=%ld", M, K, Co, ldx, ldo);
   R3D_REQUIRE(act >= 0 && act <= 2, "r3d_pointwise_conv: unknown activation %d", act);
+  if (r3d_pointwise_bx3_ok(X, ldx, W, M, K, Co)) {  // (a function of the layer's shape only: never of the batch)
+    const int rc = r3d_pointwise_bx3_launch(X, ldx, W, M, K, Co, scale, shift, act, Out, ldo, accumulate, stats_part,
+                                            (hipStream_t)stream);
+    if (rc) return rc;
+    R3D_LAUNCH_CHECK("r3d_pointwise_conv");
+    return R3D_OK;
+  }
   const long tiles = (long)r3d_cdiv(M, G_BM) * r3d_cdiv(Co, G_BN);
   R3D_REQUIRE(tiles < 0x7fffffffL, "r3d_pointwise_conv: too many tiles");
   dim3 grid((unsigned)tiles);

@@ -1,0 +1,332 @@
+// The GEMMs that decide no index -- the 1x1 convolutions (forward and input gradient) and the weight-gradient GEMM -- on
+// the bf16 matrix core with fp32 accuracy ("bf16 x 3", common.h): every fp32 operand is cut by truncation into three bf16
+// pieces (exactly), a product block is six v_mfma_f32_32x32x16_bf16 accumulating in fp32; 6 x 32 cycles cover K = 16
+// where v_mfma_f32_32x32x2_f32 needs 8 x 64 (2.67 x the fp32 matrix rate, relative error of a product 2^-22).
+//
+// Replaces, when r3d_set_matrix_arith(1) (the default) and the shapes allow it, the fp32 kernels of gemm.hip
+// (r3d_pointwise_gemm_kernel: models/dgcnn.py:64-80,121-122, models/mpti.py:18-40, models/attention.py:39-41) and of
+// train_ops.hip (r3d_gemm_tn_kernel: the weight gradients autograd computes for those layers).  Index-deciding arithmetic
+// -- kNN scores, the EdgeConv edge GEMM whose max-pool winners route the gradient, FPS -- stays on the fp32 core.
+//
+// Round 2 tried this arithmetic on these GEMMs and dropped it: the operands were cut by a separate pack pass through
+// HBM (6 B per element written and read back).  Here the cut happens between the global load and the LDS store of the
+// staging step: a workgroup of 4 waves owns a 128 x 128 (or 256 x 64) output tile, each wave a 64 x 64 quarter = 2 x 2
+// MFMA tiles, so every staged element feeds 64 outputs per wave and the ~6 VALU instructions per element of the cut
+// (208 per thread and K-step of 32) run in the shadow of the other workgroup's 48 MFMAs per wave (2 workgroups per CU:
+// 61 / 77 KB of LDS each).  LDS holds one K-step: [piece][row][32 k] bf16 with 80-byte rows, so that an MFMA operand -- 8
+// consecutive k of a row -- is ONE ds_read_b128.
+#if defined(GB_ABL) && (GB_ABL & 4)  // probe builds (tools/probe/gemm_bx3_abl.hip): 1 no stores, 2 no cut, 4 no MFMA, 8 no loads
+#define ATT_ABL 4
+#endif
+#include "common.h"
+#ifndef GB_ABL
+#define GB_ABL 0
+#endif
+
+#define GB_RS 40  // LDS row stride in bf16 units (64 B of data + 16 B: consecutive rows start 20 banks apart)
+
+enum { GB_ACT_NONE = 0, GB_ACT_RELU = 1, GB_ACT_LRELU02 = 2 };
+
+// one staged chunk: 8 consecutive k of a row, as three 16-byte piece vectors
+static __device__ __forceinline__ void gb_store_chunk(unsigned short* __restrict__ planes, int rows, int row, int kc,
+                                                      const float (&v)[8]) {
+#if GB_ABL & 2
+  r3d_bx3 f;
+  for (int i = 0; i < 4; ++i) { f.h[i] = __float_as_uint(v[i]); f.m[i] = __float_as_uint(v[4 + i]); f.l[i] = f.h[i] ^ f.m[i]; }
+#else
+  const r3d_bx3 f = r3d_bx3_split8(v);
+#endif
+  unsigned short* p = planes + row * GB_RS + 8 * kc;
+  *reinterpret_cast<r3d_u32x4*>(p) = f.h;
+  *reinterpret_cast<r3d_u32x4*>(p + rows * GB_RS) = f.m;
+  *reinterpret_cast<r3d_u32x4*>(p + 2 * rows * GB_RS) = f.l;
+}
+static __device__ __forceinline__ r3d_bx3 gb_load_frag(const unsigned short* __restrict__ planes, int rows, int row, int ks,
+                                                       int g) {
+  const unsigned short* p = planes + row * GB_RS + 16 * ks + 8 * g;
+  r3d_bx3 f;
+  f.h = *reinterpret_cast<const r3d_u32x4*>(p);
+  f.m = *reinterpret_cast<const r3d_u32x4*>(p + rows * GB_RS);
+  f.l = *reinterpret_cast<const r3d_u32x4*>(p + 2 * rows * GB_RS);
+  return f;
+}
+
+// the 64 x 64 quarter of a wave over one staged K-step of 32: 2 k-steps x (2 x 2 tiles) x 6 MFMAs
+static __device__ __forceinline__ void gb_wave_mma(const unsigned short* __restrict__ As, int a_rows, int a_row0,
+                                                   const unsigned short* __restrict__ Bs, int b_rows, int b_row0, int lane,
+                                                   f32x16 (&acc)[2][2]) {
+  const int j = lane & 31, g = lane >> 5;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    r3d_bx3 a[2], b[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      a[t] = gb_load_frag(As, a_rows, a_row0 + 32 * t + j, ks, g);
+      b[t] = gb_load_frag(Bs, b_rows, b_row0 + 32 * t + j, ks, g);
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = r3d_bx3_mma(a[tm], b[tn], acc[tm][tn]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Out[m][j] = act(scale[j] * sum_k X[m][k] W[j][k] + shift[j])   (+ Out if accumulate); K % 32 == 0, rows of X 16-byte
+// aligned.  WM x WN = 4 waves of 64 x 64.  stats_part (optional): [ceil(M / 64)][2][Co] column sums (sum v, sum v^2) of
+// every 64-row tile: the BatchNorm batch statistics from the epilogue, partitioned exactly like the fp32 kernel's.
+// ---------------------------------------------------------------------------------------------------------------
+template <int WM, int WN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r3d_pointwise_gemm_bx3_kernel(
+    const float* __restrict__ X, long ldx, const float* __restrict__ W, int M, int K, int Co,
+    const float* __restrict__ scale, const float* __restrict__ shift, int act, float* __restrict__ Out, long ldo,
+    int accumulate, float* __restrict__ stats_part) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int XU = BM / 64, WU = BN / 64;  // chunks (8 k of a row) per thread and K-step: BM * 4 / 256
+  extern __shared__ __attribute__((aligned(16))) unsigned short gb_smem[];
+  unsigned short* Xs = gb_smem;                  // [3][BM][GB_RS]
+  unsigned short* Ws = gb_smem + 3 * BM * GB_RS;  // [3][BN][GB_RS]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w / WN, wn = w - wm * WN;
+  // XCD-aware tile order, the column tiles of one row tile next to each other (gemm.hip)
+  const int tiles_n = (Co + BN - 1) / BN;
+  const int tile = r3d_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+  const int tile_m = tile / tiles_n;
+  const long m0 = (long)tile_m * BM;
+  const int n0 = (tile - tile_m * tiles_n) * BN;
+  // staging map: chunk c = tid + 256 u -> row c >> 2, k-chunk c & 3 (four consecutive threads cover the 128 bytes of a
+  // row's K-step).  Rows beyond M / Co are clamped duplicates whose products only reach outputs that are never stored.
+  const float* xp[XU];
+  const float* wp[WU];
+#pragma unroll
+  for (int u = 0; u < XU; ++u) {
+    const int c = tid + 256 * u;
+    xp[u] = X + min(m0 + (c >> 2), (long)M - 1) * ldx + 8 * (c & 3);
+  }
+#pragma unroll
+  for (int u = 0; u < WU; ++u) {
+    const int c = tid + 256 * u;
+    wp[u] = W + (long)min(n0 + (c >> 2), Co - 1) * K + 8 * (c & 3);
+  }
+  float xr[XU][8], wr[WU][8];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+      const float4 a = *reinterpret_cast<const float4*>(xp[u] + k0), b = *reinterpret_cast<const float4*>(xp[u] + k0 + 4);
+      xr[u][0] = a.x; xr[u][1] = a.y; xr[u][2] = a.z; xr[u][3] = a.w; xr[u][4] = b.x; xr[u][5] = b.y; xr[u][6] = b.z; xr[u][7] = b.w;
+    }
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {
+      const float4 a = *reinterpret_cast<const float4*>(wp[u] + k0), b = *reinterpret_cast<const float4*>(wp[u] + k0 + 4);
+      wr[u][0] = a.x; wr[u][1] = a.y; wr[u][2] = a.z; wr[u][3] = a.w; wr[u][4] = b.x; wr[u][5] = b.y; wr[u][6] = b.z; wr[u][7] = b.w;
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  gload(0);
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    // registers -> pieces -> LDS
+#pragma unroll
+    for (int u = 0; u < XU; ++u) { const int c = tid + 256 * u; gb_store_chunk(Xs, BM, c >> 2, c & 3, xr[u]); }
+#pragma unroll
+    for (int u = 0; u < WU; ++u) { const int c = tid + 256 * u; gb_store_chunk(Ws, BN, c >> 2, c & 3, wr[u]); }
+    __syncthreads();
+    if (k0 + 32 < K && !(GB_ABL & 8)) gload(k0 + 32);  // the next K-step's loads are in flight behind this step's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    gb_wave_mma(Xs, BM, 64 * wm, Ws, BN, 64 * wn, lane, acc);
+    __syncthreads();
+  }
+  // epilogue: the wave's 64 x 64 quarter
+  const long mw = m0 + 64 * wm;
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int j = n0 + 64 * wn + 32 * tn + (lane & 31);
+    const bool jok = j < Co;
+    const float sc = (scale && jok) ? scale[j] : 1.f;
+    const float sh = (shift && jok) ? shift[j] : 0.f;
+    float s1 = 0.f, s2 = 0.f;  // column sums of the values written (training: batch statistics of z)
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = mw + 32 * tm + r3d_acc_row(r, lane);
+        if (m >= M || !jok) continue;
+        if ((GB_ABL & 1) && acc[tm][tn][r] != 12345.678f) continue;
+        float v = sc * acc[tm][tn][r] + sh;
+        if (act == GB_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == GB_ACT_LRELU02) v = v > 0.f ? v : 0.2f * v;
+        Out[m * ldo + j] = accumulate ? Out[m * ldo + j] + v : v;
+        s1 += v;
+        s2 += v * v;
+      }
+    }
+    if (stats_part) {  // uniform.  The rows of one column sit in lanes l and l ^ 32; the wave owns its 64-row tile's columns
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lane < 32 && jok && mw < M) {
+        const long t64 = mw >> 6;
+        stats_part[(t64 * 2 + 0) * Co + j] = s1;
+        stats_part[(t64 * 2 + 1) * Co + j] = s2;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// part[chunk][i][j] = sum over the chunk's rows m of A[m][i] * B[m][j]   (weight gradients: A = dz (M, Ca), B = X (M, Cb)).
+// The contraction runs over the ROW axis of both operands: a staged chunk is 8 consecutive rows of one column (8 loads,
+// the lanes along the columns: coalesced), everything behind the staging is the kernel above.  The M axis is split in
+// chunks of tn_rows rows whose partial tiles a second kernel adds in ascending order (train_ops.hip).
+// ---------------------------------------------------------------------------------------------------------------
+template <int WM, int WN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r3d_gemm_tn_bx3_kernel(
+    const float* __restrict__ A, long lda, const float* __restrict__ B, long ldb, long M, int Ca, int Cb, int tn_rows,
+    float* __restrict__ part /* [chunks][Ca][Cb] */) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int XU = BM / 64, WU = BN / 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned short gb_smem[];
+  unsigned short* As = gb_smem;
+  unsigned short* Bs = gb_smem + 3 * BM * GB_RS;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w / WN, wn = w - wm * WN;
+  const int nti = (Ca + BM - 1) / BM, ntj = (Cb + BN - 1) / BN;
+  const int tile = r3d_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+  const int chunk = tile / (nti * ntj), tij = tile - chunk * (nti * ntj);
+  const int i0 = (tij % nti) * BM, j0 = (tij / nti) * BN;
+  const long m_beg = (long)chunk * tn_rows, m_end = min(M, m_beg + tn_rows);
+  // staging map: chunk c = tid + 256 u -> column c % BM (consecutive threads: consecutive columns), row group c / BM (8 rows)
+  const float* ap[XU];
+  const float* bp[WU];
+  int amc[XU], bmc[WU];
+#pragma unroll
+  for (int u = 0; u < XU; ++u) {
+    const int c = tid + 256 * u;
+    ap[u] = A + min(i0 + c % BM, Ca - 1);
+    amc[u] = c / BM;
+  }
+#pragma unroll
+  for (int u = 0; u < WU; ++u) {
+    const int c = tid + 256 * u;
+    bp[u] = B + min(j0 + c % BN, Cb - 1);
+    bmc[u] = c / BN;
+  }
+  float ar[XU][8], br[WU][8];
+  auto gload = [&](long mk) {  // rows beyond m_end must be zero: they enter every sum
+    const bool full = mk + 32 <= m_end;  // uniform
+#pragma unroll
+    for (int u = 0; u < XU; ++u)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const long m = mk + 8 * amc[u] + t;
+        ar[u][t] = full ? ap[u][m * lda] : r3d_keep(ap[u][min(m, M - 1) * lda], m < m_end);
+      }
+#pragma unroll
+    for (int u = 0; u < WU; ++u)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const long m = mk + 8 * bmc[u] + t;
+        br[u][t] = full ? bp[u][m * ldb] : r3d_keep(bp[u][min(m, M - 1) * ldb], m < m_end);
+      }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  gload(m_beg);
+  for (long mk = m_beg; mk < m_end; mk += 32) {
+#pragma unroll
+    for (int u = 0; u < XU; ++u) { const int c = tid + 256 * u; gb_store_chunk(As, BM, c % BM, amc[u], ar[u]); }
+#pragma unroll
+    for (int u = 0; u < WU; ++u) { const int c = tid + 256 * u; gb_store_chunk(Bs, BN, c % BN, bmc[u], br[u]); }
+    __syncthreads();
+    if (mk + 32 < m_end) gload(mk + 32);
+    __builtin_amdgcn_sched_barrier(0);
+    gb_wave_mma(As, BM, 64 * wm, Bs, BN, 64 * wn, lane, acc);
+    __syncthreads();
+  }
+  float* out = part + (long)chunk * Ca * Cb;
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int j = j0 + 64 * wn + 32 * tn + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + 64 * wm + 32 * tm + r3d_acc_row(r, lane);
+        if (i < Ca && j < Cb) out[(long)i * Cb + j] = acc[tm][tn][r];
+      }
+    }
+}
+
+// ===========================================================================
+// launchers (called from gemm.hip / train_ops.hip when the bf16 x 3 arithmetic is selected and the shape allows it)
+// ===========================================================================
+// three piece planes of BM + BN rows: 61440 B for 128 x 128, 76800 B for 256 x 64 (two workgroups per CU either way)
+static const size_t GB_LDS_22 = sizeof(unsigned short) * 3 * (128 + 128) * GB_RS;
+static const size_t GB_LDS_41 = sizeof(unsigned short) * 3 * (256 + 64) * GB_RS;
+
+template <typename KernelT>
+static int gb_lds_attr(KernelT k, size_t bytes) {
+  return hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : 1;
+}
+
+bool r3d_pointwise_bx3_ok(const float* X, long ldx, const float* W, long M, int K, int Co) {
+  return g_r3d_matrix_arith == 1 && K >= 32 && K % 32 == 0 && (ldx & 3) == 0 && ((uintptr_t)X & 15) == 0 &&
+         ((uintptr_t)W & 15) == 0 && Co >= 32 && M >= 64;
+}
+
+int r3d_pointwise_bx3_launch(const float* X, long ldx, const float* W, long M, int K, int Co, const float* scale,
+                             const float* shift, int act, float* Out, long ldo, int accumulate, float* stats_part,
+                             hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    R3D_REQUIRE(gb_lds_attr(r3d_pointwise_gemm_bx3_kernel<2, 2>, GB_LDS_22) == 0 &&
+                    gb_lds_attr(r3d_pointwise_gemm_bx3_kernel<4, 1>, GB_LDS_41) == 0,
+                "r3d_pointwise_conv: cannot reserve %zu B of LDS", GB_LDS_41);
+    attr = true;
+  }
+  if (Co > 64) {  // 128 x 128 tiles
+    const long tiles = (long)r3d_cdiv(M, 128) * r3d_cdiv(Co, 128);
+    R3D_REQUIRE(tiles < 0x7fffffffL, "r3d_pointwise_conv: too many tiles");
+    hipLaunchKernelGGL((r3d_pointwise_gemm_bx3_kernel<2, 2>), dim3((unsigned)tiles), dim3(256), GB_LDS_22, st, X, ldx, W, (int)M, K, Co,
+                       scale, shift, act, Out, ldo, accumulate, stats_part);
+  } else {        // 256 x 64 tiles
+    const long tiles = (long)r3d_cdiv(M, 256);
+    hipLaunchKernelGGL((r3d_pointwise_gemm_bx3_kernel<4, 1>), dim3((unsigned)tiles), dim3(256), GB_LDS_41, st, X, ldx, W, (int)M, K, Co,
+                       scale, shift, act, Out, ldo, accumulate, stats_part);
+  }
+  return R3D_OK;
+}
+
+bool r3d_gemm_tn_bx3_ok(int Ca, int Cb) { return g_r3d_matrix_arith == 1 && Ca >= 32 && Cb >= 32; }
+
+// tiles of the (Ca, Cb) output for the chunk count of train_ops.hip's tn_rows()
+int r3d_gemm_tn_bx3_tiles(int Ca, int Cb) {
+  return Cb > 64 ? r3d_cdiv(Ca, 128) * r3d_cdiv(Cb, 128) : r3d_cdiv(Ca, 256) * r3d_cdiv(Cb, 64);
+}
+
+int r3d_gemm_tn_bx3_launch(const float* A, long lda, const float* B, long ldb, long M, int Ca, int Cb, int rows, int chunks,
+                           float* part, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    R3D_REQUIRE(gb_lds_attr(r3d_gemm_tn_bx3_kernel<2, 2>, GB_LDS_22) == 0 && gb_lds_attr(r3d_gemm_tn_bx3_kernel<4, 1>, GB_LDS_41) == 0,
+                "r3d_gemm_tn: cannot reserve %zu B of LDS", GB_LDS_41);
+    attr = true;
+  }
+  const int tiles = r3d_gemm_tn_bx3_tiles(Ca, Cb);
+  if (Cb > 64)
+    hipLaunchKernelGGL((r3d_gemm_tn_bx3_kernel<2, 2>), dim3(tiles * chunks), dim3(256), GB_LDS_22, st, A, lda, B, ldb, M, Ca, Cb, rows,
+                       part);
+  else
+    hipLaunchKernelGGL((r3d_gemm_tn_bx3_kernel<4, 1>), dim3(tiles * chunks), dim3(256), GB_LDS_41, st, A, lda, B, ldb, M, Ca, Cb, rows,
+                       part);
+  return R3D_OK;
+}

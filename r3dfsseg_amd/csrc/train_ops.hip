@@ -312,11 +312,16 @@ __global__ __launch_bounds__(256) void r3d_bn_bwd_apply_kernel(
 // fp32 matrix core, the M axis split in chunks of TN_ROWS with per-chunk partial tiles that a second
 // kernel adds in ascending chunk order (deterministic, no float atomics).
 #define TN_ROWS_MAX 1024
-static int tn_rows(long M, int Ca, int Cb) {
+// gemm_bx3.hip: the same product on the bf16 matrix core in three-piece arithmetic (128 x 128 / 256 x 64 tiles, 2 per CU)
+bool r3d_gemm_tn_bx3_ok(int Ca, int Cb);
+int r3d_gemm_tn_bx3_tiles(int Ca, int Cb);
+int r3d_gemm_tn_bx3_launch(const float* A, long lda, const float* B, long ldb, long M, int Ca, int Cb, int rows, int chunks,
+                           float* part, hipStream_t st);
+static int tn_rows(long M, int Ca, int Cb, bool bx3) {
   // enough workgroups to fill the chip even for 64 x 64 outputs, chunks of at least 128 rows; never a few more than
-  // the 1024 the chip holds at once (4 per CU): 24 tiles x 43 chunks = 1032 workgroups ran as two rounds
-  const long tiles = (long)((Ca + 63) / 64) * ((Cb + 63) / 64);
-  long chunks = 1024 / tiles;
+  // the 1024 (512) the chip holds at once (4 (2) per CU): 24 tiles x 43 chunks = 1032 workgroups ran as two rounds
+  const long tiles = bx3 ? r3d_gemm_tn_bx3_tiles(Ca, Cb) : (long)((Ca + 63) / 64) * ((Cb + 63) / 64);
+  long chunks = (bx3 ? 512 : 1024) / tiles;
   if (chunks < 1) chunks = 1;
   long rows = (M + chunks - 1) / chunks;
   rows = ((rows + 31) / 32) * 32;
@@ -561,7 +566,8 @@ extern "C" int r3d_bn_bwd_apply(const float* Z, long ldz, const float* DY, long 
 }
 
 extern "C" long r3d_gemm_tn_ws_words(long M, int Ca, int Cb) {
-  const int rows = tn_rows(M, Ca, Cb);
+  const int r0 = tn_rows(M, Ca, Cb, false), r1 = tn_rows(M, Ca, Cb, true);  // (whichever arithmetic is selected later)
+  const int rows = r0 < r1 ? r0 : r1;
   return ((M + rows - 1) / rows) * (long)Ca * Cb + 16;
 }
 
@@ -569,11 +575,17 @@ extern "C" long r3d_gemm_tn_ws_words(long M, int Ca, int Cb) {
 extern "C" int r3d_gemm_tn(const float* A, long lda, const float* B, long ldb, long M, int Ca, int Cb, float alpha,
                            float* out, int accumulate, float* ws, void* stream) {
   R3D_REQUIRE(A && B && out && ws && M > 0 && Ca > 0 && Cb > 0 && lda >= Ca && ldb >= Cb, "r3d_gemm_tn: bad arguments");
-  const int rows = tn_rows(M, Ca, Cb);
+  const bool bx3 = r3d_gemm_tn_bx3_ok(Ca, Cb);
+  const int rows = tn_rows(M, Ca, Cb, bx3);
   const int chunks = r3d_cdiv(M, rows);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(r3d_gemm_tn_kernel, dim3(r3d_cdiv(Ca, 64) * r3d_cdiv(Cb, 64) * chunks), dim3(256), 0, st, A, lda, B, ldb,
-                     M, Ca, Cb, rows, ws);
+  if (bx3) {
+    const int rc = r3d_gemm_tn_bx3_launch(A, lda, B, ldb, M, Ca, Cb, rows, chunks, ws, st);
+    if (rc) return rc;
+  } else {
+    hipLaunchKernelGGL(r3d_gemm_tn_kernel, dim3(r3d_cdiv(Ca, 64) * r3d_cdiv(Cb, 64) * chunks), dim3(256), 0, st, A, lda, B,
+                       ldb, M, Ca, Cb, rows, ws);
+  }
   hipLaunchKernelGGL(r3d_chunk_reduce_kernel, dim3(r3d_cdiv((long)Ca * Cb, 256)), dim3(256), 0, st, ws, chunks,
                      (long)Ca * Cb, alpha, out, accumulate);
   R3D_LAUNCH_CHECK("r3d_gemm_tn");

@@ -179,10 +179,11 @@ def test_dptrainer_batched_step_equals_eager_step():
         learner.lr_scheduler = torch.optim.lr_scheduler.StepLR(learner.optimizer, step_size=5000, gamma=0.5)
         tr = DPTrainer(learner, batch_size=2 if mode == "batched" else 0)
         l1 = float(tr.step(eps))
+        grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
         l2 = float(tr.step(eps))
         assert tr.n_redone == 0
         res[mode] = (l1, l2, torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone(),
-                     {k: v.clone() for k, v in m.named_buffers()})
+                     {k: v.clone() for k, v in m.named_buffers()}, grads)
         if mode == "batched":
             assert tr.last_status[0] == 0 and tr.last_status[3] > 0
             m._lp_budget = 2  # far too few CG launches: the step must notice and redo its episodes on the exact schedule
@@ -191,8 +192,15 @@ def test_dptrainer_batched_step_equals_eager_step():
             assert tr.redone and tr.n_redone == 1 and np.isfinite(l3)
     a, b = res["eager"], res["batched"]
     assert abs(a[0] - b[0]) < 2e-5 * max(1.0, abs(a[0])) and abs(a[1] - b[1]) < 1e-4 * max(1.0, abs(a[1]))
-    perr = (a[2] - b[2]).abs().max().item()
-    assert perr < 2e-5, perr
+    # the step's gradients agree to rounding (the batch adds the episodes' weight gradients in another association) ...
+    for n, g in a[4].items():
+        assert (g - b[4][n]).abs().max().item() <= 2e-6 * max(g.abs().max().item(), 1e-3), n
+    # ... and so do the weights after two Adam steps -- except where a gradient element is itself rounding noise: Adam
+    # normalises every element to a step of ~lr (1e-3 here) whatever its size, so such elements may move apart by a
+    # fraction of lr (measured: a few 1e-4 for < 0.1 % of the elements, in either matrix arithmetic)
+    perr = (a[2] - b[2]).abs()
+    assert perr.max().item() < 5e-4, perr.max().item()
+    assert (perr > 2e-5).float().mean().item() < 2e-3, (perr > 2e-5).float().mean().item()
     for k in a[3]:
         np.testing.assert_allclose(a[3][k].float().cpu().numpy(), b[3][k].float().cpu().numpy(), rtol=1e-4, atol=1e-5)
 

@@ -243,3 +243,63 @@ def test_get_features_end_to_end(ops):
     assert bad.float().mean().item() < 0.03, bad.float().mean().item()
     # level-1 features depend on the first (input-space) kNN only -> exact agreement everywhere
     np.testing.assert_allclose(got[:, :64].numpy(), want[:, :64].numpy(), atol=TOL, rtol=1e-4)
+
+
+# ------------------------------------------------------------------ the same GEMMs in both matrix arithmetics
+@pytest.mark.parametrize("arith", [0, 1])
+@pytest.mark.parametrize("M,K,Co", [(4096, 192, 512), (777, 512, 256), (2048 + 37, 256, 192), (640, 128, 64), (333, 64, 64),
+                                    (1000, 64, 96), (64, 32, 32)])
+def test_pointwise_conv_both_arithmetics(ops, arith, M, K, Co):
+    """csrc/gemm.hip (fp32 matrix core) and csrc/gemm_bx3.hip (bf16 core, three-piece operands) against float64: tails in
+    M and Co, accumulation into the output, and the epilogue's column sums (the BatchNorm batch statistics)."""
+    from r3dfsseg_amd import _lib, train_ops as T
+    from r3dfsseg_amd.ops import _p, _st
+    lib = _lib.load()
+    before = lib.r3d_get_matrix_arith()
+    try:
+        _lib.check(lib.r3d_set_matrix_arith(arith))
+        x, W = _rand((M, K), 141), _rand((Co, K), 142, 1.0 / np.sqrt(K))
+        x[5, :] *= 1e4  # (a wide dynamic range inside one contraction)
+        ref = x.double() @ W.double().t()
+        xd, Wd = _dev(x), _dev(W)
+        got = ops.pointwise_conv(xd, Wd, None, None, 0)
+        scale = (x.double().abs() @ W.double().abs().t())  # the error bound of an fp32 dot product scales with sum |x w|
+        err = ((got.cpu().double() - ref).abs() / scale).max().item()
+        assert err < 4e-7, err
+        # accumulate
+        out = got.clone()
+        T.conv_acc(xd, Wd, out)
+        np.testing.assert_allclose(out.cpu().numpy(), 2 * got.cpu().numpy(), rtol=1e-6, atol=1e-6)
+        # statistics from the epilogue
+        sums = torch.empty(2 * Co, device="cuda")
+        ws = torch.empty(lib.r3d_pointwise_conv_stats_ws_words(M, Co), device="cuda")
+        raw = torch.empty(M, Co, device="cuda")
+        _lib.check(lib.r3d_pointwise_conv_stats(_p(xd), K, _p(Wd), M, K, Co, _p(raw), Co, _p(sums), _p(ws), _st()))
+        assert torch.equal(raw, got)
+        r64 = raw.cpu().double()
+        np.testing.assert_allclose(sums[:Co].cpu().numpy(), r64.sum(0).numpy(), rtol=1e-5, atol=2e-6 * r64.abs().sum(0).max().item())
+        np.testing.assert_allclose(sums[Co:].cpu().numpy(), (r64 * r64).sum(0).numpy(), rtol=1e-5)
+    finally:
+        _lib.check(lib.r3d_set_matrix_arith(before))
+
+
+@pytest.mark.parametrize("arith", [0, 1])
+@pytest.mark.parametrize("M,Ca,Cb", [(8192, 512, 192), (3000, 256, 512), (4100, 64, 128), (2048, 128, 64), (999, 192, 256),
+                                     (2048, 128, 9), (70, 96, 40)])
+def test_gemm_tn_both_arithmetics(ops, arith, M, Ca, Cb):
+    """The weight-gradient product A^T B (train_ops.hip / gemm_bx3.hip) against float64, with strided operands."""
+    from r3dfsseg_amd import _lib, train_ops as T
+    lib = _lib.load()
+    before = lib.r3d_get_matrix_arith()
+    try:
+        _lib.check(lib.r3d_set_matrix_arith(arith))
+        A, B = _rand((M, Ca + 8), 151), _rand((M, Cb + 4), 152)
+        Ad, Bd = _dev(A)[:, 8:], _dev(B)[:, :Cb]
+        ref = A[:, 8:].double().t() @ B[:, :Cb].double()
+        scale = A[:, 8:].double().abs().t() @ B[:, :Cb].double().abs()
+        got = T.gemm_tn(Ad, Bd)
+        err = ((got.cpu().double() - ref).abs() / scale).max().item()
+        assert err < 4e-7, err
+        assert torch.equal(got, T.gemm_tn(Ad, Bd)), "not deterministic"
+    finally:
+        _lib.check(lib.r3d_set_matrix_arith(before))
