@@ -218,9 +218,11 @@ static int pointwise_launch(const float* X, long ldx, const float* W, long M, in
   if (r3d_pointwise_bx3_ok(X, ldx, W, M, K, Co)) {  // (a function of the layer's shape only: never of the batch)
     const int rc = r3d_pointwise_bx3_launch(X, ldx, W, M, K, Co, scale, shift, act, Out, ldo, accumulate, stats_part,
                                             (hipStream_t)stream);
-    if (rc) return rc;
-    R3D_LAUNCH_CHECK("r3d_pointwise_conv");
-    return R3D_OK;
+    if (rc > 0) return rc;
+    if (rc == 0) {
+      R3D_LAUNCH_CHECK("r3d_pointwise_conv");
+      return R3D_OK;
+    }
   }
   const long tiles = (long)r3d_cdiv(M, G_BM) * r3d_cdiv(Co, G_BN);
   R3D_REQUIRE(tiles < 0x7fffffffL, "r3d_pointwise_conv: too many tiles");

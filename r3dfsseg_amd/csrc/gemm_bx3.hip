@@ -9,12 +9,8 @@
 // -- kNN scores, the EdgeConv edge GEMM whose max-pool winners route the gradient, FPS -- stays on the fp32 core.
 //
 // Round 2 tried this arithmetic on these GEMMs and dropped it: the operands were cut by a separate pack pass through
-// HBM (6 B per element written and read back).  Here the cut happens between the global load and the LDS store of the
-// staging step: a workgroup of 4 waves owns a 128 x 128 (or 256 x 64) output tile, each wave a 64 x 64 quarter = 2 x 2
-// MFMA tiles, so every staged element feeds 64 outputs per wave and the ~6 VALU instructions per element of the cut
-// (208 per thread and K-step of 32) run in the shadow of the other workgroup's 48 MFMAs per wave (2 workgroups per CU:
-// 61 / 77 KB of LDS each).  LDS holds one K-step: [piece][row][32 k] bf16 with 80-byte rows, so that an MFMA operand -- 8
-// consecutive k of a row -- is ONE ds_read_b128.
+// HBM (6 B per element written and read back).  Here the cut happens in registers between the global load and the MFMA
+// (pointwise kernel: X never touches LDS) or the LDS store of the staging step (weight-gradient kernel).
 #if defined(GB_ABL) && (GB_ABL & 4)  // probe builds (tools/probe/gemm_bx3_abl.hip): 1 no stores, 2 no cut, 4 no MFMA, 8 no loads
 #define ATT_ABL 4
 #endif
@@ -72,106 +68,177 @@ static __device__ __forceinline__ void gb_wave_mma(const unsigned short* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Out[m][j] = act(scale[j] * sum_k X[m][k] W[j][k] + shift[j])   (+ Out if accumulate); K % 32 == 0, rows of X 16-byte
-// aligned.  WM x WN = 4 waves of 64 x 64.  stats_part (optional): [ceil(M / 64)][2][Co] column sums (sum v, sum v^2) of
-// every 64-row tile: the BatchNorm batch statistics from the epilogue, partitioned exactly like the fp32 kernel's.
+// Out[m][j] = act(scale[j] * sum_k X[m][k] W[j][k] + shift[j])   (+ Out if accumulate); K % 16 == 0, rows of X 16-byte
+// aligned.  stats_part (optional): [ceil(M / 64)][2][Co] column sums (sum v, sum v^2) of every 64-row tile: the
+// BatchNorm batch statistics from the epilogue, partitioned exactly like the fp32 kernel's.
+//
+// A workgroup = 4 waves x 64 rows, all on the same NT x 32 columns.  The MFMA A operand of a lane -- 8 consecutive k of
+// ONE row of X -- is 32 contiguous bytes of global memory: every wave loads its own rows' operands straight into
+// registers (two dwordx4 per lane and 32-row tile, one K-step of 16 ahead) and cuts them there into the three
+// fragments; X never passes through LDS and no wave waits for another wave's share of it.  Only the W tile, which the
+// four waves share, is staged: cut by the workgroup (8 elements per thread and K-step) into LDS in fragment order
+// ([n-tile][piece][lane] blocks of 1 KB: a B operand is one lane-linear ds_read_b128), double buffered, ONE barrier per
+// K-step.  Per K-step and wave: 132 VALU instructions of cutting for 48 MFMAs (NT = 4).
 // ---------------------------------------------------------------------------------------------------------------
-template <int WM, int WN>
+template <int NT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r3d_pointwise_gemm_bx3_kernel(
     const float* __restrict__ X, long ldx, const float* __restrict__ W, int M, int K, int Co,
     const float* __restrict__ scale, const float* __restrict__ shift, int act, float* __restrict__ Out, long ldo,
     int accumulate, float* __restrict__ stats_part) {
-  constexpr int BM = 64 * WM, BN = 64 * WN;
-  constexpr int XU = BM / 64, WU = BN / 64;  // chunks (8 k of a row) per thread and K-step: BM * 4 / 256
-  extern __shared__ __attribute__((aligned(16))) unsigned short gb_smem[];
-  unsigned short* Xs = gb_smem;                  // [3][BM][GB_RS]
-  unsigned short* Ws = gb_smem + 3 * BM * GB_RS;  // [3][BN][GB_RS]
+  constexpr int BM = 256, BN = 32 * NT;
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[2][NT][3][64 * 8];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wm = w / WN, wn = w - wm * WN;
+  const int j = lane & 31, g = lane >> 5;
   // XCD-aware tile order, the column tiles of one row tile next to each other (gemm.hip)
   const int tiles_n = (Co + BN - 1) / BN;
   const int tile = r3d_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
   const int tile_m = tile / tiles_n;
-  const long m0 = (long)tile_m * BM;
+  const long mw = (long)tile_m * BM + 64 * w;  // the wave's 64 rows
   const int n0 = (tile - tile_m * tiles_n) * BN;
-  // staging map: chunk c = tid + 256 u -> row c >> 2, k-chunk c & 3 (four consecutive threads cover the 128 bytes of a
-  // row's K-step).  Rows beyond M / Co are clamped duplicates whose products only reach outputs that are never stored.
-  const float* xp[XU];
-  const float* wp[WU];
+  // rows beyond M / Co are clamped duplicates whose products only reach outputs that are never stored
+  const float* pa[2];
 #pragma unroll
-  for (int u = 0; u < XU; ++u) {
-    const int c = tid + 256 * u;
-    xp[u] = X + min(m0 + (c >> 2), (long)M - 1) * ldx + 8 * (c & 3);
-  }
+  for (int tm = 0; tm < 2; ++tm) pa[tm] = X + min(mw + 32 * tm + j, (long)M - 1) * ldx + 8 * g;
+  // W staging: thread t cuts the 8 k of half (t & 1) of row (t >> 1) of the tile (NT = 2: threads 0..127)
+  const bool wstage = tid < 2 * BN;
+  const int wrow = tid >> 1, whalf = tid & 1;
+  const float* pw = W + (long)min(n0 + wrow, Co - 1) * K + 8 * whalf;
+  unsigned short* wdst = &Bs[0][wrow >> 5][0][((wrow & 31) + 32 * whalf) * 8];
+  constexpr int BUF = NT * 3 * 64 * 8;  // bf16 per buffer
+  float araw[2][8], wraw[8];
+  auto aload = [&](int k) {
 #pragma unroll
-  for (int u = 0; u < WU; ++u) {
-    const int c = tid + 256 * u;
-    wp[u] = W + (long)min(n0 + (c >> 2), Co - 1) * K + 8 * (c & 3);
-  }
-  float xr[XU][8], wr[WU][8];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int u = 0; u < XU; ++u) {
-      const float4 a = *reinterpret_cast<const float4*>(xp[u] + k0), b = *reinterpret_cast<const float4*>(xp[u] + k0 + 4);
-      xr[u][0] = a.x; xr[u][1] = a.y; xr[u][2] = a.z; xr[u][3] = a.w; xr[u][4] = b.x; xr[u][5] = b.y; xr[u][6] = b.z; xr[u][7] = b.w;
-    }
-#pragma unroll
-    for (int u = 0; u < WU; ++u) {
-      const float4 a = *reinterpret_cast<const float4*>(wp[u] + k0), b = *reinterpret_cast<const float4*>(wp[u] + k0 + 4);
-      wr[u][0] = a.x; wr[u][1] = a.y; wr[u][2] = a.z; wr[u][3] = a.w; wr[u][4] = b.x; wr[u][5] = b.y; wr[u][6] = b.z; wr[u][7] = b.w;
+    for (int tm = 0; tm < 2; ++tm) {
+      const float4 a = *reinterpret_cast<const float4*>(pa[tm] + k), b = *reinterpret_cast<const float4*>(pa[tm] + k + 4);
+      araw[tm][0] = a.x; araw[tm][1] = a.y; araw[tm][2] = a.z; araw[tm][3] = a.w;
+      araw[tm][4] = b.x; araw[tm][5] = b.y; araw[tm][6] = b.z; araw[tm][7] = b.w;
     }
   };
-  f32x16 acc[2][2];
+  auto wload = [&](int k) {
+    if (wstage) {
+      const float4 a = *reinterpret_cast<const float4*>(pw + k), b = *reinterpret_cast<const float4*>(pw + k + 4);
+      wraw[0] = a.x; wraw[1] = a.y; wraw[2] = a.z; wraw[3] = a.w; wraw[4] = b.x; wraw[5] = b.y; wraw[6] = b.z; wraw[7] = b.w;
+    }
+  };
+  auto wstore = [&](int buf) {
+    if (wstage) {
+#if GB_ABL & 2
+      r3d_bx3 f;
+      for (int i = 0; i < 4; ++i) { f.h[i] = __float_as_uint(wraw[i]); f.m[i] = __float_as_uint(wraw[4 + i]); f.l[i] = f.h[i] ^ f.m[i]; }
+#else
+      const r3d_bx3 f = r3d_bx3_split8(wraw);
+#endif
+      unsigned short* d = wdst + buf * BUF;
+      *reinterpret_cast<r3d_u32x4*>(d) = f.h;
+      *reinterpret_cast<r3d_u32x4*>(d + 64 * 8) = f.m;
+      *reinterpret_cast<r3d_u32x4*>(d + 2 * 64 * 8) = f.l;
+    }
+  };
+  f32x16 acc[2][NT];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NT; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  gload(0);
-  for (int k0 = 0; k0 < K; k0 += 32) {
-    // registers -> pieces -> LDS
-#pragma unroll
-    for (int u = 0; u < XU; ++u) { const int c = tid + 256 * u; gb_store_chunk(Xs, BM, c >> 2, c & 3, xr[u]); }
-#pragma unroll
-    for (int u = 0; u < WU; ++u) { const int c = tid + 256 * u; gb_store_chunk(Ws, BN, c >> 2, c & 3, wr[u]); }
-    __syncthreads();
-    if (k0 + 32 < K && !(GB_ABL & 8)) gload(k0 + 32);  // the next K-step's loads are in flight behind this step's MFMAs
-    __builtin_amdgcn_sched_barrier(0);
-    gb_wave_mma(Xs, BM, 64 * wm, Ws, BN, 64 * wn, lane, acc);
-    __syncthreads();
-  }
-  // epilogue: the wave's 64 x 64 quarter
-  const long mw = m0 + 64 * wm;
-#pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    const int j = n0 + 64 * wn + 32 * tn + (lane & 31);
-    const bool jok = j < Co;
-    const float sc = (scale && jok) ? scale[j] : 1.f;
-    const float sh = (shift && jok) ? shift[j] : 0.f;
-    float s1 = 0.f, s2 = 0.f;  // column sums of the values written (training: batch statistics of z)
+  wload(0);
+  aload(0);
+  wstore(0);
+  __syncthreads();
+  for (int k = 0, it = 0; k < K; k += 16, ++it) {
+    const int cur = it & 1;
+    const bool more = k + 16 < K;  // uniform
+    r3d_bx3 fa[2];
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
+#if GB_ABL & 2
+      for (int i = 0; i < 4; ++i) { fa[tm].h[i] = __float_as_uint(araw[tm][i]); fa[tm].m[i] = __float_as_uint(araw[tm][4 + i]); fa[tm].l[i] = fa[tm].h[i] ^ fa[tm].m[i]; }
+#else
+      fa[tm] = r3d_bx3_split8(araw[tm]);
+#endif
+    }
+    if (more && !(GB_ABL & 8)) {  // the next K-step's operands are in flight behind this step's MFMAs
+      wload(k + 16);
+      aload(k + 16);
+    }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long m = mw + 32 * tm + r3d_acc_row(r, lane);
-        if (m >= M || !jok) continue;
-        if ((GB_ABL & 1) && acc[tm][tn][r] != 12345.678f) continue;
-        float v = sc * acc[tm][tn][r] + sh;
-        if (act == GB_ACT_RELU) v = fmaxf(v, 0.f);
-        else if (act == GB_ACT_LRELU02) v = v > 0.f ? v : 0.2f * v;
-        Out[m * ldo + j] = accumulate ? Out[m * ldo + j] + v : v;
-        s1 += v;
-        s2 += v * v;
+    for (int tn = 0; tn < NT; ++tn) {
+      if (n0 + 32 * tn >= Co) break;  // uniform: a column tile beyond the last column
+      r3d_bx3 fb;
+      const unsigned short* bsrc = &Bs[cur][tn][0][lane * 8];
+      fb.h = *reinterpret_cast<const r3d_u32x4*>(bsrc);
+      fb.m = *reinterpret_cast<const r3d_u32x4*>(bsrc + 64 * 8);
+      fb.l = *reinterpret_cast<const r3d_u32x4*>(bsrc + 2 * 64 * 8);
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) acc[tm][tn] = r3d_bx3_mma(fa[tm], fb, acc[tm][tn]);
+    }
+    if (more) wstore(cur ^ 1);
+    __syncthreads();
+  }
+  // Epilogue.  An accumulator register holds ONE column for the lane: stored as it lies, a wave instruction writes two
+  // 128-byte pieces of two rows, and the chip took 190 of this kernel's 450 us (192 -> 512 channels) to absorb the
+  // output that way.  So the wave's tile goes through LDS (the W buffers, free after the last barrier; wave-private
+  // regions, no barrier) 8 rows at a time and leaves as 16 bytes per lane, whole rows of BN columns per instruction:
+  // 290 us for the same layer (profiles/r03_experiments.md).
+  constexpr int ER = BN + 4;  // floats per staged row
+  float* es = reinterpret_cast<float*>(&Bs[0][0][0][0]) + w * 8 * ER;
+  constexpr int LPR = BN / 4;          // lanes per row of the tile (16 bytes each)
+  constexpr int RPI = 64 / LPR;        // rows per store instruction
+  const int erow = lane / LPR, ecol = 4 * (lane % LPR);
+  const bool cok = n0 + ecol < Co;     // (Co % 4 == 0: a lane's four columns are inside or outside together)
+  float sc[NT], sh[NT], s1[NT], s2[NT];
+#pragma unroll
+  for (int tn = 0; tn < NT; ++tn) {
+    const int jc = n0 + 32 * tn + j;
+    sc[tn] = (scale && jc < Co) ? scale[jc] : 1.f;
+    sh[tn] = (shift && jc < Co) ? shift[jc] : 0.f;
+    s1[tn] = s2[tn] = 0.f;
+  }
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // registers 4q .. 4q+3: rows 32 tm + 8 q + 4 g + (0..3)
+      const long mrow0 = mw + 32 * tm + 8 * q;
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = sc[tn] * acc[tm][tn][4 * q + i] + sh[tn];
+          if (act == GB_ACT_RELU) v = fmaxf(v, 0.f);
+          else if (act == GB_ACT_LRELU02) v = v > 0.f ? v : 0.2f * v;
+          es[(4 * g + i) * ER + 32 * tn + j] = v;
+          if (mrow0 + 4 * g + i < M) {  // column sums of the values written (training: batch statistics of z)
+            s1[tn] += v;
+            s2[tn] += v * v;
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8 / RPI; ++i) {
+        const int row = erow + RPI * i;
+        const long m = mrow0 + row;
+        const float4 v = *reinterpret_cast<const float4*>(&es[row * ER + ecol]);
+        if (m < M && cok && !(GB_ABL & 1)) {
+          float4* dst = reinterpret_cast<float4*>(&Out[m * ldo + n0 + ecol]);
+          if (accumulate) {
+            const float4 o = *dst;
+            *dst = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+          } else {
+            *dst = v;
+          }
+        }
       }
     }
-    if (stats_part) {  // uniform.  The rows of one column sit in lanes l and l ^ 32; the wave owns its 64-row tile's columns
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (lane < 32 && jok && mw < M) {
-        const long t64 = mw >> 6;
-        stats_part[(t64 * 2 + 0) * Co + j] = s1;
-        stats_part[(t64 * 2 + 1) * Co + j] = s2;
+  }
+  if (stats_part && mw < M) {  // uniform.  The rows of one column sit in lanes l and l ^ 32; the wave owns its 64-row tile
+    const long t64 = mw >> 6;
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) {
+      const int jc = n0 + 32 * tn + j;
+      const float a1 = s1[tn] + __shfl_xor(s1[tn], 32), a2 = s2[tn] + __shfl_xor(s2[tn], 32);
+      if (lane < 32 && jc < Co) {
+        stats_part[(t64 * 2 + 0) * Co + jc] = a1;
+        stats_part[(t64 * 2 + 1) * Co + jc] = a2;
       }
     }
   }
@@ -279,30 +346,23 @@ static int gb_lds_attr(KernelT k, size_t bytes) {
 }
 
 bool r3d_pointwise_bx3_ok(const float* X, long ldx, const float* W, long M, int K, int Co) {
-  return g_r3d_matrix_arith == 1 && K >= 32 && K % 32 == 0 && (ldx & 3) == 0 && ((uintptr_t)X & 15) == 0 &&
-         ((uintptr_t)W & 15) == 0 && Co >= 32 && M >= 64;
+  return g_r3d_matrix_arith == 1 && K >= 16 && K % 16 == 0 && (ldx & 3) == 0 && ((uintptr_t)X & 15) == 0 &&
+         ((uintptr_t)W & 15) == 0 && Co >= 32 && Co % 4 == 0 && M >= 64;
 }
 
 int r3d_pointwise_bx3_launch(const float* X, long ldx, const float* W, long M, int K, int Co, const float* scale,
                              const float* shift, int act, float* Out, long ldo, int accumulate, float* stats_part,
                              hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
-    R3D_REQUIRE(gb_lds_attr(r3d_pointwise_gemm_bx3_kernel<2, 2>, GB_LDS_22) == 0 &&
-                    gb_lds_attr(r3d_pointwise_gemm_bx3_kernel<4, 1>, GB_LDS_41) == 0,
-                "r3d_pointwise_conv: cannot reserve %zu B of LDS", GB_LDS_41);
-    attr = true;
-  }
-  if (Co > 64) {  // 128 x 128 tiles
-    const long tiles = (long)r3d_cdiv(M, 128) * r3d_cdiv(Co, 128);
-    R3D_REQUIRE(tiles < 0x7fffffffL, "r3d_pointwise_conv: too many tiles");
-    hipLaunchKernelGGL((r3d_pointwise_gemm_bx3_kernel<2, 2>), dim3((unsigned)tiles), dim3(256), GB_LDS_22, st, X, ldx, W, (int)M, K, Co,
-                       scale, shift, act, Out, ldo, accumulate, stats_part);
-  } else {        // 256 x 64 tiles
-    const long tiles = (long)r3d_cdiv(M, 256);
-    hipLaunchKernelGGL((r3d_pointwise_gemm_bx3_kernel<4, 1>), dim3((unsigned)tiles), dim3(256), GB_LDS_41, st, X, ldx, W, (int)M, K, Co,
-                       scale, shift, act, Out, ldo, accumulate, stats_part);
-  }
+  if ((ldo & 3) != 0 || ((uintptr_t)Out & 15) != 0) return -1;  // (the caller takes the fp32 kernel)
+  const int bn = Co > 64 ? 128 : 64;
+  const long tiles = (long)r3d_cdiv(M, 256) * r3d_cdiv(Co, bn);
+  R3D_REQUIRE(tiles < 0x7fffffffL, "r3d_pointwise_conv: too many tiles");
+  if (bn == 128)
+    hipLaunchKernelGGL((r3d_pointwise_gemm_bx3_kernel<4>), dim3((unsigned)tiles), dim3(256), 0, st, X, ldx, W, (int)M, K, Co, scale,
+                       shift, act, Out, ldo, accumulate, stats_part);
+  else
+    hipLaunchKernelGGL((r3d_pointwise_gemm_bx3_kernel<2>), dim3((unsigned)tiles), dim3(256), 0, st, X, ldx, W, (int)M, K, Co, scale,
+                       shift, act, Out, ldo, accumulate, stats_part);
   return R3D_OK;
 }
 
