@@ -68,7 +68,7 @@ static __device__ __forceinline__ void gb_wave_mma(const unsigned short* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Out[m][j] = act(scale[j] * sum_k X[m][k] W[j][k] + shift[j])   (+ Out if accumulate); K % 16 == 0, rows of X 16-byte
+// Out[m][j] = act(scale[j] * sum_k X[m][k] W[j][k] + shift[j])   (+ Out if accumulate); K % 32 == 0, rows of X 16-byte
 // aligned.  stats_part (optional): [ceil(M / 64)][2][Co] column sums (sum v, sum v^2) of every 64-row tile: the
 // BatchNorm batch statistics from the epilogue, partitioned exactly like the fp32 kernel's.
 //
@@ -86,7 +86,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
     const float* __restrict__ scale, const float* __restrict__ shift, int act, float* __restrict__ Out, long ldo,
     int accumulate, float* __restrict__ stats_part) {
   constexpr int BM = 256, BN = 32 * NT;
-  __shared__ __attribute__((aligned(16))) unsigned short Bs[2][NT][3][64 * 8];
+  // one K-step = 32 k = two MFMA steps s.  The k owned by a lane's half g are the 16 CONSECUTIVE ones [16 g, 16 g + 16)
+  // of the step (MFMA step s takes 16 g + 8 s + 0..7): a lane reads 64 contiguous bytes of its row per K-step, the two
+  // halves of a row one whole 128-byte line.  (Any assignment of k to the MFMA's contraction slots is valid as long as
+  // both operands use it: W is staged accordingly.)
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[2][2][NT][3][64 * 8];  // [buffer][s][n-tile][piece][lane]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int j = lane & 31, g = lane >> 5;
   // XCD-aware tile order, the column tiles of one row tile next to each other (gemm.hip)
@@ -95,43 +99,81 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   const int tile_m = tile / tiles_n;
   const long mw = (long)tile_m * BM + 64 * w;  // the wave's 64 rows
   const int n0 = (tile - tile_m * tiles_n) * BN;
-  // rows beyond M / Co are clamped duplicates whose products only reach outputs that are never stored
-  const float* pa[2];
+  // Operands come through buffer loads: rows beyond M / Co read as zeros (the descriptor's range check), and -- the
+  // reason for using them -- the compiler keeps these intrinsics where they are written, where it gathers plain loads
+  // of neighbouring addresses in one place and then waits for all of them at once.
+  const long m0 = (long)tile_m * BM;
+  const long arows = min((long)BM, (long)M - m0);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(X + m0 * ldx), 0, (int)(((arows - 1) * ldx + K) * 4), 0x00020000);
+  const int wrows = min(BN, Co - n0);
+  const __amdgpu_buffer_rsrc_t rw =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(W + (long)n0 * K), 0, wrows * K * 4, 0x00020000);
+  int oa[2];  // byte offsets of the lane's operands inside the tile
 #pragma unroll
-  for (int tm = 0; tm < 2; ++tm) pa[tm] = X + min(mw + 32 * tm + j, (long)M - 1) * ldx + 8 * g;
-  // W staging: thread t cuts the 8 k of half (t & 1) of row (t >> 1) of the tile (NT = 2: threads 0..127)
-  const bool wstage = tid < 2 * BN;
-  const int wrow = tid >> 1, whalf = tid & 1;
-  const float* pw = W + (long)min(n0 + wrow, Co - 1) * K + 8 * whalf;
-  unsigned short* wdst = &Bs[0][wrow >> 5][0][((wrow & 31) + 32 * whalf) * 8];
-  constexpr int BUF = NT * 3 * 64 * 8;  // bf16 per buffer
-  float araw[2][8], wraw[8];
-  auto aload = [&](int k) {
+  for (int tm = 0; tm < 2; ++tm) oa[tm] = (int)(((64 * w + 32 * tm + j) * ldx + 16 * g) * 4);
+  // W staging: BN rows x 4 chunks of 8 k per K-step, chunk c = 2 g + s; thread t cuts chunk (t & 3) of rows (t >> 2) + 64 u
+  constexpr int WU = BN / 64;
+  const int wc = tid & 3;
+  int ow[WU];
+  unsigned short* wdst[WU];
+#pragma unroll
+  for (int u = 0; u < WU; ++u) {
+    const int wrow = (tid >> 2) + 64 * u;
+    ow[u] = (wrow * K + 8 * wc) * 4;
+    wdst[u] = &Bs[0][wc & 1][wrow >> 5][0][((wrow & 31) + 32 * (wc >> 1)) * 8];
+  }
+  constexpr int BUF = 2 * NT * 3 * 64 * 8;  // bf16 per buffer
+  float araw[2][2][8], wraw[WU][8];        // araw[s][tm]
+  auto ld8 = [&](const __amdgpu_buffer_rsrc_t r, int voff, int soff, float (&d)[8]) {
+    const r3d_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    const r3d_u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16, soff, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { d[i] = __uint_as_float(a[i]); d[4 + i] = __uint_as_float(b[i]); }
+  };
+  auto aload = [&](int k, int s) {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) ld8(ra, oa[tm] + 32 * s, k * 4, araw[s][tm]);
+  };
+  auto asplit = [&](int s, r3d_bx3 (&fa)[2]) {
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
-      const float4 a = *reinterpret_cast<const float4*>(pa[tm] + k), b = *reinterpret_cast<const float4*>(pa[tm] + k + 4);
-      araw[tm][0] = a.x; araw[tm][1] = a.y; araw[tm][2] = a.z; araw[tm][3] = a.w;
-      araw[tm][4] = b.x; araw[tm][5] = b.y; araw[tm][6] = b.z; araw[tm][7] = b.w;
+#if GB_ABL & 2
+      for (int i = 0; i < 4; ++i) { fa[tm].h[i] = __float_as_uint(araw[s][tm][i]); fa[tm].m[i] = __float_as_uint(araw[s][tm][4 + i]); fa[tm].l[i] = fa[tm].h[i] ^ fa[tm].m[i]; }
+#else
+      fa[tm] = r3d_bx3_split8(araw[s][tm]);
+#endif
     }
   };
   auto wload = [&](int k) {
-    if (wstage) {
-      const float4 a = *reinterpret_cast<const float4*>(pw + k), b = *reinterpret_cast<const float4*>(pw + k + 4);
-      wraw[0] = a.x; wraw[1] = a.y; wraw[2] = a.z; wraw[3] = a.w; wraw[4] = b.x; wraw[5] = b.y; wraw[6] = b.z; wraw[7] = b.w;
-    }
+#pragma unroll
+    for (int u = 0; u < WU; ++u) ld8(rw, ow[u], k * 4, wraw[u]);
   };
   auto wstore = [&](int buf) {
-    if (wstage) {
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {
 #if GB_ABL & 2
       r3d_bx3 f;
-      for (int i = 0; i < 4; ++i) { f.h[i] = __float_as_uint(wraw[i]); f.m[i] = __float_as_uint(wraw[4 + i]); f.l[i] = f.h[i] ^ f.m[i]; }
+      for (int i = 0; i < 4; ++i) { f.h[i] = __float_as_uint(wraw[u][i]); f.m[i] = __float_as_uint(wraw[u][4 + i]); f.l[i] = f.h[i] ^ f.m[i]; }
 #else
-      const r3d_bx3 f = r3d_bx3_split8(wraw);
+      const r3d_bx3 f = r3d_bx3_split8(wraw[u]);
 #endif
-      unsigned short* d = wdst + buf * BUF;
+      unsigned short* d = wdst[u] + buf * BUF;
       *reinterpret_cast<r3d_u32x4*>(d) = f.h;
       *reinterpret_cast<r3d_u32x4*>(d + 64 * 8) = f.m;
       *reinterpret_cast<r3d_u32x4*>(d + 2 * 64 * 8) = f.l;
+    }
+  };
+  auto mma = [&](int buf, int s, const r3d_bx3 (&fa)[2], f32x16 (&acc)[2][NT]) {
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) {  // (no branch in the K loop: the wait counts below must be exact, see the loop)
+      r3d_bx3 fb;
+      const unsigned short* bsrc = &Bs[buf][s][tn][0][lane * 8];
+      fb.h = *reinterpret_cast<const r3d_u32x4*>(bsrc);
+      fb.m = *reinterpret_cast<const r3d_u32x4*>(bsrc + 64 * 8);
+      fb.l = *reinterpret_cast<const r3d_u32x4*>(bsrc + 2 * 64 * 8);
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) acc[tm][tn] = r3d_bx3_mma(fa[tm], fb, acc[tm][tn]);
     }
   };
   f32x16 acc[2][NT];
@@ -142,37 +184,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   wload(0);
-  aload(0);
+  aload(0, 0);
+  aload(0, 1);
   wstore(0);
   __syncthreads();
-  for (int k = 0, it = 0; k < K; k += 16, ++it) {
+  // The loop body is free of branches on purpose: behind a conditional load the compiler can no longer count the
+  // loads in flight and waits for ALL of them (s_waitcnt vmcnt(0)) before touching the previous step's registers --
+  // which makes the prefetch synchronous.  The last step therefore requests its own operands once more (k clamped)
+  // and stages them into the buffer nobody reads again.
+  for (int k = 0, it = 0; k < K; k += 32, ++it) {
     const int cur = it & 1;
-    const bool more = k + 16 < K;  // uniform
-    r3d_bx3 fa[2];
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-#if GB_ABL & 2
-      for (int i = 0; i < 4; ++i) { fa[tm].h[i] = __float_as_uint(araw[tm][i]); fa[tm].m[i] = __float_as_uint(araw[tm][4 + i]); fa[tm].l[i] = fa[tm].h[i] ^ fa[tm].m[i]; }
-#else
-      fa[tm] = r3d_bx3_split8(araw[tm]);
-#endif
-    }
-    if (more && !(GB_ABL & 8)) {  // the next K-step's operands are in flight behind this step's MFMAs
-      wload(k + 16);
-      aload(k + 16);
-    }
-#pragma unroll
-    for (int tn = 0; tn < NT; ++tn) {
-      if (n0 + 32 * tn >= Co) break;  // uniform: a column tile beyond the last column
-      r3d_bx3 fb;
-      const unsigned short* bsrc = &Bs[cur][tn][0][lane * 8];
-      fb.h = *reinterpret_cast<const r3d_u32x4*>(bsrc);
-      fb.m = *reinterpret_cast<const r3d_u32x4*>(bsrc + 64 * 8);
-      fb.l = *reinterpret_cast<const r3d_u32x4*>(bsrc + 2 * 64 * 8);
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm) acc[tm][tn] = r3d_bx3_mma(fa[tm], fb, acc[tm][tn]);
-    }
-    if (more) wstore(cur ^ 1);
+    const int kn = (GB_ABL & 8) ? 0 : min(k + 32, K - 32);
+    // the next K-step's operands are requested as soon as their registers are free, one K-step of MFMAs ahead of their use
+    r3d_bx3 fa0[2], fa1[2];
+    asplit(0, fa0);
+    wload(kn);
+    aload(kn, 0);
+    __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the loads to just in front of their use)
+    mma(cur, 0, fa0, acc);
+    asplit(1, fa1);
+    aload(kn, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(cur, 1, fa1, acc);
+    wstore(cur ^ 1);
     __syncthreads();
   }
   // Epilogue.  An accumulator register holds ONE column for the lane: stored as it lies, a wave instruction writes two
@@ -181,7 +215,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   // regions, no barrier) 8 rows at a time and leaves as 16 bytes per lane, whole rows of BN columns per instruction:
   // 290 us for the same layer (profiles/r03_experiments.md).
   constexpr int ER = BN + 4;  // floats per staged row
-  float* es = reinterpret_cast<float*>(&Bs[0][0][0][0]) + w * 8 * ER;
+  float* es = reinterpret_cast<float*>(&Bs[0][0][0][0][0]) + w * 8 * ER;
   constexpr int LPR = BN / 4;          // lanes per row of the tile (16 bytes each)
   constexpr int RPI = 64 / LPR;        // rows per store instruction
   const int erow = lane / LPR, ecol = 4 * (lane % LPR);
@@ -266,39 +300,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   const int chunk = tile / (nti * ntj), tij = tile - chunk * (nti * ntj);
   const int i0 = (tij % nti) * BM, j0 = (tij / nti) * BN;
   const long m_beg = (long)chunk * tn_rows, m_end = min(M, m_beg + tn_rows);
-  // staging map: chunk c = tid + 256 u -> column c % BM (consecutive threads: consecutive columns), row group c / BM (8 rows)
-  const float* ap[XU];
-  const float* bp[WU];
-  int amc[XU], bmc[WU];
+  // staging map: chunk c = tid + 256 u -> column c % BM (consecutive threads: consecutive columns), row group c / BM (8 rows).
+  // Buffer loads over the chunk's rows: rows beyond m_end read as zeros (they enter every sum), and the loop body stays
+  // free of branches, so the compiler counts the loads in flight exactly (see the pointwise kernel).
+  const int crows = (int)(m_end - m_beg);
+  const __amdgpu_buffer_rsrc_t ra =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(A + m_beg * lda), 0, (int)(((long)(crows - 1) * lda + Ca) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(B + m_beg * ldb), 0, (int)(((long)(crows - 1) * ldb + Cb) * 4), 0x00020000);
+  const int lda4 = (int)lda * 4, ldb4 = (int)ldb * 4;
+  int ao[XU], bo[WU], amc[XU], bmc[WU];
 #pragma unroll
   for (int u = 0; u < XU; ++u) {
     const int c = tid + 256 * u;
-    ap[u] = A + min(i0 + c % BM, Ca - 1);
     amc[u] = c / BM;
+    ao[u] = 8 * amc[u] * lda4 + 4 * min(i0 + c % BM, Ca - 1);
   }
 #pragma unroll
   for (int u = 0; u < WU; ++u) {
     const int c = tid + 256 * u;
-    bp[u] = B + min(j0 + c % BN, Cb - 1);
     bmc[u] = c / BN;
+    bo[u] = 8 * bmc[u] * ldb4 + 4 * min(j0 + c % BN, Cb - 1);
   }
   float ar[XU][8], br[WU][8];
-  auto gload = [&](long mk) {  // rows beyond m_end must be zero: they enter every sum
-    const bool full = mk + 32 <= m_end;  // uniform
+  auto gload = [&](int mk) {  // mk: row of the chunk (all of the offset in the vector part: that is what is range-checked)
 #pragma unroll
     for (int u = 0; u < XU; ++u)
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const long m = mk + 8 * amc[u] + t;
-        ar[u][t] = full ? ap[u][m * lda] : r3d_keep(ap[u][min(m, M - 1) * lda], m < m_end);
-      }
+      for (int t = 0; t < 8; ++t) ar[u][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, ao[u] + (mk + t) * lda4, 0, 0));
 #pragma unroll
     for (int u = 0; u < WU; ++u)
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const long m = mk + 8 * bmc[u] + t;
-        br[u][t] = full ? bp[u][m * ldb] : r3d_keep(bp[u][min(m, M - 1) * ldb], m < m_end);
-      }
+      for (int t = 0; t < 8; ++t) br[u][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, bo[u] + (mk + t) * ldb4, 0, 0));
   };
   f32x16 acc[2][2];
 #pragma unroll
@@ -307,14 +340,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  gload(m_beg);
-  for (long mk = m_beg; mk < m_end; mk += 32) {
+  gload(0);
+  for (int mk = 0; mk < crows; mk += 32) {
 #pragma unroll
     for (int u = 0; u < XU; ++u) { const int c = tid + 256 * u; gb_store_chunk(As, BM, c % BM, amc[u], ar[u]); }
 #pragma unroll
     for (int u = 0; u < WU; ++u) { const int c = tid + 256 * u; gb_store_chunk(Bs, BN, c % BN, bmc[u], br[u]); }
     __syncthreads();
-    if (mk + 32 < m_end) gload(mk + 32);
+    gload(mk + 32);  // (behind the last step: all rows out of range, zeros nobody uses)
     __builtin_amdgcn_sched_barrier(0);
     gb_wave_mma(As, BM, 64 * wm, Bs, BN, 64 * wn, lane, acc);
     __syncthreads();
@@ -346,7 +379,7 @@ static int gb_lds_attr(KernelT k, size_t bytes) {
 }
 
 bool r3d_pointwise_bx3_ok(const float* X, long ldx, const float* W, long M, int K, int Co) {
-  return g_r3d_matrix_arith == 1 && K >= 16 && K % 16 == 0 && (ldx & 3) == 0 && ((uintptr_t)X & 15) == 0 &&
+  return g_r3d_matrix_arith == 1 && K >= 32 && K % 32 == 0 && (ldx & 3) == 0 && ((uintptr_t)X & 15) == 0 &&
          ((uintptr_t)W & 15) == 0 && Co >= 32 && Co % 4 == 0 && M >= 64;
 }
 
@@ -354,7 +387,7 @@ int r3d_pointwise_bx3_launch(const float* X, long ldx, const float* W, long M, i
                              const float* shift, int act, float* Out, long ldo, int accumulate, float* stats_part,
                              hipStream_t st) {
   if ((ldo & 3) != 0 || ((uintptr_t)Out & 15) != 0) return -1;  // (the caller takes the fp32 kernel)
-  const int bn = Co > 64 ? 128 : 64;
+  const int bn = (Co > 64 && !(GB_ABL & 64)) ? 128 : 64;  // (probe bit 64: 64-column tiles for every layer)
   const long tiles = (long)r3d_cdiv(M, 256) * r3d_cdiv(Co, bn);
   R3D_REQUIRE(tiles < 0x7fffffffL, "r3d_pointwise_conv: too many tiles");
   if (bn == 128)
