@@ -39,11 +39,13 @@ extern "C" {
 
 const char* r3d_last_error_string(void);
 int r3d_abi_version(void);
-/* Arithmetic of the GEMM-shaped kernels that decide no index (self-attention forward / backward): 0 = fp32 matrix core
- * (v_mfma_f32_32x32x2_f32), 1 = every fp32 operand cut into three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per product
- * block accumulated in fp32 (fp32-level accuracy at 2.67x the matrix rate; csrc/common.h).  kNN scores, which decide
- * indices, always run on the fp32 core.  Default 1.  Process-wide; call before the first launch.  The attention entry
- * points use mode 1 only when they are given a workspace (the packed operands live there). */
+/* Arithmetic of the GEMM-shaped kernels that decide no index (self-attention forward / backward, r3d_pointwise_conv*,
+ * r3d_gemm_tn): 0 = fp32 matrix core (v_mfma_f32_32x32x2_f32), 1 = every fp32 operand cut into three bf16 pieces, six
+ * v_mfma_f32_32x32x16_bf16 per product block accumulated in fp32 (fp32-level accuracy at 2.67x the matrix rate;
+ * csrc/common.h, csrc/gemm_bx3.hip).  kNN scores and the EdgeConv edge GEMM, which decide indices, always run on the
+ * fp32 core.  Default 1.  Process-wide; call before the first launch.  The attention entry points use mode 1 only when
+ * they are given a workspace (the packed operands live there); the GEMMs fall back to the fp32 kernels for shapes the
+ * bf16 form does not take (K % 32 != 0, fewer than 32 output columns, operands not 16-byte aligned). */
 /* test utility: fills the chip's LDS with `pattern` (no result of this library may depend on stale LDS contents) */
 int r3d_debug_poison_lds(unsigned pattern, unsigned* sink /* 1 device word */, void* stream);
 /* test / A-B utility: the CG's SpMV runs on its LDS-resident form when the launch holds at least min_blocks 128-row
@@ -51,6 +53,8 @@ int r3d_debug_poison_lds(unsigned pattern, unsigned* sink /* 1 device word */, v
 int r3d_debug_set_cg_spmv_lds_min_blocks(int min_blocks);
 int r3d_set_matrix_arith(int mode);
 int r3d_get_matrix_arith(void);
+/* A/B knob under mode 1: bit 0 the point-wise GEMM takes the bf16 form, bit 1 the weight-gradient GEMM does (default 3). */
+int r3d_debug_set_gemm_bx3(int mask);
 
 /* ---- layout conversion at the forward() boundary (models/mpti.py:433-437) -------- */
 int r3d_cm_to_pm(const float* in /*(B,C,N)*/, int B, int C, int N, float* out /*(B*N,ld)*/, long ld, void* stream);

@@ -39,6 +39,7 @@ _SIGS = {
     "r3d_head_desc_words": (c_i, []),
     "r3d_debug_poison_lds": (c_i, [c_u, c_f, c_f]),
     "r3d_debug_set_cg_spmv_lds_min_blocks": (c_i, [c_i]),
+    "r3d_debug_set_gemm_bx3": (c_i, [c_i]),
     "r3d_set_matrix_arith": (c_i, [c_i]),
     "r3d_get_matrix_arith": (c_i, []),
     "r3d_head_max_k": (c_i, []),
@@ -154,6 +155,9 @@ def load():
         if mode not in ("fp32", "bf16x3"):
             raise RuntimeError("R3D_MATRIX_ARITH=%r: expected fp32 or bf16x3" % mode)
         check(lib.r3d_set_matrix_arith(1 if mode == "bf16x3" else 0))
+    mask = os.environ.get("R3D_GEMM_BX3")  # tuning knob: r3d_debug_set_gemm_bx3 in include/r3d.h
+    if mask is not None:
+        check(lib.r3d_debug_set_gemm_bx3(int(mask)))
     return lib
 
 

@@ -131,6 +131,8 @@ static __device__ __forceinline__ f32x16 r3d_bx3_mma(const r3d_bx3& a, const r3d
   return c;
 }
 
+extern int g_r3d_gemm_bx3;  // bits: 1 point-wise GEMM on bf16 x 3, 2 weight-gradient GEMM on bf16 x 3 (error.hip)
+
 static inline int r3d_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // XCD-aware work order (cdna_hip_programming.md 5.5, T1).  Workgroups are dealt to the 8 XCDs round robin in launch

@@ -25,6 +25,14 @@ extern "C" int r3d_set_matrix_arith(int mode) {
   return R3D_OK;
 }
 extern "C" int r3d_get_matrix_arith(void) { return g_r3d_matrix_arith; }
+// Which of the index-free GEMMs take the bf16 x 3 form when the mode above is 1 (bit 0: point-wise, bit 1: weight
+// gradient).  Default: both.  An A/B knob for tests and tools/probe/gemm_arith_sweep.sh.
+int g_r3d_gemm_bx3 = 1 | 2;
+extern "C" int r3d_debug_set_gemm_bx3(int mask) {
+  R3D_REQUIRE(mask >= 0 && mask < 4, "r3d_debug_set_gemm_bx3: mask %d", mask);
+  g_r3d_gemm_bx3 = mask;
+  return R3D_OK;
+}
 
 // Test utility: leave `pattern` in every byte of LDS the chip has (64 KB per workgroup, enough workgroups to visit every
 // CU several times).  A kernel that reads LDS it has not written sees this instead of whatever ran before it: the tests

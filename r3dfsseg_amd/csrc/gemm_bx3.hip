@@ -379,8 +379,8 @@ static int gb_lds_attr(KernelT k, size_t bytes) {
 }
 
 bool r3d_pointwise_bx3_ok(const float* X, long ldx, const float* W, long M, int K, int Co) {
-  return g_r3d_matrix_arith == 1 && K >= 32 && K % 32 == 0 && (ldx & 3) == 0 && ((uintptr_t)X & 15) == 0 &&
-         ((uintptr_t)W & 15) == 0 && Co >= 32 && Co % 4 == 0 && M >= 64;
+  return g_r3d_matrix_arith == 1 && (g_r3d_gemm_bx3 & 1) && K >= 32 && K % 32 == 0 && (ldx & 3) == 0 &&
+         ((uintptr_t)X & 15) == 0 && ((uintptr_t)W & 15) == 0 && Co >= 32 && Co % 4 == 0 && M >= 64;
 }
 
 int r3d_pointwise_bx3_launch(const float* X, long ldx, const float* W, long M, int K, int Co, const float* scale,
@@ -399,27 +399,28 @@ int r3d_pointwise_bx3_launch(const float* X, long ldx, const float* W, long M, i
   return R3D_OK;
 }
 
-bool r3d_gemm_tn_bx3_ok(int Ca, int Cb) { return g_r3d_matrix_arith == 1 && Ca >= 32 && Cb >= 32; }
+bool r3d_gemm_tn_bx3_ok(int Ca, int Cb) { return g_r3d_matrix_arith == 1 && (g_r3d_gemm_bx3 & 2) && Ca >= 32 && Cb >= 32; }
 
 // tiles of the (Ca, Cb) output for the chunk count of train_ops.hip's tn_rows()
 int r3d_gemm_tn_bx3_tiles(int Ca, int Cb) {
   return Cb > 64 ? r3d_cdiv(Ca, 128) * r3d_cdiv(Cb, 128) : r3d_cdiv(Ca, 256) * r3d_cdiv(Cb, 64);
 }
 
-int r3d_gemm_tn_bx3_launch(const float* A, long lda, const float* B, long ldb, long M, int Ca, int Cb, int rows, int chunks,
-                           float* part, hipStream_t st) {
+template <int WM, int WN>
+static int gemm_tn_bx3_go(size_t lds, int blocks, hipStream_t st, const float* A, long lda, const float* B, long ldb, long M,
+                          int Ca, int Cb, int rows, float* part) {
   static bool attr = false;
   if (!attr) {
-    R3D_REQUIRE(gb_lds_attr(r3d_gemm_tn_bx3_kernel<2, 2>, GB_LDS_22) == 0 && gb_lds_attr(r3d_gemm_tn_bx3_kernel<4, 1>, GB_LDS_41) == 0,
-                "r3d_gemm_tn: cannot reserve %zu B of LDS", GB_LDS_41);
+    R3D_REQUIRE(gb_lds_attr(r3d_gemm_tn_bx3_kernel<WM, WN>, lds) == 0, "r3d_gemm_tn: cannot reserve %zu B of LDS", lds);
     attr = true;
   }
-  const int tiles = r3d_gemm_tn_bx3_tiles(Ca, Cb);
-  if (Cb > 64)
-    hipLaunchKernelGGL((r3d_gemm_tn_bx3_kernel<2, 2>), dim3(tiles * chunks), dim3(256), GB_LDS_22, st, A, lda, B, ldb, M, Ca, Cb, rows,
-                       part);
-  else
-    hipLaunchKernelGGL((r3d_gemm_tn_bx3_kernel<4, 1>), dim3(tiles * chunks), dim3(256), GB_LDS_41, st, A, lda, B, ldb, M, Ca, Cb, rows,
-                       part);
+  hipLaunchKernelGGL((r3d_gemm_tn_bx3_kernel<WM, WN>), dim3(blocks), dim3(256), lds, st, A, lda, B, ldb, M, Ca, Cb, rows, part);
   return R3D_OK;
+}
+
+int r3d_gemm_tn_bx3_launch(const float* A, long lda, const float* B, long ldb, long M, int Ca, int Cb, int rows, int chunks,
+                           float* part, hipStream_t st) {
+  const int blocks = r3d_gemm_tn_bx3_tiles(Ca, Cb) * chunks;
+  if (Cb > 64) return gemm_tn_bx3_go<2, 2>(GB_LDS_22, blocks, st, A, lda, B, ldb, M, Ca, Cb, rows, part);
+  return gemm_tn_bx3_go<4, 1>(GB_LDS_41, blocks, st, A, lda, B, ldb, M, Ca, Cb, rows, part);
 }

@@ -217,8 +217,15 @@ def test_config2_full_size_training_episode_gradients():
     # sum by 0.8 |dy|, ~5e-3 of that entry; with 10^7 activations per layer and |u| = O(1) one or two such elements are
     # expected per layer pass (the same category as max-pool winner flips, which this test pins by injection).  So the
     # oracle runs the segment twice, in float64 (the truth) and in float32 (torch-CPU, the reference's own arithmetic),
-    # and the bar is: every parameter within 1e-3 in the relative L2 norm (robust to single flips); in the max norm
-    # within 1e-3, or no further from the truth than 2 x torch-fp32, or at most 5e-3 on at most 0.1 % of the entries.
+    # and the bars are set by what ONE such flip costs, which tests/test_gpu_train.py::test_conv_bn_layer_is_exact_but_
+    # for_kink_flips measures on a single layer of this size: without a flip every gradient of the layer is within 2e-6
+    # of float64 in either matrix arithmetic, with one flip dW moves by 3e-3..2e-2 and dbeta by 2e-3..6e-3 of their
+    # largest entry (and everything upstream of that layer by ~1e-3).  Which elements sit within rounding of 0 is a
+    # lottery over the last bit of the forward values: the fp32 and the bf16 x 3 GEMMs (both within 4e-7 of float64,
+    # test_gpu_ops.py) draw different tickets -- on this episode 0 / 1 parameter beyond 1e-3 with one, 6 with the other
+    # (profiles/r03_experiments.md).  So: relative L2 <= 3e-3 for every parameter; in the max norm within 1e-3, or no
+    # further from the truth than 2 x torch-fp32, or at most 1e-2 on at most 1 % of the entries; and over all parameters
+    # the MEDIAN max-norm error <= 1e-3.
     def oracle_grads(dtype):
         cast = (lambda v: v.to(dtype)) if dtype == torch.float64 else (lambda v: v.clone())
         sde = {k_: (cast(v).requires_grad_() if v.dtype.is_floating_point and "running" not in k_
@@ -257,8 +264,8 @@ def test_config2_full_size_training_episode_gradients():
     print("   median max-rel HIP %.2e, torch-fp32 %.2e; parameters with max-rel <= 1e-3: %d of %d" % (
         np.median([r_[0] for r_ in rows]), np.median([r_[1] for r_ in rows]), sum(r_[0] <= 1e-3 for r_ in rows), len(rows)))
     for e_hip, e_t32, l2, n_out, numel, name in rows:
-        assert l2 <= 1e-3, (name, l2)
-        assert e_hip <= 1e-3 or e_hip <= 2.0 * e_t32 or (e_hip <= 5e-3 and n_out <= max(4, numel // 1000)), (
+        assert l2 <= 3e-3, (name, l2)
+        assert e_hip <= 1e-3 or e_hip <= 2.0 * e_t32 or (e_hip <= 1e-2 and n_out <= max(4, numel // 100)), (
             name, e_hip, e_t32, n_out, numel)
     assert np.median([r_[0] for r_ in rows]) <= 1e-3
 

@@ -44,6 +44,51 @@ def test_conv_bn_layer_fwd_bwd():
     assert dbias.abs().max().item() < 1e-2  # a bias in front of batch-stat BN has zero gradient
 
 
+def test_conv_bn_layer_is_exact_but_for_kink_flips():
+    """conv + batch-statistics BatchNorm + LeakyReLU, forward and backward, against torch in float64 at the row count of a
+    full-size episode, in BOTH matrix arithmetics (fp32 core; bf16 core with three-piece operands, csrc/gemm_bx3.hip).
+    A gradient of this layer sums 10^7 terms behind the LeakyReLU kink: an activation within rounding of 0 takes slope 1
+    in one implementation and 0.2 in the other, and that single element moves dW / dX by up to a few 1e-2 of their largest
+    entry.  The flips are counted here (sign of the output against float64), which separates the two effects: with no
+    flip every result is within 5e-6 of float64, in either arithmetic; a case with a flip only has to agree on y."""
+    from r3dfsseg_amd import _lib, ops, train_ops as T
+    lib = _lib.load()
+    before = lib.r3d_get_matrix_arith()
+    rel = lambda a, r: ((a.double().cpu() - r).abs().max() / r.abs().max()).item()
+    clean = {0: 0, 1: 0}
+    try:
+        for seed, (M, K, C) in enumerate([(24576, 192, 512), (24576, 512, 256), (24576, 64, 128), (24576, 256, 128), (12288, 128, 64)]):
+            rs = np.random.RandomState(seed)
+            x = torch.from_numpy(rs.randn(M, K).astype(np.float32))
+            x = torch.relu(x) * 1.3 + 0.05 * x  # (what a layer sees: the previous layer's activations)
+            W = torch.from_numpy((rs.randn(C, K) / np.sqrt(K)).astype(np.float32))
+            g = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32))
+            b = torch.from_numpy(rs.uniform(-0.2, 0.2, C).astype(np.float32))
+            R = torch.from_numpy(rs.randn(M, C).astype(np.float32))
+            xr, Wr = x.double().requires_grad_(), W.double().requires_grad_()
+            bnr = torch.nn.BatchNorm1d(C).double()
+            bnr.weight.data, bnr.bias.data = g.double(), b.double()
+            y = torch.nn.functional.leaky_relu(bnr(xr @ Wr.t()), 0.2)
+            (y * R.double()).sum().backward()
+            for arith in (0, 1):
+                _lib.check(lib.r3d_set_matrix_arith(arith))
+                bn = torch.nn.BatchNorm1d(C)
+                bn.weight.data, bn.bias.data = g.clone(), b.clone()
+                bn = bn.cuda()
+                yg, saved = T.conv_bn_fwd(x.cuda(), W.cuda(), bn, ops.ACT_LRELU)
+                dW, dg, db, _, dX = T.conv_bn_bwd(saved, R.cuda())
+                assert rel(yg, y.detach()) < 5e-6
+                assert rel(bn.running_mean, bnr.running_mean) < 1e-6 and rel(bn.running_var, bnr.running_var) < 1e-5
+                flips = int(((yg.cpu() > 0) != (y.detach() > 0)).sum())
+                if flips == 0:
+                    clean[arith] += 1
+                    errs = (rel(dW, Wr.grad), rel(dX, xr.grad), rel(dg, bnr.weight.grad), rel(db, bnr.bias.grad))
+                    assert max(errs) < 5e-6, (arith, (M, K, C), errs)
+    finally:
+        _lib.check(lib.r3d_set_matrix_arith(before))
+    assert clean[0] >= 2 and clean[1] >= 2, clean  # (each arithmetic proven on at least two flip-free layers)
+
+
 def _encoder_setup(B, N, p_drop=0.0):
     from r3dfsseg_amd.mpti import MPTI_SelfAtten
     cfg = S.make_cfg(n_way=2, k_shot=1, pc_npts=N)
