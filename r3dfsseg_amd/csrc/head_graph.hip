@@ -902,6 +902,14 @@ __global__ __launch_bounds__(256) void r3d_cg_spmv_kernel(
 // gather, and the 16 row tails (p, q updates) run lane-parallel with coalesced loads and stores.  The arithmetic is
 // that of r3d_cg_spmv_kernel bit for bit, INCLUDING the <p, q> partials (one per 4 rows, added in row order): which of
 // the two kernels a solve runs on -- a matter of how many systems the launch holds -- changes no bit of its result.
+//
+// WHICH rows a wave takes is free (the whole r is in LDS), and it matters: the graph's hubs are the prototype nodes, the
+// first ~200 rows of a system, and they grow with training (after 150 optimiser steps at S: mean row 273 entries,
+// p99.9 2745; the 16 consecutive hub rows of one wave held 10 x the entries of an average wave and the iteration took
+// 181 us instead of 107).  So the 4-row groups of the system are dealt cyclically to its workgroups (group c n_wg + b is
+// the c-th of workgroup b) and the 128 rows of a workgroup cyclically to its 8 waves (local row 8 k + w is the k-th of
+// wave w): consecutive hub rows land in different waves of different workgroups.  The four <p q> products of a group
+// then sit in four waves; they meet in LDS and are added in row order as before.
 #define SL_ROWS 128
 #define SL_WAVES 8
 #define SL_RPW (SL_ROWS / SL_WAVES)
@@ -921,16 +929,23 @@ __global__ __launch_bounds__(64 * SL_WAVES) void r3d_cg_spmv_lds_kernel(
     HG_WS(row_ptr); HG_WS(col); HG_WS(val); HG_WS(dinv); HG_WS(agg); HG_WS(MW); HG_AT(n_dev, st.desc); HG_WS(r); HG_WS(p);
     HG_WS(q); HG_WS(part_pq);
   }
+  __shared__ float4 pq_s[SL_ROWS];  // the <p q> products of the workgroup's rows, by local row
   const int n = min(*n_dev, n_cap);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int row0 = blockIdx.x * SL_ROWS + w * SL_RPW;
+  const int n_wg = gridDim.x, bx = blockIdx.x;
   const int n_part = (n_cap + 3) / 4;  // partials of <p, q>: one per 4 rows, as r3d_cg_spmv_kernel with rows_per_block = 4
-  if (blockIdx.x * SL_ROWS >= n) {  // uniform: a workgroup beyond the system's rows
-    if (tid < SL_ROWS / 4 && blockIdx.x * (SL_ROWS / 4) + tid < n_part) part_pq[blockIdx.x * (SL_ROWS / 4) + tid] = f4_zero();
-    return;
-  }
-  // this wave's row bounds: one coalesced load (lane k holds row_ptr[row0 + k], k <= SL_RPW)
-  const int my_ptr = row_ptr[min(row0 + min(lane, SL_RPW), n)];
+  // the k-th row of this wave: local row l = 8 k + w of the workgroup = member l & 3 of its group l >> 2
+  auto row_of = [&](int k) {
+    const int l = SL_WAVES * k + w;
+    return 4 * ((l >> 2) * n_wg + bx) + (l & 3);
+  };
+  // (rows ascend with k, so the rows below n are a prefix of the wave's 16)
+  int nrows = 0;
+#pragma unroll
+  for (int k = 0; k < SL_RPW; ++k) nrows += row_of(k) < n ? 1 : 0;  // uniform over the wave
+  // this wave's row bounds: lane k holds those of its k-th row
+  const int my_row = min(row_of(min(lane, SL_RPW - 1)), max(n - 1, 0));
+  const int my_rb = row_ptr[my_row], my_re = row_ptr[my_row + 1];
   // stage r: 4 float4 per thread in flight
   for (int i0 = tid; i0 < n; i0 += 4 * 64 * SL_WAVES) {
     float4 v[4];
@@ -944,12 +959,11 @@ __global__ __launch_bounds__(64 * SL_WAVES) void r3d_cg_spmv_lds_kernel(
   const float4 beta = *reinterpret_cast<const float4*>(cg->beta);
   __syncthreads();
   const float4 mul = mu_s[lane];
-  const int nrows = min(SL_RPW, n - row0);  // uniform over the wave (may be <= 0)
   int jv[6], jn[6];
   float av[6], an[6];
   float mw = 0.f, mwn = 0.f;
   auto issue = [&](int k, int (&jj)[6], float (&aa)[6], float& mm) {
-    const int rb = __builtin_amdgcn_readlane(my_ptr, k), re = __builtin_amdgcn_readlane(my_ptr, k + 1);
+    const int rb = __builtin_amdgcn_readlane(my_rb, k), re = __builtin_amdgcn_readlane(my_re, k);
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
       const int e = rb + lane + 64 * u;
@@ -957,7 +971,7 @@ __global__ __launch_bounds__(64 * SL_WAVES) void r3d_cg_spmv_lds_kernel(
       jj[u] = col[ec];
       aa[u] = r3d_keep(val[ec], e < re);
     }
-    mm = MW[(long)(row0 + k) * HG_M + lane];
+    mm = MW[(long)row_of(k) * HG_M + lane];
   };
   // Rows go in two groups of 8.  A lane keeps its partial sums of the group's rows in registers and the 64 lanes'
   // partials meet in ONE transposed butterfly per group: the xor-32 step halves the rows a lane is responsible for (it
@@ -978,7 +992,7 @@ __global__ __launch_bounds__(64 * SL_WAVES) void r3d_cg_spmv_lds_kernel(
       acc[kk] = f4_zero();
       if (k < nrows) {  // uniform
         if (k + 1 < nrows) issue(k + 1, jn, an, mwn);
-        const int rb = __builtin_amdgcn_readlane(my_ptr, k), re = __builtin_amdgcn_readlane(my_ptr, k + 1);
+        const int rb = __builtin_amdgcn_readlane(my_rb, k), re = __builtin_amdgcn_readlane(my_re, k);
         float4 s = f4_zero();
         {
           float4 rj[6];
@@ -990,7 +1004,10 @@ __global__ __launch_bounds__(64 * SL_WAVES) void r3d_cg_spmv_lds_kernel(
             s.z = __builtin_fmaf(av[u], rj[u].z, s.z); s.w = __builtin_fmaf(av[u], rj[u].w, s.w);
           }
         }
-        for (int e0 = rb + 384; e0 < re; e0 += 384) {  // rows with more than 384 entries (uniform trip count)
+        // rows with more than 384 entries (uniform trip count).  (Prefetching the next 384 entries behind the current
+        // gather made the whole kernel slower -- 141 -> 194 us per iteration in the trained state: the registers it takes
+        // cost every row.)
+        for (int e0 = rb + 384; e0 < re; e0 += 384) {
           int j2[6];
           float a2[6];
 #pragma unroll
@@ -1054,7 +1071,7 @@ __global__ __launch_bounds__(64 * SL_WAVES) void r3d_cg_spmv_lds_kernel(
   const int trow = 8 * (lane & 7) + (lane >> 3);  // (meaningful for lane & 7 < 2)
   if ((lane & 7) < 2 && trow < nrows) {
     const float4 keep = (lane & 1) ? tot[1] : tot[0];
-    const int i = row0 + trow;
+    const int i = row_of(trow);
     const float4 ri = rs[i], pi = p[i], qi = q[i];
     const float u = 1.f / dinv[i];
     const float4 m = mu_s[agg[i]];
@@ -1066,20 +1083,16 @@ __global__ __launch_bounds__(64 * SL_WAVES) void r3d_cg_spmv_lds_kernel(
     q[i] = qn;
     acc_pq = make_float4(pn.x * qn.x, pn.y * qn.y, pn.z * qn.z, pn.w * qn.w);
   }
-  // one partial per 4 rows, ((r0 + r1) + r2) + r3: the order in which r3d_cg_spmv_kernel adds its four waves.  Row r of
-  // the wave sits in lane 8 (r & 7) + (r >> 3); lane c < 4 gathers the four rows 4 c .. 4 c + 3.
-  {
-    float4 t = f4_zero();
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      const int r_ = 4 * (lane & 3) + d;
-      const int src = 8 * (r_ & 7) + (r_ >> 3);
-      const float x = __shfl(acc_pq.x, src), y = __shfl(acc_pq.y, src), z = __shfl(acc_pq.z, src), w_ = __shfl(acc_pq.w, src);
-      if (d == 0) t = make_float4(x, y, z, w_);
-      else { t.x += x; t.y += y; t.z += z; t.w += w_; }
-    }
-    const int gidx = (row0 >> 2) + lane;
-    if (lane < SL_RPW / 4 && gidx < n_part) part_pq[gidx] = t;
+  // one partial per 4 rows, ((r0 + r1) + r2) + r3: the order in which r3d_cg_spmv_kernel adds its four waves.  The rows
+  // of a group are the k-th rows of four neighbouring waves: through LDS (rows beyond n contribute the zero they hold).
+  if ((lane & 7) < 2) pq_s[SL_WAVES * trow + w] = acc_pq;
+  __syncthreads();
+  if (tid < SL_ROWS / 4) {
+    const float4 a = pq_s[4 * tid], b2 = pq_s[4 * tid + 1], c2 = pq_s[4 * tid + 2], d2 = pq_s[4 * tid + 3];
+    const float4 t = make_float4(((a.x + b2.x) + c2.x) + d2.x, ((a.y + b2.y) + c2.y) + d2.y, ((a.z + b2.z) + c2.z) + d2.z,
+                                 ((a.w + b2.w) + c2.w) + d2.w);
+    const int gidx = tid * n_wg + bx;
+    if (gidx < n_part) part_pq[gidx] = t;
   }
 }
 
