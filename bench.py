@@ -115,12 +115,12 @@ def cg_iteration_bytes(nnz, n):
 MAIN_KERNEL = {
     "knn_topk": "r3d_knn_append_kernel<4, 128, 1, ...> (DGCNN kNN, k = 20)",
     "knn_topk_l2": "r3d_knn_append_kernel<8, 384, 2, ...> (201-NN of the graph nodes)",
-    "pointwise_conv": "r3d_pointwise_gemm_kernel", "edgeconv": "r3d_edgeconv_kernel / r3d_edgeconv_train_fwd2_kernel",
+    "pointwise_conv": "r3d_pointwise_gemm_bx3_kernel (bf16 x 3; fp32 arithmetic: r3d_pointwise_gemm_kernel)", "edgeconv": "r3d_edgeconv_kernel / r3d_edgeconv_train_fwd2_kernel",
     "attention": "r3d_attention_fwd_bx3_kernel (bf16 x 3; fp32 arithmetic: r3d_attention_fwd_kernel)",
     "head_prototypes": "r3d_fps_persistent_kernel",
-    "label_propagate": "r3d_cg_spmv_kernel + r3d_cg_update_kernel",
-    "label_propagate_bwd": "r3d_cg_spmv_kernel + r3d_cg_update_kernel",
-    "gemm_tn": "r3d_gemm_tn_kernel", "edgeconv_bwd": "r3d_edgeconv_bwd1_kernel + r3d_edgeconv_bwd2_kernel",
+    "label_propagate": "r3d_cg_spmv_lds_kernel + r3d_cg_update_kernel",
+    "label_propagate_bwd": "r3d_cg_spmv_lds_kernel + r3d_cg_update_kernel",
+    "gemm_tn": "r3d_gemm_tn_bx3_kernel (bf16 x 3; fp32 arithmetic: r3d_gemm_tn_kernel)", "edgeconv_bwd": "r3d_edgeconv_bwd1_kernel + r3d_edgeconv_bwd2_kernel",
     "attention_bwd": "r3d_attention_bwd_kv_bx3_kernel + r3d_attention_bwd_q_bx3_kernel (fp32 arithmetic: ..._kv_kernel + ..._q_kernel)",
     "bn_stats": "r3d_colpartial_kernel",
 }
@@ -407,7 +407,9 @@ def main():
         nodes_tot = int(hb.desc.view(-1, 32)[:, ops.HD_N_NODES].sum().item())
         by = cg_iteration_bytes(nnz, nodes_tot)
         fl = nnz * 2.0 * 4 + nodes_tot * 4 * (12.0 + 4 * CG_M)
-        cg_names = ("r3d_cg_spmv_kernel", "r3d_cg_update_kernel")
+        # (batches of >= 8 systems run the LDS-resident SpMV, smaller ones the row-per-wave form: same bits)
+        cg_names = ("r3d_cg_spmv_lds_kernel" if hb.E * ((hb.n_cap + 127) // 128) >= 256 else "r3d_cg_spmv_kernel",
+                    "r3d_cg_update_kernel")
         traffic = rocprof_us = None
         if pmc is not None and all(k in pmc for k in cg_names):
             traffic = 1024.0 * sum(FETCH_SIZE_WIDE_READ_FACTOR * pmc[k]["fetch_kb_per_launch"] + pmc[k]["write_kb_per_launch"]
@@ -415,8 +417,9 @@ def main():
         if prof is not None:
             us = [v[2] for k, v in prof.items() if k.split("(")[0] in cg_names]
             rocprof_us = sum(us) if len(us) == 2 else None
-        cg_roof = dict(kernel="r3d_cg_spmv_kernel + r3d_cg_update_kernel (one iteration of the two-level CG of the label "
-                           "propagation, %d systems per launch; entry points label_propagate / label_propagate_bwd)" % hb.E,
+        cg_roof = dict(kernel="%s + %s (one iteration of the two-level CG of the label propagation, %d systems per launch, "
+                           "graphs of the weights at the time of measurement: hub rows grow with training; entry points "
+                           "label_propagate / label_propagate_bwd)" % (cg_names + (hb.E,)),
                     bound="hbm", achieved=by / t_iter / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t_iter / 1e9 / HBM_PEAK_GBS,
                     traffic=traffic, avg_launch_ms=t_iter * 1e3, algorithmic_mb_per_launch=by / 1e6,
                     algorithmic_gflop_per_launch=fl / 1e9, csr_nnz=nnz, nodes=nodes_tot, systems_per_launch=hb.E,
@@ -458,6 +461,7 @@ def main():
     # every entry point against both ceilings (north_star: HBM GB/s for kNN / EdgeConv, MFMA utilisation for attention)
     from r3dfsseg_amd import _lib as _l0
     bx3_attention = _l0.load().r3d_get_matrix_arith() == 1
+    BX3_OPS = ("attention", "attention_bwd", "pointwise_conv", "gemm_tn")
     rooflines = {"_note": "HIP event pairs around every entry-point call of a live step (%d episodes per launch): hbm_gbs is "
                           "algorithmic bytes / device time, not HBM traffic" % E}
     for op, ms in per_step_ms.items():
@@ -467,7 +471,7 @@ def main():
         rooflines[op] = dict(bound=bnd, ms_per_step=round(ms, 4), calls_per_step=calls_per_step[op],
                              hbm_gbs=round(b_ / sec / 1e9, 1), frac_hbm=round(b_ / sec / 1e9 / HBM_PEAK_GBS, 4),
                              fp32_tflops=round(f_ / sec / 1e12, 2), frac_mfma=round(f_ / sec / 1e12 / F32_MFMA_PEAK_TF, 4))
-        if op in ("attention", "attention_bwd") and bx3_attention:
+        if op in BX3_OPS and bx3_attention:
             # six bf16 MFMA products per fp32 product: the matrix-core work actually issued, against the dense bf16 peak
             rooflines[op].update(matrix_arith="bf16 x 3", bf16_tflops_issued=round(6 * f_ / sec / 1e12, 1),
                                  frac_mfma=round(6 * f_ / sec / 1e12 / BF16_MFMA_PEAK_TF, 4),
@@ -481,11 +485,14 @@ def main():
 
     eps = args.steps * E * world / elapsed
     from r3dfsseg_amd import _lib as _l
-    matrix_arith = ("self-attention: fp32 operands as three bf16 pieces on the bf16 MFMA, six products per block, fp32 "
-                    "accumulate (fp32-level accuracy); every other GEMM and all index-deciding scores: fp32 MFMA"
+    matrix_arith = ("self-attention, 1x1-convolution GEMMs (forward and input gradient) and weight-gradient GEMMs: fp32 operands "
+                    "as three bf16 pieces on the bf16 MFMA, six products per block, fp32 accumulate (error against float64 as "
+                    "the fp32 kernels: tools/gemm_accuracy.py); index-deciding kernels (kNN scores, the EdgeConv edge GEMM "
+                    "whose max-pool winners route the gradient, FPS) and the 9-channel input layer: fp32 MFMA"
                     if _l.load().r3d_get_matrix_arith() == 1 else "fp32 MFMA everywhere")
-    dtype_str = ("f32 (self-attention products: bf16x3 split on the bf16 MFMA, fp32 accumulate; every index-deciding kernel "
-                 "and every other GEMM: fp32 MFMA)" if _l.load().r3d_get_matrix_arith() == 1 else "f32")
+    dtype_str = ("f32 (index-free GEMMs -- self-attention, 1x1 convolutions, weight gradients -- as bf16x3 split products on the "
+                 "bf16 MFMA with fp32 accumulate; every index-deciding kernel: fp32 MFMA)"
+                 if _l.load().r3d_get_matrix_arith() == 1 else "f32")
     out = {
         "metric": "episodes/sec %s %d-way %d-shot %d-pt (MPTI+attention, %s)" % (
             "ScanNet" if args.workload == "C" else "S3DIS", cfg["n_way"], cfg["k_shot"], N,

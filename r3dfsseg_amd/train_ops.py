@@ -186,8 +186,9 @@ def gemm_tn(A, B):
 def conv_acc(X, W, out):
     """out += X W^T."""
     M, ldx = _rows(X)
-    _lib.check(_lib.load().r3d_pointwise_conv_acc(_p(X), ldx, _p(W), M, X.shape[1], W.shape[0], None, None, 0, _p(out),
-                                                  out.stride(0), _st()))
+    with _timed("pointwise_conv"):
+        _lib.check(_lib.load().r3d_pointwise_conv_acc(_p(X), ldx, _p(W), M, X.shape[1], W.shape[0], None, None, 0, _p(out),
+                                                      out.stride(0), _st()))
 
 
 def add_cols(src, dst):
