@@ -173,6 +173,15 @@ int r3d_label_propagate_batched(int n_ep, const float* nodes, long ldn, int D, c
                                 const int32_t* n_dev, const int32_t* n_proto_dev, long desc_stride, int n_cap, float sigma,
                                 float alpha, int max_iter, float tol, float* Z, int32_t* ws, long ws_words, long ws_stride,
                                 int32_t* stats_out, long stats_stride, void* stream);
+/* More than 3 ways (5..8 classes; models/mpti.py:49,58 take any n_way): label columns travel as float4 per node, so Y, Z
+ * (and G, lambda of the backward) are TWO planes of 4 columns, (2, n_ep * n_cap, 4), plane 1 = classes 4..7, written /
+ * read that way by r3d_head_prototypes_batched, r3d_query_logits_ce_batched, r3d_ce_grad_batched and
+ * r3d_train_metrics_batched.  The label propagation is column-wise independent: r3d_label_propagate_batched solves plane 0
+ * and leaves graph, weights and preconditioner in ws; this entry point solves further right-hand sides (plane 1) on them.
+ * The backward is called once per plane (its outputs add). */
+int r3d_label_propagate_solve_batched(int n_ep, const float* Y, const int32_t* n_dev, long desc_stride, int n_cap, int kp1,
+                                      float alpha, int max_iter, float tol, float* Z, int32_t* ws, long ws_words,
+                                      long ws_stride, int32_t* stats_out, long stats_stride, void* stream);
 
 /* Captured episodes: enable the CG kernel nodes (three per iteration) of iterations < budget in an instantiated hipGraph holding
  * r3d_label_propagate / r3d_label_propagate_bwd launches, disable the rest (no dispatch for them).  graph: the

@@ -220,9 +220,9 @@ __global__ __launch_bounds__(256) void r3d_proto_pool_kernel(const float* __rest
 __global__ __launch_bounds__(256) void r3d_proto_sim_kernel(const float* __restrict__ pooled, int n_way, int k_shot,
                                                             const float* __restrict__ qfeat, long ldq, int D, int n_pts,
                                                             int method /*0 cosine, 1 euclidean*/, float scaler,
-                                                            float4* __restrict__ Zq) {
-  __shared__ float proto[4][AH_DMAX];
-  __shared__ float pnorm[4];
+                                                            float4* __restrict__ Zq, float4* __restrict__ Zq2 /* classes 4..7 */) {
+  __shared__ float proto[8][AH_DMAX];
+  __shared__ float pnorm[8];
   const int tid = threadIdx.x;
   const int n_classes = n_way + 1;
   if (tid < D) {
@@ -236,7 +236,9 @@ __global__ __launch_bounds__(256) void r3d_proto_sim_kernel(const float* __restr
     }
   }
   __syncthreads();
-  if (tid < 4) {
+  if (tid < D)
+    for (int k = n_classes; k < 8; ++k) proto[k][tid] = 0.f;
+  if (tid < 8) {
     float s = 0.f;
     if (tid < n_classes) for (int c = 0; c < D; ++c) s += proto[tid][c] * proto[tid][c];
     pnorm[tid] = sqrtf(s);
@@ -245,21 +247,21 @@ __global__ __launch_bounds__(256) void r3d_proto_sim_kernel(const float* __restr
   const int lane = tid & 63, w = tid >> 6;
   for (int p = blockIdx.x * 4 + w; p < n_pts; p += gridDim.x * 4) {  // one wave per query point
     const float* q = qfeat + (long)p * ldq;
-    float dot[4] = {0.f, 0.f, 0.f, 0.f}, qq = 0.f, dd[4] = {0.f, 0.f, 0.f, 0.f};
+    float dot[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, qq = 0.f, dd[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int c = lane; c < D; c += 64) {
       const float v = q[c];
       qq += v * v;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < 8; ++k) {
         dot[k] += v * proto[k][c];
         const float df = (v - proto[k][c]) + 1e-6f;  // pairwise_distance eps (torch 1.8 semantics)
         dd[k] += df * df;
       }
     }
     qq = r3d_wave_sum(qq);
-    float out[4];
+    float out[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 8; ++k) {
       const float d = r3d_wave_sum(dot[k]);
       const float e = r3d_wave_sum(dd[k]);
       if (method == 0) out[k] = d / fmaxf(sqrtf(qq) * pnorm[k], 1e-8f) * scaler;
@@ -267,6 +269,7 @@ __global__ __launch_bounds__(256) void r3d_proto_sim_kernel(const float* __restr
       if (k >= n_classes) out[k] = 0.f;
     }
     if (lane == 0) Zq[p] = make_float4(out[0], out[1], out[2], out[3]);
+    if (lane == 0 && Zq2) Zq2[p] = make_float4(out[4], out[5], out[6], out[7]);
   }
 }
 
@@ -321,12 +324,13 @@ extern "C" int r3d_clean_shot_detect(const float* feat, long ldf, int D, const f
                                        0, stream);
 }
 
-// Z (n_q*N, 4) fp32 similarity rows (feed r3d_query_logits_ce with n_proto = 0).  ws: S*2*256 floats.
+// Z (n_q*N, 4) fp32 similarity rows (feed r3d_query_logits_ce with n_proto = 0); more than 3 ways: two planes
+// (2, n_q*N, 4), classes 4..7 in plane 1 (r3d_query_logits_ce_batched with z_ep_rows = n_q*N).  ws: S*2*256 floats.
 extern "C" int r3d_protonet_head(const float* sfeat, long ldf, const float* qfeat, long ldq, int D,
                                  const int32_t* support_y, int n_way, int k_shot, int N, int n_query_pts, int method,
                                  float scaler, float* Z, float* ws, void* stream) {
   R3D_REQUIRE(sfeat && qfeat && support_y && Z && ws, "r3d_protonet_head: null pointer");
-  R3D_REQUIRE(n_way >= 1 && n_way <= 3 && D >= 1 && D <= AH_DMAX, "r3d_protonet_head: unsupported shape");
+  R3D_REQUIRE(n_way >= 1 && n_way <= 7 && D >= 1 && D <= AH_DMAX, "r3d_protonet_head: unsupported shape");
   if (method != 0 && method != 1) {
     // the reference raises NotImplementedError for anything but cosine / euclidean (protonet.py:347)
     r3d_set_error("Error! Distance computation method (%d) is unknown!", method);
@@ -335,7 +339,7 @@ extern "C" int r3d_protonet_head(const float* sfeat, long ldf, const float* qfea
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(r3d_proto_pool_kernel, dim3(n_way * k_shot), dim3(256), 0, st, sfeat, ldf, D, support_y, N, ws);
   hipLaunchKernelGGL(r3d_proto_sim_kernel, dim3(256), dim3(256), 0, st, ws, n_way, k_shot, qfeat, ldq, D, n_query_pts,
-                     method, scaler, (float4*)Z);
+                     method, scaler, (float4*)Z, n_way > 3 ? (float4*)Z + n_query_pts : nullptr);
   R3D_LAUNCH_CHECK("r3d_protonet_head");
   return R3D_OK;
 }

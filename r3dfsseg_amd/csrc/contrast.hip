@@ -425,11 +425,13 @@ __global__ __launch_bounds__(256) void r3d_contrast_point_grad_kernel(
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void r3d_train_metrics_kernel(
     const int* __restrict__ pred, const long long* __restrict__ query_y, const long long* __restrict__ gt_query_y, int n_qpts,
-    const float4* __restrict__ Z, const int* __restrict__ desc, const int* __restrict__ comp, const int* __restrict__ assign,
+    const float4* __restrict__ Z, const float4* __restrict__ Z2 /* classes 4..7 (n_way > 3), or null */,
+    const int* __restrict__ desc, const int* __restrict__ comp, const int* __restrict__ assign,
     const int* __restrict__ gt_support_y, int n_way, int k_shot, int N, float* __restrict__ out, CtEp st) {
   {
     const long ep = blockIdx.x;
     pred += ep * st.pred; query_y += ep * st.qy; gt_query_y += ep * st.qy; Z += ep * st.z; desc += ep * st.desc;
+    if (Z2) Z2 += ep * st.z;
     comp += ep * st.pws; assign += ep * st.assign; gt_support_y += ep * st.gsy; out += ep * st.out;
   }
   __shared__ int acc[4];
@@ -456,8 +458,10 @@ __global__ __launch_bounds__(256) void r3d_train_metrics_kernel(
     int c_lp = 0, c_or = 0;
     for (int pos = tid; pos < count; pos += 256) {
       const int gp = comp[off + pos];
-      const float4 z = Z[poff + assign[off + pos]];
-      const float zv[4] = {z.x, z.y, z.z, z.w};
+      const int zr = poff + assign[off + pos];
+      const float4 z = Z[zr];
+      const float4 z2 = Z2 ? Z2[zr] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float zv[8] = {z.x, z.y, z.z, z.w, z2.x, z2.y, z2.z, z2.w};
       int am = 0;
       for (int c = 1; c <= n_way; ++c) if (zv[c] > zv[am]) am = c;
       const int point_pred = (am == wy + 1) ? 1 : 0;
@@ -515,7 +519,7 @@ static int contrast_fwd_impl(int n_ep, const CtEp& ep, const float* feat, long l
   R3D_REQUIRE(feat && support_y && support_flag && W && bias && loss_out && ws, "r3d_contrast_fwd: null pointer");
   R3D_REQUIRE(ws_words >= r3d_contrast_ws_words(n_way, k_shot, N), "r3d_contrast_fwd: workspace of %ld words is shorter than "
               "r3d_contrast_ws_words(%d, %d, %d)", ws_words, n_way, k_shot, N);
-  R3D_REQUIRE(n_way >= 1 && n_way <= 3 && (k_shot + 2) * CT_K <= CT_MAXV && D <= CT_DMAX && N <= CT_NMAX,
+  R3D_REQUIRE(n_way >= 1 && n_way <= 7 && (k_shot + 2) * CT_K <= CT_MAXV && D <= CT_DMAX && N <= CT_NMAX,
               "r3d_contrast_fwd: unsupported shape n_way=%d k_shot=%d D=%d N=%d", n_way, k_shot, D, N);
   R3D_REQUIRE(n_ep >= 1 && n_ep <= 65535 && (n_ep == 1 || ep.ws >= ws_words), "r3d_contrast_fwd: %d episodes, scratch stride %ld",
               n_ep, ep.ws);
@@ -592,8 +596,11 @@ extern "C" int r3d_train_metrics_batched(int n_ep, const int32_t* pred, const in
   CtEp ep{};
   ep.pred = n_query_pts; ep.qy = n_query_pts; ep.z = z_ep_rows; ep.desc = desc_stride; ep.pws = pws_stride;
   ep.assign = assign_stride; ep.gsy = (long)n_way * k_shot * N; ep.out = 4;
+  R3D_REQUIRE(n_way >= 1 && n_way <= 7 && (n_way <= 3 || z_ep_rows > 0), "r3d_train_metrics: n_way = %d (more than 3 ways: Z as two "
+              "planes (2, n_ep * z_ep_rows, 4), batched form)", n_way);
+  const float4* Z2 = n_way > 3 ? (const float4*)Z + (long)n_ep * z_ep_rows : nullptr;
   hipLaunchKernelGGL(r3d_train_metrics_kernel, dim3(n_ep), dim3(256), 0, (hipStream_t)stream, pred, (const long long*)query_y,
-                     (const long long*)gt_query_y, n_query_pts, (const float4*)Z, desc, proto_ws, assign, gt_support_y, n_way,
+                     (const long long*)gt_query_y, n_query_pts, (const float4*)Z, Z2, desc, proto_ws, assign, gt_support_y, n_way,
                      k_shot, N, out4, ep);
   R3D_LAUNCH_CHECK("r3d_train_metrics");
   return R3D_OK;

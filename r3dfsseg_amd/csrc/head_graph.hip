@@ -1179,8 +1179,10 @@ __global__ __launch_bounds__(256) void r3d_cg_update_kernel(
 // ---------------------------------------------------------------------------
 // 6. query logits (mpti.py:558-559) + cross entropy (mpti.py:778-781)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void r3d_logits_ce_kernel(const float4* __restrict__ Z, const int* __restrict__ desc_nproto,
-                                                             int n_q, int N, int n_classes,
+// More than 4 classes (n_way > 3): Z comes as two planes of 4 columns, classes 4 .. 7 in Z2 (the label propagation is
+// column-wise independent and is solved plane after plane).
+__global__ __launch_bounds__(1024) void r3d_logits_ce_kernel(const float4* __restrict__ Z, const float4* __restrict__ Z2,
+                                                             const int* __restrict__ desc_nproto, int n_q, int N, int n_classes,
                                                              const long long* __restrict__ labels,
                                                              float* __restrict__ logits /* (n_q, n_classes, N) */,
                                                              float* __restrict__ loss_out, int* __restrict__ pred_out, HgEp st) {
@@ -1188,6 +1190,7 @@ __global__ __launch_bounds__(1024) void r3d_logits_ce_kernel(const float4* __res
   {
     const int ep = blockIdx.x;
     HG_AT(Z, st.z); HG_AT(desc_nproto, st.desc); HG_AT(logits, st.logits);
+    if (Z2) HG_AT(Z2, st.z);
     if (labels) HG_AT(labels, st.labels);
     if (loss_out) HG_AT(loss_out, st.loss);
     if (pred_out) HG_AT(pred_out, st.pred);
@@ -1197,7 +1200,8 @@ __global__ __launch_bounds__(1024) void r3d_logits_ce_kernel(const float4* __res
   for (int e = threadIdx.x; e < n_q * N; e += blockDim.x) {
     const int qi = e / N, p = e - qi * N;
     const float4 z = Z[n_proto + e];
-    const float zv[4] = {z.x, z.y, z.z, z.w};
+    const float4 z2 = Z2 ? Z2[n_proto + e] : f4_zero();
+    const float zv[8] = {z.x, z.y, z.z, z.w, z2.x, z2.y, z2.z, z2.w};
     float mx = zv[0];
     int am = 0;
     for (int c = 1; c < n_classes; ++c) if (zv[c] > mx) { mx = zv[c]; am = c; }
@@ -1416,6 +1420,30 @@ extern "C" int r3d_label_propagate(const float* nodes, long ldn, int D, const in
 // prototype counts at n_dev[e * desc_stride] / n_proto_dev[e * desc_stride], scratch ws + e * ws_stride (a multiple of 4
 // words, >= r3d_lp_ws_words), {converged, iterations} at stats_out + e * stats_stride.  Every CG launch serves all systems;
 // max_iter launches are issued, a system that converged earlier idles through the rest.
+// The solve alone, on the graph and coarse space a preceding r3d_label_propagate(_batched) left in ws: further right-hand
+// sides of the same systems (label columns 4..7 of an episode with more than 3 ways: Y and Z = plane 1 of the two-plane
+// arrays).  The CG vectors in ws are overwritten; graph, weights and preconditioner -- what the backward needs -- are not.
+extern "C" int r3d_label_propagate_solve_batched(int n_ep, const float* Y, const int32_t* n_dev, long desc_stride, int n_cap,
+                                                 int kp1, float alpha, int max_iter, float tol, float* Z, int32_t* ws,
+                                                 long ws_words, long ws_stride, int32_t* stats_out, long stats_stride,
+                                                 void* stream) {
+  R3D_REQUIRE(Y && n_dev && Z && ws, "r3d_label_propagate_solve: null pointer");
+  R3D_REQUIRE(n_cap > 0 && kp1 >= 2 && ws_words >= r3d_lp_ws_words(n_cap, kp1), "r3d_label_propagate_solve: workspace too short");
+  R3D_REQUIRE(max_iter > 0 && max_iter <= HG_MAX_ITER, "r3d_label_propagate_solve: bad solver parameters");
+  R3D_REQUIRE(((uintptr_t)ws & 15) == 0 && ((uintptr_t)Y & 15) == 0 && ((uintptr_t)Z & 15) == 0,
+              "r3d_label_propagate_solve: ws, Y and Z must be 16-byte aligned");
+  R3D_REQUIRE(n_ep >= 1 && n_ep <= 4096 && (n_ep == 1 || ((ws_stride & 3) == 0 && ws_stride >= ws_words)),
+              "r3d_label_propagate_solve: bad scratch stride");
+  HgEp ep{};
+  ep.nodes = ep.nbr = ep.y = ep.z = n_cap;
+  ep.desc = desc_stride; ep.ws = ws_stride; ep.stats = stats_stride;
+  const LpWs L = lp_carve(ws, n_cap, kp1);
+  const int rc = lp_solve(L, Y, ep.y, n_dev, n_cap, alpha, max_iter, tol, Z, ep.z, stats_out, n_ep, ep, (hipStream_t)stream);
+  if (rc) return rc;
+  R3D_LAUNCH_CHECK("r3d_label_propagate_solve");
+  return R3D_OK;
+}
+
 extern "C" int r3d_label_propagate_batched(int n_ep, const float* nodes, long ldn, int D, const int32_t* nbr, int kp1,
                                            const float* Y, const int32_t* n_dev, const int32_t* n_proto_dev, long desc_stride,
                                            int n_cap, float sigma, float alpha, int max_iter, float tol, float* Z, int32_t* ws,
@@ -1545,19 +1573,21 @@ __global__ __launch_bounds__(256) void r3d_lp_bwd_dx_kernel(
 // dL/dZ of the mean cross entropy over the query rows (mpti.py:778-781), scaled by *gscale
 __global__ void r3d_ce_grad_kernel(const float4* __restrict__ Z, const int* __restrict__ n_proto_dev, int n_cap, int n_qpts,
                                    int n_classes, const long long* __restrict__ labels, const float* __restrict__ gscale,
-                                   float4* __restrict__ G, HgEp st) {
+                                   float4* __restrict__ G, const float4* __restrict__ Z2, float4* __restrict__ G2, HgEp st) {
   {
     const int ep = blockIdx.y;
     HG_AT(Z, st.z); HG_AT(n_proto_dev, st.desc); HG_AT(labels, st.labels); HG_AT(G, st.g);
+    if (Z2) { HG_AT(Z2, st.z); HG_AT(G2, st.g); }
   }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_cap) return;
   const int n_proto = *n_proto_dev;
   const int q = i - n_proto;
-  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (q >= 0 && q < n_qpts) {
     const float4 z = Z[i];
-    const float zv[4] = {z.x, z.y, z.z, z.w};
+    const float4 z2 = Z2 ? Z2[i] : f4_zero();
+    const float zv[8] = {z.x, z.y, z.z, z.w, z2.x, z2.y, z2.z, z2.w};
     float mx = zv[0];
     for (int c = 1; c < n_classes; ++c) mx = fmaxf(mx, zv[c]);
     float se = 0.f;
@@ -1567,6 +1597,7 @@ __global__ void r3d_ce_grad_kernel(const float4* __restrict__ Z, const int* __re
     for (int c = 0; c < n_classes; ++c) g[c] = (expf(zv[c] - mx) / se - (c == lab ? 1.f : 0.f)) * sc;
   }
   G[i] = make_float4(g[0], g[1], g[2], g[3]);
+  if (G2) G2[i] = make_float4(g[4], g[5], g[6], g[7]);
 }
 
 // Backward through label propagation + affinity.  Requires ws exactly as r3d_label_propagate left it.
@@ -1625,10 +1656,15 @@ extern "C" int r3d_ce_grad_batched(int n_ep, const float* Z, const int32_t* n_pr
                                    int n_query_pts, int n_classes, const int64_t* labels, const float* gscale_dev, float* G,
                                    void* stream) {
   R3D_REQUIRE(Z && n_proto_dev && labels && gscale_dev && G && n_ep >= 1 && n_ep <= 65535, "r3d_ce_grad: bad arguments");
+  R3D_REQUIRE(n_classes >= 2 && n_classes <= 2 * HG_NC, "r3d_ce_grad: %d classes (2..%d)", n_classes, 2 * HG_NC);
   HgEp ep{};
   ep.z = ep.g = n_cap; ep.desc = desc_stride; ep.labels = n_query_pts;
+  // more than 4 classes: Z and G are (2, n_ep * n_cap, 4), plane 1 = classes 4..7
+  const long plane = (long)n_ep * n_cap;
+  const float4* Z2 = n_classes > HG_NC ? (const float4*)Z + plane : nullptr;
+  float4* G2 = n_classes > HG_NC ? (float4*)G + plane : nullptr;
   hipLaunchKernelGGL(r3d_ce_grad_kernel, dim3(r3d_cdiv(n_cap, 256), n_ep), dim3(256), 0, (hipStream_t)stream, (const float4*)Z,
-                     n_proto_dev, n_cap, n_query_pts, n_classes, (const long long*)labels, gscale_dev, (float4*)G, ep);
+                     n_proto_dev, n_cap, n_query_pts, n_classes, (const long long*)labels, gscale_dev, (float4*)G, Z2, G2, ep);
   R3D_LAUNCH_CHECK("r3d_ce_grad");
   return R3D_OK;
 }
@@ -1643,11 +1679,14 @@ extern "C" int r3d_query_logits_ce_batched(int n_ep, const float* Z, long z_ep_r
                                            int n_q, int N, int n_classes, const int64_t* labels, float* logits, float* loss_out,
                                            int32_t* pred_out, void* stream) {
   R3D_REQUIRE(Z && n_proto_dev && logits, "r3d_query_logits_ce: null pointer");
-  R3D_REQUIRE(n_q > 0 && N > 0 && n_classes >= 2 && n_classes <= HG_NC && n_ep >= 1, "r3d_query_logits_ce: bad shape");
+  R3D_REQUIRE(n_q > 0 && N > 0 && n_classes >= 2 && n_classes <= 2 * HG_NC && n_ep >= 1, "r3d_query_logits_ce: bad shape");
+  R3D_REQUIRE(n_classes <= HG_NC || z_ep_rows > 0, "r3d_query_logits_ce: more than %d classes need the batched form "
+              "(Z as two planes (2, n_ep * z_ep_rows, 4))", HG_NC);
   HgEp ep{};
   ep.z = z_ep_rows; ep.desc = desc_stride; ep.labels = (long)n_q * N; ep.logits = (long)n_q * n_classes * N; ep.loss = 1;
   ep.pred = (long)n_q * N;
-  hipLaunchKernelGGL(r3d_logits_ce_kernel, dim3(n_ep), dim3(1024), 0, (hipStream_t)stream, (const float4*)Z,
+  const float4* Z2 = n_classes > HG_NC ? (const float4*)Z + (long)n_ep * z_ep_rows : nullptr;
+  hipLaunchKernelGGL(r3d_logits_ce_kernel, dim3(n_ep), dim3(1024), 0, (hipStream_t)stream, (const float4*)Z, Z2,
                      n_proto_dev, n_q, N, n_classes, (const long long*)labels, logits, loss_out, pred_out, ep);
   R3D_LAUNCH_CHECK("r3d_query_logits_ce");
   return R3D_OK;

@@ -675,10 +675,12 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_cluster_partial_kernel(
 __global__ __launch_bounds__(HP_BLOCK) void r3d_cluster_reduce_kernel(
     int D, const int* __restrict__ desc, int max_chunks, const float* __restrict__ part,
     const int* __restrict__ part_cnt, float* __restrict__ nodes /* (n_cap, ldn) */, long ldn,
-    float* __restrict__ node_labels /* (n_cap, 4) */, int* __restrict__ cluster_count, HpEp st) {
+    float* __restrict__ node_labels /* (n_cap, 4) */, float* __restrict__ node_labels2 /* classes 4..7, or null */,
+    int* __restrict__ cluster_count, HpEp st) {
   const int seg = blockIdx.y, s = blockIdx.x, ep = blockIdx.z;
   HP_SHIFT(desc, st.desc); HP_SHIFT(part, st.ws); HP_SHIFT(part_cnt, st.ws);
   nodes += (long)ep * st.nodes * ldn; node_labels += (long)ep * st.labels * 4;
+  if (node_labels2) node_labels2 += (long)ep * st.labels * 4;
   if (cluster_count) HP_SHIFT(cluster_count, st.ccount);
   const int m = desc[HD_SEG_M + seg];
   if (s >= m) return;
@@ -695,6 +697,7 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_cluster_reduce_kernel(
   const int row = desc[HD_SEG_POFF + seg] + s;
   if (tid < D) nodes[(long)row * ldn + tid] = sum / (float)total;  // 0/0 = NaN for an empty cluster, as torch
   if (tid < 4) node_labels[(long)row * 4 + tid] = (tid == seg) ? 1.f : 0.f;
+  if (tid < 4 && node_labels2) node_labels2[(long)row * 4 + tid] = (tid + 4 == seg) ? 1.f : 0.f;
   if (tid == 0 && cluster_count) cluster_count[row] = total;
 }
 
@@ -703,10 +706,12 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_cluster_reduce_kernel(
 // ---------------------------------------------------------------------------
 __global__ void r3d_nodes_append_query_kernel(const float* __restrict__ qfeat, long ldq, int D, int nq_pts,
                                               const int* __restrict__ desc, float* __restrict__ nodes,
-                                              long ldn, float* __restrict__ node_labels, HpEp st) {
+                                              long ldn, float* __restrict__ node_labels,
+                                              float* __restrict__ node_labels2, HpEp st) {
   const int ep = blockIdx.y;
   qfeat += (long)ep * st.qfeat * ldq; HP_SHIFT(desc, st.desc);
   nodes += (long)ep * st.nodes * ldn; node_labels += (long)ep * st.labels * 4;
+  if (node_labels2) node_labels2 += (long)ep * st.labels * 4;
   const int n_proto = desc[HD_N_PROTO];
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)nq_pts * D) return;
@@ -714,14 +719,15 @@ __global__ void r3d_nodes_append_query_kernel(const float* __restrict__ qfeat, l
   const int c = (int)(i - r * D);
   nodes[(n_proto + r) * ldn + c] = qfeat[r * ldq + c];
   if (c < 4) node_labels[(n_proto + r) * 4 + c] = 0.f;
+  if (c < 4 && node_labels2) node_labels2[(n_proto + r) * 4 + c] = 0.f;
 }
 
 // ===========================================================================
 // C ABI
 // ===========================================================================
 static int check_geom(const char* fn, int n_way, int k_shot, int N, int D) {
-  if (n_way < 1 || n_way + 1 > HP_MAXSEG || n_way > 3 || k_shot < 1 || N < 1 || D < 1 || D > 256) {
-    r3d_set_error("%s: unsupported geometry n_way=%d k_shot=%d N=%d D=%d (n_way<=3, D<=256)", fn, n_way,
+  if (n_way < 1 || n_way + 1 > HP_MAXSEG || k_shot < 1 || N < 1 || D < 1 || D > 256) {
+    r3d_set_error("%s: unsupported geometry n_way=%d k_shot=%d N=%d D=%d (n_way<=7, D<=256)", fn, n_way,
                   k_shot, N, D);
     return R3D_ERR_ARG;
   }
@@ -771,7 +777,8 @@ extern "C" long r3d_head_proto_ws_words(int n_way, int k_shot, int N) { return h
 //   support_y : (n_way*k_shot, N) int32 {0,1}
 //   shot_keep : optional (n_way*k_shot) int32, 0 drops a shot's foreground (clean-shot detection)
 //   feat      : (S*N, ldf) point-major support features;  qfeat: (n_q*N, ldq) point-major query features
-//   nodes     : (n_cap, ldn) out, n_cap = (n_way+1)*k + n_q*N;  node_labels: (n_cap, 4) one-hot Y
+//   nodes     : (n_cap, ldn) out, n_cap = (n_way+1)*k + n_q*N;  node_labels: (n_cap, 4) one-hot Y; n_way > 3: two such
+//               planes, (2, n_ep * n_cap, 4), classes 0..3 and 4..7
 //   desc      : device descriptor (r3d_head_desc_words int32);  ws: scratch words
 // Every pointer addresses episode 0; episode e sits ep->... elements further on (HpEp; feature strides in ROWS).
 // fps_group: episodes whose farthest-point samplings share ONE persistent launch (flags & R3D_HEAD_FPS_ONE_LAUNCH): all
@@ -802,6 +809,10 @@ static int head_prototypes_impl(int n_ep, const HpEp& ep, int fps_group, const i
   int* assign = assign_out ? assign_out : ws + L.assign;
   HpEp e2 = ep;
   if (!assign_out) e2.assign = ep.ws;  // (single episode only)
+  // more than 4 classes: the one-hot labels are two planes of 4 columns, plane 1 (classes 4..7) behind the n_ep episodes'
+  // rows of plane 0 (the label propagation solves the planes one after the other: head_graph.hip)
+  const long label_rows = ep.labels ? ep.labels : (long)g.nseg() * k + n_query_pts;
+  float* node_labels2 = n_way > 3 ? node_labels + (long)n_ep * label_rows * 4 : nullptr;
   Cand* cand0 = (Cand*)(ws + L.cand);
   Cand* cand1 = cand0 + g.total_blocks();
   int* sel = ws + L.sel;
@@ -858,9 +869,9 @@ static int head_prototypes_impl(int n_ep, const HpEp& ep, int fps_group, const i
   hipLaunchKernelGGL(r3d_cluster_partial_kernel, dim3(k, max_chunks, g.nseg() * n_ep), dim3(HP_BLOCK), 0, st, feat, ldf, D, g,
                      comp, desc, assign, max_chunks, part, part_cnt, e2);
   hipLaunchKernelGGL(r3d_cluster_reduce_kernel, dim3(k, g.nseg(), n_ep), dim3(HP_BLOCK), 0, st, D, desc, max_chunks, part,
-                     part_cnt, nodes, ldn, node_labels, cluster_count, e2);
+                     part_cnt, nodes, ldn, node_labels, node_labels2, cluster_count, e2);
   hipLaunchKernelGGL(r3d_nodes_append_query_kernel, dim3(r3d_cdiv((long)n_query_pts * D, 256), n_ep), dim3(256), 0, st, qfeat,
-                     ldq, D, n_query_pts, desc, nodes, ldn, node_labels, e2);
+                     ldq, D, n_query_pts, desc, nodes, ldn, node_labels, node_labels2, e2);
   R3D_LAUNCH_CHECK("r3d_head_prototypes");
   return R3D_OK;
 }

@@ -51,17 +51,26 @@ class HeadLPFn(torch.autograd.Function):
         N, D = model.n_points, model.feat_dim
         S = model.n_way * model.k_shot
         gs = gloss.reshape(-1)[:1].to(torch.float32).contiguous()  # (the step's loss is the SUM over episodes: one scale)
-        G = torch.empty(E * hb.n_cap, 4, device=dev, dtype=torch.float32)
+        pl = E * hb.n_cap  # rows of one plane of label columns (ops.HeadBuffers: two planes for more than 3 ways)
+        G = torch.empty(hb.planes * pl, 4, device=dev, dtype=torch.float32)
         _lib.check(lib.r3d_ce_grad_batched(E, _p(hb.Z), _p(hb.n_proto_ptr()), 32, hb.n_cap, n_q * N, model.n_classes, _p(labels),
                                            _p(gs), _p(G), _st()))
-        lam = torch.empty(E * hb.n_cap, 4, device=dev, dtype=torch.float32)
-        dnodes = torch.empty(E * hb.n_cap, D, device=dev, dtype=torch.float32)
+        lam = torch.empty(pl, 4, device=dev, dtype=torch.float32)
+        dnodes = torch.empty(pl, D, device=dev, dtype=torch.float32)
         budget = int(min(model.lp_max_iter, ctx.budget + max(4, ctx.budget // 4)))
         with _timed("label_propagate_bwd"):
-            _lib.check(lib.r3d_label_propagate_bwd_batched(E, _p(hb.nodes), hb.nodes.stride(0), D, hb.kp1, _p(hb.Z), _p(G),
-                                                           _p(hb.n_nodes_ptr()), 32, hb.n_cap, float(model.sigma), 0.99, budget,
-                                                           float(model.lp_tol), _p(lam), _p(dnodes), D, _p(hb.lp_ws), hb.lp_words,
-                                                           hb.lp_stride, _p(hb.stats_bwd), 2, _st()))
+            for plane in range(hb.planes):  # the adjoint is column-wise independent as well: the planes' dnodes add
+                dn = dnodes if plane == 0 else torch.empty_like(dnodes)
+                stats = hb.stats_bwd if plane == 0 else torch.zeros(E, 2, device=dev, dtype=torch.int32)
+                _lib.check(lib.r3d_label_propagate_bwd_batched(
+                    E, _p(hb.nodes), hb.nodes.stride(0), D, hb.kp1, _p(hb.Z[plane * pl:]), _p(G[plane * pl:]),
+                    _p(hb.n_nodes_ptr()), 32, hb.n_cap, float(model.sigma), 0.99, budget, float(model.lp_tol), _p(lam), _p(dn),
+                    D, _p(hb.lp_ws), hb.lp_words, hb.lp_stride, _p(stats), 2, _st()))
+                if plane:
+                    dnodes.add_(dn)
+                    sb = hb.stats_bwd.view(E, 2)
+                    sb[:, 0] = torch.minimum(sb[:, 0], stats[:, 0])
+                    sb[:, 1] = torch.maximum(sb[:, 1], stats[:, 1])
         # one buffer over the batch's rows, per episode support rows then query rows: the encoder backward takes it whole
         assert E == 1 or ep_rows == (S + n_q) * N
         rows = E * (S + n_q) * N

@@ -38,8 +38,8 @@ class MPTI_SelfAtten(nn.Module):
         self.k_connect = args.k_connect
         self.sigma = args.sigma
         self.n_classes = self.n_way + 1
-        if self.n_classes > 4:
-            raise NotImplementedError("the label-propagation kernels carry at most 4 classes (n_way <= 3)")
+        if self.n_classes > 8:
+            raise NotImplementedError("the head kernels carry at most 8 classes (n_way <= 7): two planes of 4 label columns")
 
         self.encoder = DGCNN(args.edgeconv_widths, args.dgcnn_mlp_widths, args.pc_in_dim, k=args.dgcnn_k)
         self.base_learner = BaseLearner(args.dgcnn_mlp_widths[-1], args.base_widths)

@@ -245,8 +245,12 @@ class HeadBuffers:
         one = (lambda t: t[0]) if E == 1 else (lambda t: t)
         self.desc = one(torch.zeros(E, 32, **i32))
         self.nodes = torch.empty(E * self.n_cap, D, **f32)
-        self.Y = torch.empty(E * self.n_cap, 4, **f32)
-        self.Z = torch.empty(E * self.n_cap, 4, **f32)
+        # label columns travel as float4 per node.  More than 3 ways (5..8 classes): TWO planes of 4 columns, plane 1
+        # (classes 4..7) behind the E systems of plane 0 -- the label propagation is column-wise independent and solves
+        # the planes one after the other on the same graph (csrc/head_graph.hip)
+        self.planes = 1 if n_way <= 3 else 2
+        self.Y = torch.empty(self.planes * E * self.n_cap, 4, **f32)
+        self.Z = torch.empty(self.planes * E * self.n_cap, 4, **f32)
         self.proto_words = lib.r3d_head_proto_ws_words(n_way, k_shot, N)
         self.proto_stride = (self.proto_words + 3) // 4 * 4      # even (64-bit words inside), 16-byte rows
         self.proto_ws = one(torch.empty(E, self.proto_stride, **i32))
@@ -256,6 +260,7 @@ class HeadBuffers:
         self.assign = one(torch.empty(E, 2 * n_way * k_shot * N, **i32))
         self.cluster_count = one(torch.zeros(E, self.n_cap, **i32))
         self.stats = one(torch.zeros(E, 2, **i32))                # per system: {converged, CG iterations}
+        self.stats2 = torch.zeros(E, 2, **i32) if self.planes == 2 else None   # ... of the second plane's solves
         self.knn_status = torch.zeros(1, **i32)                   # ONE word for the batch (bit 0: survivor overflow)
         self.stats_bwd = one(torch.zeros(E, 2, **i32))
         # all FPS rounds in one persistent launch: its workgroups that hold points must be co-resident (~500 slots of
@@ -328,6 +333,15 @@ def label_propagate(hb, nbr, sigma, alpha=0.99, max_iter=200, tol=1e-6):
             hb.E, _p(hb.nodes), hb.nodes.stride(0), hb.D, _p(nbr), hb.kp1, _p(hb.Y), _p(hb.n_nodes_ptr()),
             _p(hb.n_proto_ptr()), 32, hb.n_cap, float(sigma), float(alpha), int(max_iter), float(tol), _p(hb.Z), _p(hb.lp_ws),
             hb.lp_words, hb.lp_stride, _p(hb.stats), 2, _st()))
+        if hb.planes == 2:  # label columns 4..7: the same systems, further right-hand sides
+            pl = hb.E * hb.n_cap
+            _lib.check(_lib.load().r3d_label_propagate_solve_batched(
+                hb.E, _p(hb.Y[pl:]), _p(hb.n_nodes_ptr()), 32, hb.n_cap, hb.kp1, float(alpha), int(max_iter), float(tol),
+                _p(hb.Z[pl:]), _p(hb.lp_ws), hb.lp_words, hb.lp_stride, _p(hb.stats2), 2, _st()))
+            # one {converged, iterations} pair per system for the callers: converged = both, iterations = the larger
+            st1 = hb.stats.view(hb.E, 2)
+            st1[:, 0] = torch.minimum(st1[:, 0], hb.stats2[:, 0])
+            st1[:, 1] = torch.maximum(st1[:, 1], hb.stats2[:, 1])
     return hb.Z
 
 
@@ -378,7 +392,7 @@ def protonet_head(sfeat_pm, qfeat_pm, support_y, n_way, k_shot, N, method, scale
         raise NotImplementedError('Error! Distance computation method (%s) is unknown!' % method)
     sy = support_y.reshape(n_way * k_shot, N).to(torch.int32).contiguous()
     dev = sfeat_pm.device
-    Z = torch.empty(Mq, 4, device=dev, dtype=torch.float32)
+    Z = torch.empty((1 if n_way <= 3 else 2) * Mq, 4, device=dev, dtype=torch.float32)  # (planes of 4 classes)
     ws = torch.empty(n_way * k_shot * 2 * 256, device=dev, dtype=torch.float32)
     _lib.check(_lib.load().r3d_protonet_head(_p(sfeat_pm), ldf, _p(qfeat_pm), ldq, sfeat_pm.shape[1], _p(sy), n_way,
                                              k_shot, N, Mq, codes[method], float(scaler), _p(Z), _p(ws), _st()))
@@ -386,14 +400,14 @@ def protonet_head(sfeat_pm, qfeat_pm, support_y, n_way, k_shot, N, method, scale
 
 
 def logits_ce_from_rows(Z, n_q, N, n_classes, labels):
-    """Z (n_q*N, 4) -> logits (n_q, n_classes, N), CE loss, argmax."""
+    """Z (n_q*N, 4) -- (2, n_q*N, 4) for more than 4 classes -- -> logits (n_q, n_classes, N), CE loss, argmax."""
     dev = Z.device
     zero = torch.zeros(1, device=dev, dtype=torch.int32)
     logits = torch.empty(n_q, n_classes, N, device=dev, dtype=torch.float32)
     loss = torch.empty((), device=dev, dtype=torch.float32)
     pred = torch.empty(n_q, N, device=dev, dtype=torch.int32)
-    _lib.check(_lib.load().r3d_query_logits_ce(_p(Z), _p(zero), n_q, N, n_classes, _p(labels), _p(logits), _p(loss),
-                                               _p(pred), _st()))
+    _lib.check(_lib.load().r3d_query_logits_ce_batched(1, _p(Z), n_q * N, _p(zero), 0, n_q, N, n_classes, _p(labels),
+                                                       _p(logits), _p(loss.view(1)), _p(pred), _st()))
     return logits, loss, pred
 
 

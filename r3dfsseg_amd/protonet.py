@@ -17,8 +17,8 @@ class ProtoNet(nn.Module):
         self.in_channels = args.pc_in_dim
         self.n_points = args.pc_npts
         self.use_attention = args.use_attention
-        if self.n_way > 3:
-            raise NotImplementedError("n_way <= 3")
+        if self.n_way > 7:
+            raise NotImplementedError("n_way <= 7 (the head kernels carry at most 8 classes)")
         self.encoder = DGCNN(args.edgeconv_widths, args.dgcnn_mlp_widths, args.pc_in_dim, k=args.dgcnn_k)
         self.base_learner = BaseLearner(args.dgcnn_mlp_widths[-1], args.base_widths)
         if self.use_attention:

@@ -40,8 +40,13 @@ def head_custody(m, cfg, sd, data, logits, loss, eval_flag=False):
     nbr_hip = tr["nbr"].reshape(-1, hb.kp1)[:n].cpu().to(torch.int64)
     assert torch.equal(nbr_hip, O.knn_l2(nodes, hb.kp1))                      # 201-NN lists: bit-exact on the HIP nodes
     A = O.affinity(nodes, cfg["k_connect"], cfg["sigma"])
-    Zo = O.label_propagate(A, hb.Y[:n, :n_way + 1].cpu())
-    assert close(hb.Z[:n, :n_way + 1].cpu(), Zo) <= TOL
+    # label columns: float4 per node, for more than 3 ways two planes of 4 (classes 4..7 behind the E systems of plane 0)
+    pl = hb.E * hb.n_cap
+    cols = lambda t: torch.cat([t[p * pl:p * pl + n] for p in range(hb.planes)], 1)[:, :n_way + 1].cpu()
+    Yh = cols(hb.Y)
+    assert torch.equal(Yh[:n_proto], torch.cat((bg_l, fg_l), 0)) and not Yh[n_proto:].any()   # one-hot rows as mpti.py:505-507
+    Zo = O.label_propagate(A, Yh)
+    assert close(cols(hb.Z), Zo) <= TOL
     want = Zo[n_proto:].view(-1, N, n_way + 1).transpose(1, 2)
     assert close(logits.cpu(), want) <= TOL                                    # every point, no fraction of outliers
     assert abs(loss.item() - torch.nn.functional.cross_entropy(want, qy).item()) <= TOL

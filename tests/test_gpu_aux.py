@@ -60,11 +60,12 @@ def test_mpti_forward_eval_true_vs_oracle():
     assert abs(loss.item() - wloss.item()) <= 5e-3 * max(1.0, abs(wloss.item()))
 
 
-@pytest.mark.parametrize("method", ["cosine", "euclidean"])
-def test_protonet_forward_vs_oracle(method):
-    """BASELINE.json configs[0]: 2-way 1-shot 512 pts, ProtoNet (there on PyTorch CPU; here on HIP)."""
+@pytest.mark.parametrize("method,n_way", [("cosine", 2), ("euclidean", 2), ("cosine", 5)])
+def test_protonet_forward_vs_oracle(method, n_way):
+    """BASELINE.json configs[0]: 2-way 1-shot 512 pts, ProtoNet (there on PyTorch CPU; here on HIP); and 5 ways (six
+    classes: the similarity rows travel as two planes of four columns)."""
     from r3dfsseg_amd.protonet import ProtoNet
-    cfg = S.workload_cfg("P", dist_method=method)
+    cfg = S.workload_cfg("P", dist_method=method, n_way=n_way)
     m, sd = _model(ProtoNet, cfg)
     data, _ = S.make_episode(cfg, 6)
     sx, sy, qx, qy = data[:4]

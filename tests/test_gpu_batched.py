@@ -51,12 +51,12 @@ def _eager_train(cfg, eps, p_drop):
     return m, bucket.flat.clone(), per, {k: v.clone() for k, v in m.named_buffers()}
 
 
-@pytest.mark.parametrize("p_drop", [0.0, 0.1])
-def test_batched_train_equals_one_episode_at_a_time(p_drop):
+@pytest.mark.parametrize("p_drop,n_way", [(0.0, 2), (0.1, 2), (0.1, 4)])  # (4 ways: two planes of label columns per system)
+def test_batched_train_equals_one_episode_at_a_time(p_drop, n_way):
     from r3dfsseg_amd.batch import EpisodeBatch
     from r3dfsseg_amd.batched import EpisodeBatchRunner
     from r3dfsseg_amd.dist import FlatGradBucket
-    cfg = S.make_cfg(n_way=2, k_shot=2, pc_npts=512)
+    cfg = S.make_cfg(n_way=n_way, k_shot=2, pc_npts=512)
     eps = _episodes(cfg, 3)
     _, want_grad, per, want_buf = _eager_train(cfg, eps, p_drop)
     m = _model(cfg, True, p_drop)
@@ -126,11 +126,11 @@ def test_batched_features_are_bitwise_those_of_the_single_episode():
         assert (got[:, 64:128] - singles[e][:, 64:128]).abs().max().item() < 1e-5
 
 
-@pytest.mark.parametrize("eval_flag", [False, True])
-def test_batched_eval_forward_equals_single_episodes(eval_flag):
+@pytest.mark.parametrize("eval_flag,n_way", [(False, 2), (True, 2), (True, 5)])
+def test_batched_eval_forward_equals_single_episodes(eval_flag, n_way):
     from r3dfsseg_amd.batch import EpisodeBatch
     from r3dfsseg_amd.batched import EpisodeBatchRunner
-    cfg = S.make_cfg(n_way=2, k_shot=2, pc_npts=512)
+    cfg = S.make_cfg(n_way=n_way, k_shot=2, pc_npts=512)
     eps = _episodes(cfg, 5, noise=0.5)
     m = _model(cfg, False)
     want = []

@@ -31,7 +31,8 @@ def _segments(support_y):
     return segs
 
 
-@pytest.mark.parametrize("n_way,k_shot,N,k_sub,seed", [(2, 2, 512, 100, 1), (3, 1, 256, 40, 2), (1, 1, 1024, 100, 3)])
+@pytest.mark.parametrize("n_way,k_shot,N,k_sub,seed", [(2, 2, 512, 100, 1), (3, 1, 256, 40, 2), (1, 1, 1024, 100, 3),
+                                                       (5, 1, 256, 40, 4)])
 def test_prototypes_bitexact_indices(ops, n_way, k_shot, N, k_sub, seed):
     cfg = S.make_cfg(n_way=n_way, k_shot=k_shot, pc_npts=N, n_subprototypes=k_sub)
     data, _ = S.make_episode(cfg, seed)
@@ -55,7 +56,7 @@ def test_prototypes_bitexact_indices(ops, n_way, k_shot, N, k_sub, seed):
     comp_off, _, _, _, sel_off, seeds_off = hb.ws_off
     assign = hb.assign.cpu().numpy()
     nodes = hb.nodes.cpu()
-    Y = hb.Y.cpu()
+    Y = torch.cat([hb.Y[p * hb.n_cap:(p + 1) * hb.n_cap] for p in range(hb.planes)], 1).cpu()  # (n_cap, 4 or 8) one-hot
     segs = _segments(support_y)
     Sn = Sx * N
     seg_off = [0] + [Sn + w * k_shot * N for w in range(n_way)]
@@ -75,7 +76,7 @@ def test_prototypes_bitexact_indices(ops, n_way, k_shot, N, k_sub, seed):
         assert desc[ops.HD_SEG_POFF + s] == row
         assert np.array_equal(assign[seg_off[s]: seg_off[s] + cnt], asg.numpy()), "assignment differs in segment %d" % s
         np.testing.assert_allclose(nodes[row:row + m].numpy(), protos.numpy(), atol=1e-6, rtol=1e-5)
-        lab = torch.zeros(m, 4)
+        lab = torch.zeros(m, 4 * hb.planes)
         lab[:, s] = 1
         assert torch.equal(Y[row:row + m], lab)
         row += m
@@ -192,9 +193,10 @@ def test_logits_and_cross_entropy(ops):
     assert torch.equal(pred.cpu().long(), want_logits.argmax(1))
 
 
-@pytest.mark.parametrize("n_way,k_shot,N,seed", [(2, 1, 512, 1), (2, 2, 512, 2)])
+@pytest.mark.parametrize("n_way,k_shot,N,seed", [(2, 1, 512, 1), (2, 2, 512, 2), (4, 1, 512, 3), (5, 2, 256, 4), (7, 1, 256, 5)])
 def test_mpti_forward_eval_vs_oracle(ops, n_way, k_shot, N, seed):
-    """Whole MPTI_SelfAtten.forward (eval) against the oracle restatement of mpti.py:414-577."""
+    """Whole MPTI_SelfAtten.forward (eval) against the oracle restatement of mpti.py:414-577.  More than 3 ways (the
+    reference takes any n_way, mpti.py:49,58): 5..8 label columns, solved as two planes of 4 on the same graph."""
     from r3dfsseg_amd.mpti import MPTI_SelfAtten
     cfg = S.make_cfg(n_way=n_way, k_shot=k_shot, pc_npts=N)
     sd = S.make_state_dict(cfg, 123)

@@ -240,16 +240,19 @@ def _train_episode(n_way=2, k_shot=2, N=512, seed=3, noise=0.0):
     return cfg, sd, m, data
 
 
-def test_head_losses_and_feature_gradients():
-    """LP loss + contrastive loss and their gradients w.r.t. the features and proj, given equal features."""
+@pytest.mark.parametrize("n_way,k_shot", [(2, 2), (4, 2), (5, 2)])  # (k_shot >= 2: mpti.py:270 samples two negative shots)
+def test_head_losses_and_feature_gradients(n_way, k_shot):
+    """LP loss + contrastive loss and their gradients w.r.t. the features and proj, given equal features.  More than 3
+    ways: the label propagation and its adjoint run as two planes of 4 label columns whose gradients add."""
     from r3dfsseg_amd import contrast, head_train
-    cfg, sd, m, data = _train_episode()
+    cfg, sd, m, data = _train_episode(n_way=n_way, k_shot=k_shot)
     sx, sy, qx, qy = data[:4]
     flag = data[10]
     rs = np.random.RandomState(11)
-    Sn, N = 4, 512
+    Sn, N = n_way * k_shot, 512
+    n_q, C = qx.shape[0], n_way + 1
     sfeat = torch.from_numpy((rs.randn(Sn * N, 192) * 0.08).astype(np.float32))
-    qfeat = torch.from_numpy((rs.randn(2 * N, 192) * 0.08).astype(np.float32))
+    qfeat = torch.from_numpy((rs.randn(n_q * N, 192) * 0.08).astype(np.float32))
     # --- device
     sg, qg = sfeat.cuda().requires_grad_(), qfeat.cuda().requires_grad_()
     closs = contrast.per_way_contrast_loss(m, sg, sy.cuda(), flag.cuda())
@@ -260,17 +263,17 @@ def test_head_losses_and_feature_gradients():
     so, qo = sfeat.clone().requires_grad_(), qfeat.clone().requires_grad_()
     sdr = {k: v.clone() for k, v in sd.items()}
     sdr["proj.weight"].requires_grad_(); sdr["proj.bias"].requires_grad_()
-    sf4 = so.view(2, 2, N, 192).transpose(2, 3)  # (n_way, k_shot, d, N)
+    sf4 = so.view(n_way, k_shot, N, 192).transpose(2, 3)  # (n_way, k_shot, d, N)
     c_ref = O.per_way_contrast_loss(sdr, sf4, sy, flag, 4, 0.1)
-    fg_p, fg_l, _, _ = O.get_foreground_prototypes(sf4, sy, 100, 3)
-    bg_p, bg_l, _, _ = O.get_background_prototypes(sf4, torch.logical_not(sy), 100, 3)
+    fg_p, fg_l, _, _ = O.get_foreground_prototypes(sf4, sy, 100, C)
+    bg_p, bg_l, _, _ = O.get_background_prototypes(sf4, torch.logical_not(sy), 100, C)
     protos = torch.cat((bg_p, fg_p), 0)
-    Y = torch.zeros(protos.shape[0] + 2 * N, 3)
+    Y = torch.zeros(protos.shape[0] + n_q * N, C)
     Y[:protos.shape[0]] = torch.cat((bg_l, fg_l), 0)
     node = torch.cat((protos, qo), 0)
     A = O.affinity(node, 200, 1.0)
     Z = O.label_propagate(A, Y)
-    qpred = Z[protos.shape[0]:].view(-1, N, 3).transpose(1, 2)
+    qpred = Z[protos.shape[0]:].view(-1, N, C).transpose(1, 2)
     lp_ref = torch.nn.functional.cross_entropy(qpred, qy)
     (lp_ref + 0.1 * c_ref).backward()
     assert abs(closs.item() - c_ref.item()) < 1e-4 * max(1, abs(c_ref.item())), (closs.item(), c_ref.item())
@@ -279,6 +282,47 @@ def test_head_losses_and_feature_gradients():
     e_w, e_b = _rel(m.proj.weight.grad.cpu(), sdr["proj.weight"].grad), _rel(m.proj.bias.grad.cpu(), sdr["proj.bias"].grad)
     print("head gradient errors: sfeat %.2e qfeat %.2e proj.w %.2e proj.b %.2e" % (e_s, e_q, e_w, e_b))
     assert e_s < 2e-3 and e_q < 2e-3 and e_w < 1e-3 and e_b < 1e-3
+
+
+@pytest.mark.parametrize("n_way,k_shot", [(4, 2), (6, 2)])
+def test_training_episode_with_more_than_three_ways(n_way, k_shot):
+    """A whole training episode with 5 / 7 classes (models/mpti.py:49,58 take any n_way) through MPTI_SelfAtten.forward
+    and backward: losses, the four debug metrics (mpti.py:515-568) and the feature / proj gradients against the oracle's
+    head on the HIP features (201-NN lists injected, as in the full-size test)."""
+    from r3dfsseg_amd import ops
+    cfg, sd, m, data = _train_episode(n_way=n_way, k_shot=k_shot, N=512, seed=9, noise=0.2)
+    ep = [t.cuda() for t in data]
+    sx, sy, qx, qy, gsy, gqy, flag = data[0], data[1], data[2], data[3], data[6], data[7], data[10]
+    N, Sn = 512, n_way * k_shot
+    m._trace = {}
+    out = m(ep[0], ep[1], ep[2], ep[3], gt_support_y=ep[6], gt_query_y=ep[7], train=True, support_flag=ep[10],
+            lp_iters=m.lp_max_iter)
+    (out[1] + 0.1 * out[2]).backward()
+    assert m.lp_converged(backward=True)
+    assert out[0].shape == (qx.shape[0], n_way + 1, N)
+    tr = m._trace
+    sfeat, qfeat = tr["sfeat"], tr["qfeat"]
+    so = sfeat.detach().cpu().reshape(Sn, N, -1).transpose(1, 2).contiguous().requires_grad_()
+    qo = qfeat.detach().cpu().reshape(qx.shape[0], N, -1).transpose(1, 2).contiguous().requires_grad_()
+    sdh = {k_: v.clone() for k_, v in sd.items()}
+    sdh["proj.weight"].requires_grad_(); sdh["proj.bias"].requires_grad_()
+    hb = m._head[1]
+    n_proto, n = int(hb.desc[ops.HD_N_PROTO].item()), int(hb.desc[ops.HD_N_NODES].item())
+    nbr_hip = tr["nbr"].reshape(hb.n_cap, hb.kp1)[:n].cpu().to(torch.int64)
+    assert torch.equal(nbr_hip, O.knn_l2(hb.nodes[:n].cpu(), hb.kp1))
+    ref, aux = O.mpti_head(sdh, cfg, so, qo, sx, sy, qy, gt_support_y=gsy, gt_query_y=gqy, train=True, support_flag=flag,
+                           nbr_override=nbr_hip, return_aux=True)
+    assert aux["n_proto"] == n_proto
+    (ref[1] + 0.1 * ref[2]).backward()
+    assert abs(out[1].item() - ref[1].item()) <= 1e-4 * max(1.0, abs(ref[1].item())), (out[1].item(), ref[1].item())
+    assert abs(out[2].item() - ref[2].item()) <= 1e-4 * max(1.0, abs(ref[2].item())), (out[2].item(), ref[2].item())
+    np.testing.assert_allclose(out[0].detach().cpu().numpy(), ref[0].detach().numpy(), atol=1e-4)
+    e_s = _rel(sfeat.grad.cpu(), so.grad.transpose(1, 2).reshape(Sn * N, -1))
+    e_q = _rel(qfeat.grad.cpu(), qo.grad.transpose(1, 2).reshape(qx.shape[0] * N, -1))
+    e_w = _rel(m.proj.weight.grad.cpu(), sdh["proj.weight"].grad)
+    assert max(e_s, e_q, e_w) <= 2e-3, (e_s, e_q, e_w)
+    for i, (a, b) in enumerate(zip(out[3:], ref[3:])):
+        assert abs(float(a) - float(b)) <= 2e-3, (i, float(a), float(b))
 
 
 def test_learner_train_step_runs_and_descends():
