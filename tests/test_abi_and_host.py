@@ -65,7 +65,7 @@ def test_unsupported_configs_raise():
     with pytest.raises(NotImplementedError):
         MPTI_SelfAtten(SimpleNamespace(**S.make_cfg(edgeconv_widths=[[64, 32]] * 3)))
     with pytest.raises(NotImplementedError):
-        MPTI_SelfAtten(SimpleNamespace(**S.make_cfg(n_way=4)))
+        MPTI_SelfAtten(SimpleNamespace(**S.make_cfg(n_way=8)))  # (up to 7 ways: two planes of four label columns)
 
 
 def test_product_never_imports_oracle():
