@@ -29,6 +29,42 @@ def test_library_exports_every_declared_symbol():
     assert lib.r3d_lp_ws_words(4396, 201) > 0
 
 
+def test_binding_signatures_match_the_header():
+    """Every prototype of include/r3d.h against the ctypes signature the binding declares for it: argument count, and per
+    argument the class of its type (pointer / int / long / float / double / unsigned).  A binding that has drifted from the
+    header passes a long where the library reads an int -- silently, on this ABI."""
+    import re
+    txt = open(_lib.HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", " ", txt)
+    protos = re.findall(r"([A-Za-z_][A-Za-z0-9_ \*]*?)\b(r3d_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S)
+    assert len(protos) >= 80, len(protos)
+
+    def cls(decl):
+        d = " ".join(decl.split())
+        if "*" in d:
+            return "ptr"
+        base = d.rsplit(" ", 1)[0] if " " in d else d  # drop the parameter name
+        for key, name in (("unsigned", "uint"), ("double", "double"), ("float", "float"), ("long", "long"), ("int", "int")):
+            if key in base:
+                return name
+        raise AssertionError("unparsed parameter %r" % decl)
+
+    ctype_cls = {_lib.c_f: "ptr", _lib.c_i: "int", _lib.c_l: "long", _lib.c_fl: "float", _lib.c_d: "double", _lib.c_u: "uint",
+                 ctypes.c_char_p: "ptr"}
+    seen = set()
+    for ret, name, args in protos:
+        seen.add(name)
+        res, argt = _lib._SIGS[name]
+        params = [a for a in (x.strip() for x in args.split(",")) if a and a != "void"]
+        assert len(params) == len(argt), (name, len(params), len(argt))
+        for i, (p_, t_) in enumerate(zip(params, argt)):
+            want = "ptr" if hasattr(t_, "contents") else ctype_cls[t_]  # (ctypes.POINTER(...) types: host pointers)
+            assert cls(p_) == want, (name, i, p_, t_)
+        assert cls(ret + " x") == ctype_cls[res], (name, ret, res)
+    assert seen == set(_lib._SIGS), seen ^ set(_lib._SIGS)
+
+
 def test_abi_argument_validation_without_gpu():
     """Bad arguments are rejected on the host before any launch (error convention of include/r3d.h)."""
     lib = _lib.load()
