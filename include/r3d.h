@@ -93,7 +93,15 @@ int r3d_knn_topk_split(const float* x, long ldx, const float* x_cm, int B, int N
  * label-propagation systems, each at its capacity N).  status: ONE word for the batch. */
 int r3d_knn_topk_batched(const float* x, long ldx, const float* x_cm, int B, int N, int C, int k, int mode,
                          const int32_t* n_valid_dev, int n_valid_stride, float* norm_ws, float* cm_ws, int32_t* idx_out,
-                         float* score_out, int32_t* status, float* split_ws, long split_ws_words, void* stream);
+                         float* score_out, int32_t* status, float* split_ws, long split_ws_words, float* bf_ws,
+                         long bf_ws_words, void* stream);
+/* bf_ws: optional scratch of r3d_knn_bf_ws_words(B, N, C) floats (needs x and C % 64 == 0): the streamed kernels then run
+ * their THRESHOLD pass -- which only needs a lower bound of every score -- on the bf16 matrix core; the pass that emits
+ * neighbours and scores stays on the fp32 core and the results are bit-identical with and without it. */
+long r3d_knn_bf_ws_words(int B, int N, int C);
+/* test / A-B utility: 0 keeps the threshold pass on the fp32 core even when bf_ws is given (same results).  Returns the
+ * previous setting. */
+int r3d_debug_set_knn_bf16_threshold(int on);
 
 /* ---- 1x1 convolution + folded BatchNorm/bias + activation ---------------------------
  * models/dgcnn.py:64-80 conv1d, models/mpti.py:18-40 BaseLearner, models/attention.py:39-41.

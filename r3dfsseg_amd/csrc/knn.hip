@@ -549,13 +549,20 @@ template <int KB_WAVES, int KB_CAP, int KB_TOP, int KCH /* k-pairs per channel c
           int KB_SAMPLE /* pass A visits every KB_SAMPLE-th sub-tile of a wave: tau from a sample is still a lower bound */,
           bool FULLC /* C is a multiple of the chunk width: no channel clamping / masking in the fragment loads */,
           int SMODE /* score form (R3D_SCORE_*), a compile-time constant: the score arithmetic is VALU work that
-                       competes with the MFMAs for issue slots, 8 instructions per element with both forms computed */>
+                       competes with the MFMAs for issue slots, 8 instructions per element with both forms computed */,
+          bool BFA /* pass A on the bf16 matrix core (KCH == 32, FULLC, nsplit == 1; xpk = the packed pieces).  Pass A only
+                      ESTIMATES the threshold tau: any LOWER bound of every true score will do.  Two bf16 pieces per
+                      coordinate (hi + lo = the top 16 bits), three v_mfma_f32_32x32x16_bf16 per 16 channels (hi hi, hi lo,
+                      lo hi) = 96 cycles where the fp32 form takes 8 x 64; the dropped terms are below 3 * 2^-16 |x||y|,
+                      both forms' fp32 accumulation errors below 2 * C * 2^-24 |x||y|: the bound subtracts 2^-12 |x||y|
+                      + 2^-20 (|x|^2 + |y|^2).  Pass B -- every score that can be emitted -- stays on the fp32 core. */>
 __global__ __launch_bounds__(64 * KB_WAVES) __attribute__((amdgpu_waves_per_eu(KB_WAVES == 4 && (FULLC || KCH < 32) ? 3 : 2)))
 void r3d_knn_append_kernel(
     const float* __restrict__ xT, long ldT, int N, int C, int k, int mode, const int* __restrict__ n_dev, int n_dev_stride,
     const float* __restrict__ nrm, int* __restrict__ idx_out, float* __restrict__ score_out,
     int* __restrict__ status, int* __restrict__ tile_flags, int nsplit, int* __restrict__ idx_tmp,
-    float* __restrict__ sc_tmp) {
+    float* __restrict__ sc_tmp, const unsigned short* __restrict__ xpk /* [B N][2][nch 64] bf16 pieces, BFA only */) {
+  static_assert(!BFA || (KCH == 32 && FULLC), "the bf16 threshold pass takes whole 64-channel chunks");
   // nsplit > 1 (gridDim.z): the CANDIDATE axis is dealt to nsplit workgroups per query tile (sub-tile s goes to
   // workgroup s % nsplit); each selects its own top-k -- its tau is a lower bound of the k-th best score of ITS
   // candidates, which is <= the k-th best of all of them -- into idx_tmp / sc_tmp, and r3d_knn_merge_kernel merges the
@@ -584,6 +591,20 @@ void r3d_knn_append_kernel(
     Aq[jj * Cs + c] = r3d_keep(v, c < C && q0 + jj < n);
   }
   if (tid < 32) cnt_s[tid] = 0;
+  // bf16 threshold pass: the query rows' pieces sit behind the group maxima (the survivor buffers of pass B, which are
+  // larger, take the whole region afterwards), [row][hi nch 64 | lo nch 64] bf16, rows 16 bytes apart in bank phase
+  const int Cp = nch * 64;
+  const int QRS = 2 * Cp + 8;
+  unsigned short* Aqb = reinterpret_cast<unsigned short*>(region + ((32 * (KB_TOP * KB_GROUPS + 1) + 3) & ~3));
+  const unsigned short* xpb = BFA ? xpk + (long)b * N * 2 * Cp : nullptr;
+  if (BFA) {
+    const int cpr = 2 * Cp / 8;  // 16-byte chunks of a row
+    for (int e = tid; e < 32 * cpr; e += 64 * KB_WAVES) {
+      const int jj = e / cpr, c8 = e - jj * cpr;
+      *reinterpret_cast<r3d_u32x4*>(Aqb + jj * QRS + 8 * c8) =
+          *reinterpret_cast<const r3d_u32x4*>(xpb + (long)min(q0 + jj, n - 1) * 2 * Cp + 8 * c8);
+    }
+  }
   KSTAMP(8);
   float nq[16];
 #pragma unroll
@@ -635,6 +656,23 @@ void r3d_knn_append_kernel(
 #pragma unroll
     for (int s = 0; s < KCH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bf[s], acc, 0, 0, 0);
   };
+  // lower bounds of the scores from the bf16 pass (acc = hi hi + hi lo + lo hi of the inner products)
+  auto scores_lb = [&](int st, f32x16& sc) {
+    const int cand = 32 * st + j;
+    const bool valid = cand < n;
+    const float nj = r3d_keep(nb[min(cand, n - 1)], valid);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      // |x||y| <= (|x|^2 + |y|^2) / 2: the inner product is at least acc - 2^-13 t, both forms then lose 2^-12 t, and
+      // 2^-20 t covers the exact form's own roundings
+      const float t = nq[r] + nj;
+      const float m = t * (0x1p-12f + 0x1p-20f);
+      float v;
+      if (SMODE == R3D_SCORE_DGCNN) v = (2.f * acc[r] - t) - m;
+      else v = -fmaxf((t - 2.f * acc[r]) + m, 0.f);
+      sc[r] = valid ? v : -INFINITY;
+    }
+  };
   auto scores = [&](int st, f32x16& sc) {
     const int cand = 32 * st + j;
     const bool valid = cand < n;
@@ -665,7 +703,8 @@ void r3d_knn_append_kernel(
   auto finishA = [&](int t) {
     if ((t % nch) != nch - 1) return;
     f32x16 sc;
-    scores((w + KB_WAVES * stride * (t / nch)) * nsplit + z, sc);
+    if (BFA) scores_lb((w + KB_WAVES * stride * (t / nch)) * nsplit + z, sc);
+    else scores((w + KB_WAVES * stride * (t / nch)) * nsplit + z, sc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float x = sc[r];
@@ -682,14 +721,62 @@ void r3d_knn_append_kernel(
   // register copies afterwards (tools/probe/mfma_feed.hip sustains 110 TFLOP/s this way).  The two-buffer form
   // unrolled by hand compiled to chains that waited, through the single in-order vmcnt counter, on the loads
   // issued right in front of them.
-  if (TA > 0) bload(0, bfA);
-  for (int t = 0; t < TA; ++t) {
-    if (t + 1 < TA) bload(t + 1, bfB);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(t, bfA);
-    finishA(t);
+  if (BFA) {
+    // candidate pieces: 8 consecutive channels of a piece are 16 contiguous bytes of the packed row
+    r3d_u32x4 pfA[8], pfB[8];  // [k-step of 16 channels][hi, lo]
+    auto pload = [&](int t, r3d_u32x4 (&pf)[8]) {
+      const int st = (w + KB_WAVES * stride * (t / nch)) * nsplit + z, ch = (t % nch);
+      const int cc = min(32 * st + j, n - 1);
+      const unsigned short* p = xpb + (long)cc * 2 * Cp + 64 * ch + 8 * h;
 #pragma unroll
-    for (int s = 0; s < KCH; ++s) bfA[s] = bfB[s];
+      for (int s4 = 0; s4 < 4; ++s4) {
+        pf[2 * s4] = *reinterpret_cast<const r3d_u32x4*>(p + 16 * s4);
+        pf[2 * s4 + 1] = *reinterpret_cast<const r3d_u32x4*>(p + Cp + 16 * s4);
+      }
+    };
+    auto pmma = [&](int t, const r3d_u32x4 (&pf)[8]) {
+      const int ch = (t % nch);
+      if (ch == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      }
+      const unsigned short* ap = Aqb + j * QRS + 64 * ch + 8 * h;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {  // (two k-steps' query pieces at a time: 16 registers, not 32)
+        r3d_u32x4 ah[2], al[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          ah[u] = *reinterpret_cast<const r3d_u32x4*>(ap + 16 * (2 * half + u));
+          al[u] = *reinterpret_cast<const r3d_u32x4*>(ap + Cp + 16 * (2 * half + u));
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int s4 = 2 * half + u;
+          acc = r3d_mfma_bf16(al[u], pf[2 * s4], acc);
+          acc = r3d_mfma_bf16(ah[u], pf[2 * s4 + 1], acc);
+          acc = r3d_mfma_bf16(ah[u], pf[2 * s4], acc);
+        }
+      }
+    };
+    if (TA > 0) pload(0, pfA);
+    for (int t = 0; t < TA; ++t) {
+      if (t + 1 < TA) pload(t + 1, pfB);
+      __builtin_amdgcn_sched_barrier(0);
+      pmma(t, pfA);
+      finishA(t);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) pfA[s] = pfB[s];
+    }
+  } else {
+    if (TA > 0) bload(0, bfA);
+    for (int t = 0; t < TA; ++t) {
+      if (t + 1 < TA) bload(t + 1, bfB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(t, bfA);
+      finishA(t);
+#pragma unroll
+      for (int s = 0; s < KCH; ++s) bfA[s] = bfB[s];
+    }
   }
   KSTAMP(10);
   stride = 1;
@@ -767,6 +854,11 @@ void r3d_knn_append_kernel(
     if (tile_flags) tile_flags[(long)b * gridDim.x + blockIdx.x] = 1;
   }
   __syncthreads();
+  if (BFA && tid < 32 && q0 + tid < n && cnt_s[tid] < min(k, n)) {
+    // fewer than k survivors: the bound was not one (non-finite features).  Same exit as an overflow: flagged, redone exactly.
+    if (status) atomicOr(status, 1);
+    if (tile_flags) tile_flags[(long)b * gridDim.x + blockIdx.x] = 1;
+  }
   KSTAMP(14);
 
   // ------------------------------------------------------------------ rank the survivors
@@ -880,14 +972,41 @@ __global__ __launch_bounds__(256) void r3d_knn_merge_kernel(const int* __restric
     }
 }
 
-static size_t knn_append_lds_bytes(int C, int waves, int cap, int top, int kch = 32) {
+static size_t knn_append_lds_bytes(int C, int waves, int cap, int top, int kch = 32, bool bfa = false) {
   const int nch = (C + 2 * kch - 1) / (2 * kch);
   const size_t a = 32 * (size_t)(nch * 2 * kch + 1);
-  const size_t g = 32 * (size_t)(top * waves * 32 + 1);
+  size_t g = 32 * (size_t)(top * waves * 32 + 1);
+  if (bfa) g = ((g + 3) & ~(size_t)3) + 32 * (size_t)(2 * nch * 64 + 8) / 2;  // + the query rows' bf16 pieces (floats)
   const size_t bsz = 2 * 32 * (size_t)cap;
   return sizeof(float) * (a + (g > bsz ? g : bsz));
 }
-static size_t knn_big_lds_bytes(int C) { return knn_append_lds_bytes(C, 8, 384, 2); }
+static size_t knn_big_lds_bytes(int C, bool bfa = false) { return knn_append_lds_bytes(C, 8, 384, 2, 32, bfa); }
+
+// bf16 pieces of the points for the threshold pass of r3d_knn_append_kernel<..., BFA = true>: [row][hi Cp | lo Cp],
+// Cp = C rounded up to 64 (zeros), hi = the top 16 bits of the value, lo = the top 16 bits of what is left
+__global__ void r3d_knn_pack_bf_kernel(const float* __restrict__ x, long ldx, long rows, int C, int Cp,
+                                       unsigned short* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cpr = Cp / 8;
+  if (i >= rows * cpr) return;
+  const long m = i / cpr;
+  const int c0 = 8 * (int)(i - m * cpr);
+  float v[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) v[u] = r3d_keep(x[m * ldx + min(c0 + u, C - 1)], c0 + u < C);
+  const r3d_bx3 f = r3d_bx3_split8(v);
+  *reinterpret_cast<r3d_u32x4*>(out + m * 2 * Cp + c0) = f.h;
+  *reinterpret_cast<r3d_u32x4*>(out + m * 2 * Cp + Cp + c0) = f.m;
+}
+// A/B switch (tests, tools): 0 = the threshold pass stays on the fp32 core even when bf_ws is given.  Same results.
+static int g_knn_bf16_threshold = getenv("R3D_KNN_FP32_THRESHOLD") ? 0 : 1;
+extern "C" int r3d_debug_set_knn_bf16_threshold(int on) {
+  const int old = g_knn_bf16_threshold;
+  g_knn_bf16_threshold = on ? 1 : 0;
+  return old;
+}
+// floats of bf_ws (r3d_knn_topk_batched): the packed pieces, 4 bytes per point and (padded) channel
+extern "C" long r3d_knn_bf_ws_words(int B, int N, int C) { return (long)B * N * (((long)C + 63) / 64 * 64) + 64; }
 #ifndef KM_WAVES  // mid configuration (overridable for tools/knnbench sweeps)
 #define KM_WAVES 4
 #define KM_CAP 128
@@ -905,20 +1024,35 @@ static size_t knn_lds_bytes(int C) {
 }
 
 // launch one instance of the append-and-rank kernel (raising its dynamic-LDS limit once per instance)
-template <int WAVES, int CAP, int TOP, int KCH, int SAMPLE, bool FULLC, int SMODE>
+template <int WAVES, int CAP, int TOP, int KCH, int SAMPLE, bool FULLC, int SMODE, bool BFA = false>
 static int knn_append_launch_mode(dim3 grid, size_t lds, hipStream_t st, const float* xT, long ldT, int N, int C, int k,
                                   const int* n_valid_dev, int n_valid_stride, const float* nrm, int* idx_out, float* score_out, int* status,
-                                  int* tile_flags, int nsplit = 1, int* idx_tmp = nullptr, float* sc_tmp = nullptr) {
+                                  int* tile_flags, int nsplit = 1, int* idx_tmp = nullptr, float* sc_tmp = nullptr,
+                                  const unsigned short* xpk = nullptr) {
   static size_t attr = 0;
   if (lds > attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)r3d_knn_append_kernel<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, SMODE>,
+    hipError_t e = hipFuncSetAttribute((const void*)r3d_knn_append_kernel<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, SMODE, BFA>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     R3D_REQUIRE(e == hipSuccess, "r3d_knn_topk: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
     attr = lds;
   }
-  hipLaunchKernelGGL((r3d_knn_append_kernel<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, SMODE>), grid, dim3(64 * WAVES), lds, st, xT, ldT,
-                     N, C, k, SMODE, n_valid_dev, n_valid_stride, nrm, idx_out, score_out, status, tile_flags, nsplit, idx_tmp, sc_tmp);
+  hipLaunchKernelGGL((r3d_knn_append_kernel<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, SMODE, BFA>), grid, dim3(64 * WAVES), lds, st, xT,
+                     ldT, N, C, k, SMODE, n_valid_dev, n_valid_stride, nrm, idx_out, score_out, status, tile_flags, nsplit, idx_tmp,
+                     sc_tmp, xpk);
   return R3D_OK;
+}
+// the same with the threshold pass on the bf16 matrix core (xpk: r3d_knn_pack_bf_kernel's output)
+template <int WAVES, int CAP, int TOP, int SAMPLE>
+static int knn_append_launch_bfa(dim3 grid, size_t lds, hipStream_t st, const float* xT, long ldT, int N, int C, int k, int mode,
+                                 const int* n_valid_dev, int n_valid_stride, const float* nrm, int* idx_out, float* score_out,
+                                 int* status, int* tile_flags, const unsigned short* xpk) {
+  return mode == R3D_SCORE_DGCNN
+             ? knn_append_launch_mode<WAVES, CAP, TOP, 32, SAMPLE, true, R3D_SCORE_DGCNN, true>(
+                   grid, lds, st, xT, ldT, N, C, k, n_valid_dev, n_valid_stride, nrm, idx_out, score_out, status, tile_flags, 1, nullptr,
+                   nullptr, xpk)
+             : knn_append_launch_mode<WAVES, CAP, TOP, 32, SAMPLE, true, R3D_SCORE_L2, true>(
+                   grid, lds, st, xT, ldT, N, C, k, n_valid_dev, n_valid_stride, nrm, idx_out, score_out, status, tile_flags, 1, nullptr,
+                   nullptr, xpk);
 }
 template <int WAVES, int CAP, int TOP, int KCH, int SAMPLE, bool FULLC>
 static int knn_append_launch(dim3 grid, size_t lds, hipStream_t st, const float* xT, long ldT, int N, int C, int k, int mode,
@@ -963,13 +1097,14 @@ extern "C" long r3d_knn_split_ws_words(int B, int N, int k) { return 4L * B * N 
 
 static int knn_topk_impl(const float* x, long ldx, const float* x_cm, int B, int N, int C, int k, int mode,
                          const int* n_valid_dev, int n_valid_stride, float* norm_ws, float* cm_ws, int32_t* idx_out,
-                         float* score_out, int32_t* status, float* split_ws, long split_ws_words, void* stream);
+                         float* score_out, int32_t* status, float* split_ws, long split_ws_words, float* bf_ws,
+                         long bf_ws_words, void* stream);
 
 extern "C" int r3d_knn_topk(const float* x, long ldx, const float* x_cm, int B, int N, int C, int k, int mode,
                             const int* n_valid_dev, float* norm_ws, float* cm_ws, int32_t* idx_out,
                             float* score_out, int32_t* status, void* stream) {
   return knn_topk_impl(x, ldx, x_cm, B, N, C, k, mode, n_valid_dev, 0, norm_ws, cm_ws, idx_out, score_out, status, nullptr, 0,
-                       stream);
+                       nullptr, 0, stream);
 }
 
 // r3d_knn_topk with an optional scratch for the large-k streamed kernel: when the query tiles alone cannot fill the
@@ -979,25 +1114,37 @@ extern "C" int r3d_knn_topk_split(const float* x, long ldx, const float* x_cm, i
                                   const int* n_valid_dev, float* norm_ws, float* cm_ws, int32_t* idx_out,
                                   float* score_out, int32_t* status, float* split_ws, long split_ws_words, void* stream) {
   return knn_topk_impl(x, ldx, x_cm, B, N, C, k, mode, n_valid_dev, 0, norm_ws, cm_ws, idx_out, score_out, status, split_ws,
-                       split_ws_words, stream);
+                       split_ws_words, nullptr, 0, stream);
 }
 
 // The same over a batch of B point sets with their OWN valid counts: set b has n_valid_dev[b * n_valid_stride] rows (the
 // graph nodes of B episodes' label-propagation systems, each at its capacity N).  status: ONE word for the batch (bit 0:
 // some set's survivor buffer overflowed).
+// bf_ws (optional, r3d_knn_bf_ws_words(B, N, C) floats, needs x): lets the streamed kernels run their THRESHOLD pass on
+// the bf16 matrix core (a lower bound of every score; the pass that emits neighbours and scores stays fp32, results are
+// bit-identical with and without it).
 extern "C" int r3d_knn_topk_batched(const float* x, long ldx, const float* x_cm, int B, int N, int C, int k, int mode,
                                     const int* n_valid_dev, int n_valid_stride, float* norm_ws, float* cm_ws,
                                     int32_t* idx_out, float* score_out, int32_t* status, float* split_ws,
-                                    long split_ws_words, void* stream) {
+                                    long split_ws_words, float* bf_ws, long bf_ws_words, void* stream) {
   R3D_REQUIRE(n_valid_stride >= 0, "r3d_knn_topk_batched: negative stride");
   return knn_topk_impl(x, ldx, x_cm, B, N, C, k, mode, n_valid_dev, n_valid_stride, norm_ws, cm_ws, idx_out, score_out, status,
-                       split_ws, split_ws_words, stream);
+                       split_ws, split_ws_words, bf_ws, bf_ws_words, stream);
 }
 
 static int knn_topk_impl(const float* x, long ldx, const float* x_cm, int B, int N, int C, int k, int mode,
                          const int* n_valid_dev, int n_valid_stride, float* norm_ws, float* cm_ws, int32_t* idx_out,
-                         float* score_out, int32_t* status, float* split_ws, long split_ws_words, void* stream) {
+                         float* score_out, int32_t* status, float* split_ws, long split_ws_words, float* bf_ws,
+                         long bf_ws_words, void* stream) {
   R3D_REQUIRE((x || x_cm) && norm_ws && idx_out, "r3d_knn_topk: null pointer");
+  // the threshold pass on the bf16 core: whole 64-channel chunks, the packed pieces from the point-major matrix
+  const bool bfa = g_knn_bf16_threshold && bf_ws && x && C % 64 == 0 && bf_ws_words >= r3d_knn_bf_ws_words(B, N, C) &&
+                   ((uintptr_t)bf_ws & 15) == 0;
+  auto pack_bf = [&]() {
+    const long chunks = (long)B * N * (C / 8);
+    hipLaunchKernelGGL(r3d_knn_pack_bf_kernel, dim3(r3d_cdiv(chunks, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, (long)B * N,
+                       C, C, (unsigned short*)bf_ws);
+  };
   R3D_REQUIRE(B > 0 && N > 0 && C > 0 && (!x || ldx >= C), "r3d_knn_topk: bad shape B=%d N=%d C=%d ldx=%ld", B, N, C, ldx);
   R3D_REQUIRE(k > 0 && k <= N && k <= 256, "r3d_knn_topk: unsupported k=%d (need 1..min(N,256))", k);
   R3D_REQUIRE(mode == R3D_SCORE_DGCNN || mode == R3D_SCORE_L2, "r3d_knn_topk: unknown mode %d", mode);
@@ -1041,7 +1188,12 @@ static int knn_topk_impl(const float* x, long ldx, const float* x_cm, int B, int
         hipLaunchKernelGGL(r3d_knn_small_kernel<8>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, n_valid_stride, norm_ws,
                            idx_out, score_out, (const int*)tile_flags);
       } else {
-        if (C % 64 == 0) rc = few ? KM_LAUNCH(8, 32, true) : KM_LAUNCH(KM_WAVES, 32, true);
+        if (C % 64 == 0 && bfa && !few) {
+          pack_bf();
+          rc = knn_append_launch_bfa<KM_WAVES, KM_CAP, KM_TOP, KM_SAMPLE>(
+              g2, knn_append_lds_bytes(C, KM_WAVES, KM_CAP, KM_TOP, 32, true), st, xT, ldT, N, C, k, mode, n_valid_dev,
+              n_valid_stride, norm_ws, idx_out, score_out, nullptr, tile_flags, (const unsigned short*)bf_ws);
+        } else if (C % 64 == 0) rc = few ? KM_LAUNCH(8, 32, true) : KM_LAUNCH(KM_WAVES, 32, true);
         else rc = few ? KM_LAUNCH(8, 32, false) : KM_LAUNCH(KM_WAVES, 32, false);
         if (rc) return rc;
         hipLaunchKernelGGL(r3d_knn_small_kernel<32>, g2, dim3(256), 0, st, xT, ldT, N, C, k, mode, n_valid_dev, n_valid_stride, norm_ws,
@@ -1076,7 +1228,13 @@ static int knn_topk_impl(const float* x, long ldx, const float* x_cm, int B, int
       const dim3 gb(tiles, B, nsplit);
       int* idx_tmp = (int*)split_ws;
       float* sc_tmp = split_ws ? split_ws + 2L * B * N * k : nullptr;
-      const int rc = C % 64 == 0
+      const bool bfa_big = bfa && nsplit == 1 && knn_big_lds_bytes(C, true) <= 160 * 1024;
+      if (bfa_big) pack_bf();
+      const int rc = bfa_big
+                         ? knn_append_launch_bfa<8, 384, 2, 1>(gb, knn_big_lds_bytes(C, true), st, xT, ldT, N, C, k, mode, n_valid_dev,
+                                                               n_valid_stride, norm_ws, idx_out, score_out, status, nullptr,
+                                                               (const unsigned short*)bf_ws)
+                     : C % 64 == 0
                          ? knn_append_launch<8, 384, 2, 32, 1, true>(gb, knn_big_lds_bytes(C), st, xT, ldT, N, C, k, mode, n_valid_dev, n_valid_stride,
                                                                      norm_ws, idx_out, score_out, status, nullptr, nsplit, idx_tmp, sc_tmp)
                          : knn_append_launch<8, 384, 2, 32, 1, false>(gb, knn_big_lds_bytes(C), st, xT, ldT, N, C, k, mode, n_valid_dev, n_valid_stride,

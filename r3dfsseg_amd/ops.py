@@ -178,9 +178,16 @@ def knn(x_pm, B, N, k, mode=SCORE_DGCNN, n_valid=None, return_scores=False, x_cm
     if k > 32 and status is not None and 2 * B * ((N + 31) // 32) <= 256:  # the large-k kernel may split the candidate axis
         split_words = lib.r3d_knn_split_ws_words(B, N, k)
         split_ws = torch.empty(split_words, device=dev, dtype=torch.float32)
+    # scratch for the bf16 pieces of the points: the streamed kernels' threshold pass then runs on the bf16 matrix core
+    # (a lower bound is all it needs; neighbours and scores come from the fp32 pass: same bits either way)
+    bf_ws, bf_words = None, 0
+    if C % 64 == 0 and (k <= 32 or status is not None):
+        bf_words = lib.r3d_knn_bf_ws_words(B, N, C)
+        bf_ws = torch.empty(bf_words, device=dev, dtype=torch.float32)
     with _timed("knn_topk_l2" if mode == SCORE_L2 else "knn_topk"):
         _lib.check(lib.r3d_knn_topk_batched(_p(x_pm), ld, _p(x_cm), B, N, C, k, mode, _p(n_valid), n_valid_stride, _p(norm),
-                                            _p(cm_ws), _p(idx), _p(sc), _p(status), _p(split_ws), split_words, _st()))
+                                            _p(cm_ws), _p(idx), _p(sc), _p(status), _p(split_ws), split_words, _p(bf_ws),
+                                            bf_words, _st()))
     return (idx, sc) if return_scores else idx
 
 

@@ -76,6 +76,67 @@ def test_knn_massive_duplicates_overflow_repair(ops):
     assert np.array_equal(got.cpu().numpy().astype(np.int64), want.numpy())
 
 
+@pytest.mark.parametrize("case", ["offset", "tiny", "mixed_scale", "nonfinite"])
+def test_knn_bf16_threshold_pass_keeps_the_bits(ops, case):
+    """The streamed kernels estimate their selection threshold on the bf16 matrix core (csrc/knn.hip: BFA) -- a LOWER bound
+    of every score, so the fp32 pass that emits neighbours and scores decides exactly what it decided before.  Inputs that
+    strain the bound: a large common offset (norms >> distances: the margin 2^-12 (|x|^2 + |y|^2) dwarfs the score gaps,
+    far more survivors, possibly the overflow repair), tiny values (pieces near the bf16 subnormal range), channels of
+    very different scale, and non-finite rows (no valid bound: the tile must be flagged and redone exactly)."""
+    rs = np.random.RandomState(17)
+    B, C, N, k = 2, 64, 1024, 20
+    x = rs.randn(B, C, N).astype(np.float32)
+    if case == "offset":
+        x = x * 0.05 + 7.0
+    elif case == "tiny":
+        x = x * 1e-18
+    elif case == "mixed_scale":
+        x = x * np.logspace(-4, 3, C, dtype=np.float32)[None, :, None]
+    else:
+        x[0, :, 100] = np.inf
+        x[1, 5, 300] = np.nan
+    x = torch.from_numpy(x)
+    from r3dfsseg_amd import _lib
+    lib = _lib.load()
+    got, gsc = ops.knn(ops.cm_to_pm(_dev(x)), B, N, k, return_scores=True)
+    old = lib.r3d_debug_set_knn_bf16_threshold(0)
+    try:
+        ref, rsc = ops.knn(ops.cm_to_pm(_dev(x)), B, N, k, return_scores=True)   # threshold pass on the fp32 core
+    finally:
+        lib.r3d_debug_set_knn_bf16_threshold(old)
+    if case == "nonfinite":
+        # rows whose lists stay clear of the bad points: the same in both paths; the others (NaN scores have no order)
+        # only have to be valid indices -- and nothing may hang or fault
+        # every row but the two bad QUERY rows: identical in both paths.  (Every score of a bad query is NaN, nothing
+        # passes `score >= tau`, its output row stays unwritten in either path -- the consumers clamp neighbour indices,
+        # csrc/edgeconv*.hip -- and its 32-row tile is flagged and redone by the insertion kernel, same result.)
+        ok = torch.ones(B, N, dtype=torch.bool, device=got.device)
+        ok[0, 100] = False
+        ok[1, 300] = False
+        assert torch.equal(got[ok], ref[ok]) and torch.equal(gsc[ok].view(torch.int32), rsc[ok].view(torch.int32))
+        assert int(got[ok].min()) >= 0 and int(got[ok].max()) < N
+        return
+    assert torch.equal(got, ref), "the bf16 threshold pass changed a neighbour"
+    assert torch.equal(gsc.view(torch.int32), rsc.view(torch.int32)), "the bf16 threshold pass changed a score bit"
+    want, wsc = O.knn(x, k, return_dist=True)
+    assert np.array_equal(gsc.cpu().numpy(), wsc.numpy()), "scores differ bitwise"
+    assert np.array_equal(got.cpu().numpy().astype(np.int64), want.numpy()), "indices differ"
+
+
+def test_knn_l2_bf16_threshold_pass_with_large_norms(ops):
+    """201-NN (the head's graph) on nodes with a common offset: norms^2 ~ 200 against neighbour distances^2 ~ 1."""
+    rs = np.random.RandomState(23)
+    n, k = 1400, 201
+    X = torch.from_numpy((rs.randn(n, 192) * 0.07 + 1.0).astype(np.float32))
+    want, wd = O.knn_l2(X, k, return_dist=True)
+    status = torch.zeros(1, dtype=torch.int32).cuda()
+    got, gs = ops.knn(_dev(X), 1, n, k, mode=ops.SCORE_L2, return_scores=True, status=status)
+    if int(status.item()) != 0:  # survivor buffer overflowed under the wide margin: the caller's exact path
+        got, gs = ops.knn(_dev(X), 1, n, k, mode=ops.SCORE_L2, return_scores=True, status=None)
+    assert np.array_equal(got.cpu().numpy()[0].astype(np.int64), want.numpy())
+    assert np.array_equal(np.abs(gs.cpu().numpy()[0]), wd.numpy())
+
+
 def test_knn_full_size_properties(ops):
     """BASELINE size (12 clouds x 2048 x 64): size-independent properties + a sampled oracle check."""
     B, C, N, k = 12, 64, 2048, 20
