@@ -553,15 +553,22 @@ template <int KB_WAVES, int KB_CAP, int KB_TOP, int KCH /* k-pairs per channel c
           bool BFA /* pass A on the bf16 matrix core (KCH == 32, FULLC, nsplit == 1; xpk = the packed pieces).  Pass A only
                       ESTIMATES the threshold tau: any LOWER bound of every true score will do.  Two bf16 pieces per
                       coordinate (hi + lo = the top 16 bits), three v_mfma_f32_32x32x16_bf16 per 16 channels (hi hi, hi lo,
-                      lo hi) = 96 cycles where the fp32 form takes 8 x 64; the dropped terms are below 3 * 2^-16 |x||y|,
-                      both forms' fp32 accumulation errors below 2 * C * 2^-24 |x||y|: the bound subtracts 2^-12 |x||y|
-                      + 2^-20 (|x|^2 + |y|^2).  Pass B -- every score that can be emitted -- stays on the fp32 core. */>
+                      lo hi) = 96 cycles where the fp32 form takes 8 x 64.  The pieces are cut from the points MINUS
+                      their set's mean (a distance does not see a common offset, a 16-bit inner product does: with the
+                      eval-mode features of a random-weight model, norms 1000 x the neighbour distances, the uncentred
+                      bound let every other tile overflow its buffer).  With x', y' the centred points the score is
+                      2 x'.y' - |x'|^2 - |y'|^2 in real arithmetic; the dropped piece products are below 3 * 2^-16
+                      |x'||y'|, the bf16 form's accumulation below C * 2^-24 |x'||y'|, the exact fp32 form's own roundings
+                      (it works on the uncentred points) below (C + 3) 2^-24 (|x|^2 + |y|^2) in the worst case: the
+                      bound subtracts 2^-12 (|x'|^2 + |y'|^2) + (C + 8) 2^-24 (|x|^2 + |y|^2).  Pass B -- every score
+                      that can be emitted -- stays on the fp32 core. */>
 __global__ __launch_bounds__(64 * KB_WAVES) __attribute__((amdgpu_waves_per_eu(KB_WAVES == 4 && (FULLC || KCH < 32) ? 3 : 2)))
 void r3d_knn_append_kernel(
     const float* __restrict__ xT, long ldT, int N, int C, int k, int mode, const int* __restrict__ n_dev, int n_dev_stride,
     const float* __restrict__ nrm, int* __restrict__ idx_out, float* __restrict__ score_out,
     int* __restrict__ status, int* __restrict__ tile_flags, int nsplit, int* __restrict__ idx_tmp,
-    float* __restrict__ sc_tmp, const unsigned short* __restrict__ xpk /* [B N][2][nch 64] bf16 pieces, BFA only */) {
+    float* __restrict__ sc_tmp, const unsigned short* __restrict__ xpk /* [B N][2][nch 64] bf16 pieces, BFA only */,
+    const float* __restrict__ cnorm /* [B N] squared norms of the CENTRED points the pieces were cut from, BFA only */) {
   static_assert(!BFA || (KCH == 32 && FULLC), "the bf16 threshold pass takes whole 64-channel chunks");
   // nsplit > 1 (gridDim.z): the CANDIDATE axis is dealt to nsplit workgroups per query tile (sub-tile s goes to
   // workgroup s % nsplit); each selects its own top-k -- its tau is a lower bound of the k-th best score of ITS
@@ -612,6 +619,14 @@ void r3d_knn_append_kernel(
     const int row = q0 + r3d_acc_row(r, lane);
     nq[r] = r3d_keep(nb[min(row, n - 1)], row < n);
   }
+  // bf16 threshold pass: score >= 2 acc - kq[row] - kj[candidate], k = |x'|^2 (1 + 2^-12) + |x|^2 (C + 8) 2^-24 (see BFA
+  // above: the second term is the WORST case of the exact form's C sequential fp32 accumulations, not the typical
+  // sqrt(C) -- with 2^-20 in its place one row in a few thousand kept k - 1 survivors)
+  const float* cnb = BFA ? cnorm + (long)b * N : nullptr;
+  const float slack = (float)(C + 8) * 0x1p-24f;
+  auto bound_k = [&](int i) { return cnb[i] * (1.f + 0x1p-12f) + nb[i] * slack; };
+  float* kq_s = reinterpret_cast<float*>(Aqb + 32 * QRS);  // [32] behind the query pieces
+  if (BFA && tid < 32) kq_s[tid] = bound_k(min(q0 + tid, n - 1));
   __syncthreads();
 
   const int nsub = ((n + 31) / 32 - z + nsplit - 1) / nsplit;  // sub-tiles of this workgroup: z, z + nsplit, ...
@@ -660,16 +675,11 @@ void r3d_knn_append_kernel(
   auto scores_lb = [&](int st, f32x16& sc) {
     const int cand = 32 * st + j;
     const bool valid = cand < n;
-    const float nj = r3d_keep(nb[min(cand, n - 1)], valid);
+    const float kj = bound_k(min(cand, n - 1));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      // |x||y| <= (|x|^2 + |y|^2) / 2: the inner product is at least acc - 2^-13 t, both forms then lose 2^-12 t, and
-      // 2^-20 t covers the exact form's own roundings
-      const float t = nq[r] + nj;
-      const float m = t * (0x1p-12f + 0x1p-20f);
-      float v;
-      if (SMODE == R3D_SCORE_DGCNN) v = (2.f * acc[r] - t) - m;
-      else v = -fmaxf((t - 2.f * acc[r]) + m, 0.f);
+      const float d = (kq_s[r3d_acc_row(r, lane)] + kj) - 2.f * acc[r];  // >= the true squared distance
+      const float v = SMODE == R3D_SCORE_DGCNN ? -d : -fmaxf(d, 0.f);
       sc[r] = valid ? v : -INFINITY;
     }
   };
@@ -807,9 +817,11 @@ void r3d_knn_append_kernel(
     __syncthreads();
   }
   KSTAMP(11);
+  // (rows beyond n are never emitted: nothing is appended for them -- their pass-B scores, from zeroed fragments, have
+  // nothing to do with a threshold taken from the clamped row's bf16 pieces, and would overflow the buffer for nothing)
   float tauq[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) tauq[r] = tau_s[r3d_acc_row(r, lane)];
+  for (int r = 0; r < 16; ++r) tauq[r] = q0 + r3d_acc_row(r, lane) < n ? tau_s[r3d_acc_row(r, lane)] : INFINITY;
   __syncthreads();  // gmax region is reused as the survivor buffers from here on
 
   // ------------------------------------------------------------------ pass B: append survivors
@@ -855,8 +867,9 @@ void r3d_knn_append_kernel(
   }
   __syncthreads();
   if (BFA && tid < 32 && q0 + tid < n && cnt_s[tid] < min(k, n)) {
-    // fewer than k survivors: the bound was not one (non-finite features).  Same exit as an overflow: flagged, redone exactly.
-    if (status) atomicOr(status, 1);
+    // fewer than k survivors: the bound was not one (non-finite features).  Same exit as an overflow: flagged (bit 1 tells
+    // the two apart for diagnosis; callers test the word against 0), redone exactly.
+    if (status) atomicOr(status, 2);
     if (tile_flags) tile_flags[(long)b * gridDim.x + blockIdx.x] = 1;
   }
   KSTAMP(14);
@@ -976,27 +989,73 @@ static size_t knn_append_lds_bytes(int C, int waves, int cap, int top, int kch =
   const int nch = (C + 2 * kch - 1) / (2 * kch);
   const size_t a = 32 * (size_t)(nch * 2 * kch + 1);
   size_t g = 32 * (size_t)(top * waves * 32 + 1);
-  if (bfa) g = ((g + 3) & ~(size_t)3) + 32 * (size_t)(2 * nch * 64 + 8) / 2;  // + the query rows' bf16 pieces (floats)
+  if (bfa) g = ((g + 3) & ~(size_t)3) + 32 * (size_t)(2 * nch * 64 + 8) / 2 + 32;  // + the query rows' bf16 pieces, bound terms
   const size_t bsz = 2 * 32 * (size_t)cap;
   return sizeof(float) * (a + (g > bsz ? g : bsz));
 }
 static size_t knn_big_lds_bytes(int C, bool bfa = false) { return knn_append_lds_bytes(C, 8, 384, 2, 32, bfa); }
 
 // bf16 pieces of the points for the threshold pass of r3d_knn_append_kernel<..., BFA = true>: [row][hi Cp | lo Cp],
-// Cp = C rounded up to 64 (zeros), hi = the top 16 bits of the value, lo = the top 16 bits of what is left
-__global__ void r3d_knn_pack_bf_kernel(const float* __restrict__ x, long ldx, long rows, int C, int Cp,
-                                       unsigned short* __restrict__ out) {
+// Cp = C rounded up to 64 (zeros), cut from the point MINUS its set's mean: hi = the top 16 bits of the value, lo = the top
+// 16 bits of what is left.  Any mean will do (the bound only needs pieces, centred norms and inner products to belong to
+// the same shifted points); it is the plain fp32 mean over the set's valid rows.
+__global__ __launch_bounds__(1024) void r3d_knn_mean_kernel(const float* __restrict__ x, long ldx, int N, int C,
+                                                            const int* __restrict__ n_dev, int n_dev_stride, int Cp,
+                                                            float* __restrict__ mean /* [B][Cp] */) {
+  __shared__ float part[16][64];
+  const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+  const int n = n_dev ? min(n_dev[(long)b * n_dev_stride], N) : N;
+  float s = 0.f;
+  if (c < C) {
+    const float* p = x + (long)b * N * ldx + c;
+    int r = ph;
+    for (; r + 7 * 16 < n; r += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(long)(r + 16 * u) * ldx];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; r < n; r += 16) s += p[(long)r * ldx];
+  }
+  part[ph][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (ph == 0 && c < Cp) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += part[q][threadIdx.x];
+    mean[(long)b * Cp + c] = c < C && n > 0 ? t / (float)n : 0.f;
+  }
+}
+__global__ void r3d_knn_pack_bf_kernel(const float* __restrict__ x, long ldx, long rows, int N, int C, int Cp,
+                                       const float* __restrict__ mean, unsigned short* __restrict__ out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int cpr = Cp / 8;
   if (i >= rows * cpr) return;
   const long m = i / cpr;
   const int c0 = 8 * (int)(i - m * cpr);
+  const float* mu = mean + (m / N) * Cp + c0;
   float v[8];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) v[u] = r3d_keep(x[m * ldx + min(c0 + u, C - 1)], c0 + u < C);
+  for (int u = 0; u < 8; ++u) v[u] = r3d_keep(x[m * ldx + min(c0 + u, C - 1)] - mu[u], c0 + u < C);
   const r3d_bx3 f = r3d_bx3_split8(v);
   *reinterpret_cast<r3d_u32x4*>(out + m * 2 * Cp + c0) = f.h;
   *reinterpret_cast<r3d_u32x4*>(out + m * 2 * Cp + Cp + c0) = f.m;
+}
+// squared norms of the centred points (one wave per row; fixed order)
+__global__ __launch_bounds__(256) void r3d_knn_cnorm_kernel(const float* __restrict__ x, long ldx, long rows, int N, int C, int Cp,
+                                                            const float* __restrict__ mean, float* __restrict__ cnorm) {
+  const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* mu = mean + (m / N) * Cp;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float d = x[m * ldx + c] - mu[c];
+    s = __builtin_fmaf(d, d, s);
+  }
+  s = r3d_wave_sum(s);
+  if (lane == 0) cnorm[m] = s;
 }
 // A/B switch (tests, tools): 0 = the threshold pass stays on the fp32 core even when bf_ws is given.  Same results.
 static int g_knn_bf16_threshold = getenv("R3D_KNN_FP32_THRESHOLD") ? 0 : 1;
@@ -1006,7 +1065,11 @@ extern "C" int r3d_debug_set_knn_bf16_threshold(int on) {
   return old;
 }
 // floats of bf_ws (r3d_knn_topk_batched): the packed pieces, 4 bytes per point and (padded) channel
-extern "C" long r3d_knn_bf_ws_words(int B, int N, int C) { return (long)B * N * (((long)C + 63) / 64 * 64) + 64; }
+// (pieces B N Cp | means B Cp | centred squared norms B N)
+extern "C" long r3d_knn_bf_ws_words(int B, int N, int C) {
+  const long Cp = ((long)C + 63) / 64 * 64;
+  return (long)B * N * Cp + (long)B * Cp + (long)B * N + 64;
+}
 #ifndef KM_WAVES  // mid configuration (overridable for tools/knnbench sweeps)
 #define KM_WAVES 4
 #define KM_CAP 128
@@ -1028,7 +1091,7 @@ template <int WAVES, int CAP, int TOP, int KCH, int SAMPLE, bool FULLC, int SMOD
 static int knn_append_launch_mode(dim3 grid, size_t lds, hipStream_t st, const float* xT, long ldT, int N, int C, int k,
                                   const int* n_valid_dev, int n_valid_stride, const float* nrm, int* idx_out, float* score_out, int* status,
                                   int* tile_flags, int nsplit = 1, int* idx_tmp = nullptr, float* sc_tmp = nullptr,
-                                  const unsigned short* xpk = nullptr) {
+                                  const unsigned short* xpk = nullptr, const float* cnorm = nullptr) {
   static size_t attr = 0;
   if (lds > attr) {
     hipError_t e = hipFuncSetAttribute((const void*)r3d_knn_append_kernel<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, SMODE, BFA>,
@@ -1038,21 +1101,21 @@ static int knn_append_launch_mode(dim3 grid, size_t lds, hipStream_t st, const f
   }
   hipLaunchKernelGGL((r3d_knn_append_kernel<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, SMODE, BFA>), grid, dim3(64 * WAVES), lds, st, xT,
                      ldT, N, C, k, SMODE, n_valid_dev, n_valid_stride, nrm, idx_out, score_out, status, tile_flags, nsplit, idx_tmp,
-                     sc_tmp, xpk);
+                     sc_tmp, xpk, cnorm);
   return R3D_OK;
 }
 // the same with the threshold pass on the bf16 matrix core (xpk: r3d_knn_pack_bf_kernel's output)
 template <int WAVES, int CAP, int TOP, int SAMPLE>
 static int knn_append_launch_bfa(dim3 grid, size_t lds, hipStream_t st, const float* xT, long ldT, int N, int C, int k, int mode,
                                  const int* n_valid_dev, int n_valid_stride, const float* nrm, int* idx_out, float* score_out,
-                                 int* status, int* tile_flags, const unsigned short* xpk) {
+                                 int* status, int* tile_flags, const unsigned short* xpk, const float* cnorm) {
   return mode == R3D_SCORE_DGCNN
              ? knn_append_launch_mode<WAVES, CAP, TOP, 32, SAMPLE, true, R3D_SCORE_DGCNN, true>(
                    grid, lds, st, xT, ldT, N, C, k, n_valid_dev, n_valid_stride, nrm, idx_out, score_out, status, tile_flags, 1, nullptr,
-                   nullptr, xpk)
+                   nullptr, xpk, cnorm)
              : knn_append_launch_mode<WAVES, CAP, TOP, 32, SAMPLE, true, R3D_SCORE_L2, true>(
                    grid, lds, st, xT, ldT, N, C, k, n_valid_dev, n_valid_stride, nrm, idx_out, score_out, status, tile_flags, 1, nullptr,
-                   nullptr, xpk);
+                   nullptr, xpk, cnorm);
 }
 template <int WAVES, int CAP, int TOP, int KCH, int SAMPLE, bool FULLC>
 static int knn_append_launch(dim3 grid, size_t lds, hipStream_t st, const float* xT, long ldT, int N, int C, int k, int mode,
@@ -1140,10 +1203,16 @@ static int knn_topk_impl(const float* x, long ldx, const float* x_cm, int B, int
   // the threshold pass on the bf16 core: whole 64-channel chunks, the packed pieces from the point-major matrix
   const bool bfa = g_knn_bf16_threshold && bf_ws && x && C % 64 == 0 && bf_ws_words >= r3d_knn_bf_ws_words(B, N, C) &&
                    ((uintptr_t)bf_ws & 15) == 0;
+  float* bf_mean = bf_ws ? bf_ws + (long)B * N * C : nullptr;  // (C == Cp here)
+  float* bf_cnorm = bf_ws ? bf_mean + (long)B * C : nullptr;
   auto pack_bf = [&]() {
+    hipStream_t s_ = (hipStream_t)stream;
+    hipLaunchKernelGGL(r3d_knn_mean_kernel, dim3(C / 64, B), dim3(1024), 0, s_, x, ldx, N, C, n_valid_dev, n_valid_stride, C, bf_mean);
     const long chunks = (long)B * N * (C / 8);
-    hipLaunchKernelGGL(r3d_knn_pack_bf_kernel, dim3(r3d_cdiv(chunks, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, (long)B * N,
-                       C, C, (unsigned short*)bf_ws);
+    hipLaunchKernelGGL(r3d_knn_pack_bf_kernel, dim3(r3d_cdiv(chunks, 256)), dim3(256), 0, s_, x, ldx, (long)B * N, N, C, C, bf_mean,
+                       (unsigned short*)bf_ws);
+    hipLaunchKernelGGL(r3d_knn_cnorm_kernel, dim3(r3d_cdiv((long)B * N, 4)), dim3(256), 0, s_, x, ldx, (long)B * N, N, C, C, bf_mean,
+                       bf_cnorm);
   };
   R3D_REQUIRE(B > 0 && N > 0 && C > 0 && (!x || ldx >= C), "r3d_knn_topk: bad shape B=%d N=%d C=%d ldx=%ld", B, N, C, ldx);
   R3D_REQUIRE(k > 0 && k <= N && k <= 256, "r3d_knn_topk: unsupported k=%d (need 1..min(N,256))", k);
@@ -1192,7 +1261,7 @@ static int knn_topk_impl(const float* x, long ldx, const float* x_cm, int B, int
           pack_bf();
           rc = knn_append_launch_bfa<KM_WAVES, KM_CAP, KM_TOP, KM_SAMPLE>(
               g2, knn_append_lds_bytes(C, KM_WAVES, KM_CAP, KM_TOP, 32, true), st, xT, ldT, N, C, k, mode, n_valid_dev,
-              n_valid_stride, norm_ws, idx_out, score_out, nullptr, tile_flags, (const unsigned short*)bf_ws);
+              n_valid_stride, norm_ws, idx_out, score_out, nullptr, tile_flags, (const unsigned short*)bf_ws, bf_cnorm);
         } else if (C % 64 == 0) rc = few ? KM_LAUNCH(8, 32, true) : KM_LAUNCH(KM_WAVES, 32, true);
         else rc = few ? KM_LAUNCH(8, 32, false) : KM_LAUNCH(KM_WAVES, 32, false);
         if (rc) return rc;
@@ -1233,7 +1302,7 @@ static int knn_topk_impl(const float* x, long ldx, const float* x_cm, int B, int
       const int rc = bfa_big
                          ? knn_append_launch_bfa<8, 384, 2, 1>(gb, knn_big_lds_bytes(C, true), st, xT, ldT, N, C, k, mode, n_valid_dev,
                                                                n_valid_stride, norm_ws, idx_out, score_out, status, nullptr,
-                                                               (const unsigned short*)bf_ws)
+                                                               (const unsigned short*)bf_ws, bf_cnorm)
                      : C % 64 == 0
                          ? knn_append_launch<8, 384, 2, 32, 1, true>(gb, knn_big_lds_bytes(C), st, xT, ldT, N, C, k, mode, n_valid_dev, n_valid_stride,
                                                                      norm_ws, idx_out, score_out, status, nullptr, nsplit, idx_tmp, sc_tmp)

@@ -123,18 +123,58 @@ def test_knn_bf16_threshold_pass_keeps_the_bits(ops, case):
     assert np.array_equal(got.cpu().numpy().astype(np.int64), want.numpy()), "indices differ"
 
 
+def _knn_l2_systems(ops, Xs, k):
+    """201-NN of several systems in one launch (what the batched head does: no candidate split, so the append kernel runs
+    with the bf16 threshold pass) -> (status word, indices (B, n, k), scores)."""
+    B, n = len(Xs), Xs[0].shape[0]
+    X = torch.cat(Xs, 0)
+    nv = torch.full((B,), n, dtype=torch.int32).cuda()
+    status = torch.zeros(1, dtype=torch.int32).cuda()
+    got, gs = ops.knn(_dev(X), B, n, k, mode=ops.SCORE_L2, n_valid=nv, n_valid_stride=1, return_scores=True, status=status)
+    return int(status.item()), got.cpu(), gs.cpu()
+
+
 def test_knn_l2_bf16_threshold_pass_with_large_norms(ops):
-    """201-NN (the head's graph) on nodes with a common offset: norms^2 ~ 200 against neighbour distances^2 ~ 1."""
+    """201-NN (the head's graphs, 4 systems per launch) on nodes with a common offset: norms^2 ~ 200 against neighbour
+    distances^2 ~ 1 -- the threshold pass cuts its bf16 pieces from the points minus their system's mean, or its margin
+    would swallow the score gaps."""
     rs = np.random.RandomState(23)
     n, k = 1400, 201
-    X = torch.from_numpy((rs.randn(n, 192) * 0.07 + 1.0).astype(np.float32))
-    want, wd = O.knn_l2(X, k, return_dist=True)
-    status = torch.zeros(1, dtype=torch.int32).cuda()
-    got, gs = ops.knn(_dev(X), 1, n, k, mode=ops.SCORE_L2, return_scores=True, status=status)
-    if int(status.item()) != 0:  # survivor buffer overflowed under the wide margin: the caller's exact path
-        got, gs = ops.knn(_dev(X), 1, n, k, mode=ops.SCORE_L2, return_scores=True, status=None)
-    assert np.array_equal(got.cpu().numpy()[0].astype(np.int64), want.numpy())
-    assert np.array_equal(np.abs(gs.cpu().numpy()[0]), wd.numpy())
+    Xs = [torch.from_numpy((rs.randn(n, 192) * 0.07 + 1.0 + 0.1 * b).astype(np.float32)) for b in range(4)]
+    status, got, gs = _knn_l2_systems(ops, Xs, k)
+    assert status == 0, "survivor buffer overflowed: the bound is too loose"
+    from r3dfsseg_amd import _lib
+    old = _lib.load().r3d_debug_set_knn_bf16_threshold(0)
+    try:
+        status0, ref, rs0 = _knn_l2_systems(ops, Xs, k)   # threshold pass on the fp32 core
+    finally:
+        _lib.load().r3d_debug_set_knn_bf16_threshold(old)
+    assert status0 == 0 and torch.equal(got, ref) and torch.equal(gs.view(torch.int32), rs0.view(torch.int32))
+    for b in range(4):
+        want, wd = O.knn_l2(Xs[b], k, return_dist=True)
+        assert np.array_equal(got[b].numpy().astype(np.int64), want.numpy())
+        assert np.array_equal(np.abs(gs[b].numpy()), wd.numpy())
+
+
+def test_knn_l2_rows_beyond_n_append_nothing(ops):
+    """A query tile that reaches beyond the n valid rows: those rows are computed from zeroed fragments (their pass-B score
+    is minus the candidate's squared norm) and must not append survivors.  With the threshold taken from bf16 pieces of the
+    clamped LAST valid row they did, overflowed the survivor buffer whenever many candidates had a smaller squared norm
+    than that row's 201st distance, and sent the whole batch to the exact fall-back (found in the batched training step:
+    4396 nodes = 137 tiles + 12 rows).  Points of very different scale make that the rule here."""
+    rs = np.random.RandomState(29)
+    n, k = 32 * 40 + 12, 201
+    Xs = []
+    for b in range(4):
+        scale = rs.uniform(0.3, 1.5, size=(n, 1)).astype(np.float32)
+        scale[-1] = 1.5
+        Xs.append(torch.from_numpy(rs.randn(n, 192).astype(np.float32) * 0.1 * scale))
+    status, got, gs = _knn_l2_systems(ops, Xs, k)
+    assert status == 0, "survivor buffer overflowed (rows beyond n?)"
+    for b in range(4):
+        want, wd = O.knn_l2(Xs[b], k, return_dist=True)
+        assert np.array_equal(got[b].numpy().astype(np.int64), want.numpy())
+        assert np.array_equal(np.abs(gs[b].numpy()), wd.numpy())
 
 
 def test_knn_full_size_properties(ops):
