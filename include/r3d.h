@@ -181,6 +181,15 @@ int r3d_label_propagate_batched(int n_ep, const float* nodes, long ldn, int D, c
                                 const int32_t* n_dev, const int32_t* n_proto_dev, long desc_stride, int n_cap, float sigma,
                                 float alpha, int max_iter, float tol, float* Z, int32_t* ws, long ws_words, long ws_stride,
                                 int32_t* stats_out, long stats_stride, void* stream);
+/* Runtime guard for schedules with several streams in flight: recomputes the directed gaussian weights of
+ * the graphs a preceding r3d_label_propagate(_batched) left in ws -- to be called with nothing else on the chip -- and adds
+ * to *mismatch_out the number of entries whose bits differ from the ones the solve used.  scratch:
+ * n_ep * r3d_graph_weights_verify_words(n_cap, kp1) floats. */
+long r3d_graph_weights_verify_words(int n_cap, int kp1);
+int r3d_graph_weights_verify(int n_ep, const float* nodes, long ldn, int D, const int32_t* n_dev, long desc_stride, int n_cap,
+                             int kp1, float sigma, int32_t* ws, long ws_words, long ws_stride, float* scratch,
+                             int32_t* mismatch_out, void* stream);
+
 /* More than 3 ways (5..8 classes; models/mpti.py:49,58 take any n_way): label columns travel as float4 per node, so Y, Z
  * (and G, lambda of the backward) are TWO planes of 4 columns, (2, n_ep * n_cap, 4), plane 1 = classes 4..7, written /
  * read that way by r3d_head_prototypes_batched, r3d_query_logits_ce_batched, r3d_ce_grad_batched and

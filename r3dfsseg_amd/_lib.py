@@ -107,6 +107,8 @@ _SIGS = {
                                           c_f, c_l, c_l, c_f, c_f, c_l, c_f, c_l, c_f, c_l, c_f, c_l, c_l, c_i, c_f]),
     "r3d_head_prototypes_bwd_batched": (c_i, [c_i, c_f, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_l, c_f, c_l, c_f, c_l, c_f, c_l,
                                               c_f, c_l, c_l, c_f, c_l, c_l, c_f]),
+    "r3d_graph_weights_verify_words": (c_l, [c_i, c_i]),
+    "r3d_graph_weights_verify": (c_i, [c_i, c_f, c_l, c_i, c_f, c_l, c_i, c_i, c_fl, c_f, c_l, c_l, c_f, c_f, c_f]),
     "r3d_label_propagate_solve_batched": (c_i, [c_i, c_f, c_f, c_l, c_i, c_i, c_fl, c_i, c_fl, c_f, c_f, c_l, c_l, c_f, c_l, c_f]),
     "r3d_label_propagate_batched": (c_i, [c_i, c_f, c_l, c_i, c_f, c_i, c_f, c_f, c_f, c_l, c_i, c_fl, c_fl, c_i, c_fl, c_f, c_f,
                                           c_l, c_l, c_f, c_l, c_f]),

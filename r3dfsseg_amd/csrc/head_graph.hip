@@ -1286,6 +1286,61 @@ extern "C" int r3d_lp_ws_offsets(int n_cap, int kp1, long* out6) {
   return R3D_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Runtime guard of the multi-stream schedule (packed fp32 arithmetic beside bf16-MFMA-dense waves computed
+// wrong graph weights on this chip; the library is built without those instructions and tests/test_gpu_concurrency.py
+// gates it, but the cause is not established).  Recomputes the directed gaussian weights of the systems whose graph a
+// preceding r3d_label_propagate(_batched) left in ws -- call it with nothing else on the chip -- into `scratch`
+// (r3d_graph_weights_verify_words floats per system) and counts the entries whose BITS differ from the ones the solve
+// used: *mismatch_out += count (device int).  ~2 ms for 32 systems of workload S.
+// ---------------------------------------------------------------------------
+__global__ void r3d_weights_compare_kernel(const int* __restrict__ row_ptr, const int* __restrict__ n_dev, int n_cap,
+                                           const float* __restrict__ wdir, const float* __restrict__ wdir2, long scratch_stride,
+                                           int* __restrict__ mismatch, HgEp st) {
+  const int ep = blockIdx.y;
+  HG_WS(row_ptr); HG_AT(n_dev, st.desc); HG_WS(wdir);
+  wdir2 += (long)ep * scratch_stride;
+  const int n = min(*n_dev, n_cap);
+  const long nnz2 = 2L * row_ptr[n];
+  int bad = 0;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nnz2; e += (long)gridDim.x * blockDim.x)
+    bad += __float_as_uint(wdir[e]) != __float_as_uint(wdir2[e]) ? 1 : 0;
+  bad = (int)r3d_wave_sum((float)bad);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(mismatch, bad);
+}
+extern "C" long r3d_graph_weights_verify_words(int n_cap, int kp1) {
+  const long nnz_cap = 2L * n_cap * (kp1 - 1);
+  return 2 * nnz_cap + nnz_cap + n_cap + 64;  // wdir | val | dinv
+}
+extern "C" int r3d_graph_weights_verify(int n_ep, const float* nodes, long ldn, int D, const int32_t* n_dev, long desc_stride,
+                                        int n_cap, int kp1, float sigma, int32_t* ws, long ws_words, long ws_stride,
+                                        float* scratch, int32_t* mismatch_out, void* stream) {
+  R3D_REQUIRE(nodes && n_dev && ws && scratch && mismatch_out, "r3d_graph_weights_verify: null pointer");
+  R3D_REQUIRE(n_cap > 0 && kp1 >= 2 && ws_words >= r3d_lp_ws_words(n_cap, kp1) && n_ep >= 1 &&
+                  (n_ep == 1 || ((ws_stride & 3) == 0 && ws_stride >= ws_words)),
+              "r3d_graph_weights_verify: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const LpWs L = lp_carve(ws, n_cap, kp1);
+  const long nnz_cap = 2L * n_cap * (kp1 - 1), per = r3d_graph_weights_verify_words(n_cap, kp1);
+  // the kernel addresses its outputs through the systems' scratch stride: run it system by system into the guard's own
+  // arrays (outputs are plain pointers there)
+  for (int e = 0; e < n_ep; ++e) {
+    HgEp one{};
+    float* base = scratch + (long)e * per;
+    int32_t* wse = ws + (long)e * ws_stride;
+    const LpWs Le = lp_carve(wse, n_cap, kp1);
+    hipLaunchKernelGGL(r3d_graph_weights_kernel, dim3(n_cap, 1), dim3(256), 0, st, nodes + (long)e * n_cap * ldn, ldn, D, Le.outb,
+                       (int)Le.words, n_dev + (long)e * desc_stride, n_cap, Le.row_ptr, Le.col, sigma, base + 2 * nnz_cap,
+                       base + 3 * nnz_cap, base, one);
+  }
+  HgEp ep{};
+  ep.desc = desc_stride; ep.ws = ws_stride;
+  hipLaunchKernelGGL(r3d_weights_compare_kernel, dim3(256, n_ep), dim3(256), 0, st, L.row_ptr, n_dev, n_cap, L.wdir, scratch, per,
+                     mismatch_out, ep);
+  R3D_LAUNCH_CHECK("r3d_graph_weights_verify");
+  return R3D_OK;
+}
+
 // {converged, iterations} of every system -> stats_out (stride st.stats words)
 __global__ void r3d_cg_stats_kernel(const CgState* __restrict__ cg, int* __restrict__ stats_out, HgEp st) {
   const int ep = blockIdx.x;

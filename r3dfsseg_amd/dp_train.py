@@ -10,7 +10,7 @@ from . import dist as D
 
 
 class DPTrainer:
-    def __init__(self, learner, n_slots=0, example=None, lp_budget=None, batch_size=0):
+    def __init__(self, learner, n_slots=0, example=None, lp_budget=None, batch_size=0, guard_every=64):
         """batch_size > 0 (the throughput path, batched.py): the local episodes of a step go through ONE launch sequence
         per batch of up to batch_size episodes -- every kernel works on the whole batch, the weight gradients are summed
         inside the dW GEMMs straight into the bucket.
@@ -18,6 +18,12 @@ class DPTrainer:
         hipGraphs, n_slots in flight on separate HIP streams (episode_graph.EpisodeGraphs; `example` = one episode fixing
         the shapes); every slot accumulates into its own gradient row and the rows are summed into the bucket.
         Neither: eager launches, one episode after the other (the reference's schedule)."""
+        # guard_every (n_slots > 1 only): every that many steps the slots' label-propagation edge weights are recomputed
+        # on the drained chip and compared bit for bit (EpisodeGraphs.verify_graph_weights): kernels of several streams
+        # share the chip in that schedule, and wrong weights next to bf16-MFMA-dense waves are what round 2 found
+        # before the library was rebuilt without packed fp32 arithmetic.  0 switches the guard off.
+        self.guard_every = guard_every
+        self.n_steps = 0
         self.learner = learner
         self.model = learner.model
         self.bucket = D.FlatGradBucket(self.model.parameters())
@@ -78,6 +84,12 @@ class DPTrainer:
             if self.graphs is not None:
                 total = self.graphs.run(episodes, apply_bn=False)
                 bad, overflow, _, _ = self.graphs.step_status()
+                self.n_steps += 1
+                if self.guard_every and self.graphs.n_slots > 1 and self.n_steps % self.guard_every == 0:
+                    wrong = self.graphs.verify_graph_weights()
+                    if wrong:
+                        raise RuntimeError("guard: %d label-propagation edge weights computed beside other streams' kernels "
+                                           "differ from their recomputation on the idle chip" % wrong)
                 if bad or overflow:
                     self.redone = True
                     self.n_redone += 1

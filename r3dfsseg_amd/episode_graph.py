@@ -284,6 +284,19 @@ class EpisodeGraphs:
         self._probes.append((ev, c))
         return total
 
+    def verify_graph_weights(self):
+        """Runtime guard of the multi-stream schedule: with every stream drained, recompute the
+        label-propagation edge weights of each slot's last episode alone on the chip and compare their bits with what the
+        slot's solve used while other slots' kernels ran beside it.  Returns the number of differing entries (host int)."""
+        from . import ops
+        torch.cuda.synchronize()
+        bad = 0
+        for sl in self.slots:
+            last = sl.state.last
+            if last is not None:
+                bad += int(ops.graph_weights_verify(last[1], self.model.sigma).item())
+        return bad
+
     def check(self):
         """Host check (synchronises): (number of replays whose label propagation did not converge or whose
         201-NN survivor buffer overflowed since the last check, sum of the CG iterations, max CG iterations)."""

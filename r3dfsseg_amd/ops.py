@@ -352,6 +352,19 @@ def label_propagate(hb, nbr, sigma, alpha=0.99, max_iter=200, tol=1e-6):
     return hb.Z
 
 
+def graph_weights_verify(hb, sigma):
+    """Recompute the gaussian edge weights of the graphs the last label_propagate left in hb (call with the chip otherwise
+    idle) and return the number of entries whose bits differ from the ones the solve used (device int32 tensor)."""
+    lib = _lib.load()
+    dev = hb.nodes.device
+    scratch = torch.empty(hb.E * lib.r3d_graph_weights_verify_words(hb.n_cap, hb.kp1), device=dev, dtype=torch.float32)
+    bad = torch.zeros(1, device=dev, dtype=torch.int32)
+    _lib.check(lib.r3d_graph_weights_verify(hb.E, _p(hb.nodes), hb.nodes.stride(0), hb.D, _p(hb.n_nodes_ptr()), 32, hb.n_cap,
+                                            hb.kp1, float(sigma), _p(hb.lp_ws), hb.lp_words, hb.lp_stride, _p(scratch), _p(bad),
+                                            _st()))
+    return bad
+
+
 def query_logits_ce(hb, n_q, n_classes, labels):
     """labels (E, n_q, N) int64 or None -> logits (E, n_q, n_classes, N), loss (E,), pred (E, n_q, N) int32 (E = 1: without
     the episode axis)."""

@@ -46,7 +46,7 @@ def _worker(rank, world, port, out):
 
 def test_two_rank_flat_bucket_allreduce():
     world, port = 2, _free_port()
-    with mp.Manager() as mgr:
+    with mp.get_context("spawn").Manager() as mgr:
         out = mgr.dict()
         mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
         out = dict(out)

@@ -191,3 +191,25 @@ def test_learner_graph_path_equals_eager_path():
         np.testing.assert_allclose(outs[False][2][k].float().numpy(), outs[True][2][k].float().numpy(), rtol=1e-4, atol=1e-5)
     assert torch.equal(outs[False][3], outs[True][3]) and torch.equal(outs[False][6], outs[True][6])
     assert abs(outs[False][4] - outs[True][4]) < 1e-4 and outs[False][5] == outs[True][5] and outs[False][7] == outs[True][7]
+
+
+def test_graph_weight_guard_of_the_multi_stream_schedule():
+    """DPTrainer's runtime guard for schedules with several streams in flight (EpisodeGraphs.verify_graph_weights): the
+    label-propagation edge weights every slot's last solve used, recomputed alone on the drained chip, must have the same
+    bits -- and a single flipped bit in a slot's weights must be reported."""
+    from r3dfsseg_amd.episode_graph import EpisodeGraphs
+    cfg = S.make_cfg(n_way=2, k_shot=2, pc_npts=512)
+    m = _model(cfg, False)
+    eps = _episodes(cfg, 6)
+    g = EpisodeGraphs(m, eps[0][:4], n_slots=3, train=False)
+    g.run([e[:4] for e in eps])
+    assert g.step_status()[:2] == (0, 0)
+    assert g.verify_graph_weights() == 0
+    hb = g.slots[1].state.last[1]
+    nnz_cap = 2 * hb.n_cap * (hb.kp1 - 1)
+    wdir0 = hb.lp_off["val"] + nnz_cap          # (the directed weights follow the symmetric values in the workspace)
+    ws = hb.lp_ws.view(-1)
+    ws[wdir0 + 5] ^= 1                           # one bit of one weight
+    assert g.verify_graph_weights() == 1
+    ws[wdir0 + 5] ^= 1
+    assert g.verify_graph_weights() == 0
