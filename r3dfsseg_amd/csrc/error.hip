@@ -26,10 +26,11 @@ extern "C" int r3d_set_matrix_arith(int mode) {
 }
 extern "C" int r3d_get_matrix_arith(void) { return g_r3d_matrix_arith; }
 // Which of the index-free GEMMs take the bf16 x 3 form when the mode above is 1 (bit 0: point-wise, bit 1: weight
-// gradient).  Default: both.  An A/B knob for tests and tools/probe/gemm_arith_sweep.sh.
-int g_r3d_gemm_bx3 = 1 | 2;
+// gradient; bit 2: the point-wise kernel with W cut once per call, gemm_bx3.hip).  Default: all.  An A/B knob for tests
+// and tools/probe/gemm_arith_sweep.sh.
+int g_r3d_gemm_bx3 = 1 | 2 | 4;
 extern "C" int r3d_debug_set_gemm_bx3(int mask) {
-  R3D_REQUIRE(mask >= 0 && mask < 4, "r3d_debug_set_gemm_bx3: mask %d", mask);
+  R3D_REQUIRE(mask >= 0 && mask < 8, "r3d_debug_set_gemm_bx3: mask %d", mask);
   g_r3d_gemm_bx3 = mask;
   return R3D_OK;
 }

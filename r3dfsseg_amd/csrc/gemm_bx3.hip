@@ -15,6 +15,7 @@
 #define ATT_ABL 4
 #endif
 #include "common.h"
+#include <type_traits>
 #ifndef GB_ABL
 #define GB_ABL 0
 #endif
@@ -279,6 +280,213 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The same product with W cut ONCE per call (r3d_w_pack_bx3_kernel: the pieces in the order the main kernel's LDS image
+// wants them, 24 KB per (128-column tile, K-step) -- L2-resident: W is at most 512 x 512) and 32-row wave tiles:
+// 64 accumulator registers instead of 128, ~150 registers in all -> THREE workgroups per CU where the kernel above
+// fits two, and per K-step and wave 88 VALU instructions of cutting (X only) for 48 MFMAs instead of 264 for 96.
+// A workgroup = 4 waves x 32 rows on the same NT x 32 columns; the W tile of the next K-step is copied global -> LDS
+// behind the current step's MFMAs (two halves of 3 x 16 bytes per thread), one barrier per K-step.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void r3d_w_pack_bx3_kernel(const float* __restrict__ W, int K, int Co, int BN /* 128 or 64 */,
+                                      unsigned short* __restrict__ out) {
+  const int NT = BN / 32, ksteps = K / 32;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (column n of the padded matrix, chunk of 8 k)
+  const int Cop = (Co + BN - 1) / BN * BN;
+  if (i >= (long)Cop * (K / 8)) return;
+  const int n = (int)(i / (K / 8)), c8 = (int)(i - (long)n * (K / 8));
+  const int ks = c8 >> 2, c = c8 & 3;  // chunk c of K-step ks: memory k = 32 ks + 8 c + 0..7 = 16 g + 8 s + i with c = 2 g + s
+  float v[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) v[u] = r3d_keep(W[(long)min(n, Co - 1) * K + 32 * ks + 8 * c + u], n < Co);
+  const r3d_bx3 f = r3d_bx3_split8(v);
+  const int ct = n / BN, tn = (n % BN) >> 5, lane = (n & 31) + 32 * (c >> 1), sx = c & 1;
+  // [ct][ks][s][tn][piece][lane][8]
+  unsigned short* d = out + ((((long)(ct * ksteps + ks) * 2 + sx) * NT + tn) * 3) * 512 + lane * 8;
+  *reinterpret_cast<r3d_u32x4*>(d) = f.h;
+  *reinterpret_cast<r3d_u32x4*>(d + 512) = f.m;
+  *reinterpret_cast<r3d_u32x4*>(d + 1024) = f.l;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void r3d_pointwise_gemm_bx3p_kernel(
+    const float* __restrict__ X, long ldx, const unsigned short* __restrict__ Wp, int M, int K, int Co,
+    const float* __restrict__ scale, const float* __restrict__ shift, int act, float* __restrict__ Out, long ldo,
+    int accumulate, float* __restrict__ stats_part) {
+  constexpr int BM = 128, BN = 32 * NT;
+  constexpr int TILE = 2 * NT * 3 * 512;  // bf16 of one (column tile, K-step) image
+  constexpr int CPT = TILE / 8 / 256;     // 16-byte chunks per thread and K-step: 6 (NT = 4) or 3 (NT = 2)
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[2][TILE];
+  __shared__ float st_s[2][2][BN];        // [64-row tile of the workgroup][sum, sum of squares][column] of its upper wave
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int j = lane & 31, g = lane >> 5;
+  const int tiles_n = (Co + BN - 1) / BN, ksteps = K / 32;
+  const int tile = r3d_xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+  const int tile_m = tile / tiles_n, ct = tile - tile_m * tiles_n;
+  const long m0 = (long)tile_m * BM, mw = m0 + 32 * w;  // the wave's 32 rows
+  const int n0 = ct * BN;
+  const long arows = min((long)BM, (long)M - m0);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(X + m0 * ldx), 0, (int)(((arows - 1) * ldx + K) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(Wp + (long)ct * ksteps * TILE), 0, ksteps * TILE * 2, 0x00020000);
+  const int oa = (int)(((32 * w + j) * ldx + 16 * g) * 4);
+  float araw[16];
+  auto aload = [&](int k) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const r3d_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, oa + 16 * q, k * 4, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) araw[4 * q + i] = __uint_as_float(v[i]);
+    }
+  };
+  // W image of K-step ks: chunk (tid + 256 u) of the 24 / 12 KB, copied as it lies
+  constexpr int H0 = (CPT + 1) / 2;  // chunks [0, H0) travel in the first half of a step, [H0, CPT) in the second
+  r3d_u32x4 wst[CPT];
+  auto wload = [&](int ks, int half) {
+#pragma unroll
+    for (int u = 0; u < CPT; ++u)
+      if ((u < H0) == (half == 0)) wst[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, (tid + 256 * u) * 16, ks * TILE * 2, 0);
+  };
+  auto wstore = [&](int buf, int half) {
+#pragma unroll
+    for (int u = 0; u < CPT; ++u)
+      if ((u < H0) == (half == 0)) *reinterpret_cast<r3d_u32x4*>(&Bs[buf][(tid + 256 * u) * 8]) = wst[u];
+  };
+  f32x16 acc[NT];
+#pragma unroll
+  for (int b = 0; b < NT; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+  auto mma = [&](int buf, int sx, const r3d_bx3& fa) {
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) {
+      r3d_bx3 fb;
+      const unsigned short* bsrc = &Bs[buf][((sx * NT + tn) * 3) * 512 + lane * 8];
+      fb.h = *reinterpret_cast<const r3d_u32x4*>(bsrc);
+      fb.m = *reinterpret_cast<const r3d_u32x4*>(bsrc + 512);
+      fb.l = *reinterpret_cast<const r3d_u32x4*>(bsrc + 1024);
+      acc[tn] = r3d_bx3_mma(fa, fb, acc[tn]);
+    }
+  };
+  wload(0, 0);
+  wload(0, 1);
+  aload(0);
+  wstore(0, 0);
+  wstore(0, 1);
+  __syncthreads();
+  // branch-free loop body (exact wait counts, see the kernel above): the last step requests its own operands again
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const int cur = ks & 1, kn = min(ks + 1, ksteps - 1);
+    const r3d_bx3 fa0 = r3d_bx3_split8(&araw[0]), fa1 = r3d_bx3_split8(&araw[8]);
+    aload(32 * kn);
+    wload(kn, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(cur, 0, fa0);
+    wstore(cur ^ 1, 0);
+    wload(kn, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(cur, 1, fa1);
+    wstore(cur ^ 1, 1);
+    __syncthreads();
+  }
+  // Epilogue: the wave's 32 rows x BN columns through LDS (the W buffers, free after the last barrier), whole rows out.
+  // The SIMD's vector ISSUE is what bounds this kernel (SQ counters: 4.2 VALU + 1.8 LDS instructions per MFMA with a
+  // one-size-fits-all epilogue -- ~37 issue cycles against the MFMA's 32), and the epilogue is paid per output element
+  // whatever K is: so it comes in variants chosen by wave-uniform branches -- PLAIN (no scale / shift / activation:
+  // raw z of a training layer, input gradients), STATS (column sums wanted), FULL (no row or column of the tile
+  // beyond M / Co: no bounds arithmetic per element).
+  constexpr int ER = BN + 4;
+  float* es = reinterpret_cast<float*>(&Bs[0][0]) + w * 8 * ER;
+  constexpr int LPR = BN / 4, RPI = 64 / LPR;
+  const int erow = lane / LPR, ecol = 4 * (lane % LPR);
+  float s1[NT], s2[NT];
+#pragma unroll
+  for (int tn = 0; tn < NT; ++tn) s1[tn] = s2[tn] = 0.f;
+  auto epilogue = [&](auto PLAIN_, auto STATS_, auto FULL_) {
+    constexpr bool PLAIN = decltype(PLAIN_)::value, STATS = decltype(STATS_)::value, FULL = decltype(FULL_)::value;
+    const bool cok = FULL || n0 + ecol < Co;
+    float sc[NT], sh[NT];
+    if (!PLAIN) {
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn) {
+        const int jc = n0 + 32 * tn + j;
+        sc[tn] = (scale && (FULL || jc < Co)) ? scale[jc] : 1.f;
+        sh[tn] = (shift && (FULL || jc < Co)) ? shift[jc] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // registers 4q .. 4q+3: rows 8 q + 4 g + (0..3)
+      const int rleft = FULL ? 8 : (int)min((long)8, (long)M - (mw + 8 * q));  // valid rows of this group of 8 (uniform)
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = acc[tn][4 * q + i];
+          if (!PLAIN) {
+            v = sc[tn] * v + sh[tn];
+            if (act == GB_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (act == GB_ACT_LRELU02) v = fmaxf(v, 0.2f * v);
+          }
+          es[(4 * g + i) * ER + 32 * tn + j] = v;
+          if (STATS) {
+            const float u = FULL ? v : r3d_keep(v, 4 * g + i < rleft);  // (rows beyond M hold zeros anyway; PLAIN keeps them 0)
+            s1[tn] += u;
+            s2[tn] += u * u;
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8 / RPI; ++i) {
+        const int row = erow + RPI * i;
+        const float4 v = *reinterpret_cast<const float4*>(&es[row * ER + ecol]);
+        if ((FULL || row < rleft) && cok) {
+          float4* dst = reinterpret_cast<float4*>(&Out[(mw + 8 * q + row) * ldo + n0 + ecol]);
+          if (accumulate) {
+            const float4 o = *dst;
+            *dst = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+          } else {
+            *dst = v;
+          }
+        }
+      }
+    }
+  };
+  {
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+    const bool plain = !scale && !shift && act == GB_ACT_NONE, full = mw + 32 <= M && n0 + BN <= Co, stats = stats_part != nullptr;
+    if (plain) {
+      if (stats) { if (full) epilogue(T_{}, T_{}, T_{}); else epilogue(T_{}, T_{}, F_{}); }
+      else       { if (full) epilogue(T_{}, F_{}, T_{}); else epilogue(T_{}, F_{}, F_{}); }
+    } else {
+      if (stats) epilogue(F_{}, T_{}, F_{});  // (not a combination the model launches: one generic variant)
+      else       { if (full) epilogue(F_{}, F_{}, T_{}); else epilogue(F_{}, F_{}, F_{}); }
+    }
+  }
+  if (stats_part) {  // uniform.  A 64-row tile = two waves: the lower one adds the upper one's sums (fixed order)
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) {
+      const float a1 = s1[tn] + __shfl_xor(s1[tn], 32), a2 = s2[tn] + __shfl_xor(s2[tn], 32);
+      if ((w & 1) && lane < 32) { st_s[w >> 1][0][32 * tn + j] = a1; st_s[w >> 1][1][32 * tn + j] = a2; }
+      s1[tn] = a1;
+      s2[tn] = a2;
+    }
+    __syncthreads();
+    if (!(w & 1) && lane < 32 && mw < M) {
+      const long t64 = mw >> 6;
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn) {
+        const int jc = n0 + 32 * tn + j;
+        if (jc < Co) {
+          stats_part[(t64 * 2 + 0) * Co + jc] = s1[tn] + st_s[w >> 1][0][32 * tn + j];
+          stats_part[(t64 * 2 + 1) * Co + jc] = s2[tn] + st_s[w >> 1][1][32 * tn + j];
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // part[chunk][i][j] = sum over the chunk's rows m of A[m][i] * B[m][j]   (weight gradients: A = dz (M, Ca), B = X (M, Cb)).
 // The contraction runs over the ROW axis of both operands: a staged chunk is 8 consecutive rows of one column (8 loads,
 // the lanes along the columns: coalesced), everything behind the staging is the kernel above.  The M axis is split in
@@ -383,10 +591,57 @@ bool r3d_pointwise_bx3_ok(const float* X, long ldx, const float* W, long M, int 
          ((uintptr_t)X & 15) == 0 && ((uintptr_t)W & 15) == 0 && Co >= 32 && Co % 4 == 0 && M >= 64;
 }
 
+// Scratch for the packed W of r3d_pointwise_gemm_bx3p_kernel: one buffer per stream (launches of one stream are ordered;
+// captured graphs keep the pointer of the stream they were captured on, and every slot replays on its own stream),
+// grown on demand -- never while the stream is capturing (hipMalloc is illegal there): the caller then takes the kernel
+// that cuts W itself.
+#include <mutex>
+#include <vector>
+struct WPackBuf { hipStream_t st; void* p; size_t cap; };
+static unsigned short* wpack_scratch(hipStream_t st, size_t bytes) {
+  static std::mutex mu;
+  static std::vector<WPackBuf> pool;
+  std::lock_guard<std::mutex> lock(mu);
+  for (auto& b : pool)
+    if (b.st == st) {
+      if (b.cap >= bytes) return (unsigned short*)b.p;
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+      void* p = nullptr;
+      if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+      b.p = p; b.cap = bytes;  // (the old buffer is leaked on purpose: a captured graph may still point at it)
+      return (unsigned short*)p;
+    }
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+  void* p = nullptr;
+  const size_t cap = bytes < (4u << 20) ? (4u << 20) : bytes;  // (512 x 512 pieces = 1.5 MB: one size fits the model)
+  if (hipMalloc(&p, cap) != hipSuccess) return nullptr;
+  pool.push_back(WPackBuf{st, p, cap});
+  return (unsigned short*)p;
+}
+
 int r3d_pointwise_bx3_launch(const float* X, long ldx, const float* W, long M, int K, int Co, const float* scale,
                              const float* shift, int act, float* Out, long ldo, int accumulate, float* stats_part,
                              hipStream_t st) {
   if ((ldo & 3) != 0 || ((uintptr_t)Out & 15) != 0) return -1;  // (the caller takes the fp32 kernel)
+  if (!(GB_ABL & 128) && (g_r3d_gemm_bx3 & 4) && M >= 256) {  // W cut once per call, 32-row wave tiles, 3 workgroups per CU
+    const int bnp = Co > 64 ? 128 : 64;
+    const int Cop = r3d_cdiv(Co, bnp) * bnp;
+    unsigned short* wp = wpack_scratch(st, (size_t)Cop * K * 6);
+    if (wp) {
+      hipLaunchKernelGGL(r3d_w_pack_bx3_kernel, dim3(r3d_cdiv((long)Cop * (K / 8), 256)), dim3(256), 0, st, W, K, Co, bnp, wp);
+      const long tiles = (long)r3d_cdiv(M, 128) * (Cop / bnp);
+      R3D_REQUIRE(tiles < 0x7fffffffL, "r3d_pointwise_conv: too many tiles");
+      if (bnp == 128)
+        hipLaunchKernelGGL((r3d_pointwise_gemm_bx3p_kernel<4>), dim3((unsigned)tiles), dim3(256), 0, st, X, ldx, wp, (int)M, K, Co,
+                           scale, shift, act, Out, ldo, accumulate, stats_part);
+      else
+        hipLaunchKernelGGL((r3d_pointwise_gemm_bx3p_kernel<2>), dim3((unsigned)tiles), dim3(256), 0, st, X, ldx, wp, (int)M, K, Co,
+                           scale, shift, act, Out, ldo, accumulate, stats_part);
+      return R3D_OK;
+    }
+  }
   const int bn = (Co > 64 && !(GB_ABL & 64)) ? 128 : 64;  // (probe bit 64: 64-column tiles for every layer)
   const long tiles = (long)r3d_cdiv(M, 256) * r3d_cdiv(Co, bn);
   R3D_REQUIRE(tiles < 0x7fffffffL, "r3d_pointwise_conv: too many tiles");
