@@ -221,13 +221,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   constexpr int RPI = 64 / LPR;        // rows per store instruction
   const int erow = lane / LPR, ecol = 4 * (lane % LPR);
   const bool cok = n0 + ecol < Co;     // (Co % 4 == 0: a lane's four columns are inside or outside together)
-  float sc[NT], sh[NT], s1[NT], s2[NT];
+  // (column sums per 32-row half first, the halves added lower first: the association of the packed-W kernel below, whose
+  // 64-row statistics tile is two waves -- which of the two kernels a launch takes must not change a bit of the result)
+  float sc[NT], sh[NT], s1[2][NT], s2[2][NT];
 #pragma unroll
   for (int tn = 0; tn < NT; ++tn) {
     const int jc = n0 + 32 * tn + j;
     sc[tn] = (scale && jc < Co) ? scale[jc] : 1.f;
     sh[tn] = (shift && jc < Co) ? shift[jc] : 0.f;
-    s1[tn] = s2[tn] = 0.f;
+    s1[0][tn] = s2[0][tn] = s1[1][tn] = s2[1][tn] = 0.f;
   }
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm) {
@@ -240,11 +242,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
         for (int i = 0; i < 4; ++i) {
           float v = sc[tn] * acc[tm][tn][4 * q + i] + sh[tn];
           if (act == GB_ACT_RELU) v = fmaxf(v, 0.f);
-          else if (act == GB_ACT_LRELU02) v = v > 0.f ? v : 0.2f * v;
+          else if (act == GB_ACT_LRELU02) v = fmaxf(v, 0.2f * v);
           es[(4 * g + i) * ER + 32 * tn + j] = v;
-          if (mrow0 + 4 * g + i < M) {  // column sums of the values written (training: batch statistics of z)
-            s1[tn] += v;
-            s2[tn] += v * v;
+          {  // column sums of the values written (training: batch statistics of z); rows beyond M add zeros
+            const float u = r3d_keep(v, mrow0 + 4 * g + i < M);
+            s1[tm][tn] += u;
+            s2[tm][tn] += u * u;
           }
         }
       }
@@ -270,7 +273,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
 #pragma unroll
     for (int tn = 0; tn < NT; ++tn) {
       const int jc = n0 + 32 * tn + j;
-      const float a1 = s1[tn] + __shfl_xor(s1[tn], 32), a2 = s2[tn] + __shfl_xor(s2[tn], 32);
+      const float a1 = (s1[0][tn] + __shfl_xor(s1[0][tn], 32)) + (s1[1][tn] + __shfl_xor(s1[1][tn], 32));
+      const float a2 = (s2[0][tn] + __shfl_xor(s2[0][tn], 32)) + (s2[1][tn] + __shfl_xor(s2[1][tn], 32));
       if (lane < 32 && jc < Co) {
         stats_part[(t64 * 2 + 0) * Co + jc] = a1;
         stats_part[(t64 * 2 + 1) * Co + jc] = a2;
@@ -591,29 +595,29 @@ bool r3d_pointwise_bx3_ok(const float* X, long ldx, const float* W, long M, int 
          ((uintptr_t)X & 15) == 0 && ((uintptr_t)W & 15) == 0 && Co >= 32 && Co % 4 == 0 && M >= 64;
 }
 
-// Scratch for the packed W of r3d_pointwise_gemm_bx3p_kernel: one buffer per stream (launches of one stream are ordered;
-// captured graphs keep the pointer of the stream they were captured on, and every slot replays on its own stream),
-// grown on demand -- never while the stream is capturing (hipMalloc is illegal there): the caller then takes the kernel
-// that cuts W itself.
+// Scratch for the packed W of r3d_pointwise_gemm_bx3p_kernel: one buffer per stream (launches of one stream are
+// ordered), grown on demand.  NEVER for a stream that is capturing: a captured launch would bake this pointer into a
+// graph that may replay on any stream beside other graphs captured on the same one (episode_graph.py captures its slots
+// one after the other and replays them concurrently: two slots sharing the buffer computed with each other's weights
+// pieces, caught by tests/test_gpu_parity_full.py) -- captured launch sequences take the kernel that cuts W itself,
+// which gives the same bits.
 #include <mutex>
 #include <vector>
 struct WPackBuf { hipStream_t st; void* p; size_t cap; };
 static unsigned short* wpack_scratch(hipStream_t st, size_t bytes) {
   static std::mutex mu;
   static std::vector<WPackBuf> pool;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
   std::lock_guard<std::mutex> lock(mu);
   for (auto& b : pool)
     if (b.st == st) {
       if (b.cap >= bytes) return (unsigned short*)b.p;
-      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-      if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
       void* p = nullptr;
       if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-      b.p = p; b.cap = bytes;  // (the old buffer is leaked on purpose: a captured graph may still point at it)
+      b.p = p; b.cap = bytes;  // (the old buffer stays allocated: launches already queued on the stream still read it)
       return (unsigned short*)p;
     }
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
   void* p = nullptr;
   const size_t cap = bytes < (4u << 20) ? (4u << 20) : bytes;  // (512 x 512 pieces = 1.5 MB: one size fits the model)
   if (hipMalloc(&p, cap) != hipSuccess) return nullptr;

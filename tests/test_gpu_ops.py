@@ -384,6 +384,32 @@ def test_pointwise_conv_both_arithmetics(ops, arith, M, K, Co):
         _lib.check(lib.r3d_set_matrix_arith(before))
 
 
+@pytest.mark.parametrize("M,K,Co", [(4096, 192, 512), (2048 + 37, 256, 192), (640, 128, 64), (1000, 64, 96)])
+def test_pointwise_conv_same_bits_from_both_bf16_kernels(ops, M, K, Co):
+    """The two bf16 x 3 kernels of csrc/gemm_bx3.hip -- W cut once per call into a scratch of the library (the default),
+    W cut inside the kernel (taken when that scratch cannot be had: the first call on a capturing stream) -- must give
+    the same bits, outputs AND the BatchNorm column sums of the epilogue: a captured graph and the eager launch sequence
+    may end up on different ones."""
+    from r3dfsseg_amd import _lib
+    from r3dfsseg_amd.ops import _p, _st
+    lib = _lib.load()
+    x, W = _dev(_rand((M, K), 161)), _dev(_rand((Co, K), 162, 1.0 / np.sqrt(K)))
+    sc, sh = _dev(_rand((Co,), 163) * 0.3 + 1.0), _dev(_rand((Co,), 164) * 0.3)
+    res = {}
+    try:
+        for mask in (3, 7):
+            _lib.check(lib.r3d_debug_set_gemm_bx3(mask))
+            sums = torch.empty(2 * Co, device="cuda")
+            ws = torch.empty(lib.r3d_pointwise_conv_stats_ws_words(M, Co), device="cuda")
+            raw = torch.empty(M, Co, device="cuda")
+            _lib.check(lib.r3d_pointwise_conv_stats(_p(x), K, _p(W), M, K, Co, _p(raw), Co, _p(sums), _p(ws), _st()))
+            res[mask] = (raw, sums, ops.pointwise_conv(x, W, sc, sh, 2))
+    finally:
+        _lib.check(lib.r3d_debug_set_gemm_bx3(7))
+    for a, b in zip(res[3], res[7]):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
 @pytest.mark.parametrize("arith", [0, 1])
 @pytest.mark.parametrize("M,Ca,Cb", [(8192, 512, 192), (3000, 256, 512), (4100, 64, 128), (2048, 128, 64), (999, 192, 256),
                                      (2048, 128, 9), (70, 96, 40)])
