@@ -97,3 +97,36 @@ def test_full_size_graph_slots_match_eager():
     assert bad == 0
     for e in range(len(eps)):
         np.testing.assert_allclose(out[e].cpu().numpy(), eager[e].cpu().numpy(), atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("workload,E", [("S", 3), ("C", 2)])
+def test_full_size_batched_step_equals_one_episode_at_a_time(workload, E):
+    """The headline schedule at BASELINE sizes (configs[1] S3DIS 2-way 5-shot 2048 pts; configs[3] ScanNet 3-way 5-shot 4096
+    pts): E training episodes through ONE launch sequence against the same episodes one at a time on the eager path --
+    per episode the losses and logits to rounding, the BatchNorm running statistics bit for bit (a segment's reductions
+    are partitioned by the segment, never by the batch), the summed gradient to 1e-5 (weight gradients add over the batch
+    in another order)."""
+    import test_gpu_batched as TB
+    from r3dfsseg_amd.batch import EpisodeBatch
+    from r3dfsseg_amd.batched import EpisodeBatchRunner
+    from r3dfsseg_amd.dist import FlatGradBucket
+    cfg = S.workload_cfg(workload)
+    eps = TB._episodes(cfg, E)
+    _, want_grad, per, want_buf = TB._eager_train(cfg, eps, 0.1)
+    m = TB._model(cfg, True, 0.1)
+    bucket = FlatGradBucket(m.parameters())
+    run = EpisodeBatchRunner(m)
+    run.begin_step()
+    loss, logits, metrics, lp, cl = run.train_batch(EpisodeBatch.from_episodes(eps), [p.grad for p in bucket.params])
+    bad, ovf, its, mx = run.step_status()
+    assert bad == 0 and ovf == 0
+    for e, w in enumerate(per):
+        assert abs(lp[e].item() - w["lp"]) <= 2e-5 * max(1.0, abs(w["lp"])), (e, lp[e].item(), w["lp"])
+        assert abs(cl[e].item() - w["cl"]) <= 2e-5 * max(1.0, abs(w["cl"])), (e, cl[e].item(), w["cl"])
+        np.testing.assert_allclose(logits[e].cpu().numpy(), w["logits"].cpu().numpy(), atol=5e-5, rtol=1e-5)
+        np.testing.assert_allclose(metrics[e].cpu().numpy(), np.array(w["metrics"], dtype=np.float32), atol=1e-6)
+    run.apply_running_stats()
+    for k, v in m.named_buffers():
+        assert torch.equal(v, want_buf[k]), k
+    err = (bucket.flat - want_grad).abs().max().item() / want_grad.abs().max().item()
+    assert err < 1e-5, err
