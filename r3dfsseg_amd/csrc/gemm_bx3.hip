@@ -15,7 +15,9 @@
 #define ATT_ABL 4
 #endif
 #include "common.h"
+#include <mutex>
 #include <type_traits>
+#include <vector>
 #ifndef GB_ABL
 #define GB_ABL 0
 #endif
@@ -601,8 +603,6 @@ bool r3d_pointwise_bx3_ok(const float* X, long ldx, const float* W, long M, int 
 // one after the other and replays them concurrently: two slots sharing the buffer computed with each other's weights
 // pieces, caught by tests/test_gpu_parity_full.py) -- captured launch sequences take the kernel that cuts W itself,
 // which gives the same bits.
-#include <mutex>
-#include <vector>
 struct WPackBuf { hipStream_t st; void* p; size_t cap; };
 static unsigned short* wpack_scratch(hipStream_t st, size_t bytes) {
   static std::mutex mu;
