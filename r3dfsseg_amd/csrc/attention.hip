@@ -16,6 +16,7 @@
 //     from the S^T accumulator registers (accumulator row r of lane half h is key
 //     r3d_acc_row(r): both halves feed one MFMA k-pair, no data movement).
 // 4 waves share the K/V tiles through double-buffered LDS.
+#include <stdlib.h>
 #include "common.h"
 #include <type_traits>
 
@@ -520,6 +521,14 @@ __global__ void r3d_attention_combine_kernel(const float* __restrict__ part, int
 // rounds x (key tiles per workgroup + 2 tiles' worth of fixed work) + a merge term.
 static int attention_split(int B, int N, int slots) {
   const int T = B * r3d_cdiv(N, 128), ntiles = r3d_cdiv(N, 32);
+  // Default since round 3: NO split.  The split has to be the same whether an episode runs alone or in a batch (a
+  // cloud's partials, their merge order and hence its output bits must not depend on the batch), and a 32-episode step has
+  // 6144 query tiles to fill the chip with: split like ONE episode (4 ways forward, 2 ways backward at S) it paid 1.6 ms
+  // per step for the merge kernels plus the extra prologues -- 349 -> 359 episodes/s without, against 7.80 -> 8.04 ms
+  // for a single episode per step (profiles/r03_experiments.md).  R3D_ATT_SPLIT=0 restores the cost model below (chosen
+  // per episode), R3D_ATT_SPLIT=n forces n.
+  static const int forced = getenv("R3D_ATT_SPLIT") ? atoi(getenv("R3D_ATT_SPLIT")) : 1;
+  if (forced > 0) return forced < ntiles ? forced : ntiles;
   int best = 1;
   float best_cost = 1e30f;
   for (int s = 1; s <= 16 && s <= ntiles; ++s) {
@@ -536,7 +545,7 @@ static int attention_slots(int which);  // defined below the kernels
 // forward: split * M * AT_PROW; backward: M (row dots) + split * M * 128 (dK | dV partials, reused for dQ)
 // Bs: the number of clouds the key-axis split is chosen for.  A batch of episodes is split like ONE episode (Bs = clouds
 // per episode), so a cloud's partials, their merge order and hence its output bits are the same whether its episode
-// runs alone or inside a batch; the price is partial traffic a large batch would not need (~1 % of a training step).
+// runs alone or inside a batch.  (Moot with the default of no split, see attention_split.)
 static long attention_part_words(int B, int N, int Bs) {
   int smax = 1;
   for (int w = 0; w < ATT_N; ++w) {
