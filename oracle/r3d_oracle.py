@@ -114,6 +114,10 @@ def _bn(sd, prefix, x, train, new_stats):
     w, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
     rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
     if train:
+        # a second pass through the same layer (support clouds, then query clouds: mpti.py:434,436) continues from the
+        # statistics the first one left, as the module's buffers do
+        if new_stats is not None and prefix + ".running_mean" in new_stats:
+            rm, rv = new_stats[prefix + ".running_mean"], new_stats[prefix + ".running_var"]
         rm2, rv2 = rm.detach().clone(), rv.detach().clone()
         y = F.batch_norm(x, rm2, rv2, w, b, True, 0.1, 1e-5)
         if new_stats is not None:
@@ -144,10 +148,17 @@ def dgcnn_forward(sd, x, k=20, n_edgeconv=3, prefix="encoder", train=False,
     per-layer (B,64,N) int64 winning neighbour slot of the max over K
     (dgcnn.py:118): two edges whose activations agree to the last bits may swap
     winners between implementations, which moves a gradient from one edge to
-    the other; gradient parity tests pin the winner."""
+    the other; gradient parity tests pin the winner.  An entry of idx_override may be a callable: it receives this
+    function's own lists and returns the patched ones (sparse override: only the rows where the reference's
+    GEMM-ordered choice differs, tests/test_oracle_golden_head.py)."""
     outs, idxs = [], []
     for i in range(n_edgeconv):
-        idx = knn(x, k) if idx_override is None else idx_override[i]
+        if idx_override is None:
+            idx = knn(x, k)
+        elif callable(idx_override[i]):
+            idx = idx_override[i](knn(x, k))
+        else:
+            idx = idx_override[i]
         idxs.append(idx)
         e = get_edge_feature(x, K=k, idx=idx)
         e = conv_block(sd, "%s.edge_convs.%d" % (prefix, i), e, 2, 2, train, new_stats)
@@ -226,12 +237,19 @@ def assign_to_seeds(feat, seeds):
     return torch.from_numpy(out.astype(np.int64))
 
 
+def fps_sample_count(n, k):
+    """Samples torch_cluster.fps(feat, None, ratio=k / n) draws (call site models/mpti.py:612-613): the published
+    implementation computes ceil(float32(n) * float32(ratio)) -- k or k + 1 depending on the two roundings (k = 100:
+    101 for 5.8 % of the n <= 20480; k = 4: always 4).  tests/golden/head_*.npz hold both cases."""
+    return min(int(np.ceil(np.float32(n) * np.float32(k / n))), n)
+
+
 def get_multiple_prototypes(feat, k):
     """feat (n,d) -> prototypes (m,d), assignments (n,), m, seeds (m,d)."""
     n = feat.shape[0]
     assert n > 0
     if k / n < 1:
-        fps_index = torch.unique(fps(feat, k))  # sorted ascending, de-duplicated
+        fps_index = torch.unique(fps(feat, fps_sample_count(n, k)))  # sorted ascending, de-duplicated
         m = len(fps_index)
         seeds = feat[fps_index]
         assignments = assign_to_seeds(feat, seeds)

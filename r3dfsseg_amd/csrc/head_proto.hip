@@ -183,10 +183,22 @@ static __device__ __forceinline__ void cand_better(float& v, int& p, float v2, i
   if (v2 > v || (v2 == v && p2 < p)) { v = v2; p = p2; }
 }
 
+// Samples torch_cluster.fps draws from n points at ratio = k / n (models/mpti.py:612-613; n > k): the published
+// implementation (csrc/cpu/fps_cpu.cpp, csrc/cuda/fps_cuda.cu) takes ceil(float32(n) * float32(ratio)), ratio = the
+// Python double k / n rounded to float32 -- k or k + 1 depending on how the two roundings fall (k = 100: 101 samples
+// for 5.8 % of the n <= 20480).  Restated with the same roundings; tests/golden/head_*.npz hold both cases as the
+// reference's own forward produced them (oracle/gen_golden_head.py).
+static __device__ __forceinline__ int hp_fps_count(int n, int k) {
+  const float ratio = __double2float_rn(__ddiv_rn((double)k, (double)n));
+  const int m = (int)ceilf(__fmul_rn((float)n, ratio));
+  return m < n ? m : n;
+}
+
+// `rounds` = k + 1: every sampled segment runs the extra round; r3d_fps_finalize_kernel keeps hp_fps_count of them.
 template <int DP>  // feature dimension rounded up to a multiple of 64 (registers hold the whole point)
 __global__ __launch_bounds__(HP_BLOCK) void r3d_fps_round_kernel(
     const float* __restrict__ featC /* (D, pitch) compacted channel-major */, long pitch, int D, SegGeom g,
-    const int* __restrict__ desc, int k, int round,
+    const int* __restrict__ desc, int k, int rounds, int round,
     float* __restrict__ mind, const Cand* __restrict__ cand_prev, Cand* __restrict__ cand_next,
     int* __restrict__ sel /* [nseg][HP_MAXK] */, HpEp st) {
   __shared__ float seedf[DP];
@@ -210,7 +222,7 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_fps_round_kernel(
   // --- this thread's point: ALL its channel loads are issued first (they do not depend on the
   //     seed), so their latency hides behind the seed election below
   const int pos = bis * HP_BLOCK + tid;
-  const bool have = pos < count && round < k - 1;
+  const bool have = pos < count && round < rounds - 1;
   float xv[DP];
   float md_old = INFINITY;
   {
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_fps_round_kernel(
   __syncthreads();
   const int seed_pos = seed_pos_s;
   if (bis == 0 && tid == 0) sel[seg * HP_MAXK + round] = seed_pos;
-  if (round == k - 1) return;
+  if (round == rounds - 1) return;
   // --- stage the seed's feature vector
   for (int c = tid; c < D; c += HP_BLOCK) seedf[c] = featC[(long)c * pitch + g.off(seg) + seed_pos];
   __syncthreads();
@@ -338,7 +350,7 @@ extern "C" int r3d_fps_debug_read(unsigned long long* out, int n) {
 template <int DP, bool FULL>
 __global__ __launch_bounds__(HP_BLOCK) void r3d_fps_persistent_kernel(
     const float* __restrict__ featC, long pitch, const float* __restrict__ featP, int D, SegGeom g, int* __restrict__ desc,
-    int k, unsigned long long* __restrict__ xch /* [k][tb_dense] candidates, then [nseg][HP_MAXK] results */, int tb_dense,
+    int k, int rounds /* k + 1 */, unsigned long long* __restrict__ xch /* [rounds][tb_dense] candidates, then [nseg][HP_MAXK] results */, int tb_dense,
     int* __restrict__ sel, HpEp st, int ep0) {
   __shared__ float seedf[DP];
   __shared__ float red_v[4];
@@ -377,12 +389,12 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_fps_persistent_kernel(
     for (int c = 0; c < DP; ++c) xv[c] = fp[(long)min(c, D - 1) * pitch];
   }
   const float* rows = featP + g.off(seg) * HP_DP;
-  unsigned long long* res = xch + (long)k * tb_dense + (long)seg * HP_MAXK;  // the segment's result word of every round
+  unsigned long long* res = xch + (long)rounds * tb_dense + (long)seg * HP_MAXK;  // the segment's result word of every round
   float md = INFINITY;
   int seed_pos = 0;
-  for (int round = 0; round < k; ++round) {
+  for (int round = 0; round < rounds; ++round) {
     if (bis == 0 && tid == 0) sel[seg * HP_MAXK + round] = seed_pos;
-    if (round == k - 1) break;
+    if (round == rounds - 1) break;
     __syncthreads();  // seedf / red_* of the previous round are no longer read
     for (int c = tid; c < D; c += HP_BLOCK) seedf[c] = rows[(long)seed_pos * HP_DP + c];
     __syncthreads();
@@ -481,7 +493,8 @@ __global__ __launch_bounds__(HP_MAXK) void r3d_fps_finalize_kernel(SegGeom g, in
       m = count;
       if (tid < HP_MAXK) seeds[seg * HP_MAXK + tid] = tid < count ? tid : -1;
     } else {
-      a[tid] = tid < k ? sel[seg * HP_MAXK + tid] : 0x7fffffff;
+      const int kseg = hp_fps_count(count, k);  // k or k + 1 samples (torch_cluster's float-rounded count)
+      a[tid] = tid < kseg ? sel[seg * HP_MAXK + tid] : 0x7fffffff;
       __syncthreads();
       for (int sz = 2; sz <= HP_MAXK; sz <<= 1)
         for (int st = sz >> 1; st > 0; st >>= 1) {
@@ -494,7 +507,7 @@ __global__ __launch_bounds__(HP_MAXK) void r3d_fps_finalize_kernel(SegGeom g, in
           __syncthreads();
         }
       // unique on the sorted list
-      const bool keep = tid < k && (tid == 0 || a[tid] != a[tid - 1]);
+      const bool keep = tid < kseg && (tid == 0 || a[tid] != a[tid - 1]);
       __syncthreads();
       // rank = number of kept entries before tid (k <= 128: serial count is fine)
       __shared__ int keepf[HP_MAXK];
@@ -777,7 +790,7 @@ extern "C" long r3d_head_proto_ws_words(int n_way, int k_shot, int N) { return h
 //   support_y : (n_way*k_shot, N) int32 {0,1}
 //   shot_keep : optional (n_way*k_shot) int32, 0 drops a shot's foreground (clean-shot detection)
 //   feat      : (S*N, ldf) point-major support features;  qfeat: (n_q*N, ldq) point-major query features
-//   nodes     : (n_cap, ldn) out, n_cap = (n_way+1)*k + n_q*N;  node_labels: (n_cap, 4) one-hot Y; n_way > 3: two such
+//   nodes     : (n_cap, ldn) out, n_cap = (n_way+1)*(k+1) + n_q*N;  node_labels: (n_cap, 4) one-hot Y; n_way > 3: two such
 //               planes, (2, n_ep * n_cap, 4), classes 0..3 and 4..7
 //   desc      : device descriptor (r3d_head_desc_words int32);  ws: scratch words
 // Every pointer addresses episode 0; episode e sits ep->... elements further on (HpEp; feature strides in ROWS).
@@ -795,7 +808,8 @@ static int head_prototypes_impl(int n_ep, const HpEp& ep, int fps_group, const i
   R3D_REQUIRE(ws_words >= r3d_head_proto_ws_words(n_way, k_shot, N),
               "r3d_head_prototypes: workspace of %ld words, r3d_head_proto_ws_words = %ld needed", ws_words,
               r3d_head_proto_ws_words(n_way, k_shot, N));
-  R3D_REQUIRE(k >= 1 && k <= HP_MAXK, "r3d_head_prototypes: k=%d unsupported (1..%d)", k, HP_MAXK);
+  R3D_REQUIRE(k >= 1 && k < HP_MAXK, "r3d_head_prototypes: k=%d unsupported (1..%d)", k, HP_MAXK - 1);
+  const int kr = k + 1;  // sampling rounds run and prototype slots per segment (hp_fps_count: k or k + 1 samples)
   R3D_REQUIRE(n_ep >= 1 && n_ep <= 4096 && fps_group >= 1, "r3d_head_prototypes: %d episodes, %d per FPS launch", n_ep, fps_group);
   R3D_REQUIRE(((uintptr_t)ws & 15) == 0, "r3d_head_prototypes: ws must be 16-byte aligned");
   R3D_REQUIRE(n_ep == 1 || (assign_out && (ep.ws & 3) == 0 && ep.ws >= ws_words),
@@ -811,7 +825,7 @@ static int head_prototypes_impl(int n_ep, const HpEp& ep, int fps_group, const i
   if (!assign_out) e2.assign = ep.ws;  // (single episode only)
   // more than 4 classes: the one-hot labels are two planes of 4 columns, plane 1 (classes 4..7) behind the n_ep episodes'
   // rows of plane 0 (the label propagation solves the planes one after the other: head_graph.hip)
-  const long label_rows = ep.labels ? ep.labels : (long)g.nseg() * k + n_query_pts;
+  const long label_rows = ep.labels ? ep.labels : (long)g.nseg() * kr + n_query_pts;
   float* node_labels2 = n_way > 3 ? node_labels + (long)n_ep * label_rows * 4 : nullptr;
   Cand* cand0 = (Cand*)(ws + L.cand);
   Cand* cand1 = cand0 + g.total_blocks();
@@ -831,17 +845,17 @@ static int head_prototypes_impl(int n_ep, const HpEp& ep, int fps_group, const i
                      featP, e2);
   if (flags & 1 /* R3D_HEAD_FPS_ONE_LAUNCH */) {
     const int tb_dense = (int)((g.cap(0) + HP_BLOCK - 1) / HP_BLOCK) + g.nseg();  // the segments' counts add up to cap(0)
-    r3d_fill_words_ep(xch, 0u, 2L * k * tb_dense + 2L * HP_MAXSEG * HP_MAXK, n_ep, e2.ws, st);
+    r3d_fill_words_ep(xch, 0u, 2L * kr * tb_dense + 2L * HP_MAXSEG * HP_MAXK, n_ep, e2.ws, st);
     for (int e0 = 0; e0 < n_ep; e0 += fps_group) {
       const int ne = n_ep - e0 < fps_group ? n_ep - e0 : fps_group;
 #define FPS_ONE(DPAD)                                                                                                   \
       do {                                                                                                              \
         if (D == DPAD)                                                                                                  \
           hipLaunchKernelGGL((r3d_fps_persistent_kernel<DPAD, true>), dim3(tb_dense, ne), dim3(HP_BLOCK), 0, st, featC, pitch, \
-                             featP, D, g, desc, k, xch, tb_dense, sel, e2, e0);                                         \
+                             featP, D, g, desc, k, kr, xch, tb_dense, sel, e2, e0);                                         \
         else                                                                                                            \
           hipLaunchKernelGGL((r3d_fps_persistent_kernel<DPAD, false>), dim3(tb_dense, ne), dim3(HP_BLOCK), 0, st, featC, pitch, \
-                             featP, D, g, desc, k, xch, tb_dense, sel, e2, e0);                                         \
+                             featP, D, g, desc, k, kr, xch, tb_dense, sel, e2, e0);                                         \
       } while (0)
       if (D <= 64) FPS_ONE(64);
       else if (D <= 128) FPS_ONE(128);
@@ -850,10 +864,10 @@ static int head_prototypes_impl(int n_ep, const HpEp& ep, int fps_group, const i
 #undef FPS_ONE
     }
   } else {
-    for (int t = 0; t < k; ++t) {
+    for (int t = 0; t < kr; ++t) {
   #define FPS_LAUNCH(DPAD)                                                                                          \
       hipLaunchKernelGGL(r3d_fps_round_kernel<DPAD>, dim3(tb, n_ep), dim3(HP_BLOCK), 0, st, featC, pitch, D, g,      \
-                         desc, k, t, mind, (t & 1) ? cand0 : cand1, (t & 1) ? cand1 : cand0, sel, e2)
+                         desc, k, kr, t, mind, (t & 1) ? cand0 : cand1, (t & 1) ? cand1 : cand0, sel, e2)
       if (D <= 64) FPS_LAUNCH(64);
       else if (D <= 128) FPS_LAUNCH(128);
       else if (D <= 192) FPS_LAUNCH(192);
@@ -863,12 +877,12 @@ static int head_prototypes_impl(int n_ep, const HpEp& ep, int fps_group, const i
   }
   hipLaunchKernelGGL(r3d_fps_finalize_kernel, dim3(n_ep), dim3(HP_MAXK), 0, st, g, k, n_query_pts, sel, seeds, desc, e2);
   r3d_fill_words_ep(best_packed, 0xffffffffu, 2 * cap, n_ep, e2.ws, st);
-  hipLaunchKernelGGL(r3d_assign_kernel, dim3(tb, r3d_cdiv(k, AS_TILE), n_ep), dim3(HP_BLOCK), 0, st, featC, pitch, D, g, desc,
+  hipLaunchKernelGGL(r3d_assign_kernel, dim3(tb, r3d_cdiv(kr, AS_TILE), n_ep), dim3(HP_BLOCK), 0, st, featC, pitch, D, g, desc,
                      seeds, best_packed, e2);
   hipLaunchKernelGGL(r3d_assign_unpack_kernel, dim3(r3d_cdiv(cap, 256), n_ep), dim3(256), 0, st, best_packed, cap, assign, e2);
-  hipLaunchKernelGGL(r3d_cluster_partial_kernel, dim3(k, max_chunks, g.nseg() * n_ep), dim3(HP_BLOCK), 0, st, feat, ldf, D, g,
+  hipLaunchKernelGGL(r3d_cluster_partial_kernel, dim3(kr, max_chunks, g.nseg() * n_ep), dim3(HP_BLOCK), 0, st, feat, ldf, D, g,
                      comp, desc, assign, max_chunks, part, part_cnt, e2);
-  hipLaunchKernelGGL(r3d_cluster_reduce_kernel, dim3(k, g.nseg(), n_ep), dim3(HP_BLOCK), 0, st, D, desc, max_chunks, part,
+  hipLaunchKernelGGL(r3d_cluster_reduce_kernel, dim3(kr, g.nseg(), n_ep), dim3(HP_BLOCK), 0, st, D, desc, max_chunks, part,
                      part_cnt, nodes, ldn, node_labels, node_labels2, cluster_count, e2);
   hipLaunchKernelGGL(r3d_nodes_append_query_kernel, dim3(r3d_cdiv((long)n_query_pts * D, 256), n_ep), dim3(256), 0, st, qfeat,
                      ldq, D, n_query_pts, desc, nodes, ldn, node_labels, node_labels2, e2);

@@ -245,7 +245,9 @@ class HeadBuffers:
         self.E = E
         self.n_way, self.k_shot, self.N, self.n_q_pts, self.k_sub, self.kp1, self.D = \
             n_way, k_shot, N, n_q_pts, k_sub, k_connect + 1, D
-        self.n_cap = (n_way + 1) * k_sub + n_q_pts
+        # k_sub + 1 prototype slots per class: torch_cluster's float-rounded sample count gives k or k + 1 seeds
+        # (csrc/head_proto.hip::hp_fps_count, models/mpti.py:612-613)
+        self.n_cap = (n_way + 1) * (k_sub + 1) + n_q_pts
         assert lib.r3d_head_desc_words() == 32
         i32 = dict(device=device, dtype=torch.int32)
         f32 = dict(device=device, dtype=torch.float32)

@@ -68,8 +68,9 @@ def test_prototypes_bitexact_indices(ops, n_way, k_shot, N, k_sub, seed):
         assert np.array_equal(comp, ids.numpy()), "compaction order"
         f = feat[ids]
         if cnt > k_sub:
-            want_sel = O.fps(f, k_sub).numpy()
-            got_sel = ws[sel_off + s * 128: sel_off + s * 128 + k_sub]
+            kseg = O.fps_sample_count(cnt, k_sub)  # k or k + 1 (torch_cluster's float-rounded count)
+            want_sel = O.fps(f, kseg).numpy()
+            got_sel = ws[sel_off + s * 128: sel_off + s * 128 + kseg]
             assert np.array_equal(got_sel, want_sel), "FPS order differs in segment %d" % s
         protos, asg, m, seeds = O.get_multiple_prototypes(f, k_sub)
         assert desc[ops.HD_SEG_M + s] == m
@@ -83,6 +84,39 @@ def test_prototypes_bitexact_indices(ops, n_way, k_shot, N, k_sub, seed):
     assert desc[ops.HD_N_PROTO] == row and desc[ops.HD_N_NODES] == row + n_q * N
     assert torch.equal(nodes[row:row + n_q * N], qfeat)
     assert (Y[row:row + n_q * N] == 0).all()
+
+
+@pytest.mark.parametrize("fg_counts", [(149, 163), (364, 101), (150, 297)])
+def test_prototype_count_follows_torch_cluster(ops, fg_counts):
+    """torch_cluster.fps draws ceil(float32(n) * float32(k / n)) samples: 101 for n = 149, 163, 297, 364 at k = 100
+    (models/mpti.py:612-613; tests/golden/head_eval.npz holds the n = 364 case as the reference's forward produced it).
+    Segment sizes are forced through the masks; seeds, assignments and prototypes against the oracle."""
+    n_way, k_shot, N, k_sub, D = 2, 1, 512, 100, 192
+    rs = np.random.RandomState(sum(fg_counts))
+    support_y = torch.zeros(n_way, k_shot, N, dtype=torch.int32)
+    for w, c in enumerate(fg_counts):
+        support_y[w, 0, torch.from_numpy(rs.permutation(N)[:c])] = 1
+    feat = torch.from_numpy((rs.randn(n_way * N, D) * 0.1).astype(np.float32))
+    qfeat = torch.from_numpy((rs.randn(n_way * N, D) * 0.1).astype(np.float32))
+    hb = ops.HeadBuffers(n_way, k_shot, N, n_way * N, k_sub, 200, D, "cuda")
+    for one_launch in (True, False):  # the persistent launch and the launch-per-round form
+        hb.fps_one_launch = one_launch
+        hb.desc.zero_()
+        ops.head_prototypes(hb, support_y.reshape(n_way, N).contiguous().cuda(), None, feat.cuda(), qfeat.cuda())
+        torch.cuda.synchronize()
+        desc = hb.desc.cpu().numpy()
+        nodes = hb.nodes.cpu()
+        row = 0
+        for s, ids in enumerate(_segments(support_y)):
+            f = feat[ids]
+            want = O.fps_sample_count(len(ids), k_sub)
+            if s > 0:
+                assert want == (101 if fg_counts[s - 1] != 150 else 100)
+            protos, asg, m, _ = O.get_multiple_prototypes(f, k_sub)
+            assert m == want and desc[ops.HD_SEG_M + s] == m, (s, m, want, desc[ops.HD_SEG_M + s])
+            np.testing.assert_allclose(nodes[row:row + m].numpy(), protos.numpy(), atol=1e-6, rtol=1e-5)
+            row += m
+        assert desc[ops.HD_N_PROTO] == row
 
 
 def _graph_nodes(n_proto, n_q_pts, seed, scale=0.06):
@@ -101,7 +135,7 @@ def test_label_propagation_vs_closed_form(ops, n_proto, n_q_pts, cap_extra):
     n = n_proto + n_q_pts
     x, Y = _graph_nodes(n_proto, n_q_pts, 5)
     hb = ops.HeadBuffers(2, 1, n_q_pts // 2, n_q_pts, (n_proto + cap_extra) // 3, 200, 192, "cuda")
-    assert hb.n_cap == n + cap_extra
+    assert hb.n_cap == n + cap_extra + 3  # one spare prototype slot per class (k or k + 1 FPS samples)
     hb.nodes[:n] = x.cuda()
     hb.nodes[n:] = 7.0  # garbage beyond n must be ignored
     hb.Y.zero_()
