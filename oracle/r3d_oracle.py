@@ -12,10 +12,17 @@ Parity pinning
   reference's ``models/dgcnn.py`` / ``models/attention.py`` in the build
   container and commits the outputs under ``tests/golden/``.
 * Rows a6, a8-a16 (BaseLearner, prototypes, affinity, label propagation, losses,
-  clean-shot detection, ProtoNet) cannot be imported (faiss / torch_cluster /
-  torch_scatter are absent) and the reference holds no tests or fixtures for
-  them: **parity unpinned** -- this file is a restatement from the source text,
-  each function citing the lines it follows.
+  clean-shot detection, ProtoNet): ``models/mpti.py`` / ``models/protonet.py`` need
+  faiss / torch_cluster / torch_scatter (absent here), ``.cuda()`` and torch 1.8.
+  ``oracle/gen_golden_head.py`` supplies that environment (numpy statements of the
+  two third-party primitives from their published algorithms, an identity
+  ``.cuda()``, torch 1.8's ``pairwise_distance``) and runs the reference's own
+  ``MPTI_SelfAtten.forward`` / ``ProtoNet.forward``; the outputs are committed under
+  ``tests/golden/head_*.npz`` and ``tests/test_oracle_golden_head.py`` holds this file
+  to them (eval, eval=True, training step with gradients and running statistics).
+  Pinned: every line of the reference's own logic.  Unpinned: the third-party
+  primitives themselves (faiss search, torch_cluster.fps; versions not recorded by
+  the reference) -- restated twice, independently, and compared.
 
 All floating point is fp32 on torch-CPU.  Index-producing steps (kNN, FPS,
 nearest-seed assignment, 201-NN) call the C library ``oracle/r3d_oracle.c``

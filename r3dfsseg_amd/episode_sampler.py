@@ -21,6 +21,8 @@ the reference is everything that gives an episode its MEANING:
 
 Host numpy only (as the reference): this is the caller side of the hot path, SURVEY.md 8(f) N3.
 """
+import random
+
 import numpy as np
 
 
@@ -65,9 +67,11 @@ class SyntheticBlocks:
 
 
 def sample_pointcloud(block, num_point, sampled_classes, sampled_class, support, rng, partial_noise=False,
-                      pc_attribs="xyzrgbXYZ"):
+                      pc_attribs="xyzrgbXYZ", pyrng=None):
     """loader.py:202-352 (sample_pointcloud_universal, clean labels): -> (cloud (num_point, 9) f64, label, gt_label).
-    support: binary mask of `sampled_class`; query: 1-based position in `sampled_classes`, 0 elsewhere."""
+    support: binary mask of `sampled_class`; query: 1-based position in `sampled_classes`, 0 elsewhere.
+    rng: the numpy stream (the reference draws from the global np.random); pyrng: Python's `random` stream, which the
+    reference uses for ONE draw, the foreground flip of partial noise (loader.py:325)."""
     sampled_classes = list(sampled_classes)
     N = block.shape[0]
     if partial_noise:  # loader.py:222-223: plain random sample
@@ -110,15 +114,16 @@ def sample_pointcloud(block, num_point, sampled_classes, sampled_class, support,
                     break
             target = target.copy()
             target[m] = True
-        if rng.uniform(0, 1) > 0.7 and len(fg_objs):
+        if (pyrng.uniform(0, 1) if pyrng is not None else rng.uniform(0, 1)) > 0.7 and len(fg_objs):
             target = target.copy()
             target[data[:, -1] == rng.choice(fg_objs, 1)[0]] = False
     assert np.sum(target) > 0  # loader.py:350
     return cloud, target, to_target(labels)
 
 
-def _sample_k(source, num_point, scans, sampled_class, sampled_classes, support, rng, partial_noise=False):
-    out = [sample_pointcloud(source.load(s), num_point, sampled_classes, sampled_class, support, rng, partial_noise)
+def _sample_k(source, num_point, scans, sampled_class, sampled_classes, support, rng, partial_noise=False, pyrng=None):
+    out = [sample_pointcloud(source.load(s), num_point, sampled_classes, sampled_class, support, rng, partial_noise,
+                             pyrng=pyrng)
            for s in scans]
     return (np.stack([o[0] for o in out]), np.stack([o[1] for o in out]), np.stack([o[2] for o in out]))
 
@@ -141,7 +146,8 @@ class NoiseEpisodeSampler:
         self.n_way, self.k_shot, self.n_queries, self.num_point = n_way, k_shot, n_queries, num_point
         self.mode, self.noise_ratio, self.noise_type = mode, noise_ratio, noise_type
         self.noise_pair_dict = noise_pair_dict
-        self.rng = np.random.RandomState(seed)
+        self.rng = np.random.RandomState(seed)    # np.random.seed(seed) in the reference's process
+        self.pyrng = random.Random(seed)          # random.seed(seed): loader.py:325 draws from Python's generator
 
     def sample_classes(self):
         return self.rng.choice(self.classes, self.n_way, replace=False)  # loader.py:618
@@ -193,10 +199,17 @@ class NoiseEpisodeSampler:
                     noisy = cls
                     while noisy == cls:
                         noisy = rng.choice(way_range, 1)[0]
-                scan = rng.choice(unused(noisy), 1, replace=False)
+                candidates = unused(noisy)
+                scan = rng.choice(candidates, 1, replace=False)
+                if self.noise_type == "partial":  # loader.py:763-770: a block with fewer than 3 objects or classes is re-drawn
+                    def poor(name):
+                        blk = self.source.load(name)
+                        return len(np.unique(blk[:, -1])) < 3 or len(np.unique(blk[:, 6])) < 3
+                    while poor(scan[0]):
+                        scan = rng.choice(candidates, 1, replace=False)
                 black.extend(scan)
                 n_pc, n_mask, n_gt = _sample_k(self.source, self.num_point, scan, noisy, sampled_classes, True, rng,
-                                               partial_noise=self.noise_type == "partial")
+                                               partial_noise=self.noise_type == "partial", pyrng=self.pyrng)
                 s_pc, s_mask, s_gt = (np.concatenate([a, b], 0) for a, b in ((s_pc, n_pc), (s_mask, n_mask), (s_gt, n_gt)))
                 count[noisy] += 1
                 if count[noisy] == k_shot - n_noise - 1:

@@ -128,7 +128,7 @@ def test_hip_protonet_against_reference_outputs():
     data, _ = S.make_episode(cfg, seed=10)
     g = np.load(os.path.join(GOLD, "protonet.npz"))
     for dm in ("cosine", "euclidean"):
-        m = ProtoNet(SimpleNamespace(dist_method=dm, **cfg))
+        m = ProtoNet(SimpleNamespace(**dict(cfg, dist_method=dm)))
         m.load_state_dict({k: v for k, v in sd.items() if k in m.state_dict()})
         m.cuda().eval()
         with torch.no_grad():
