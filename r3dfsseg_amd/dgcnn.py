@@ -148,8 +148,8 @@ class DGCNN(nn.Module):
     def forward(self, x):
         """Reference signature: x (B, C, N) -> (edgeconv_0 (B,64,N), out (B,mlp[-1],N))."""
         B, _, N = x.shape
-        x = x.contiguous().float()
-        cat, h = self.forward_pm(ops.cm_to_pm(x), B, N, x_cm=x)
+        x_pm, x_cm = ops.input_layouts(x)
+        cat, h = self.forward_pm(x_pm, B, N, x_cm=x_cm)
         outs = [ops.pm_to_cm(cat[:, 64 * l:64 * (l + 1)], B, N) for l in range(self.n_edgeconv)]
         out = ops.pm_to_cm(h, B, N)
         if self.return_edgeconvs:

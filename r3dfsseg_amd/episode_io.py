@@ -6,12 +6,12 @@ One episode = eight arrays under fixed names (loader.py:1686-1704):
     query_ptclouds   (n_q, N, 9) f32             query_labels     (n_q, N) i64
     sampled_classes  (n_way,) i32                support_clusters / query_clusters i32
     gt_support_masks (n_way, k_shot, N) i32
-The reference stores them as HDF5 datasets (`<index>.h5`).  This module reads and writes the same names in
-`.npz` containers natively and in `.h5` files when h5py is importable (it is not part of this image, so the
-h5 branch is exercised only where h5py exists).  `collate_test` reproduces batch_test_task_collate_test
-(loader.py:1676-1683): clouds are stored POINT-major on disk and the model takes them CHANNEL-major, so the
-transpose runs on the GPU (r3d_pm_to_cm) after one contiguous host-to-device copy of the raw array instead
-of a strided host transpose + copy.
+The reference stores them as HDF5 datasets (`<index>.h5`).  This module reads and writes that container -- through
+h5py where it is importable, else through the HDF5 C library of the image (h5lite.py; checked against a file the
+reference's own write_episode produced under real h5py, tests/golden/episode_ref.h5) -- and the same names in `.npz`.  `collate_test` reproduces batch_test_task_collate_test
+(loader.py:1676-1683): clouds are stored POINT-major on disk and the model signature is CHANNEL-major; as in the
+reference the collate returns the transposed VIEW, and the encoder consumes the point-major rows directly -- the only
+re-layout on the path is the channel-major operand the first kNN packs for itself (ops.input_layouts).
 """
 import os
 import queue
@@ -27,22 +27,28 @@ EPISODE_FIELDS = (
 )
 
 
-def _h5():
+def _h5py():
     try:
         import h5py
-    except ImportError as e:  # the image has no h5py: say so instead of guessing at the file format
-        raise RuntimeError("reading / writing .h5 episode files needs h5py (not installed here); "
-                           "use the .npz container with the same dataset names") from e
-    return h5py
+        return h5py
+    except ImportError:
+        return None
 
 
 def write_episode(out_filename, data):
-    """data: the 8-tuple of loader.py:1686 in EPISODE_FIELDS order."""
+    """data: the 8-tuple of loader.py:1686 in EPISODE_FIELDS order.  `.h5`: the reference's container (one contiguous
+    dataset per name, loader.py:1690-1701) through h5py where it is importable, else through the HDF5 C library
+    (h5lite.py); anything else: `.npz` with the same names."""
     arrays = {name: np.asarray(a, dtype=dt) for (name, dt), a in zip(EPISODE_FIELDS, data)}
     if out_filename.endswith(".h5"):
-        with _h5().File(out_filename, "w") as f:
-            for name, a in arrays.items():
-                f.create_dataset(name, data=a, dtype=a.dtype)
+        h5py = _h5py()
+        if h5py is not None:
+            with h5py.File(out_filename, "w") as f:
+                for name, a in arrays.items():
+                    f.create_dataset(name, data=a, dtype=a.dtype)
+        else:
+            from . import h5lite
+            h5lite.write_datasets(out_filename, list(arrays.items()))
     else:
         np.savez(out_filename, **arrays)
 
@@ -50,8 +56,17 @@ def write_episode(out_filename, data):
 def read_episode(file_name):
     """-> the 8-tuple of loader.py:1706-1721 (numpy arrays)."""
     if file_name.endswith(".h5"):
-        with _h5().File(file_name, "r") as f:
-            return tuple(f[name][:] for name, _ in EPISODE_FIELDS)
+        h5py = _h5py()
+        if h5py is not None:
+            with h5py.File(file_name, "r") as f:
+                got = [f[name][:] for name, _ in EPISODE_FIELDS]
+        else:
+            from . import h5lite
+            try:
+                got = h5lite.read_datasets(file_name, [name for name, _ in EPISODE_FIELDS])
+            except KeyError as e:
+                raise ValueError(str(e)) from e
+        return tuple(a.astype(dt, copy=False) for a, (_, dt) in zip(got, EPISODE_FIELDS))
     with np.load(file_name) as f:
         missing = [name for name, _ in EPISODE_FIELDS if name not in f]
         if missing:
@@ -60,15 +75,14 @@ def read_episode(file_name):
 
 
 def _to_channel_major(a, device):
-    """(..., N, C) point-major numpy -> (..., C, N) tensor on `device`."""
-    lead, (N, C) = a.shape[:-2], a.shape[-2:]
+    """(..., N, C) point-major numpy -> the (..., C, N) tensor the model signature asks for, as the reference's collate
+    builds it (loader.py:1666,1679: `torch.from_numpy(a).transpose(2, 3)`): a transposed VIEW of the point-major rows,
+    after one contiguous host-to-device copy of the raw array.  No transpose runs here or in the model: the encoder takes
+    the rows as they lie and its first kNN builds its channel-major operand from them (ops.input_layouts)."""
     t = torch.from_numpy(np.ascontiguousarray(a))
-    if torch.device(device).type != "cuda":
-        return t.transpose(-1, -2).contiguous()
-    from . import ops
-    pm = t.reshape(-1, C).to(device, non_blocking=True)           # one contiguous copy, rows = points
-    B = int(np.prod(lead)) if lead else 1
-    return ops.pm_to_cm(pm, B, N).reshape(*lead, C, N)
+    if torch.device(device).type == "cuda":
+        t = t.to(device, non_blocking=True)
+    return t.transpose(-1, -2)
 
 
 def collate_test(data, device="cpu"):

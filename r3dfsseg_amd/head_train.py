@@ -103,7 +103,7 @@ def mpti_train_forward(model, support_x, support_y, query_x, query_y, gt_support
     # two getFeatures calls, each with its own BatchNorm batch statistics (mpti.py:434,436), through one launch sequence
     # over the S + Q clouds
     seg = SegLayout(1, S, query_x.shape[0], N)
-    sfeat, qfeat = T.get_features_train(model, torch.cat((sx, query_x), 0), seed, seg=seg)
+    sfeat, qfeat = T.get_features_train(model, ops.cat_clouds(sx, query_x, 0), seed, seg=seg)
     if model._trace is not None:  # parity tests read the features and, after backward(), their gradients
         sfeat.retain_grad()
         qfeat.retain_grad()

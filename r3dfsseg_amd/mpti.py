@@ -74,15 +74,15 @@ class MPTI_SelfAtten(nn.Module):
         """x (B, C_in, N) -> point-major features (B*N, feat_dim): [level1 | att | base].  group > 0: x is a batch of episodes
         of `group` clouds each (the attention then splits its key axis as for one episode: batch-independent bits)."""
         B, _, N = x.shape
-        x = x.contiguous().float()
+        x_pm, x_cm = ops.input_layouts(x)  # point-major views (the collate's) as they lie: no transpose kernel
         self.encoder.trace = [] if self._trace is not None else None
-        cat, level2 = self.encoder.forward_pm(ops.cm_to_pm(x), B, N, x_cm=x)
+        cat, level2 = self.encoder.forward_pm(x_pm, B, N, x_cm=x_cm)
         if self._trace is not None:
             self._trace.setdefault("idx", []).append(self.encoder.trace)
             self._trace.setdefault("cat", []).append(cat)
             self.encoder.trace = None
         d1 = 64
-        feat = torch.empty(B * N, self.feat_dim, device=x.device, dtype=torch.float32)
+        feat = torch.empty(B * N, self.feat_dim, device=x_pm.device, dtype=torch.float32)
         ops.copy_cols(cat[:, :d1], feat[:, :d1])
         if self.use_attention:
             self.att_learner.forward_pm(level2, B, N, feat[:, d1:d1 + 64], group=group)
@@ -197,7 +197,7 @@ class MPTI_SelfAtten(nn.Module):
         sx = support_x.reshape(E, S, self.in_channels, N)
         # eval-mode BatchNorm uses running statistics, so all clouds of all episodes share one pass; rows per episode:
         # its S support clouds, then its n_q query clouds
-        feat = self.getFeatures_pm(torch.cat((sx, query_x), 1).reshape(E * (S + n_q), self.in_channels, N), group=S + n_q)
+        feat = self.getFeatures_pm(ops.cat_clouds(sx, query_x, 1).reshape(E * (S + n_q), self.in_channels, N), group=S + n_q)
         ep_rows = (S + n_q) * N
         sfeat, qfeat = feat, feat[S * N:]
         shot_keep = None

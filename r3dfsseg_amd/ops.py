@@ -132,6 +132,36 @@ def cm_to_pm(x, out=None):
     return out
 
 
+def is_point_major_view(x):
+    """x (..., C, N): a transposed VIEW of a point-major buffer (..., N, C) -- what the reference's collate hands over
+    (`torch.from_numpy(raw).transpose(2, 3)`, dataloaders/loader.py:1666,1679: the on-disk layout, never materialised)."""
+    if x.dtype != torch.float32 or x.dim() < 3:
+        return False
+    C, N = x.shape[-2], x.shape[-1]
+    return x.stride(-1) == C and x.stride(-2) == 1 and x.transpose(-1, -2).is_contiguous()
+
+
+def input_layouts(x):
+    """x (B, C, N) as the caller hands it -> (x_pm (B*N, C), x_cm (B, C, N) contiguous or None).
+    A transposed view of point-major rows is used AS IT LIES: x_pm is that buffer (no transpose kernel, no copy) and
+    x_cm is None, so the first kNN builds its channel-major operand from the point-major rows itself -- the read it
+    does for every later layer anyway (r3d_knn_topk_batched packs x_pm when no channel-major copy is given).  A
+    contiguous channel-major tensor goes through r3d_cm_to_pm and doubles as the first kNN's operand."""
+    B, C, N = x.shape
+    if is_point_major_view(x):
+        return x.transpose(1, 2).reshape(B * N, C), None
+    x = x.contiguous().float()
+    return cm_to_pm(x), x
+
+
+def cat_clouds(a, b, dim=1):
+    """cat((a, b), dim) of cloud tensors (..., C, N) that keeps the point-major rows of point-major views (the result is
+    again such a view: one contiguous copy of rows instead of a strided gather into channel-major)."""
+    if is_point_major_view(a) and is_point_major_view(b):
+        return torch.cat((a.transpose(-1, -2), b.transpose(-1, -2)), dim).transpose(-1, -2)
+    return torch.cat((a, b), dim)
+
+
 def pm_to_cm(x_pm, B, N):
     """(B*N, C) point-major view -> (B, C, N) contiguous."""
     M, ld = _rows(x_pm)

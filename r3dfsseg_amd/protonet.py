@@ -29,8 +29,8 @@ class ProtoNet(nn.Module):
 
     def getFeatures_pm(self, x):
         B, _, N = x.shape
-        x = x.contiguous().float()
-        cat, level2 = self.encoder.forward_pm(ops.cm_to_pm(x), B, N, x_cm=x)
+        x_pm, x_cm = ops.input_layouts(x)
+        cat, level2 = self.encoder.forward_pm(x_pm, B, N, x_cm=x_cm)
         feat = torch.empty(B * N, self.feat_dim, device=x.device, dtype=torch.float32)
         ops.copy_cols(cat[:, :64], feat[:, :64])
         if self.use_attention:

@@ -340,12 +340,11 @@ class EncoderTrainFn(torch.autograd.Function):
         if seg is None:
             seg = SegLayout(1, B, 0, N)
         assert seg.B == B and seg.N == N
-        x = x.contiguous().float()
-        x_pm = ops.cm_to_pm(x)
+        x_pm, x_cm = ops.input_layouts(x)
         cat = torch.empty(M, 64 * enc.n_edgeconv, device=dev, dtype=torch.float32)
         inp, ec_saved = x_pm, []
         for l in range(enc.n_edgeconv):
-            idx = ops.knn(inp, B, N, enc.k, x_cm=x if l == 0 else None)
+            idx = ops.knn(inp, B, N, enc.k, x_cm=x_cm if l == 0 else None)
             out = cat[:, 64 * l:64 * (l + 1)]
             ec_saved.append(edgeconv_train_fwd(inp, idx, enc.edge_convs[l], B, N, out, seg))
             inp = out

@@ -111,7 +111,7 @@ def test_prototype_count_follows_torch_cluster(ops, fg_counts):
             f = feat[ids]
             want = O.fps_sample_count(len(ids), k_sub)
             if s > 0:
-                assert want == (101 if fg_counts[s - 1] != 150 else 100)
+                assert want == (101 if fg_counts[s - 1] in (149, 163, 297, 364) else 100)  # (n = 101 and 150 draw 100)
             protos, asg, m, _ = O.get_multiple_prototypes(f, k_sub)
             assert m == want and desc[ops.HD_SEG_M + s] == m, (s, m, want, desc[ops.HD_SEG_M + s])
             np.testing.assert_allclose(nodes[row:row + m].numpy(), protos.numpy(), atol=1e-6, rtol=1e-5)
