@@ -85,7 +85,8 @@ def test_hip_path_against_reference_outputs(name):
     dloss = abs(float(loss) - float(g["loss"]))
     print("%s: prototypes within 1e-4: %.4f, logits within 1e-4: %.4f (max %.2e), arg-max agreement %.4f, |loss - ref| %.2e"
           % (name, frac_p, frac, float(err.max()), agree, dloss))
-    assert frac_p >= 0.97 and frac >= 0.97 and agree >= 0.995 and dloss <= 2e-3
+    # measured on MI355X: prototypes 1.0000, logits 0.993-1.0000 (eval: max 7e-6), arg-max 1.0000, loss 6e-6
+    assert frac_p >= 0.99 and frac >= 0.985 and agree >= 0.999 and dloss <= 1e-4
 
     if train:
         assert abs(float(out[2]) - float(g["contrast"])) <= 1e-3 * max(1.0, abs(float(g["contrast"])))
@@ -97,7 +98,7 @@ def test_hip_path_against_reference_outputs(name):
             if f.startswith("buf/"):
                 got = sdn[f[4:]].detach().cpu().numpy()
                 worst = max(worst, float(np.abs(got - g[f]).max()))
-                np.testing.assert_allclose(got, g[f], atol=5e-5, rtol=1e-4, err_msg=f)
+                np.testing.assert_allclose(got, g[f], atol=5e-6, rtol=1e-5, err_msg=f)
         # parameter gradients of lp_loss + 0.1 * contrastive: norm and a sample of entries per tensor
         rel = {}
         for pname, p in m.named_parameters():
@@ -117,7 +118,8 @@ def test_hip_path_against_reference_outputs(name):
         ws = sorted(v[1] for v in rel.values())
         print("%s: running statistics max |diff| %.2e; gradient norms max rel diff %.2e; sampled entries rel-L2 median %.2e max %.2e"
               % (name, worst, wn, ws[len(ws) // 2], ws[-1]))
-        assert wn <= 5e-2 and ws[len(ws) // 2] <= 2e-2, {k: v for k, v in rel.items() if v[0] > 5e-2 or v[1] > 2e-2}
+        # measured: statistics 2.4e-7, norms 3e-4, sampled entries 5e-5 .. 3e-4 median, 6e-4 max
+        assert wn <= 5e-3 and ws[len(ws) // 2] <= 2e-3 and ws[-1] <= 1e-2, {k: v for k, v in rel.items() if v[0] > 5e-3 or v[1] > 2e-3}
 
 
 def test_hip_protonet_against_reference_outputs():
@@ -137,4 +139,4 @@ def test_hip_protonet_against_reference_outputs():
         err = (logits.cpu() - ref).abs() / ref.abs().clamp(min=1.0)
         frac = float((err <= 1e-4).float().mean())
         print("protonet %s: logits within 1e-4: %.4f (max %.2e)" % (dm, frac, float(err.max())))
-        assert frac >= 0.98 and abs(float(loss) - float(g["loss_" + dm])) <= 1e-3
+        assert frac >= 0.99 and abs(float(loss) - float(g["loss_" + dm])) <= 1e-4
