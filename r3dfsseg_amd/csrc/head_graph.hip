@@ -41,39 +41,92 @@ struct HgEp {
 
 // ---------------------------------------------------------------------------
 // 2. bitmaps: outb[i] = { j : j in nbr(i) } ; sym[i] = outb[i] | { j : i in nbr(j) }
+//    No global atomics.  r3d_graph_bits_kernel: one wave per row i builds outb[i] in LDS (its 200 neighbours, LDS
+//    atomics) and stores it whole.  r3d_graph_transpose_kernel: the in-edges are the TRANSPOSE of that bit matrix: a
+//    wave holds one word of 64 consecutive rows, `ballot` of bit b over the lanes IS column 32w + b of those rows (64
+//    bits of the transposed row), tiles of 1024 rows x 256 columns meet in LDS and leave as 128-byte row pieces.
+//    The union with the out-edges is taken by r3d_graph_rowlen_kernel, which reads every word anyway.
+//    (First version: three device-scope atomicOr per edge, 84 M per 32-system step, 1.95 ms; one atomic per edge with
+//    row-owned out-edges: 1.13 ms.)  Neither bitmap needs a zero fill: every word up to n_cap rows is stored.
 // ---------------------------------------------------------------------------
-__global__ void r3d_graph_bits_kernel(const int* __restrict__ nbr, int kp1, const int* __restrict__ n_dev,
-                                      int n_cap, int words, unsigned* __restrict__ outb,
-                                      unsigned* __restrict__ sym, HgEp st) {
+__global__ __launch_bounds__(256) void r3d_graph_bits_kernel(const int* __restrict__ nbr, int kp1, const int* __restrict__ n_dev,
+                                                             int n_cap, int words, unsigned* __restrict__ outb, HgEp st) {
+  __shared__ unsigned bm[4][1024];  // n_cap <= 32768 (checked at the entry points)
   const int ep = blockIdx.y;
-  nbr += (long)ep * st.nbr * kp1; HG_AT(n_dev, st.desc); HG_WS(outb); HG_WS(sym);
+  nbr += (long)ep * st.nbr * kp1; HG_AT(n_dev, st.desc); HG_WS(outb);
   const int n = min(*n_dev, n_cap);
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = kp1 - 1;
-  if (e >= (long)n * k) return;
-  const int i = (int)(e / k);
-  const int t = (int)(e - (long)i * k) + 1;  // column 0 is dropped (mpti.py:736)
-  const int j = nbr[(long)i * kp1 + t];
-  if (j < 0 || j >= n || j == i) return;      // diagonal is zeroed by the reference (mpti.py:755)
-  atomicOr(&outb[(long)i * words + (j >> 5)], 1u << (j & 31));
-  atomicOr(&sym[(long)i * words + (j >> 5)], 1u << (j & 31));
-  atomicOr(&sym[(long)j * words + (i >> 5)], 1u << (i & 31));
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + w;
+  unsigned* b = bm[w];
+  for (int wd = lane; wd < words; wd += 64) b[wd] = 0u;
+  __syncthreads();
+  if (i < n) {
+    const int k = kp1 - 1;
+    for (int t = lane; t < k; t += 64) {
+      const int j = nbr[(long)i * kp1 + 1 + t];    // column 0 is dropped (mpti.py:736)
+      if (j < 0 || j >= n || j == i) continue;     // diagonal is zeroed by the reference (mpti.py:755)
+      atomicOr(&b[j >> 5], 1u << (j & 31));
+    }
+  }
+  __syncthreads();
+  if (i < n_cap)
+    for (int wd = lane; wd < words; wd += 64) outb[(long)i * words + wd] = b[wd];
+}
+
+#define BT_ROWS 1024  // source rows per workgroup = 32 words of every transposed row
+#define BT_CW 8       // source column words per workgroup = 256 transposed rows
+__global__ __launch_bounds__(256) void r3d_graph_transpose_kernel(const unsigned* __restrict__ outb, int words, int n_cap,
+                                                                  unsigned* __restrict__ inb /* inb[c] bit r = outb[r] bit c */,
+                                                                  HgEp st) {
+  __shared__ unsigned tile[BT_CW * 32][BT_ROWS / 32 + 1];
+  const int ep = blockIdx.z;
+  HG_WS(outb); HG_WS(inb);
+  const int c0w = blockIdx.x * BT_CW, r0 = blockIdx.y * BT_ROWS;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int sb = w; sb < BT_ROWS / 64; sb += 4) {  // sub-blocks of 64 source rows, one lane per row
+    const int r = r0 + sb * 64 + lane;
+    unsigned v[BT_CW];
+#pragma unroll
+    for (int cw = 0; cw < BT_CW; ++cw) v[cw] = (r < n_cap && c0w + cw < words) ? outb[(long)r * words + c0w + cw] : 0u;
+#pragma unroll
+    for (int cw = 0; cw < BT_CW; ++cw) {
+#pragma unroll
+      for (int b = 0; b < 32; ++b) {
+        const unsigned long long m = __ballot((v[cw] >> b) & 1u);
+        if (lane == b) {
+          tile[cw * 32 + b][2 * sb] = (unsigned)m;
+          tile[cw * 32 + b][2 * sb + 1] = (unsigned)(m >> 32);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < BT_CW * 32 * (BT_ROWS / 32); e += 256) {
+    const int c = e >> 5, wd = e & 31;
+    const int col = c0w * 32 + c, ow = r0 / 32 + wd;
+    if (col < n_cap && ow < words) inb[(long)col * words + ow] = tile[c][wd];
+  }
 }
 
 // ---------------------------------------------------------------------------
 // 3a. row lengths + exclusive scan (single workgroup; n_cap <= 32768)
 // ---------------------------------------------------------------------------
-__global__ void r3d_graph_rowlen_kernel(const unsigned* __restrict__ sym, int words,
+__global__ void r3d_graph_rowlen_kernel(unsigned* __restrict__ sym /* in: in-edges; out: in | out edges */,
+                                        const unsigned* __restrict__ outb, int words,
                                         const int* __restrict__ n_dev, int n_cap, int* __restrict__ row_len, HgEp st) {
   const int ep = blockIdx.y;
-  HG_WS(sym); HG_AT(n_dev, st.desc); HG_WS(row_len);
+  HG_WS(sym); HG_WS(outb); HG_AT(n_dev, st.desc); HG_WS(row_len);
   const int n = min(*n_dev, n_cap);
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n_cap) return;
   int c = 0;
   if (row < n)
-    for (int wd = lane; wd < words; wd += 64) c += __popc(sym[(long)row * words + wd]);
+    for (int wd = lane; wd < words; wd += 64) {
+      const unsigned v = sym[(long)row * words + wd] | outb[(long)row * words + wd];
+      sym[(long)row * words + wd] = v;
+      c += __popc(v);
+    }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
   if (lane == 0) row_len[row] = c;
@@ -1441,12 +1494,12 @@ static int label_propagate_impl(int n_ep, const HgEp& ep, const float* nodes, lo
   hipStream_t st = (hipStream_t)stream;
   const LpWs L = lp_carve(ws, n_cap, kp1);
   const long words = L.words;
-  r3d_fill_words_ep(L.outb, 0u, 2L * n_cap * words, n_ep, ep.ws, st);
-  const long edges = (long)n_cap * (kp1 - 1);
-  hipLaunchKernelGGL(r3d_graph_bits_kernel, dim3(r3d_cdiv(edges, 256), n_ep), dim3(256), 0, st, nbr, kp1, n_dev, n_cap,
-                     (int)words, L.outb, L.sym, ep);
-  hipLaunchKernelGGL(r3d_graph_rowlen_kernel, dim3(r3d_cdiv(n_cap, 4), n_ep), dim3(256), 0, st, L.sym, (int)words, n_dev,
-                     n_cap, L.row_len, ep);
+  hipLaunchKernelGGL(r3d_graph_bits_kernel, dim3(r3d_cdiv(n_cap, 4), n_ep), dim3(256), 0, st, nbr, kp1, n_dev, n_cap,
+                     (int)words, L.outb, ep);
+  hipLaunchKernelGGL(r3d_graph_transpose_kernel, dim3(r3d_cdiv(words, BT_CW), r3d_cdiv(n_cap, BT_ROWS), n_ep), dim3(256), 0, st,
+                     L.outb, (int)words, n_cap, L.sym, ep);
+  hipLaunchKernelGGL(r3d_graph_rowlen_kernel, dim3(r3d_cdiv(n_cap, 4), n_ep), dim3(256), 0, st, L.sym, L.outb, (int)words,
+                     n_dev, n_cap, L.row_len, ep);
   hipLaunchKernelGGL(r3d_scan_kernel, dim3(n_ep), dim3(1024), 0, st, L.row_len, n_cap, L.row_ptr, ep);
   hipLaunchKernelGGL(r3d_graph_cols_kernel, dim3(r3d_cdiv(n_cap, 4), n_ep), dim3(256), 0, st, L.sym, (int)words, n_dev,
                      n_cap, L.row_ptr, L.col, ep);
