@@ -140,3 +140,27 @@ def test_hip_protonet_against_reference_outputs():
         frac = float((err <= 1e-4).float().mean())
         print("protonet %s: logits within 1e-4: %.4f (max %.2e)" % (dm, frac, float(err.max())))
         assert frac >= 0.99 and abs(float(loss) - float(g["loss_" + dm])) <= 1e-4
+
+
+def test_miou_of_the_device_predictions_against_the_references():
+    """north_star: mIoU within +-0.2 pt of the reference.  The query predictions of the reference's own forward (arg-max
+    of the stored logits, eval_noise.py:85-95) through the reference's metric (eval_noise.py:23-72, restated in the
+    oracle) against the device's predictions through the device histogram, over the two-way eval fixtures."""
+    from oracle import r3d_oracle as O
+    from r3dfsseg_amd.metrics import MIoUAccumulator
+    test_classes = [3, 6, 9, 11]
+    acc = MIoUAccumulator(test_classes)
+    preds, gts, l2cs = [], [], []
+    for i, name in enumerate(("head_eval", "head_clean")):
+        cfg, sd, data, mode, g = fixture(name)
+        m = _model(cfg, sd, False)
+        ep = [t.cuda() if torch.is_tensor(t) else t for t in data]
+        with torch.no_grad():
+            logits, _ = m(ep[0], ep[1], ep[2], ep[3], gt_support_y=ep[6], eval=(mode == "clean"), lp_iters=m.lp_max_iter)
+        l2c = [test_classes[i], test_classes[i + 2]]
+        acc.update(logits.argmax(1), ep[3], l2c)
+        preds.append(g["logits"].argmax(1)); gts.append(data[3].numpy()); l2cs.append(l2c)
+    miou, _ = acc.compute()
+    want, _ = O.evaluate_metric(preds, gts, l2cs, test_classes)
+    print("mIoU device %.6f reference %.6f" % (miou, want))
+    assert abs(miou - want) <= 0.002
