@@ -131,7 +131,10 @@ int r3d_attention_fwd(const float* qkv, long ld, int B, int N, float* out, long 
  * FPS (start index 0, ties lowest index) -> sorted unique seeds -> nearest-seed assignment ->
  * cluster means, for background + each way, then query rows appended: fills node rows
  * [0, n_proto) and [n_proto, n_proto + n_query_pts) of `nodes` and the label matrix Y.
- * desc: device int32[r3d_head_desc_words()] = {seg_count[8], seg_m[8], seg_poff[8], n_proto, n_nodes,..}. */
+ * desc: device int32[r3d_head_desc_words()] = {seg_count[8], seg_m[8], seg_poff[8], n_proto, n_nodes,..}.
+ * Seeds per segment of n > k points: what torch_cluster.fps(feat, None, ratio = k / n) draws at the call site
+ * models/mpti.py:612-613, ceil(float32(n) * float32(k / n)) = k or k + 1 (101 for 5.8 % of the n <= 20480 at k = 100),
+ * so a segment can hold k + 1 prototypes: nodes / node_labels need (n_way + 1) * (k + 1) + n_query_pts rows, k < r3d_head_max_k(). */
 int r3d_head_desc_words(void);
 int r3d_head_max_k(void);
 long r3d_head_proto_ws_words(int n_way, int k_shot, int N);
