@@ -136,6 +136,12 @@ def committed_profile(workload, mode):
         return None, None
     rows = {}
     for l in open(names[-1]):
+        if l.startswith("#"):  # "# rocprofv3 --kernel-trace -- python3 tools/one_step.py MODE W E STEPS   (...": steps of the profile
+            try:
+                rows["_steps"] = int(l.split("(")[0].split()[-1])
+            except (ValueError, IndexError):
+                pass
+            continue
         f = l.split()
         if len(f) >= 5 and "r3d_" in l[:16]:
             try:
@@ -441,20 +447,39 @@ def main():
             ach, peak, unit = fl / calls / t_launch / 1e12, F32_MFMA_PEAK_TF, "TFLOP/s"
         else:
             ach, peak, unit = by / calls / t_launch / 1e9, HBM_PEAK_GBS, "GB/s"
-        traffic = rocprof_us = None
+        traffic = rocprof_us = rocprof_ms_step = frac_kernel = None
         main = MAIN_KERNEL.get(kern, kern)
+
+        def base(name):  # "void r3d_x_kernel<5>(float const*, ..." -> "r3d_x_kernel"
+            return name.split("(")[0].split("<")[0].replace("void ", "").strip()
+        # the two kNN entry points run instances of ONE kernel template: told apart by their template arguments
+        by_template = {"knn_topk": ("r3d_knn_append_kernel<4, 128, 1,",), "knn_topk_l2": ("r3d_knn_append_kernel<8, 384, 2,",)}
+
+        def mine(name):
+            if kern in by_template:
+                return name.replace("void ", "").startswith(by_template[kern])
+            return bool(base(name)) and base(name) in main
         if pmc is not None:
-            hit = [v for k, v in pmc.items() if k.split("(")[0].split("<")[0] in main]
+            hit = [v for k, v in pmc.items() if mine(k)]
             if hit:
                 traffic = 1024.0 * max(FETCH_SIZE_WIDE_READ_FACTOR * v["fetch_kb_per_launch"] + v["write_kb_per_launch"] for v in hit)
         if prof is not None:
-            us = [v[2] for k, v in prof.items() if k.split("(")[0].split("<")[0] in main]
-            rocprof_us = max(us) if us else None
+            hits = [v for k, v in prof.items() if k != "_steps" and mine(k)]
+            if hits:
+                rocprof_us = max(v[2] for v in hits)  # average duration of the entry point's longest kernel
+                if prof.get("_steps"):
+                    # the entry point's main kernels in the committed kernel trace of the same workload and schedule: their
+                    # time per step, and the roofline fraction from kernel time alone (no helper kernels, no launch gaps)
+                    rocprof_ms_step = sum(v[1] for v in hits) / prof["_steps"]
+                    frac_kernel = (fl / (rocprof_ms_step * 1e-3) / 1e12 / F32_MFMA_PEAK_TF) if bound == "mfma" else \
+                        (by / (rocprof_ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS)
         roof = dict(kernel="%s (entry point %s, %d episodes per launch)" % (main, kern, E), bound=bound, achieved=ach, peak=peak,
                     unit=unit, frac=ach / peak, traffic=traffic, avg_launch_ms=t_launch * 1e3, launches_per_step=calls,
                     algorithmic_gflop_per_launch=fl / calls / 1e9, algorithmic_mb_per_launch=by / calls / 1e6,
                     hbm_gbs=by / calls / t_launch / 1e9, fp32_tflops=fl / calls / t_launch / 1e12,
-                    rocprofv3_kernel_us=rocprof_us, rocprofv3_summary=prof_name, pmc_summary=pmc_name,
+                    rocprofv3_kernel_us=rocprof_us, rocprofv3_main_kernels_ms_per_step=rocprof_ms_step,
+                    event_ms_per_step=per_step_ms[kern], frac_kernel_time_only=frac_kernel,
+                    rocprofv3_summary=prof_name, pmc_summary=pmc_name,
                     note="one HIP event pair per entry-point call on the launch stream (launches of the batched step do not "
                          "overlap; the pair includes the entry point's small helper kernels); traffic = %.0f x FETCH_SIZE + "
                          "WRITE_SIZE of the main kernel from the committed PMC passes" % FETCH_SIZE_WIDE_READ_FACTOR)
