@@ -113,3 +113,29 @@ def test_point_major_input_gives_the_same_bits_as_channel_major(tmp_path):
         (out[1] + 0.1 * out[2]).backward()
         outs.append((out[0].detach().clone(), m.encoder.edge_convs[0].layer[0].weight.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.gpu
+def test_batched_eval_from_collated_views_equals_channel_major():
+    """EpisodeBatch keeps point-major views (stacking copies rows, x_all is again a view) and the batched forward gives
+    the bits of the same episodes handed over as contiguous channel-major tensors."""
+    from types import SimpleNamespace
+    from r3dfsseg_amd import ops
+    from r3dfsseg_amd.batch import EpisodeBatch
+    from r3dfsseg_amd.mpti import MPTI_SelfAtten
+    cfg = S.make_cfg(n_way=2, k_shot=2, pc_npts=256)
+    m = MPTI_SelfAtten(SimpleNamespace(**cfg))
+    m.load_state_dict(S.make_state_dict(cfg, 123))
+    m.cuda().eval()
+    views, dense = [], []
+    for seed in (3, 4, 5):
+        _, data, raw = _raw_episode(seed=seed)
+        out, _ = EIO.collate_test(raw, "cuda")
+        views.append(out)
+        dense.append([t.contiguous() for t in out])
+    bv, bd = EpisodeBatch.from_episodes(views), EpisodeBatch.from_episodes(dense)
+    assert ops.is_point_major_view(bv.x_all) and bd.x_all.is_contiguous() and torch.equal(bv.x_all, bd.x_all)
+    with torch.no_grad():
+        lv, _ = m.forward_episodes(bv, lp_iters=m.lp_max_iter)
+        ld, _ = m.forward_episodes(bd, lp_iters=m.lp_max_iter)
+    assert torch.equal(lv, ld)
