@@ -139,3 +139,25 @@ def test_batched_eval_from_collated_views_equals_channel_major():
         lv, _ = m.forward_episodes(bv, lp_iters=m.lp_max_iter)
         ld, _ = m.forward_episodes(bd, lp_iters=m.lp_max_iter)
     assert torch.equal(lv, ld)
+
+
+@pytest.mark.gpu
+def test_feeder_on_the_device_matches_host_collate(tmp_path):
+    """The reader thread's copies (its own stream, event handed to the consumer) deliver the files' arrays, in order."""
+    _, _, raw = _raw_episode(seed=6)
+    want = []
+    for i in range(12):
+        ep = raw[:3] + (raw[3] + i,) + raw[4:]
+        EIO.write_episode(str(tmp_path / ("%d.npz" % i)), ep)
+        want.append(EIO.collate_test(ep, "cpu")[0])
+    files = EIO.list_episode_files(str(tmp_path))
+    busy = torch.zeros(1 << 24, device="cuda")
+    got = []
+    for out, _ in EIO.EpisodeFeeder(files, device="cuda", depth=4):
+        busy.mul_(1.0001)  # kernels in flight on the consumer's stream while the next copies run
+        got.append([t.clone() for t in out])
+    torch.cuda.synchronize()
+    assert len(got) == 12
+    for g, w in zip(got, want):
+        for a, b in zip(g, w):
+            assert a.is_cuda and torch.equal(a.cpu(), b)
