@@ -137,6 +137,9 @@ int r3d_attention_fwd(const float* qkv, long ld, int B, int N, float* out, long 
  * so a segment can hold k + 1 prototypes: nodes / node_labels need (n_way + 1) * (k + 1) + n_query_pts rows, k < r3d_head_max_k(). */
 int r3d_head_desc_words(void);
 int r3d_head_max_k(void);
+/* out[n], n in [0, n_max): the seeds a segment of n points gets at k (n <= k: n), as the device evaluates the count above
+ * (device int32 out; for tests that hold it to the host arithmetic over every n). */
+int r3d_fps_sample_count_table(int k, int n_max, int32_t* out, void* stream);
 long r3d_head_proto_ws_words(int n_way, int k_shot, int N);
 int r3d_head_proto_ws_offsets(int n_way, int k_shot, int N, long* out6 /* comp,mind,assign,cand,sel,seeds */);
 /* flags: R3D_HEAD_FPS_ONE_LAUNCH = all FPS rounds in one persistent launch (points stay in registers; needs the

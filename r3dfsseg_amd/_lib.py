@@ -43,6 +43,7 @@ _SIGS = {
     "r3d_set_matrix_arith": (c_i, [c_i]),
     "r3d_get_matrix_arith": (c_i, []),
     "r3d_head_max_k": (c_i, []),
+    "r3d_fps_sample_count_table": (c_i, [c_i, c_i, c_f, c_f]),
     "r3d_head_proto_ws_words": (c_l, [c_i, c_i, c_i]),
     "r3d_head_proto_ws_offsets": (c_i, [c_i, c_i, c_i, ctypes.POINTER(c_l)]),
     "r3d_head_prototypes": (c_i, [c_f, c_f, c_f, c_l, c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_l,

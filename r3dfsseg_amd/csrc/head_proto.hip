@@ -754,6 +754,19 @@ static int check_geom(const char* fn, int n_way, int k_shot, int N, int D) {
 extern "C" int r3d_head_desc_words(void) { return HD_WORDS; }
 extern "C" int r3d_head_max_k(void) { return HP_MAXK; }
 
+// out[n] = the seeds a segment of n points gets at k (n in [0, n_max)): the device's evaluation of hp_fps_count, so that
+// a test can hold it to numpy's float32 arithmetic for EVERY point count (tests/test_gpu_head.py)
+__global__ void r3d_fps_count_table_kernel(int k, int n_max, int* __restrict__ out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < n_max) out[n] = n > k ? hp_fps_count(n, k) : n;
+}
+extern "C" int r3d_fps_sample_count_table(int k, int n_max, int32_t* out, void* stream) {
+  R3D_REQUIRE(out && k >= 1 && n_max >= 1, "r3d_fps_sample_count_table: bad arguments");
+  hipLaunchKernelGGL(r3d_fps_count_table_kernel, dim3(r3d_cdiv(n_max, 256)), dim3(256), 0, (hipStream_t)stream, k, n_max, out);
+  R3D_LAUNCH_CHECK("r3d_fps_sample_count_table");
+  return R3D_OK;
+}
+
 // Scratch layout (4-byte words) of r3d_head_prototypes.
 struct HpWs {
   long comp, mind, assign, cand, sel, seeds, part, part_cnt, featC, xch, best, featP, total;

@@ -280,3 +280,22 @@ def test_mpti_forward_without_attention_vs_oracle(ops):
         assert ((got - f).abs() / f.abs().clamp(min=1.0)).max().item() <= 1e-4
     from custody import head_custody
     head_custody(m, cfg, sd, data, logits, loss)
+
+
+def test_device_sample_count_equals_the_host_arithmetic_for_every_n(ops):
+    """hp_fps_count (double division, rounding to float32, float32 product, ceil) on the device against numpy's float32
+    arithmetic -- the published torch_cluster count -- for every point count up to 65536 and several k."""
+    from r3dfsseg_amd import _lib
+    lib = _lib.load()
+    n_max = 65537
+    for k in (4, 40, 100, 127):
+        out = torch.empty(n_max, device="cuda", dtype=torch.int32)
+        _lib.check(lib.r3d_fps_sample_count_table(k, n_max, ops._p(out), ops._st()))
+        got = out.cpu().numpy()
+        n = np.arange(n_max)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            want = np.ceil(n.astype(np.float32) * (k / n.astype(np.float64)).astype(np.float32)).astype(np.int64)
+        want = np.where(n > k, np.minimum(want, n), n)
+        assert np.array_equal(got, want), (k, np.nonzero(got != want)[0][:10])
+        assert set(np.unique(got[k + 1:])) <= {k, k + 1}
+    assert O.fps_sample_count(364, 100) == 101  # the oracle's statement of the same rule
