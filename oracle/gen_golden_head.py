@@ -154,8 +154,18 @@ def _quiet(fn, *a, **k):
         return fn(*a, **k)
 
 
-def run_mpti(cfg, sd, data, mode, record):
-    """mode: 'eval' (train=False, eval=False), 'clean' (eval=True: clean-shot detection), 'train'."""
+def row_hash(I):
+    """order-free 64-bit fingerprint of every neighbour row (a set hash: sum of a mixed value per entry)"""
+    v = I.astype(np.uint64)
+    v = (v + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+    v ^= v >> np.uint64(29)
+    v *= np.uint64(0xBF58476D1CE4E5B9)
+    return v.sum(1, dtype=np.uint64)
+
+
+def run_mpti(cfg, sd, data, mode, record, compact=False):
+    """mode: 'eval' (train=False, eval=False), 'clean' (eval=True: clean-shot detection), 'train'.
+    compact: the full-size fixtures (BASELINE configs[1] / [2]) store samples and fingerprints of the large arrays."""
     from models.mpti import MPTI_SelfAtten  # the reference
     model = MPTI_SelfAtten(ref_args(cfg))
     model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=True)
@@ -236,8 +246,9 @@ def run_mpti(cfg, sd, data, mode, record):
     record["knnfix_idx"] = np.array([i for _, _, _, i in flat], np.int16).reshape(-1, cfg["dgcnn_k"])
     record["logits"] = logits.detach().numpy()
     sfeat, qfeat = cap["getFeatures"][0], cap["getFeatures"][1]
-    record["support_feat_s4"] = sfeat.detach().numpy()[:, ::4, ::4].copy()
-    record["query_feat_s4"] = qfeat.detach().numpy()[:, ::4, ::4].copy()
+    fs = (slice(None), slice(None, None, 8), slice(None, None, 16)) if compact else (slice(None), slice(None, None, 4), slice(None, None, 4))
+    record["support_feat_s4"] = sfeat.detach().numpy()[fs].copy()
+    record["query_feat_s4"] = qfeat.detach().numpy()[fs].copy()
     # prototype calls in the order of the forward: [contrast calls ...] fg way 0.., bg
     n_head_calls = cfg["n_way"] + 1
     protos = cap["getMutiplePrototypes"][-n_head_calls:]
@@ -261,14 +272,22 @@ def run_mpti(cfg, sd, data, mode, record):
     A = cap["calculateLocalConstrainedAffinity"][0].detach()
     record["A_rowsum"] = A.sum(1).numpy()
     rs = np.random.RandomState(78)
-    rows = rs.randint(0, A.shape[0], 16)
+    rows = rs.randint(0, A.shape[0], 4 if compact else 16)
     record["A_rows"] = rows.astype(np.int32)
     record["A_vals"] = A[rows].numpy()
     record["Z"] = cap["label_propagate"][0].detach().numpy()
     I, D, G = KNN_CALLS[-1]
-    record["knn_idx"] = I.astype(np.int16 if I.max() < 32768 else np.int32)
     record["knn_gap"] = G  # squared distance of the first dropped minus the last kept neighbour
     record["knn_dlast"] = D[:, -1].copy()
+    if compact:
+        # every row's SET fingerprint, and the rows themselves where the reference's own margin is within rounding
+        record["knn_sethash"] = row_hash(I[:, 1:])
+        tie = np.nonzero(np.abs(G) < 2e-5 * np.maximum(1.0, D[:, -1]))[0]
+        record["knn_tie_rows"] = tie.astype(np.int32)
+        record["knn_tie_idx"] = I[tie].astype(np.int16 if I.max() < 32768 else np.int32)
+        record["knn_col0"] = I[:, 0].astype(np.int16 if I.max() < 32768 else np.int32)
+    else:
+        record["knn_idx"] = I.astype(np.int16 if I.max() < 32768 else np.int32)
     if mode == "clean":
         pl, flag = cap["Mean_pl_support_y_multi_scale"][0]
         for w, v in enumerate(pl):
@@ -296,6 +315,13 @@ FIXTURES = {
     "head_train_cleanset": (dict(), dict(seed=8, train=True), "train"),  # clean support set: the extra negatives branch
     "head_eval_3way": (dict(n_way=3, k_shot=1), dict(seed=9), "eval"),
 }
+# BASELINE.json configs[1] / configs[2] at their own size (2-way 5-shot 2048 points, n = 4396 nodes; configs[2]: out-of-
+# distribution noise at ratio 0.4 through the clean-shot detection) and one training step of it: stored compactly
+FIXTURES_S = {
+    "head_eval_S": (dict(k_shot=5, pc_npts=2048), dict(seed=11), "eval"),
+    "head_clean_S": (dict(k_shot=5, pc_npts=2048), dict(seed=12, noise_ratio=0.4, noise_mode="ood"), "clean"),
+    "head_train_S": (dict(k_shot=5, pc_npts=2048), dict(seed=13, noise_ratio=0.4, train=True), "train"),
+}
 
 
 def main():
@@ -303,16 +329,22 @@ def main():
     torch.set_num_threads(1)
     install_environment()
     os.makedirs(OUT, exist_ok=True)
-    for name, (over, ep, mode) in FIXTURES.items():
+    only = sys.argv[1:]
+    torch.set_num_threads(1)
+    for name, (over, ep, mode) in list(FIXTURES.items()) + list(FIXTURES_S.items()):
+        if only and name not in only:
+            continue
         cfg = head_cfg(**over)
         sd = S.make_state_dict(cfg, seed=123)
         data, _ = S.make_episode(cfg, **ep)
         data = to_torch(data)
         rec = {}
-        run_mpti(cfg, sd, data, mode, rec)
+        run_mpti(cfg, sd, data, mode, rec, compact=name in FIXTURES_S)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
         print(name, "fps (n, count):", rec["fps_counts_all"].tolist()[-4:], "loss", rec["loss"],
               os.path.getsize(os.path.join(OUT, name + ".npz")))
+    if only and "protonet" not in only:
+        return
     cfg = S.make_cfg(n_way=2, k_shot=1, pc_npts=512)  # BASELINE configs[0]
     sd = S.make_state_dict(cfg, seed=123)
     data = to_torch(S.make_episode(cfg, seed=10)[0])

@@ -29,6 +29,8 @@ class HeadLPFn(torch.autograd.Function):
             hb.fps_one_launch = False
         ops.head_prototypes(hb, sy, None, sfeat, qfeat, ep_rows)
         nbr = ops.knn_nodes(hb, exact=model._lp_force)
+        if model.nbr_patch is not None:  # parity tests only (mpti.MPTI_SelfAtten.nbr_patch)
+            nbr = model.nbr_patch(nbr)
         if model._trace is not None:
             model._trace["nbr"] = nbr
         # same launch-budget policy as eval (mpti.py: _lp_next_budget); MPTILearner_V3.train / DPTrainer.step check

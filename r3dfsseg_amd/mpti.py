@@ -68,6 +68,9 @@ class MPTI_SelfAtten(nn.Module):
         # parity tests set this to a dict; forward() then leaves its index decisions and intermediate tensors in it
         # (neighbour lists per encoder pass and layer, max-pool winners, features, shot flags, 201-NN lists)
         self._trace = None
+        # parity tests only: callable (nbr (E, n_cap, k + 1) int32) -> nbr that replaces rows of the device's own 201-NN
+        # lists (the reference's choice on its near-tie rows, tests/test_gpu_golden_head.py); None in every product path
+        self.nbr_patch = None
 
     # ------------------------------------------------------------------ features (mpti.py:579-595)
     def getFeatures_pm(self, x, group=0):
@@ -213,6 +216,8 @@ class MPTI_SelfAtten(nn.Module):
         sy = support_y.reshape(E, S, N).to(torch.int32).contiguous()
         ops.head_prototypes(hb, sy, shot_keep, sfeat, qfeat, ep_rows)
         nbr = ops.knn_nodes(hb, exact=bool(lp_iters))
+        if self.nbr_patch is not None:
+            nbr = self.nbr_patch(nbr)
         ops.label_propagate(hb, nbr, self.sigma, 0.99, lp_iters or self._lp_next_budget(), self.lp_tol)
         self._lp_post(hb)
         labels = query_y.reshape(E, n_q, N).to(torch.int64).contiguous() if query_y is not None else None

@@ -345,6 +345,8 @@ class EncoderTrainFn(torch.autograd.Function):
         inp, ec_saved = x_pm, []
         for l in range(enc.n_edgeconv):
             idx = ops.knn(inp, B, N, enc.k, x_cm=x_cm if l == 0 else None)
+            if enc.idx_patch is not None:  # parity tests only (dgcnn.DGCNN.idx_patch)
+                idx = enc.idx_patch(l, idx.view(B, N, enc.k)).view(idx.shape)
             out = cat[:, 64 * l:64 * (l + 1)]
             ec_saved.append(edgeconv_train_fwd(inp, idx, enc.edge_convs[l], B, N, out, seg))
             inp = out

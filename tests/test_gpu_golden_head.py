@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from r3dfsseg_amd import synthetic as S  # noqa: E402
-from test_oracle_golden_head import FIXTURES, GOLD, fixture  # noqa: E402
+from test_oracle_golden_head import ALL_FIXTURES, FIXTURES, FIXTURES_S, GOLD, fixture, row_hash  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -39,13 +39,78 @@ def _model(cfg, sd, train):
     return m
 
 
-@pytest.mark.parametrize("name", list(FIXTURES))
-def test_hip_path_against_reference_outputs(name):
+def _reference_near_tie_rows(g, n_support_clouds):
+    """DGCNN.idx_patch that writes the REFERENCE's neighbour rows over the device's own wherever the reference's margin
+    (k-th against (k+1)-th score of models/dgcnn.py:18-20) is within fp32 rounding or its GEMM order chose differently from
+    the channel-ascending chain -- the rows oracle/gen_golden_head.py stores (call = 3 * getFeatures call + layer; the device
+    runs the support and the query clouds of an episode as one batch of clouds, support first)."""
+    where = g["knnfix_where"].astype(np.int64)
+    rows = torch.from_numpy(g["knnfix_idx"].astype(np.int32))
+
+    def patch(layer, idx):
+        sel = np.nonzero(where[:, 0] % 3 == layer)[0]
+        if not len(sel):
+            return idx
+        cloud = torch.from_numpy(where[sel, 1] + (where[sel, 0] >= 3) * n_support_clouds).to(idx.device)
+        point = torch.from_numpy(where[sel, 2]).to(idx.device)
+        idx = idx.clone()
+        idx[cloud, point] = rows[sel].to(idx.device)
+        return idx
+    return patch
+
+
+def _reference_near_tie_lists(g, seen):
+    """MPTI_SelfAtten.nbr_patch: the reference's 201-NN rows (faiss' BLAS formulation, models/mpti.py:733-736) written over
+    the device's own on the rows whose margin -- first dropped against last kept squared distance -- is within rounding.
+    `seen` receives the number of rows where the device's own SET differed from the reference's, and how many of those lie
+    outside the near-tie rows (must be none)."""
+    gap, dlast = g["knn_gap"], g["knn_dlast"]
+    tie = np.nonzero(np.abs(gap) < 2e-5 * np.maximum(1.0, dlast))[0]
+    if "knn_idx" in g.files:
+        ref_rows = g["knn_idx"][tie].astype(np.int32)
+        want_hash = row_hash(g["knn_idx"].astype(np.int64)[:, 1:])
+    else:
+        assert np.array_equal(tie, g["knn_tie_rows"])
+        ref_rows = g["knn_tie_idx"].astype(np.int32)
+        want_hash = g["knn_sethash"]
+
+    def patch(nbr):
+        n = len(gap)
+        own = nbr[0, :n].cpu().numpy().astype(np.int64)
+        bad = np.nonzero(row_hash(own[:, 1:]) != want_hash)[0]
+        seen["flipped"], seen["outside"] = len(bad), int((~np.isin(bad, tie)).sum())
+        nbr = nbr.clone()
+        nbr[0, torch.from_numpy(tie).to(nbr.device)] = torch.from_numpy(ref_rows).to(nbr.device)
+        return nbr
+    return patch
+
+
+# Bars = at most 3x what was measured on MI355X (the test prints the figures).  free: nothing injected, the device decides
+# every index on its own features -- a near-tie row may flip and move a handful of points; patched: the reference's own
+# choice on ITS near-tie rows written over the device's lists (every other row must then agree by itself), which makes
+# the end-to-end comparison a statement about every single point.
+#            logits: (fraction within 1e-4, max relative error, arg-max agreement, |loss - ref|)
+BARS = {
+    ("eval", True): dict(frac=1.0, emax=3e-5, agree=1.0, dloss=2e-5),
+    ("eval", False): dict(frac=0.985, emax=None, agree=0.998, dloss=1e-4),
+    ("train", True): dict(frac=1.0, emax=1e-4, agree=1.0, dloss=2e-5, gnorm=2e-3, gmed=1e-3, gmax=2e-3),
+    ("train", False): dict(frac=0.985, emax=None, agree=0.998, dloss=1e-4, gnorm=5e-3, gmed=2e-3, gmax=1e-2),
+}
+
+
+@pytest.mark.parametrize("patched", [False, True], ids=["free", "patched"])
+@pytest.mark.parametrize("name", list(ALL_FIXTURES))
+def test_hip_path_against_reference_outputs(name, patched):
     from r3dfsseg_amd import ops
     cfg, sd, data, mode, g = fixture(name)
     n_way, N = cfg["n_way"], cfg["pc_npts"]
     train = mode == "train"
+    bar = BARS[("train" if train else "eval", patched)]
     m = _model(cfg, sd, train)
+    seen = {}
+    if patched:
+        m.encoder.idx_patch = _reference_near_tie_rows(g, n_way * cfg["k_shot"])
+        m.nbr_patch = _reference_near_tie_lists(g, seen)
     ep = [t.cuda() if torch.is_tensor(t) else t for t in data]
     if train:
         out = m(ep[0], ep[1], ep[2], ep[3], gt_support_y=ep[6], gt_query_y=ep[7], train=True, support_flag=ep[10],
@@ -83,10 +148,15 @@ def test_hip_path_against_reference_outputs(name):
     frac = float((err <= 1e-4).float().mean())
     agree = float((logits.cpu().argmax(1) == ref.argmax(1)).float().mean())
     dloss = abs(float(loss) - float(g["loss"]))
-    print("%s: prototypes within 1e-4: %.4f, logits within 1e-4: %.4f (max %.2e), arg-max agreement %.4f, |loss - ref| %.2e"
-          % (name, frac_p, frac, float(err.max()), agree, dloss))
-    # measured on MI355X: prototypes 1.0000, logits 0.993-1.0000 (eval: max 7e-6), arg-max 1.0000, loss 6e-6
-    assert frac_p >= 0.99 and frac >= 0.985 and agree >= 0.998 and dloss <= 1e-4
+    print("%s %s: prototypes within 1e-4: %.4f, logits within 1e-4: %.4f (max %.2e), arg-max agreement %.4f, |loss - ref| %.2e"
+          % (name, "patched" if patched else "free", frac_p, frac, float(err.max()), agree, dloss))
+    # measured on MI355X, free: prototypes 1.0000, logits 0.993-1.0000 (eval: max 7e-6), arg-max 1.0000, loss 6e-6
+    if patched:
+        print("%s: 201-NN rows whose set differed from the reference's before the patch: %d (outside its near-tie rows: %d)"
+              % (name, seen["flipped"], seen["outside"]))
+        assert seen["outside"] == 0
+    assert frac_p >= (1.0 if patched else 0.99) and frac >= bar["frac"] and agree >= bar["agree"] and dloss <= bar["dloss"]
+    assert bar["emax"] is None or float(err.max()) <= bar["emax"]
 
     if train:
         assert abs(float(out[2]) - float(g["contrast"])) <= 1e-3 * max(1.0, abs(float(g["contrast"])))
@@ -119,7 +189,8 @@ def test_hip_path_against_reference_outputs(name):
         print("%s: running statistics max |diff| %.2e; gradient norms max rel diff %.2e; sampled entries rel-L2 median %.2e max %.2e"
               % (name, worst, wn, ws[len(ws) // 2], ws[-1]))
         # measured: statistics 2.4e-7, norms 3e-4, sampled entries 5e-5 .. 3e-4 median, 6e-4 max
-        assert wn <= 5e-3 and ws[len(ws) // 2] <= 2e-3 and ws[-1] <= 1e-2, {k: v for k, v in rel.items() if v[0] > 5e-3 or v[1] > 2e-3}
+        assert wn <= bar["gnorm"] and ws[len(ws) // 2] <= bar["gmed"] and ws[-1] <= bar["gmax"], \
+            {k: v for k, v in rel.items() if v[0] > bar["gnorm"] or v[1] > bar["gmed"]}
 
 
 def test_hip_protonet_against_reference_outputs():
