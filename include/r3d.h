@@ -291,7 +291,8 @@ int r3d_add_cols(const float* src, long ld_src, float* dst, long ld_dst, long M,
  * ws: r3d_edgeconv_train_ws_words(B, N) floats. */
 long r3d_edgeconv_train_ws_words(int B, int N);
 int r3d_edge_stats1(const float* PQ, const int32_t* idx, int B, int N, int K, int clouds_a, int clouds_b,
-                    float* sums_out /*[seg][2][64]*/, float* ws, void* stream);
+                    float* sums_out /*[seg][2][64]*/, float* esum /*opt (B*N,64): sum_t e1 of every point*/, float* ws,
+                    void* stream);
 /* one-pass training forward: z2 statistics + per point/channel max and min of z2 over the K edges; BatchNorm2 +
  * LeakyReLU is monotone per channel, so r3d_edge_select finishes the layer once the statistics are folded */
 int r3d_edgeconv_train_fwd_minmax(const float* PQ, const int32_t* idx, const float* s1, const float* t1, long bn_stride,
@@ -304,12 +305,15 @@ int r3d_edge_select(float* zmax /*in: max, out: selected z*/, const float* zmin,
  * words.  The backward gathers along it instead of scattering with float atomics: deterministic gradients. */
 long r3d_edge_reverse_ws_words(int B, int N, int K);
 int r3d_edge_reverse(const int32_t* idx, int B, int N, int K, int32_t* rev_ws, long ws_words, void* stream);
-/* bn2_sums [seg][2][64] in; dW2 (64,64) summed over the WHOLE batch, bn1_sums [seg][2][64], dPQ (B*N,128) out */
+/* bn2_sums [seg][2][64] in; dW2 (64,64) summed over the WHOLE batch, bn1_sums [seg][2][64], dPQ (B*N,128) out.
+ * zwin (B*N,64): z2 of every max-pool winner (zmax after r3d_edge_select); esum: from r3d_edge_stats1.  Both given, N % 8 == 0
+ * and r3d_set_matrix_arith(1): the three edge GEMMs of the backward run on the bf16 matrix core in three-piece arithmetic
+ * (none decides an index: the winner and its side of the LeakyReLU kink come from argmax / zwin); else on the fp32 core. */
 int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float* s1, const float* t1, const float* mean1,
                      const float* invstd1, const float* W2, const float* s2, const float* t2, const float* mean2,
                      const float* invstd2, long bn_stride, const float* bn2_sums, const float* dout, long lddo,
-                     const int32_t* argmax, int B, int N, int K, int clouds_a, int clouds_b,
-                     float* DY1 /*(B*N*K,64) scratch*/, float* BE /*(B*N,128) scratch*/,
+                     const int32_t* argmax, const float* zwin /*opt*/, const float* esum /*opt*/, int B, int N, int K,
+                     int clouds_a, int clouds_b, float* DY1 /*(B*N*K,64) scratch*/, float* BE /*(B*N,128) scratch*/,
                      const int32_t* rev_ws /* r3d_edge_reverse of the same idx */, float* dW2, float* bn1_sums, float* dPQ,
                      float* ws, void* stream);
 

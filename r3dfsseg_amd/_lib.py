@@ -70,10 +70,10 @@ _SIGS = {
     "r3d_gemm_tn": (c_i, [c_f, c_l, c_f, c_l, c_l, c_i, c_i, c_fl, c_f, c_i, c_f, c_f]),
     "r3d_add_cols": (c_i, [c_f, c_l, c_f, c_l, c_l, c_i, c_f]),
     "r3d_edgeconv_train_ws_words": (c_l, [c_i, c_i]),
-    "r3d_edge_stats1": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f]),
+    "r3d_edge_stats1": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),
     "r3d_edge_reverse_ws_words": (c_l, [c_i, c_i, c_i]),
     "r3d_edge_reverse": (c_i, [c_f, c_i, c_i, c_i, c_f, c_l, c_f]),
-    "r3d_edgeconv_bwd": (c_i, [c_f] * 11 + [c_l, c_f, c_f, c_l, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "r3d_edgeconv_bwd": (c_i, [c_f] * 11 + [c_l, c_f, c_f, c_l, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "r3d_attention_fwd_train": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_fl, c_u, c_f, c_f, c_f]),
     "r3d_attention_bwd": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_l, c_f, c_fl, c_u, c_f, c_fl, c_f, c_l, c_f, c_f]),
     "r3d_attention_bwd_ws": (c_i, [c_f, c_l, c_i, c_i, c_f, c_l, c_f, c_l, c_f, c_fl, c_u, c_f, c_fl, c_f, c_l, c_f, c_i, c_f]),

@@ -34,7 +34,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    hdr = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "edge_tile.h")]
+    hdr = [os.path.join(CSRC, h) for h in ("common.h", "edge_tile.h", "edgeconv_bwd_bx3.h")]
     objs = []
     procs = []
     for s in [x for x in SOURCES if os.path.exists(os.path.join(CSRC, x))]:

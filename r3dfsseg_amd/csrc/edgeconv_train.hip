@@ -53,7 +53,8 @@ static __device__ __forceinline__ int ec_seg(const r3d_segmap& cs, int cloud) {
 // ---- BN1 statistics over edges: partial[chunk][2][64] ------------------------------------------
 template <int RT>
 __global__ __launch_bounds__(256) void r3d_edge_stats1_kernel(const float* __restrict__ PQ, const int* __restrict__ idx,
-                                                              EcGeom gm, int n_chunks, float* __restrict__ part) {
+                                                              EcGeom gm, int n_chunks, float* __restrict__ part,
+                                                              float* __restrict__ esum /* (points, 64) sum_t e1, or null */) {
   constexpr int K = 4 * RT;
   __shared__ float sa[4][64], sb[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -71,12 +72,15 @@ __global__ __launch_bounds__(256) void r3d_edge_stats1_kernel(const float* __res
       float pv[K];  // all K neighbour rows in flight (four at a time was a chain of K/4 L2 round trips per point)
 #pragma unroll
       for (int t = 0; t < K; ++t) pv[t] = PQ[(cloud0 + __builtin_amdgcn_readlane(my_idx, t)) * 128 + lane];
+      float ps = 0.f;  // the point's own sum (the bf16 x 3 backward takes sum_t e1-hat from it)
 #pragma unroll
       for (int t = 0; t < K; ++t) {
         const float e = pv[t] + q;
         a += e;
         b += e * e;
+        ps += e;
       }
+      if (esum) esum[pt * 64 + lane] = ps;
     }
     sa[w][lane] = a;
     sb[w][lane] = b;
@@ -143,6 +147,8 @@ struct EcBn {  // BatchNorm vectors of both edge layers, segment s at + s * stri
   const float *s1, *t1, *mean1, *invstd1, *s2, *t2, *mean2, *invstd2;
   long stride;
 };
+#include "edgeconv_bwd_bx3.h"
+
 template <int RT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT <= 5 ? 3 : 2))) void r3d_edgeconv_bwd1_kernel(
     const float* __restrict__ PQ, const int* __restrict__ idx, EcBn bn, const float* __restrict__ W2,
@@ -531,7 +537,8 @@ template <int RT>
 __global__ __launch_bounds__(256) void r3d_edgeconv_bwd2_kernel(
     const float* __restrict__ PQ, const float* __restrict__ s1, const float* __restrict__ mean1,
     const float* __restrict__ invstd1, long bn_stride, const float* __restrict__ bn1_sums /* [seg][2][64] */,
-    const float* __restrict__ DY1, const float* __restrict__ BE, const int* __restrict__ rev_ptr, const int* __restrict__ rev,
+    const float* __restrict__ DY1, const float* __restrict__ BE, const float* __restrict__ esum /* null: BE holds sum_t e1-hat */,
+    const int* __restrict__ rev_ptr, const int* __restrict__ rev,
     int e_off, EcGeom gm, r3d_segmap cs /* clouds */, int n_chunks, float* __restrict__ dPQ /* (M,128), every entry written */) {
   // rev holds edge ids of the batch the reverse list was built for; this call's clouds start e_off edges into it
   constexpr int K = 4 * RT;
@@ -549,7 +556,8 @@ __global__ __launch_bounds__(256) void r3d_edgeconv_bwd2_kernel(
       const long pt = pt_;
       const int rb = rev_ptr[pt], re = rev_ptr[pt + 1];
       const float pj = PQ[pt * 128 + lane];
-      const float bs = BE[pt * 128 + lane], es = BE[pt * 128 + 64 + lane];
+      const float bs = BE[pt * 128 + lane];
+      const float es = esum ? (esum[pt * 64 + lane] - (float)K * mu1) * is1 : BE[pt * 128 + 64 + lane];
       float asum = 0.f, gsum = 0.f;
       for (int e0 = rb; e0 < re; e0 += 16) {  // 16 incoming edges = 32 rows in flight per trip; adds in list order
         const int my_e = rev[min(e0 + min(lane, 15), re - 1)];
@@ -611,8 +619,9 @@ static void et_reduce_chunks(const float* part, int N, int clouds_a, int clouds_
 
 // sums_out [seg][2][64] = (sum e1, sum e1^2) over the edges of every segment of clouds (clouds_a, clouds_b alternating;
 // clouds_b == 0: segments of clouds_a clouds)
+// esum (optional, (B*N, 64)): sum_t e1 of every point -- what r3d_edgeconv_bwd's bf16 x 3 form takes sum_t e1-hat from
 extern "C" int r3d_edge_stats1(const float* PQ, const int32_t* idx, int B, int N, int K, int clouds_a, int clouds_b,
-                               float* sums_out, float* ws, void* stream) {
+                               float* sums_out, float* esum, float* ws, void* stream) {
   R3D_REQUIRE(PQ && idx && sums_out && ws, "r3d_edge_stats1: null pointer");
   int rc = et_check("r3d_edge_stats1", B, N, K, clouds_a, clouds_b);
   if (rc) return rc;
@@ -621,7 +630,7 @@ extern "C" int r3d_edge_stats1(const float* PQ, const int32_t* idx, int B, int N
   const int n_chunks = et_chunks(B, N);
   const int grid = et_grid8(n_chunks, 2048);
 #define E2_CASE(RT) \
-  case RT: hipLaunchKernelGGL(r3d_edge_stats1_kernel<RT>, dim3(grid), dim3(256), 0, st, PQ, idx, gm, n_chunks, ws); break
+  case RT: hipLaunchKernelGGL(r3d_edge_stats1_kernel<RT>, dim3(grid), dim3(256), 0, st, PQ, idx, gm, n_chunks, ws, esum); break
   switch (K / 4) {
     E2_CASE(1); E2_CASE(2); E2_CASE(3); E2_CASE(4); E2_CASE(5); E2_CASE(6); E2_CASE(7); E2_CASE(8);
   }
@@ -723,6 +732,22 @@ static int bwd1_launch_rt(int n_chunks, hipStream_t st, const float* PQ, const i
   return R3D_OK;
 }
 
+template <int RT>
+static int bwd1_bx3_launch_rt(int n_chunks, hipStream_t st, const float* PQ, const int32_t* idx, EcBn bn, const float* W2,
+                              const float* bn2_sums, const float* dout, long lddo, const int32_t* argmax, const float* zwin,
+                              EcGeom gm, r3d_segmap cs, float* DY1, float* BE, float* part_dw, float* part_bn, int* grid_out) {
+  static int resident = 0;  // workgroups the chip holds at once (persistent loop over the chunks); two dW2 partials each
+  if (!resident) {
+    resident = e2_resident_blocks(r3d_edgeconv_bwd1_bx3_kernel<RT>, EB_LDS_BYTES, ET_MAXBLK / 2);
+    R3D_REQUIRE(resident > 0, "r3d_edgeconv_bwd: cannot reserve %d B of LDS", (int)EB_LDS_BYTES);
+  }
+  const int grid = et_grid8(n_chunks, resident);
+  hipLaunchKernelGGL(r3d_edgeconv_bwd1_bx3_kernel<RT>, dim3(grid), dim3(256), EB_LDS_BYTES, st, PQ, idx, bn, W2, bn2_sums, dout,
+                     lddo, argmax, zwin, gm, cs, n_chunks, DY1, BE, part_dw, part_bn);
+  *grid_out = grid;
+  return R3D_OK;
+}
+
 // Reverse neighbour list of a layer's kNN lists (used by r3d_edgeconv_bwd): rev_ws = B*N + 1 offsets followed by B*N*K
 // edge ids.  Deterministic; no reference counterpart (autograd's scatter-add does this implicitly, dgcnn.py:38).
 extern "C" long r3d_edge_reverse_ws_words(int B, int N, int K) { return (long)B * N + 1 + (long)B * N * K + 16; }
@@ -743,11 +768,15 @@ extern "C" int r3d_edge_reverse(const int32_t* idx, int B, int N, int K, int32_t
 // winners, computed by the caller with r3d_colstats_seg mode 1 on zmax).  Outputs: dW2 (64,64) summed over the WHOLE batch,
 // bn1_sums [seg][2][64] (sum dy1, sum dy1*ehat1), dPQ (B*N,128) (every entry written).  Scratch: DY1 B*N*K*64 floats, BE
 // B*N*128 floats, ws r3d_edgeconv_train_ws_words(B, N); rev_ws from r3d_edge_reverse on the same idx.
+// zwin (B*N, 64): z2 of every (point, channel)'s max-pool winner as r3d_edge_select left it in zmax; esum (B*N, 64): sum_t e1
+// from r3d_edge_stats1.  With both given, N % 8 == 0 and r3d_set_matrix_arith(1) (the default) the edge GEMMs run on the
+// bf16 matrix core in three-piece arithmetic (edgeconv_bwd_bx3.h); otherwise (either may be NULL) on the fp32 core.
 extern "C" int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float* s1, const float* t1, const float* mean1,
                                 const float* invstd1, const float* W2, const float* s2, const float* t2, const float* mean2,
                                 const float* invstd2, long bn_stride, const float* bn2_sums, const float* dout, long lddo,
-                                const int32_t* argmax, int B, int N, int K, int clouds_a, int clouds_b, float* DY1, float* BE,
-                                const int32_t* rev_ws, float* dW2, float* bn1_sums, float* dPQ, float* ws, void* stream) {
+                                const int32_t* argmax, const float* zwin, const float* esum, int B, int N, int K, int clouds_a,
+                                int clouds_b, float* DY1, float* BE, const int32_t* rev_ws, float* dW2, float* bn1_sums,
+                                float* dPQ, float* ws, void* stream) {
   R3D_REQUIRE(PQ && idx && s1 && t1 && mean1 && invstd1 && W2 && s2 && t2 && mean2 && invstd2 && bn2_sums && dout &&
                   argmax && DY1 && BE && rev_ws && dW2 && bn1_sums && dPQ && ws,
               "r3d_edgeconv_bwd: null pointer");
@@ -762,18 +791,22 @@ extern "C" int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float
   float* part_bn = ws + (long)ET_MAXBLK * 4096;
   const EcBn bn{s1, t1, mean1, invstd1, s2, t2, mean2, invstd2, bn_stride};
   int grid = 0;
+  const bool bx3 = g_r3d_matrix_arith == 1 && zwin && esum && N % EB_PTS == 0 && (lddo & 3) == 0 && ((uintptr_t)dout & 15) == 0;
 #define E2_CASE(RT)                                                                                                        \
   case RT:                                                                                                                 \
-    rc = bwd1_launch_rt<RT>(n_chunks, st, PQ, idx, bn, W2, bn2_sums, dout, lddo, argmax, gm, cs, DY1, BE, part_dw, part_bn, \
-                            &grid);                                                                                        \
+    rc = bx3 ? bwd1_bx3_launch_rt<RT>(n_chunks, st, PQ, idx, bn, W2, bn2_sums, dout, lddo, argmax, zwin, gm, cs, DY1, BE,  \
+                                      part_dw, part_bn, &grid)                                                             \
+             : bwd1_launch_rt<RT>(n_chunks, st, PQ, idx, bn, W2, bn2_sums, dout, lddo, argmax, gm, cs, DY1, BE, part_dw,   \
+                                  part_bn, &grid);                                                                         \
     break
   switch (K / 4) {
     E2_CASE(1); E2_CASE(2); E2_CASE(3); E2_CASE(4); E2_CASE(5); E2_CASE(6); E2_CASE(7); E2_CASE(8);
   }
 #undef E2_CASE
   if (rc) return rc;
-  hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(4096 / 64, 1), dim3(1024), 0, st, part_dw, grid, 0, 4096, dW2, 0L, 4096,
-                     (float*)nullptr, 0L);
+  // dW2 partials: one per workgroup (fp32 form) or one per pair of waves (bf16 x 3 form), added in ascending order
+  hipLaunchKernelGGL(r3d_part_reduce_kernel, dim3(4096 / 64, 1), dim3(1024), 0, st, part_dw, bx3 ? 2 * grid : grid, 0, 4096, dW2,
+                     0L, 4096, (float*)nullptr, 0L);
   et_reduce_chunks(part_bn, N, clouds_a, clouds_b, n_seg, bn1_sums, st);
   const int32_t* rev_ptr = rev_ws;
   const int32_t* rev = rev_ws + (long)B * N + 1;
@@ -781,7 +814,7 @@ extern "C" int r3d_edgeconv_bwd(const float* PQ, const int32_t* idx, const float
 #define E2_CASE(RT)                                                                                                       \
   case RT:                                                                                                                \
     hipLaunchKernelGGL(r3d_edgeconv_bwd2_kernel<RT>, dim3(grid2), dim3(256), 0, st, PQ, s1, mean1, invstd1, bn_stride, bn1_sums, \
-                       DY1, BE, rev_ptr, rev, 0, gm, cs, n_chunks, dPQ);                                                  \
+                       DY1, BE, bx3 ? esum : (const float*)nullptr, rev_ptr, rev, 0, gm, cs, n_chunks, dPQ);              \
     break
   switch (K / 4) {
     E2_CASE(1); E2_CASE(2); E2_CASE(3); E2_CASE(4); E2_CASE(5); E2_CASE(6); E2_CASE(7); E2_CASE(8);

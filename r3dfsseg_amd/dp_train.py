@@ -9,6 +9,11 @@ import torch
 from . import dist as D
 
 
+class SolverMiss(RuntimeError):
+    """An episode whose label propagation (forward or adjoint CG) did not converge even on the conservative schedule: the
+    one failure a rank reports through the gradient bucket's failure slot instead of raising before the collective."""
+
+
 class DPTrainer:
     def __init__(self, learner, n_slots=0, example=None, lp_budget=None, batch_size=0, guard_every=64):
         """batch_size > 0 (the throughput path, batched.py): the local episodes of a step go through ONE launch sequence
@@ -30,6 +35,7 @@ class DPTrainer:
         self.graphs = None
         self.runner = None
         self.batch_size = batch_size
+        self.last_outputs = []  # per-episode results of the last step: (loss, lp_loss, contrast_loss, logits (n_q, C, N), metrics (4,))
         self.redone = False   # did the last step fall back to the conservative schedule?
         self.n_redone = 0     # ... and how many steps did so far
         self.last_status = (0, 0, 0, 0)
@@ -62,24 +68,29 @@ class DPTrainer:
             self.bucket.zero_()
             self.runner.begin_step()
             total = None
+            outs = []
             for b in batches:
-                loss = self.runner.train_batch(b, [p.grad for p in self.bucket.params])[0].sum()
+                o = self.runner.train_batch(b, [p.grad for p in self.bucket.params])
+                outs += [(o[0][e], o[3][e], o[4][e], o[1][e], o[2][e]) for e in range(b.E)]
+                loss = o[0].sum()
                 total = loss if total is None else total + loss
             self.last_status = self.runner.step_status()
-            failed = None
+            failed, apply_stats = None, self.runner.apply_running_stats
             if self.last_status[0] or self.last_status[1]:
                 eps = [b.episode(e) for b in batches for e in range(b.E)]
                 try:
-                    total = self._eager_pass(eps, logger, conservative=True)  # updates the running statistics itself
-                except RuntimeError as exc:
-                    failed = exc
+                    total, outs, apply_stats = self._eager_pass(eps, logger, conservative=True)
+                except SolverMiss as exc:
+                    failed, apply_stats = exc, None
                 self.redone = True
                 self.n_redone += 1
-            else:
-                self.runner.apply_running_stats()
-            self._reduce_and_step(n_local, failed)
+            self.last_outputs = outs
+            # (the running statistics only move once the collective has said that no rank failed: an abandoned step leaves
+            # neither Adam nor the BatchNorm buffers touched)
+            self._reduce_and_step(n_local, failed, apply_stats)
             return total / max(n_local, 1)
-        failed = None
+        failed, apply_stats = None, None
+        self.last_outputs = []
         try:
             if self.graphs is not None:
                 total = self.graphs.run(episodes, apply_bn=False)
@@ -93,24 +104,28 @@ class DPTrainer:
                 if bad or overflow:
                     self.redone = True
                     self.n_redone += 1
-                    total = self._eager_pass(episodes, logger, conservative=True)  # updates the running statistics itself
+                    total, self.last_outputs, apply_stats = self._eager_pass(episodes, logger, conservative=True)
                 else:
-                    self.graphs.apply_running_stats(len(episodes))
+                    n_ep = len(episodes)
+                    apply_stats = lambda: self.graphs.apply_running_stats(n_ep)
                     torch.sum(self.rows, 0, out=self.bucket.store)
             else:
-                total = self._eager_pass(episodes, logger, conservative=False)
-        except RuntimeError as exc:
-            failed, total = exc, torch.zeros((), device=self.bucket.store.device)
-        self._reduce_and_step(len(episodes), failed)
+                total, self.last_outputs, apply_stats = self._eager_pass(episodes, logger, conservative=False)
+        except SolverMiss as exc:  # (anything else -- a launch failure, a guard mismatch -- is not recoverable: it propagates)
+            failed, total, apply_stats = exc, torch.zeros((), device=self.bucket.store.device), None
+        self._reduce_and_step(len(episodes), failed, apply_stats)
         return total / max(len(episodes), 1)
 
-    def _reduce_and_step(self, n_local, failed):
-        """The step's ONE collective (gradients + episode count + failure flag), then Adam -- or, if any rank could not
-        produce an exact gradient, the same error on every rank."""
+    def _reduce_and_step(self, n_local, failed, apply_stats=None):
+        """The step's ONE collective (gradients + episode count + failure flag), then the BatchNorm running statistics of
+        the step's episodes and Adam -- or, if any rank could not produce an exact gradient, the same error on every rank
+        with neither touched."""
         n_failed = self.bucket.all_reduce_mean(n_local, failed=failed is not None)
         if n_failed:
             raise RuntimeError("training step abandoned on all ranks: %d rank(s) could not solve their episodes exactly%s" % (
-                n_failed, (" (this rank: %s)" % failed) if failed is not None else ""))
+                n_failed, (" (this rank: %s)" % failed) if failed is not None else "")) from failed
+        if apply_stats is not None:
+            apply_stats()
         self.learner.optimizer.step()
         self.learner.lr_scheduler.step()
 
@@ -122,23 +137,31 @@ class DPTrainer:
     def _eager_pass(self, episodes, logger, conservative):
         """Forward + backward of every episode into the bucket (parameter .grad tensors are views into it).  An attempt
         on the adaptive schedule that misses (CG budget, 201-NN overflow, FPS time-out) is discarded -- its gradient AND
-        its BatchNorm statistics -- and the episode is redone on the conservative schedule."""
+        its BatchNorm statistics -- and the episode is redone on the conservative schedule.  Returns (sum of the losses,
+        per-episode results, a callable that folds the kept attempts' BatchNorm statistics into the running buffers, episode
+        after episode: the caller runs it once the step is known to be kept)."""
         from . import train_ops as T
         self.bucket.zero_()
         total = None
-        for data in episodes:
+        outs = []
+        rec = T.BNRecorder(len(episodes), self.bucket.store.device)
+        rec.index_dev = torch.zeros(1, device=self.bucket.store.device, dtype=torch.int32)
+        for n_kept, data in enumerate(episodes):
             (support_x, support_y, query_x, query_y, support_c, query_c, gt_support_y, gt_query_y, bg_pcd_x, bg_pcd_y,
              support_flag) = data
             for lp_iters in ((self.model.lp_max_iter,) if conservative else (None, self.model.lp_max_iter)):
                 keep = self.bucket.flat.clone() if lp_iters is None and total is not None else None
-                with T.deferred_running_stats(self.model) as rec:
+                rec.index_dev.fill_(2 * n_kept)  # (a discarded attempt's records are overwritten by the attempt that is kept)
+                saved, T.bn_recorder = T.bn_recorder, rec
+                try:
                     out = self.model(support_x, support_y, query_x, query_y, gt_support_y=gt_support_y,
                                      gt_query_y=gt_query_y, train=True, logger=logger, support_flag=support_flag,
                                      lp_iters=lp_iters)
                     loss = out[1] + 0.1 * out[2]  # mpti_learner.py:66
                     loss.backward()               # accumulates into the bucket views
+                finally:
+                    T.bn_recorder = saved
                 if self.model.lp_converged(backward=True):
-                    rec.apply(1)
                     break
                 if lp_iters is None:              # drop the inexact gradient again, then the conservative schedule
                     if keep is not None:
@@ -146,6 +169,8 @@ class DPTrainer:
                     else:
                         self.bucket.zero_()       # (first episode of the step: nothing to keep)
             else:
-                raise RuntimeError("label propagation did not converge in %d CG iterations" % self.model.lp_max_iter)
+                raise SolverMiss("label propagation did not converge in %d CG iterations" % self.model.lp_max_iter)
             total = loss.detach() if total is None else total + loss.detach()
-        return total
+            outs.append((loss.detach(), out[1].detach(), out[2].detach(), out[0].detach(), torch.stack([torch.as_tensor(v, device=loss.device, dtype=torch.float32) for v in out[3:]])))
+        n = len(episodes)
+        return total, outs, (lambda: rec.apply(n))

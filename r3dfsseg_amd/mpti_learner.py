@@ -29,6 +29,8 @@ class MPTILearner_V3(object):
         self.model.cuda()
         self.episode_graphs = bool(getattr(args, 'episode_graphs', False))
         self._trainer = None          # DPTrainer with one captured slot (train)
+        self._batch_trainer = None    # DPTrainer(batch_size=E) behind train_batch
+        self._batch_runner = None     # EpisodeBatchRunner behind test_batch
         self._eval_graphs = {}        # eval flag -> EpisodeGraphs with one captured slot (test)
         synthetic = 'synthetic' in (getattr(args, 'pretrain_checkpoint_path', None), getattr(args, 'model_checkpoint_path', None))
         if synthetic:
@@ -128,6 +130,54 @@ class MPTILearner_V3(object):
         accuracy = correct / (query_y.shape[0] * query_y.shape[1])
         return (loss, lp_loss, contrastive_loss, accuracy, query_acc_LP, query_acc_original, clean_ratio_LP_avg,
                 original_clean_ratio)
+
+    def train_batch(self, datas, logger):
+        """E episodes per optimiser step: ``datas`` is a list of the lists train() takes (dataloaders/loader.py:1666-1671),
+        all of one shape.  The E episodes go through ONE launch sequence (batched.EpisodeBatchRunner: every kernel works on
+        the whole batch, BatchNorm statistics stay per episode and getFeatures call), their gradients are averaged --
+        over all ranks' episodes when torch.distributed is initialised: one all-reduce -- and Adam steps ONCE.  Returns
+        a list with train()'s 8-tuple for every episode, so the driver loop keeps its per-episode bookkeeping
+        (INTEGRATION.md shows the change to mpti_train_noise.py:57-98).  Against the reference's schedule (one Adam step
+        per episode, mpti_learner.py:68-72) this is a larger-batch optimiser: per episode every number returned is what
+        train() computes for it from the same weights (tests/test_gpu_batched.py); the step equals the eager schedule's
+        accumulate-E-then-step (tests/test_gpu_learner_batch.py).  The step fails closed like train(): a solver miss redoes
+        the episodes on the conservative schedule, and neither Adam nor the BatchNorm running statistics move on a step
+        that could not be solved exactly."""
+        from .dp_train import DPTrainer
+        E = len(datas)
+        if self._batch_trainer is None or self._batch_trainer.batch_size != E:
+            self._batch_trainer = DPTrainer(self, batch_size=E)
+        tr = self._batch_trainer
+        tr.step(datas, logger=logger)
+        outs = tr.last_outputs
+        qy = torch.stack([d[3] for d in datas], 0)
+        logits = torch.stack([o[3] for o in outs], 0)
+        acc = torch.eq(logits.argmax(dim=2), qy).float().mean(dim=(1, 2))
+        host = torch.cat((acc[:, None], torch.stack([o[4] for o in outs], 0).to(acc.dtype)), 1).tolist()  # the step's host read
+        res = []
+        for e, o in enumerate(outs):
+            accuracy, m = host[e][0], host[e][1:]
+            if logger is not None:
+                logger.cprint('after label propagation: QUERY prediction acc: {:.3f}, original_acc: {:.3f}'.format(m[0], m[1]))
+                logger.cprint('after label propagation: clean_ratio_LP: {:.3f}, clean_ratio_original: {:.3f}'.format(m[2], m[3]))
+            res.append((o[0], o[1], o[2], accuracy) + tuple(o[4].unbind(0)))
+        return res
+
+    def test_batch(self, datas, sampled_classes=None, step=None, path=None, eval=False):
+        """test() for E episodes of one shape in ONE launch sequence (MPTI_SelfAtten.forward_episodes): a list of
+        (pred (n_q, N), loss, accuracy), per episode what test() returns for it.  A batch in which any system missed its CG
+        launch budget (or overflowed the 201-NN survivor buffer) is redone episode by episode through test()."""
+        from .batch import EpisodeBatch
+        self.model.eval()
+        b = datas if isinstance(datas, EpisodeBatch) else EpisodeBatch.from_episodes(datas)
+        with torch.no_grad():
+            logits, loss = self.model.forward_episodes(b, eval=eval)
+            pred = logits.argmax(dim=2)
+            acc = torch.eq(pred, b.query_y).float().mean(dim=(1, 2)).tolist()
+        if not self.model.lp_converged():
+            return [self.test(b.episode(e)[:4] + [None, None, b.gt_support_y[e]], sampled_classes, step, path, eval)
+                    for e in range(b.E)]
+        return [(pred[e], loss[e], acc[e]) for e in range(b.E)]
 
     def _test_graph(self, data, eval):
         from .episode_graph import EpisodeGraphs

@@ -271,8 +271,9 @@ def edgeconv_train_fwd(inp, idx, ec, B, N, out, seg=None):
     sums1 = _f(seg.n_seg * 128, dev).view(seg.n_seg, 2, 64)
     sums2 = _f(seg.n_seg * 128, dev).view(seg.n_seg, 2, 64)
     counts = seg.counts(per_row=K)  # edges per segment
+    esum = torch.empty(M, 64, device=dev, dtype=torch.float32)  # sum_t e1 per point, for the backward
     with _timed("edgeconv"):
-        _lib.check(lib.r3d_edge_stats1(_p(PQ), _p(idx3), B, N, K, seg.S, seg.Q, _p(sums1), _p(ws), _st()))
+        _lib.check(lib.r3d_edge_stats1(_p(PQ), _p(idx3), B, N, K, seg.S, seg.Q, _p(sums1), _p(esum), _p(ws), _st()))
     bn1 = bn_fold(sums1, counts, ec.layer[1])
     sc1, sh1, _, _ = bn1.ptrs()
     with _timed("edgeconv"):  # ONE edge-GEMM pass: z2 statistics and per-point max / min of z2
@@ -283,12 +284,12 @@ def edgeconv_train_fwd(inp, idx, ec, B, N, out, seg=None):
     with _timed("edgeconv"):  # BN2 + LeakyReLU is monotone per channel: pick max or min, in place
         _lib.check(lib.r3d_edge_select(_p(zmax), _p(zmin), _p(argmax), _p(argmin), sc2, sh2, bn2.stride, M, seg.rows_a,
                                        seg.rows_b, _p(out), out.stride(0), _st()))
-    return (inp, idx3, Wpq, PQ, W2, bn1, bn2, argmax, zmax, C, seg)
+    return (inp, idx3, Wpq, PQ, W2, bn1, bn2, argmax, zmax, C, seg, esum)
 
 
 def edgeconv_train_bwd(saved, dout, B, N, dx_acc):
     """Returns (dW1 (64,2C,1,1), dg1, db1, dW2 (64,64,1,1), dg2, db2); input gradient accumulated into dx_acc."""
-    inp, idx3, Wpq, PQ, W2, bn1, bn2, argmax, zmax, C, seg = saved
+    inp, idx3, Wpq, PQ, W2, bn1, bn2, argmax, zmax, C, seg, esum = saved
     lib = _lib.load()
     dev = PQ.device
     K = idx3.shape[-1]
@@ -307,7 +308,8 @@ def edgeconv_train_bwd(saved, dout, B, N, dx_acc):
     s2, t2, m2, i2 = bn2.ptrs()
     with _timed("edgeconv_bwd"):
         _lib.check(lib.r3d_edgeconv_bwd(_p(PQ), _p(idx3), s1, t1, m1, i1, _p(W2), s2, t2, m2, i2, bn1.stride, _p(bn2_sums),
-                                        _p(dout), dout.stride(0), _p(argmax), B, N, K, seg.S, seg.Q, _p(DY1), _p(BE), _p(rev),
+                                        _p(dout), dout.stride(0), _p(argmax), _p(zmax), _p(esum), B, N, K, seg.S, seg.Q, _p(DY1),
+                                        _p(BE), _p(rev),
                                         _p(dW2), _p(bn1_sums), _p(dPQ), _p(ws), _st()))
     t1s = bn1_sums.sum(0) if seg.n_seg > 1 else bn1_sums[0]
     t2s = bn2_sums.sum(0) if seg.n_seg > 1 else bn2_sums[0]

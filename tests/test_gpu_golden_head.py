@@ -4,9 +4,11 @@ models/protonet.py:245-275 run on torch-CPU -- see that file for the environment
 
 The tight statements are split over two links: oracle == reference on these fixtures (tests/test_oracle_golden_head.py,
 CPU, 2e-5 / exact indices with the reference's near-tie neighbour rows injected) and HIP == oracle (the chain-of-custody
-tests).  Here nothing is injected: the device decides every index on its own features, so a near-tie may flip a
-neighbour and move a handful of points; the bars say how much of the output must still agree with the reference and the
-test prints the measured figures.
+tests).  Here the device runs end to end, twice per fixture: "free" (nothing injected: the device decides every index on its
+own features, so a near-tie may flip a neighbour and move a handful of points) and "patched" (the reference's own choice on
+its near-tie rows written over the device's lists: then EVERY logit has to agree).  The fixtures *_S are BASELINE.json
+configs[1] / configs[2] at their own size (2-way 5-shot 2048 points; ood noise 0.4 through the clean-shot detection; one
+training step).
 """
 import os
 import sys
@@ -85,17 +87,31 @@ def _reference_near_tie_lists(g, seen):
     return patch
 
 
-# Bars = at most 3x what was measured on MI355X (the test prints the figures).  free: nothing injected, the device decides
-# every index on its own features -- a near-tie row may flip and move a handful of points; patched: the reference's own
-# choice on ITS near-tie rows written over the device's lists (every other row must then agree by itself), which makes
-# the end-to-end comparison a statement about every single point.
-#            logits: (fraction within 1e-4, max relative error, arg-max agreement, |loss - ref|)
-BARS = {
-    ("eval", True): dict(frac=1.0, emax=3e-5, agree=1.0, dloss=2e-5),
-    ("eval", False): dict(frac=0.985, emax=None, agree=0.998, dloss=1e-4),
-    ("train", True): dict(frac=1.0, emax=1e-4, agree=1.0, dloss=2e-5, gnorm=2e-3, gmed=1e-3, gmax=2e-3),
-    ("train", False): dict(frac=0.985, emax=None, agree=0.998, dloss=1e-4, gnorm=5e-3, gmed=2e-3, gmax=1e-2),
-}
+# Bars = at most 3x what was measured on MI355X (the test prints the figures; round 4).
+# patched: the reference's own choice on ITS near-tie rows (encoder kNN and 201-NN) written over the device's lists -- every
+#   other row must then agree by itself -- which makes the end-to-end comparison a statement about EVERY point: measured
+#   max logit error 5e-6 .. 9e-6 (512-point fixtures), 1.7e-5 .. 1.9e-5 (2048 points x 5 shots), arg-max identical,
+#   gradient norms 7e-5 .. 3e-4, sampled gradient entries 4e-4 .. 6e-4 (worst tensor).
+# free: nothing injected, the device decides every index on its own features.  A near-tie row may flip; in eval mode that
+#   moves a handful of points (measured: 0 .. 2.5 % of the logits beyond 1e-4, arg-max identical).  In TRAINING mode at full
+#   size one flipped neighbour changes a max-pooled feature, with it a farthest-point-sampling decision and so the prototype
+#   SET (head_train_S: 23 % of the prototypes within 1e-4): the reference run twice with its GEMM's summation order changed
+#   would differ from itself the same way, so there the free run only has to reproduce the loss.
+def _bars(name, patched, train):
+    big = name.endswith("_S")
+    if patched:
+        b = dict(frac=1.0, frac_p=1.0, emax=6e-5 if big else 3e-5, agree=1.0, dloss=5e-6)
+    elif name in ("head_eval", "head_clean"):
+        b = dict(frac=1.0, frac_p=1.0, emax=3e-5, agree=1.0, dloss=5e-6)
+    elif big and train:
+        b = dict(frac=0.0, frac_p=0.0, emax=None, agree=0.0, dloss=1e-3)
+    elif big:
+        b = dict(frac=0.93, frac_p=0.97, emax=None, agree=0.999, dloss=2e-5)
+    else:
+        b = dict(frac=0.98, frac_p=0.99, emax=None, agree=0.999, dloss=2e-5)
+    if train:
+        b.update(gnorm=1e-3, gmed=8e-4, gmax=2e-3, grads=patched or not big)
+    return b
 
 
 @pytest.mark.parametrize("patched", [False, True], ids=["free", "patched"])
@@ -105,7 +121,7 @@ def test_hip_path_against_reference_outputs(name, patched):
     cfg, sd, data, mode, g = fixture(name)
     n_way, N = cfg["n_way"], cfg["pc_npts"]
     train = mode == "train"
-    bar = BARS[("train" if train else "eval", patched)]
+    bar = _bars(name, patched, train)
     m = _model(cfg, sd, train)
     seen = {}
     if patched:
@@ -155,10 +171,10 @@ def test_hip_path_against_reference_outputs(name, patched):
         print("%s: 201-NN rows whose set differed from the reference's before the patch: %d (outside its near-tie rows: %d)"
               % (name, seen["flipped"], seen["outside"]))
         assert seen["outside"] == 0
-    assert frac_p >= (1.0 if patched else 0.99) and frac >= bar["frac"] and agree >= bar["agree"] and dloss <= bar["dloss"]
+    assert frac_p >= bar["frac_p"] and frac >= bar["frac"] and agree >= bar["agree"] and dloss <= bar["dloss"]
     assert bar["emax"] is None or float(err.max()) <= bar["emax"]
 
-    if train:
+    if train and bar["grads"]:
         assert abs(float(out[2]) - float(g["contrast"])) <= 1e-3 * max(1.0, abs(float(g["contrast"])))
         np.testing.assert_allclose(np.array([float(v) for v in out[3:]]), g["metrics"], atol=3e-3)
         # BatchNorm running statistics after the two getFeatures calls of the step (support, then query)

@@ -192,6 +192,48 @@ def test_edgeconv_train_layer_every_k(K):
         assert _rel(got.cpu().double(), ref) < 5e-4, (name, K, _rel(got.cpu().double(), ref))
 
 
+@pytest.mark.parametrize("B,N,K,S,Q", [(4, 2048, 20, 3, 1), (6, 136, 12, 2, 1), (2, 512, 32, 2, 0)])
+def test_edgeconv_backward_same_in_both_arithmetics(B, N, K, S, Q):
+    """The EdgeConv backward on the bf16 matrix core in three-piece arithmetic (csrc/edgeconv_bwd_bx3.h: the default)
+    against the fp32-core kernels (r3d_set_matrix_arith(0)) on the same forward: every output to 2e-5 of its largest entry
+    (measured: ~1e-6), segments of S + Q clouds with their own BatchNorm statistics, chunk tails (N % 32 != 0), and the
+    default form bit-identical from run to run."""
+    from r3dfsseg_amd import _lib, ops, train_ops as T
+    lib = _lib.load()
+    rs = np.random.RandomState(7 + K)
+    C = 64
+    x = torch.from_numpy(rs.randn(B * N, C).astype(np.float32)).cuda()
+    idx = torch.from_numpy(np.stack([[rs.permutation(N)[:K] for _ in range(N)] for _ in range(B)]).astype(np.int32)).cuda()
+    conv1, conv2 = torch.nn.Conv2d(2 * C, 64, 1, bias=False).cuda(), torch.nn.Conv2d(64, 64, 1, bias=False).cuda()
+    bn1, bn2 = torch.nn.BatchNorm2d(64).cuda().train(), torch.nn.BatchNorm2d(64).cuda().train()
+    with torch.no_grad():
+        for bn in (bn1, bn2):
+            bn.weight.copy_(torch.from_numpy(rs.uniform(-1.5, 1.5, 64).astype(np.float32)))  # max AND min winners
+            bn.bias.copy_(torch.from_numpy(rs.randn(64).astype(np.float32) * 0.3))
+    ec = SimpleNamespace(layer=[conv1, bn1, None, conv2, bn2])
+    R = torch.from_numpy(rs.randn(B * N, 64).astype(np.float32)).cuda()
+    seg = ops.SegLayout(B // (S + Q), S, Q, N)
+    out = torch.empty(B * N, 64, device="cuda")
+    saved = T.edgeconv_train_fwd(x, idx, ec, B, N, out, seg)
+    before = lib.r3d_get_matrix_arith()
+    res = {}
+    try:
+        for arith in (0, 1, 1):
+            lib.r3d_set_matrix_arith(arith)
+            dx = torch.zeros(B * N, C, device="cuda")
+            grads = T.edgeconv_train_bwd(saved, R, B, N, dx)
+            torch.cuda.synchronize()
+            res.setdefault(arith, []).append([dx] + [g.clone() for g in grads])
+    finally:
+        lib.r3d_set_matrix_arith(before)
+    names = ("dx", "dW1", "dg1", "db1", "dW2", "dg2", "db2")
+    for a, b in zip(res[1][0], res[1][1]):
+        assert torch.equal(a, b)
+    worst = {n: _rel(a, b) for n, a, b in zip(names, res[1][0], res[0][0])}
+    print("bf16 x 3 against fp32 core, max |diff| / max |value|:", {k: "%.1e" % v for k, v in worst.items()})
+    assert max(worst.values()) < 2e-5, worst
+
+
 def test_attention_dropout_mask_and_backward():
     """Dropout mask is a stateless hash: replicate it on the host, feed it to the oracle."""
     from r3dfsseg_amd import ops, _lib
