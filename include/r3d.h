@@ -96,12 +96,16 @@ int r3d_knn_topk_batched(const float* x, long ldx, const float* x_cm, int B, int
                          float* score_out, int32_t* status, float* split_ws, long split_ws_words, float* bf_ws,
                          long bf_ws_words, void* stream);
 /* bf_ws: optional scratch of r3d_knn_bf_ws_words(B, N, C) floats (needs x and C % 64 == 0): the streamed kernels then run
- * their THRESHOLD pass -- which only needs a lower bound of every score -- on the bf16 matrix core; the pass that emits
- * neighbours and scores stays on the fp32 core and the results are bit-identical with and without it. */
+ * their THRESHOLD pass -- which only needs a lower bound of every score -- on the bf16 matrix core, and (x 16-byte aligned,
+ * ldx % 4 == 0) their second pass as a bf16 FILTER: a candidate whose score's upper bound reaches the threshold is kept,
+ * and only the kept ones (~k + 10 per query) get their exact score -- the fp32 fmaf chain in channel order, bit for bit
+ * the accumulation of the all-pairs fp32 pass it replaces.  Indices and scores are bit-identical with and without bf_ws. */
 long r3d_knn_bf_ws_words(int B, int N, int C);
 /* test / A-B utility: 0 keeps the threshold pass on the fp32 core even when bf_ws is given (same results).  Returns the
  * previous setting. */
 int r3d_debug_set_knn_bf16_threshold(int on);
+/* the same for the second pass: 0 keeps it the all-pairs fp32 pass (same results) */
+int r3d_debug_set_knn_bf16_filter(int on);
 
 /* ---- 1x1 convolution + folded BatchNorm/bias + activation ---------------------------
  * models/dgcnn.py:64-80 conv1d, models/mpti.py:18-40 BaseLearner, models/attention.py:39-41.

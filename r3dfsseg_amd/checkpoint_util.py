@@ -24,8 +24,11 @@ def _numpy_scalar_globals():
     (mpti_train_noise.py:135-152), which pickle as numpy's `scalar` reconstructor plus a dtype -- data, no code.  Files
     written under numpy < 2 name the reconstructor numpy.core.multiarray.scalar, newer ones numpy._core.multiarray.scalar."""
     import numpy as np
-    import numpy._core.multiarray as ncm
-    allowed = [ncm.scalar, (ncm.scalar, 'numpy.core.multiarray.scalar'), np.dtype]
+    try:
+        import numpy._core.multiarray as ncm   # numpy >= 1.26 / 2.x
+    except ImportError:
+        import numpy.core.multiarray as ncm    # older numpy: the only name it pickles under
+    allowed = [ncm.scalar, (ncm.scalar, 'numpy.core.multiarray.scalar'), (ncm.scalar, 'numpy._core.multiarray.scalar'), np.dtype]
     for t in (np.float64, np.float32, np.float16, np.int64, np.int32, np.bool_):
         allowed.append(type(np.dtype(t)))
     return allowed
@@ -118,6 +121,8 @@ def load_model_checkpoint(model, model_checkpoint_path, optimizer=None, mode='te
 
 def save_model_checkpoint(learner, output_dir, iteration, loss, iou, best=True):
     """What mpti_train_noise.py:135-152 writes: checkpoint.tar (best so far) or checkpoint_<iteration>.tar."""
+    from . import dist as D
+    D.warn_rank_local_stats(learner.model, 'checkpoint written')
     name = 'checkpoint.tar' if best else 'checkpoint_%d.tar' % iteration
     path = os.path.join(output_dir, name)
     torch.save(dict(zip(TRAIN_KEYS, (iteration, learner.model.state_dict(), learner.optimizer.state_dict(), loss, iou))),

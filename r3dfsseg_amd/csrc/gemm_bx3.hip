@@ -603,15 +603,17 @@ bool r3d_pointwise_bx3_ok(const float* X, long ldx, const float* W, long M, int 
 // one after the other and replays them concurrently: two slots sharing the buffer computed with each other's weights
 // pieces, caught by tests/test_gpu_parity_full.py) -- captured launch sequences take the kernel that cuts W itself,
 // which gives the same bits.
-struct WPackBuf { hipStream_t st; void* p; size_t cap; };
+struct WPackBuf { int dev; hipStream_t st; void* p; size_t cap; };
 static unsigned short* wpack_scratch(hipStream_t st, size_t bytes) {
   static std::mutex mu;
   static std::vector<WPackBuf> pool;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lock(mu);
   for (auto& b : pool)
-    if (b.st == st) {
+    if (b.dev == dev && b.st == st) {  // (the null stream is one handle on every device: the device is part of the key)
       if (b.cap >= bytes) return (unsigned short*)b.p;
       void* p = nullptr;
       if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
@@ -621,7 +623,7 @@ static unsigned short* wpack_scratch(hipStream_t st, size_t bytes) {
   void* p = nullptr;
   const size_t cap = bytes < (4u << 20) ? (4u << 20) : bytes;  // (512 x 512 pieces = 1.5 MB: one size fits the model)
   if (hipMalloc(&p, cap) != hipSuccess) return nullptr;
-  pool.push_back(WPackBuf{st, p, cap});
+  pool.push_back(WPackBuf{dev, st, p, cap});
   return (unsigned short*)p;
 }
 

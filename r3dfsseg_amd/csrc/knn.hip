@@ -561,15 +561,26 @@ template <int KB_WAVES, int KB_CAP, int KB_TOP, int KCH /* k-pairs per channel c
                       |x'||y'|, the bf16 form's accumulation below C * 2^-24 |x'||y'|, the exact fp32 form's own roundings
                       (it works on the uncentred points) below (C + 3) 2^-24 (|x|^2 + |y|^2) in the worst case: the
                       bound subtracts 2^-12 (|x'|^2 + |y'|^2) + (C + 8) 2^-24 (|x|^2 + |y|^2).  Pass B -- every score
-                      that can be emitted -- stays on the fp32 core. */>
+                      that can be emitted -- stays on the fp32 core. */,
+          bool BFB = false /* (needs BFA) pass B on the bf16 matrix core as well, as a FILTER: the same pieces give an UPPER
+                      bound of every score (the error terms of the lower bound, with the other sign); a candidate is
+                      appended iff its upper bound reaches tau -- every true top-k member is (its exact score is at least the
+                      k-th best >= tau) together with the few whose bound straddles tau -- and only the appended ones
+                      (~k + 10 per query instead of all N) get the EXACT score: the channel-ascending fp32 fmaf chain from
+                      0 over the point-major rows, bit for bit what v_mfma_f32_32x32x2_f32 accumulates (the diagonal
+                      of that product is how r3d_sqnorm_kernel computes the norms), then the same three roundings of the
+                      score form.  Indices and scores are those of the all-pairs fp32 pass; 12 bf16 MFMAs of 32 cycles
+                      per 64 channels and 32 x 32 scores replace 32 fp32 MFMAs of 64. */>
 __global__ __launch_bounds__(64 * KB_WAVES) __attribute__((amdgpu_waves_per_eu(KB_WAVES == 4 && (FULLC || KCH < 32) ? 3 : 2)))
 void r3d_knn_append_kernel(
     const float* __restrict__ xT, long ldT, int N, int C, int k, int mode, const int* __restrict__ n_dev, int n_dev_stride,
     const float* __restrict__ nrm, int* __restrict__ idx_out, float* __restrict__ score_out,
     int* __restrict__ status, int* __restrict__ tile_flags, int nsplit, int* __restrict__ idx_tmp,
-    float* __restrict__ sc_tmp, const unsigned short* __restrict__ xpk /* [B N][2][nch 64] bf16 pieces, BFA only */,
-    const float* __restrict__ cnorm /* [B N] squared norms of the CENTRED points the pieces were cut from, BFA only */) {
+    float* __restrict__ sc_tmp, const unsigned short* __restrict__ xpk /* [B][2 pieces][nch 8 chunks][N][8] bf16, BFA only */,
+    const float* __restrict__ cnorm /* [B N] squared norms of the CENTRED points the pieces were cut from, BFA only */,
+    const float* __restrict__ xpm /* point-major rows (16-byte aligned, ldx % 4 == 0), BFB only */, long ldx) {
   static_assert(!BFA || (KCH == 32 && FULLC), "the bf16 threshold pass takes whole 64-channel chunks");
+  static_assert(!BFB || BFA, "the bf16 filter pass shares the threshold pass's pieces");
   // nsplit > 1 (gridDim.z): the CANDIDATE axis is dealt to nsplit workgroups per query tile (sub-tile s goes to
   // workgroup s % nsplit); each selects its own top-k -- its tau is a lower bound of the k-th best score of ITS
   // candidates, which is <= the k-th best of all of them -- into idx_tmp / sc_tmp, and r3d_knn_merge_kernel merges the
@@ -605,11 +616,16 @@ void r3d_knn_append_kernel(
   unsigned short* Aqb = reinterpret_cast<unsigned short*>(region + ((32 * (KB_TOP * KB_GROUPS + 1) + 3) & ~3));
   const unsigned short* xpb = BFA ? xpk + (long)b * N * 2 * Cp : nullptr;
   if (BFA) {
-    const int cpr = 2 * Cp / 8;  // 16-byte chunks of a row
+    // the packed pieces are CHUNK-major: chunk c8 (8 channels of one piece; hi chunks first, then lo) of all N points lies
+    // contiguous, 16 bytes per point -- the MFMA operand of a lane is one such 16-byte unit, and the 32 lanes of a half-wave
+    // (32 consecutive candidates, one chunk) read 512 contiguous bytes = 4 cache lines per instruction.  (Point-major
+    // pieces, a row of 2 Cp bf16 per point, made every lane touch its own line: 32 line look-ups per instruction, and
+    // the bf16 passes ran at the L1's look-up rate -- 5 500 cycles per 32 x 32 sub-tile for 384 cycles of MFMA.)
+    const int cpr = 2 * Cp / 8;  // 16-byte chunks of a point
     for (int e = tid; e < 32 * cpr; e += 64 * KB_WAVES) {
-      const int jj = e / cpr, c8 = e - jj * cpr;
+      const int c8 = e >> 5, jj = e & 31;
       *reinterpret_cast<r3d_u32x4*>(Aqb + jj * QRS + 8 * c8) =
-          *reinterpret_cast<const r3d_u32x4*>(xpb + (long)min(q0 + jj, n - 1) * 2 * Cp + 8 * c8);
+          *reinterpret_cast<const r3d_u32x4*>(xpb + ((long)c8 * N + min(q0 + jj, n - 1)) * 8);
     }
   }
   KSTAMP(8);
@@ -625,8 +641,11 @@ void r3d_knn_append_kernel(
   const float* cnb = BFA ? cnorm + (long)b * N : nullptr;
   const float slack = (float)(C + 8) * 0x1p-24f;
   auto bound_k = [&](int i) { return cnb[i] * (1.f + 0x1p-12f) + nb[i] * slack; };
-  float* kq_s = reinterpret_cast<float*>(Aqb + 32 * QRS);  // [32] behind the query pieces
+  float* kq_s = reinterpret_cast<float*>(Aqb + 32 * QRS);  // [32] behind the query pieces (+ [32] for the upper bound)
   if (BFA && tid < 32) kq_s[tid] = bound_k(min(q0 + tid, n - 1));
+  // upper bound of the scores (BFB): score <= 2 acc - ku[row] - ku[candidate], ku = |x'|^2 (1 - 2^-12) - |x|^2 (C + 8) 2^-24
+  auto bound_ku = [&](int i) { return cnb[i] * (1.f - 0x1p-12f) - nb[i] * slack; };
+  if (BFB && tid < 32) kq_s[32 + tid] = bound_ku(min(q0 + tid, n - 1));
   __syncthreads();
 
   const int nsub = ((n + 31) / 32 - z + nsplit - 1) / nsplit;  // sub-tiles of this workgroup: z, z + nsplit, ...
@@ -683,6 +702,17 @@ void r3d_knn_append_kernel(
       sc[r] = valid ? v : -INFINITY;
     }
   };
+  auto scores_ub = [&](int st, f32x16& sc) {
+    const int cand = 32 * st + j;
+    const bool valid = cand < n;
+    const float kj = bound_ku(min(cand, n - 1));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = (kq_s[32 + r3d_acc_row(r, lane)] + kj) - 2.f * acc[r];  // <= the squared distance the exact form computes
+      const float v = SMODE == R3D_SCORE_DGCNN ? -d : -fmaxf(d, 0.f);
+      sc[r] = valid ? v : -INFINITY;
+    }
+  };
   auto scores = [&](int st, f32x16& sc) {
     const int cand = 32 * st + j;
     const bool valid = cand < n;
@@ -731,43 +761,44 @@ void r3d_knn_append_kernel(
   // register copies afterwards (tools/probe/mfma_feed.hip sustains 110 TFLOP/s this way).  The two-buffer form
   // unrolled by hand compiled to chains that waited, through the single in-order vmcnt counter, on the loads
   // issued right in front of them.
+  // candidate pieces: 8 consecutive channels of a piece are 16 contiguous bytes of the packed row
+  r3d_u32x4 pfA[8], pfB[8];  // [k-step of 16 channels][hi, lo]
+  auto pload = [&](int t, r3d_u32x4 (&pf)[8]) {
+    const int st = (w + KB_WAVES * stride * (t / nch)) * nsplit + z, ch = (t % nch);
+    const int cc = min(32 * st + j, n - 1);
+    const unsigned short* p = xpb + ((long)(8 * ch + h) * N + cc) * 8;  // chunk 8 ch + 2 s4 + h of the hi piece
+    const long cs2 = 2L * N * 8, lo = (long)(Cp / 8) * N * 8;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      pf[2 * s4] = *reinterpret_cast<const r3d_u32x4*>(p + s4 * cs2);
+      pf[2 * s4 + 1] = *reinterpret_cast<const r3d_u32x4*>(p + lo + s4 * cs2);
+    }
+  };
+  auto pmma = [&](int t, const r3d_u32x4 (&pf)[8]) {
+    const int ch = (t % nch);
+    if (ch == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    }
+    const unsigned short* ap = Aqb + j * QRS + 64 * ch + 8 * h;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {  // (two k-steps' query pieces at a time: 16 registers, not 32)
+      r3d_u32x4 ah[2], al[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        ah[u] = *reinterpret_cast<const r3d_u32x4*>(ap + 16 * (2 * half + u));
+        al[u] = *reinterpret_cast<const r3d_u32x4*>(ap + Cp + 16 * (2 * half + u));
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int s4 = 2 * half + u;
+        acc = r3d_mfma_bf16(al[u], pf[2 * s4], acc);
+        acc = r3d_mfma_bf16(ah[u], pf[2 * s4 + 1], acc);
+        acc = r3d_mfma_bf16(ah[u], pf[2 * s4], acc);
+      }
+    }
+  };
   if (BFA) {
-    // candidate pieces: 8 consecutive channels of a piece are 16 contiguous bytes of the packed row
-    r3d_u32x4 pfA[8], pfB[8];  // [k-step of 16 channels][hi, lo]
-    auto pload = [&](int t, r3d_u32x4 (&pf)[8]) {
-      const int st = (w + KB_WAVES * stride * (t / nch)) * nsplit + z, ch = (t % nch);
-      const int cc = min(32 * st + j, n - 1);
-      const unsigned short* p = xpb + (long)cc * 2 * Cp + 64 * ch + 8 * h;
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        pf[2 * s4] = *reinterpret_cast<const r3d_u32x4*>(p + 16 * s4);
-        pf[2 * s4 + 1] = *reinterpret_cast<const r3d_u32x4*>(p + Cp + 16 * s4);
-      }
-    };
-    auto pmma = [&](int t, const r3d_u32x4 (&pf)[8]) {
-      const int ch = (t % nch);
-      if (ch == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      }
-      const unsigned short* ap = Aqb + j * QRS + 64 * ch + 8 * h;
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {  // (two k-steps' query pieces at a time: 16 registers, not 32)
-        r3d_u32x4 ah[2], al[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          ah[u] = *reinterpret_cast<const r3d_u32x4*>(ap + 16 * (2 * half + u));
-          al[u] = *reinterpret_cast<const r3d_u32x4*>(ap + Cp + 16 * (2 * half + u));
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int s4 = 2 * half + u;
-          acc = r3d_mfma_bf16(al[u], pf[2 * s4], acc);
-          acc = r3d_mfma_bf16(ah[u], pf[2 * s4 + 1], acc);
-          acc = r3d_mfma_bf16(ah[u], pf[2 * s4], acc);
-        }
-      }
-    };
     if (TA > 0) pload(0, pfA);
     for (int t = 0; t < TA; ++t) {
       if (t + 1 < TA) pload(t + 1, pfB);
@@ -825,8 +856,11 @@ void r3d_knn_append_kernel(
   __syncthreads();  // gmax region is reused as the survivor buffers from here on
 
   // ------------------------------------------------------------------ pass B: append survivors
-  float* bufv = region;                      // [32][KB_CAP]
-  int* bufi = (int*)(region + 32 * KB_CAP);  // [32][KB_CAP]
+  // (BFB: the filter pass appends indices only, at the start of the region -- 32 KB_CAP words lie below the query pieces,
+  // which that pass still reads; the exact scores are written behind them once the pass is over)
+  static_assert(!BFB || 32 * KB_CAP <= 32 * (KB_TOP * KB_GROUPS + 1), "the index buffer must end in front of the query pieces");
+  float* bufv = region + (BFB ? 32 * KB_CAP : 0);          // [32][KB_CAP]
+  int* bufi = (int*)(region + (BFB ? 0 : 32 * KB_CAP));    // [32][KB_CAP]
   bool overflow = false;
   auto finishB = [&](int t) {
     if ((t % nch) != nch - 1) return;
@@ -847,18 +881,46 @@ void r3d_knn_append_kernel(
       }
     }
   };
+  // the bf16 filter (BFB): append the INDEX of every candidate whose score's upper bound reaches tau
+  auto finishBF = [&](int t) {
+    if ((t % nch) != nch - 1) return;
+    const int st = (w + KB_WAVES * (t / nch)) * nsplit + z;
+    f32x16 sc;
+    scores_ub(st, sc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (sc[r] >= tauq[r]) {
+        const int q = r3d_acc_row(r, lane);
+        const int slot = atomicAdd(&cnt_s[q], 1);
+        if (slot < KB_CAP) bufi[q * KB_CAP + slot] = 32 * st + j;
+        else overflow = true;
+      }
+    }
+  };
   // one-unit prefetch: the next fragment's loads are issued in front of the current MFMA chain and handed over by
   // register copies afterwards (tools/probe/mfma_feed.hip sustains 110 TFLOP/s this way).  The two-buffer form
   // unrolled by hand compiled to chains that waited, through the single in-order vmcnt counter, on the loads
   // issued right in front of them.
-  if (T > 0) bload(0, bfA);
-  for (int t = 0; t < T; ++t) {
-    if (t + 1 < T) bload(t + 1, bfB);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(t, bfA);
-    finishB(t);
+  if (BFB) {
+    if (T > 0) pload(0, pfA);
+    for (int t = 0; t < T; ++t) {
+      if (t + 1 < T) pload(t + 1, pfB);
+      __builtin_amdgcn_sched_barrier(0);
+      pmma(t, pfA);
+      finishBF(t);
 #pragma unroll
-    for (int s = 0; s < KCH; ++s) bfA[s] = bfB[s];
+      for (int s = 0; s < 8; ++s) pfA[s] = pfB[s];
+    }
+  } else {
+    if (T > 0) bload(0, bfA);
+    for (int t = 0; t < T; ++t) {
+      if (t + 1 < T) bload(t + 1, bfB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(t, bfA);
+      finishB(t);
+#pragma unroll
+      for (int s = 0; s < KCH; ++s) bfA[s] = bfB[s];
+    }
   }
   KSTAMP(12);
   if (__any(overflow) && lane == 0) {
@@ -874,6 +936,79 @@ void r3d_knn_append_kernel(
   }
   KSTAMP(14);
 
+  // ------------------------------------------------------------------ exact scores of the survivors (BFB)
+  // The survivors of this wave's queries, dealt to the lanes as one flat list: a lane evaluates its survivor's score as
+  // the channel-ascending fmaf chain from 0 (== the fp32 MFMA's accumulation) over the point-major row, then the score
+  // form's own roundings exactly as `scores` above.  Rows are read 32 channels (8 x 16 bytes) at a time with the next
+  // request in flight behind the current chain.
+  if (BFB) {
+    constexpr int QW = 32 / KB_WAVES;
+    int off[QW + 1];
+    off[0] = 0;
+#pragma unroll
+    for (int i = 0; i < QW; ++i) off[i + 1] = off[i] + __builtin_amdgcn_readfirstlane(min(cnt_s[QW * w + i], KB_CAP));
+    const int total = off[QW];
+    const int nseg = C / 32;                      // (C % 64 == 0)
+    const int T2 = ((total + 63) / 64) * nseg;    // (round, segment) units of this wave
+    int q_cur = 0, slot_cur = 0;
+    bool ok_cur = false;
+    const float4* xr_cur = nullptr;
+    auto locate = [&](int t, int& q, int& slot, bool& ok, const float4*& xr) {
+      const int f = 64 * (t / nseg) + lane;
+      ok = f < total;
+      int ql = 0;
+#pragma unroll
+      for (int i = 1; i < QW; ++i) ql += f >= off[i] ? 1 : 0;
+      ql = ok ? ql : 0;
+      q = QW * w + ql;
+      slot = ok ? f - off[ql] : 0;
+      const int cand = min(max(bufi[q * KB_CAP + slot], 0), n - 1);
+      xr = reinterpret_cast<const float4*>(xpm + ((long)b * N + cand) * ldx) + 8 * (t % nseg);
+    };
+    float4 xa[8], xb[8];
+    int qn = 0, slotn = 0;
+    bool okn = false;
+    const float4* xrn = nullptr;
+    if (T2 > 0) {
+      locate(0, q_cur, slot_cur, ok_cur, xr_cur);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xa[u] = xr_cur[u];
+    }
+    float a = 0.f;
+    for (int t = 0; t < T2; ++t) {
+      const int tn = min(t + 1, T2 - 1);  // (the last unit requests its own rows again: no branch around the loads)
+      locate(tn, qn, slotn, okn, xrn);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xb[u] = xrn[u];
+      __builtin_amdgcn_sched_barrier(0);
+      const int sg = t % nseg;
+      if (sg == 0) a = 0.f;
+      const float* aq = Aq + q_cur * Cs + 32 * sg;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a = __builtin_fmaf(aq[4 * u], xa[u].x, a);
+        a = __builtin_fmaf(aq[4 * u + 1], xa[u].y, a);
+        a = __builtin_fmaf(aq[4 * u + 2], xa[u].z, a);
+        a = __builtin_fmaf(aq[4 * u + 3], xa[u].w, a);
+      }
+      if (sg == nseg - 1 && ok_cur) {
+        const int cand = min(max(bufi[q_cur * KB_CAP + slot_cur], 0), n - 1);
+        const float nj = nb[cand], nqq = nb[min(q0 + q_cur, n - 1)];
+        float v;
+        if (SMODE == R3D_SCORE_DGCNN) {
+          const float inner = -2.f * a;
+          v = ((-nj) - inner) - nqq;
+        } else {
+          const float dis = (nqq + nj) - 2.f * a;
+          v = -fmaxf(dis, 0.f);
+        }
+        bufv[q_cur * KB_CAP + slot_cur] = v;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xa[u] = xb[u];
+      q_cur = qn; slot_cur = slotn; ok_cur = okn;
+    }
+  }
   // ------------------------------------------------------------------ rank the survivors
   for (int qq = 0; qq < 32 / KB_WAVES; ++qq) {
     const int q = (32 / KB_WAVES) * w + qq;
@@ -889,8 +1024,8 @@ void r3d_knn_append_kernel(
 #pragma unroll
     for (int i = 0; i < KB_CAP / 64; ++i) {
       const int e = 64 * i + lane;
-      mv[i] = e < M ? bufv[q * KB_CAP + e] : -INFINITY;
       mi[i] = e < M ? bufi[q * KB_CAP + e] : 0x7fffffff;
+      mv[i] = e < M ? bufv[q * KB_CAP + e] : -INFINITY;
       khi[i] = f2key(mv[i] + 0.0f);  // -0 -> +0: equal scores must have equal keys
       klo[i] = 0x7fffffffu - (unsigned)mi[i];
       key[i] = ((unsigned long long)khi[i] << 32) | klo[i];
@@ -989,13 +1124,14 @@ static size_t knn_append_lds_bytes(int C, int waves, int cap, int top, int kch =
   const int nch = (C + 2 * kch - 1) / (2 * kch);
   const size_t a = 32 * (size_t)(nch * 2 * kch + 1);
   size_t g = 32 * (size_t)(top * waves * 32 + 1);
-  if (bfa) g = ((g + 3) & ~(size_t)3) + 32 * (size_t)(2 * nch * 64 + 8) / 2 + 32;  // + the query rows' bf16 pieces, bound terms
+  if (bfa) g = ((g + 3) & ~(size_t)3) + 32 * (size_t)(2 * nch * 64 + 8) / 2 + 64;  // + the query rows' bf16 pieces, bound terms
   const size_t bsz = 2 * 32 * (size_t)cap;
   return sizeof(float) * (a + (g > bsz ? g : bsz));
 }
 static size_t knn_big_lds_bytes(int C, bool bfa = false) { return knn_append_lds_bytes(C, 8, 384, 2, 32, bfa); }
 
-// bf16 pieces of the points for the threshold pass of r3d_knn_append_kernel<..., BFA = true>: [row][hi Cp | lo Cp],
+// bf16 pieces of the points for the bf16 passes of r3d_knn_append_kernel<..., BFA = true>, per set [piece][chunk of 8
+// channels][point][8] (chunk-major: see the kernel's staging loop for why),
 // Cp = C rounded up to 64 (zeros), cut from the point MINUS its set's mean: hi = the top 16 bits of the value, lo = the top
 // 16 bits of what is left.  Any mean will do (the bound only needs pieces, centred norms and inner products to belong to
 // the same shifted points); it is the plain fp32 mean over the set's valid rows.
@@ -1032,15 +1168,20 @@ __global__ void r3d_knn_pack_bf_kernel(const float* __restrict__ x, long ldx, lo
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int cpr = Cp / 8;
   if (i >= rows * cpr) return;
-  const long m = i / cpr;
-  const int c0 = 8 * (int)(i - m * cpr);
-  const float* mu = mean + (m / N) * Cp + c0;
+  // consecutive threads: consecutive points of one chunk (the stores are contiguous; the 32-byte reads of a point's row
+  // come out of L2 for the other chunks' threads)
+  const long set = i / ((long)N * cpr), r = i - set * ((long)N * cpr);
+  const int c8 = (int)(r / N), pt = (int)(r - (long)c8 * N);
+  const long m = set * N + pt;
+  const int c0 = 8 * c8;
+  const float* mu = mean + set * Cp + c0;
   float v[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) v[u] = r3d_keep(x[m * ldx + min(c0 + u, C - 1)] - mu[u], c0 + u < C);
   const r3d_bx3 f = r3d_bx3_split8(v);
-  *reinterpret_cast<r3d_u32x4*>(out + m * 2 * Cp + c0) = f.h;
-  *reinterpret_cast<r3d_u32x4*>(out + m * 2 * Cp + Cp + c0) = f.m;
+  unsigned short* o = out + set * N * 2 * Cp;
+  *reinterpret_cast<r3d_u32x4*>(o + ((long)c8 * N + pt) * 8) = f.h;
+  *reinterpret_cast<r3d_u32x4*>(o + ((long)(cpr + c8) * N + pt) * 8) = f.m;
 }
 // squared norms of the centred points (one wave per row; fixed order)
 __global__ __launch_bounds__(256) void r3d_knn_cnorm_kernel(const float* __restrict__ x, long ldx, long rows, int N, int C, int Cp,
@@ -1059,6 +1200,15 @@ __global__ __launch_bounds__(256) void r3d_knn_cnorm_kernel(const float* __restr
 }
 // A/B switch (tests, tools): 0 = the threshold pass stays on the fp32 core even when bf_ws is given.  Same results.
 static int g_knn_bf16_threshold = getenv("R3D_KNN_FP32_THRESHOLD") ? 0 : 1;
+// ... and: 0 = pass B stays the all-pairs fp32 pass (no bf16 filter + exact scores of the survivors).  Same results.
+static int g_knn_bf16_filter = getenv("R3D_KNN_FP32_PASS_B") ? 0 : 1;
+// (2: also in the k > 32 configuration, where it loses -- 230 survivors per query, each a row gather the L1 serves one line
+// look-up at a time: measured 6.9 ms against 5.6 ms per 32 graphs of 4 396 nodes; kept for tests and tools/knnbench)
+extern "C" int r3d_debug_set_knn_bf16_filter(int on) {
+  const int old = g_knn_bf16_filter;
+  g_knn_bf16_filter = on < 0 ? 0 : on > 2 ? 2 : on;
+  return old;
+}
 extern "C" int r3d_debug_set_knn_bf16_threshold(int on) {
   const int old = g_knn_bf16_threshold;
   g_knn_bf16_threshold = on ? 1 : 0;
@@ -1087,35 +1237,38 @@ static size_t knn_lds_bytes(int C) {
 }
 
 // launch one instance of the append-and-rank kernel (raising its dynamic-LDS limit once per instance)
-template <int WAVES, int CAP, int TOP, int KCH, int SAMPLE, bool FULLC, int SMODE, bool BFA = false>
+template <int WAVES, int CAP, int TOP, int KCH, int SAMPLE, bool FULLC, int SMODE, bool BFA = false, bool BFB = false>
 static int knn_append_launch_mode(dim3 grid, size_t lds, hipStream_t st, const float* xT, long ldT, int N, int C, int k,
                                   const int* n_valid_dev, int n_valid_stride, const float* nrm, int* idx_out, float* score_out, int* status,
                                   int* tile_flags, int nsplit = 1, int* idx_tmp = nullptr, float* sc_tmp = nullptr,
-                                  const unsigned short* xpk = nullptr, const float* cnorm = nullptr) {
+                                  const unsigned short* xpk = nullptr, const float* cnorm = nullptr, const float* xpm = nullptr,
+                                  long ldx = 0) {
   static size_t attr = 0;
   if (lds > attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)r3d_knn_append_kernel<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, SMODE, BFA>,
+    hipError_t e = hipFuncSetAttribute((const void*)r3d_knn_append_kernel<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, SMODE, BFA, BFB>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     R3D_REQUIRE(e == hipSuccess, "r3d_knn_topk: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
     attr = lds;
   }
-  hipLaunchKernelGGL((r3d_knn_append_kernel<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, SMODE, BFA>), grid, dim3(64 * WAVES), lds, st, xT,
-                     ldT, N, C, k, SMODE, n_valid_dev, n_valid_stride, nrm, idx_out, score_out, status, tile_flags, nsplit, idx_tmp,
-                     sc_tmp, xpk, cnorm);
+  hipLaunchKernelGGL((r3d_knn_append_kernel<WAVES, CAP, TOP, KCH, SAMPLE, FULLC, SMODE, BFA, BFB>), grid, dim3(64 * WAVES), lds, st,
+                     xT, ldT, N, C, k, SMODE, n_valid_dev, n_valid_stride, nrm, idx_out, score_out, status, tile_flags, nsplit,
+                     idx_tmp, sc_tmp, xpk, cnorm, xpm, ldx);
   return R3D_OK;
 }
 // the same with the threshold pass on the bf16 matrix core (xpk: r3d_knn_pack_bf_kernel's output)
+// xpm != nullptr: the filter pass on the bf16 core as well, exact scores for the survivors alone (BFB)
 template <int WAVES, int CAP, int TOP, int SAMPLE>
 static int knn_append_launch_bfa(dim3 grid, size_t lds, hipStream_t st, const float* xT, long ldT, int N, int C, int k, int mode,
                                  const int* n_valid_dev, int n_valid_stride, const float* nrm, int* idx_out, float* score_out,
-                                 int* status, int* tile_flags, const unsigned short* xpk, const float* cnorm) {
-  return mode == R3D_SCORE_DGCNN
-             ? knn_append_launch_mode<WAVES, CAP, TOP, 32, SAMPLE, true, R3D_SCORE_DGCNN, true>(
-                   grid, lds, st, xT, ldT, N, C, k, n_valid_dev, n_valid_stride, nrm, idx_out, score_out, status, tile_flags, 1, nullptr,
-                   nullptr, xpk, cnorm)
-             : knn_append_launch_mode<WAVES, CAP, TOP, 32, SAMPLE, true, R3D_SCORE_L2, true>(
-                   grid, lds, st, xT, ldT, N, C, k, n_valid_dev, n_valid_stride, nrm, idx_out, score_out, status, tile_flags, 1, nullptr,
-                   nullptr, xpk, cnorm);
+                                 int* status, int* tile_flags, const unsigned short* xpk, const float* cnorm,
+                                 const float* xpm = nullptr, long ldx = 0) {
+#define KB_GO(SM, FB)                                                                                                            \
+  knn_append_launch_mode<WAVES, CAP, TOP, 32, SAMPLE, true, SM, true, FB>(grid, lds, st, xT, ldT, N, C, k, n_valid_dev, n_valid_stride, \
+                                                                          nrm, idx_out, score_out, status, tile_flags, 1, nullptr,   \
+                                                                          nullptr, xpk, cnorm, xpm, ldx)
+  if (xpm) return mode == R3D_SCORE_DGCNN ? KB_GO(R3D_SCORE_DGCNN, true) : KB_GO(R3D_SCORE_L2, true);
+  return mode == R3D_SCORE_DGCNN ? KB_GO(R3D_SCORE_DGCNN, false) : KB_GO(R3D_SCORE_L2, false);
+#undef KB_GO
 }
 template <int WAVES, int CAP, int TOP, int KCH, int SAMPLE, bool FULLC>
 static int knn_append_launch(dim3 grid, size_t lds, hipStream_t st, const float* xT, long ldT, int N, int C, int k, int mode,
@@ -1203,6 +1356,8 @@ static int knn_topk_impl(const float* x, long ldx, const float* x_cm, int B, int
   // the threshold pass on the bf16 core: whole 64-channel chunks, the packed pieces from the point-major matrix
   const bool bfa = g_knn_bf16_threshold && bf_ws && x && C % 64 == 0 && bf_ws_words >= r3d_knn_bf_ws_words(B, N, C) &&
                    ((uintptr_t)bf_ws & 15) == 0;
+  // the filter pass on it as well: exact scores come from the point-major rows, read as 16-byte vectors
+  const float* xpm = bfa && g_knn_bf16_filter && (ldx & 3) == 0 && ((uintptr_t)x & 15) == 0 ? x : nullptr;
   float* bf_mean = bf_ws ? bf_ws + (long)B * N * C : nullptr;  // (C == Cp here)
   float* bf_cnorm = bf_ws ? bf_mean + (long)B * C : nullptr;
   auto pack_bf = [&]() {
@@ -1261,7 +1416,7 @@ static int knn_topk_impl(const float* x, long ldx, const float* x_cm, int B, int
           pack_bf();
           rc = knn_append_launch_bfa<KM_WAVES, KM_CAP, KM_TOP, KM_SAMPLE>(
               g2, knn_append_lds_bytes(C, KM_WAVES, KM_CAP, KM_TOP, 32, true), st, xT, ldT, N, C, k, mode, n_valid_dev,
-              n_valid_stride, norm_ws, idx_out, score_out, nullptr, tile_flags, (const unsigned short*)bf_ws, bf_cnorm);
+              n_valid_stride, norm_ws, idx_out, score_out, nullptr, tile_flags, (const unsigned short*)bf_ws, bf_cnorm, xpm, ldx);
         } else if (C % 64 == 0) rc = few ? KM_LAUNCH(8, 32, true) : KM_LAUNCH(KM_WAVES, 32, true);
         else rc = few ? KM_LAUNCH(8, 32, false) : KM_LAUNCH(KM_WAVES, 32, false);
         if (rc) return rc;
@@ -1302,7 +1457,7 @@ static int knn_topk_impl(const float* x, long ldx, const float* x_cm, int B, int
       const int rc = bfa_big
                          ? knn_append_launch_bfa<8, 384, 2, 1>(gb, knn_big_lds_bytes(C, true), st, xT, ldT, N, C, k, mode, n_valid_dev,
                                                                n_valid_stride, norm_ws, idx_out, score_out, status, nullptr,
-                                                               (const unsigned short*)bf_ws, bf_cnorm)
+                                                               (const unsigned short*)bf_ws, bf_cnorm, g_knn_bf16_filter > 1 ? xpm : nullptr, ldx)
                      : C % 64 == 0
                          ? knn_append_launch<8, 384, 2, 32, 1, true>(gb, knn_big_lds_bytes(C), st, xT, ldT, N, C, k, mode, n_valid_dev, n_valid_stride,
                                                                      norm_ws, idx_out, score_out, status, nullptr, nsplit, idx_tmp, sc_tmp)

@@ -84,7 +84,25 @@ def sync_running_stats(model):
     for mod in model.modules():  # BatchNorm-folded weights are derived data
         if hasattr(mod, "_folded") and mod._folded is not None:
             mod._folded = (None, mod._folded[1])
+    model.__dict__["_rank_local_stats"] = False
     return flat.numel()
+
+
+def mark_rank_local_stats(model):
+    """Called by the trainer after a multi-rank step: this rank's running statistics now hold episodes the other ranks'
+    do not.  warn_rank_local_stats() -- used where a model is saved or evaluated -- then says so once, instead of N ranks
+    silently saving / evaluating N different models (the fix is a collective, which only the caller can place where every
+    rank reaches it: DPTrainer.sync_running_stats())."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        model.__dict__["_rank_local_stats"] = True
+
+
+def warn_rank_local_stats(model, what):
+    if model.__dict__.get("_rank_local_stats"):
+        import warnings
+        warnings.warn("%s with per-rank BatchNorm running statistics: call DPTrainer.sync_running_stats() (on every rank) "
+                      "first, or the ranks %s different models" % (what, "save" if "checkpoint" in what else "evaluate"))
+        model.__dict__["_rank_local_stats"] = False  # (said once per training phase)
 
 
 def all_reduce_histogram(hist):

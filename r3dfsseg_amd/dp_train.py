@@ -126,6 +126,7 @@ class DPTrainer:
                 n_failed, (" (this rank: %s)" % failed) if failed is not None else "")) from failed
         if apply_stats is not None:
             apply_stats()
+            D.mark_rank_local_stats(self.model)
         self.learner.optimizer.step()
         self.learner.lr_scheduler.step()
 

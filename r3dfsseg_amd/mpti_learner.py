@@ -167,8 +167,10 @@ class MPTILearner_V3(object):
         """test() for E episodes of one shape in ONE launch sequence (MPTI_SelfAtten.forward_episodes): a list of
         (pred (n_q, N), loss, accuracy), per episode what test() returns for it.  A batch in which any system missed its CG
         launch budget (or overflowed the 201-NN survivor buffer) is redone episode by episode through test()."""
+        from . import dist as D
         from .batch import EpisodeBatch
         self.model.eval()
+        D.warn_rank_local_stats(self.model, 'evaluation')
         b = datas if isinstance(datas, EpisodeBatch) else EpisodeBatch.from_episodes(datas)
         with torch.no_grad():
             logits, loss = self.model.forward_episodes(b, eval=eval)
@@ -205,6 +207,8 @@ class MPTILearner_V3(object):
                 return out
         [support_x, support_y, query_x, query_y, _, _, gt_support_y] = data
         self.model.eval()
+        from . import dist as D
+        D.warn_rank_local_stats(self.model, 'evaluation')
         with torch.no_grad():
             logits, loss = self.model(support_x, support_y, query_x, query_y, gt_support_y=gt_support_y,
                                       sampled_classes=sampled_classes, step=step, path=path, support_flag=None,

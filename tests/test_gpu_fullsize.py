@@ -99,10 +99,12 @@ def test_full_size_graph_slots_match_eager():
         np.testing.assert_allclose(out[e].cpu().numpy(), eager[e].cpu().numpy(), atol=2e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize("workload,E", [("S", 3), ("C", 2)])
+@pytest.mark.parametrize("workload,E", [("S", 3), ("C", 2), ("S", 32)])
 def test_full_size_batched_step_equals_one_episode_at_a_time(workload, E):
     """The headline schedule at BASELINE sizes (configs[1] S3DIS 2-way 5-shot 2048 pts; configs[3] ScanNet 3-way 5-shot 4096
-    pts): E training episodes through ONE launch sequence against the same episodes one at a time on the eager path --
+    pts; ("S", 32) is the HEADLINE schedule of bench.py at its own size -- 32 episodes per launch sequence, BASELINE
+    configs[4]'s per-GPU share: FPS groups of 6 + 6 + 6 + 6 + 6 + 2 episodes, the LDS-resident SpMV, 24 GB of strided
+    buffers): E training episodes through ONE launch sequence against the same episodes one at a time on the eager path --
     per episode the losses and logits to rounding, the BatchNorm running statistics bit for bit (a segment's reductions
     are partitioned by the segment, never by the batch), the summed gradient to 1e-5 (weight gradients add over the batch
     in another order)."""
@@ -130,3 +132,27 @@ def test_full_size_batched_step_equals_one_episode_at_a_time(workload, E):
         assert torch.equal(v, want_buf[k]), k
     err = (bucket.flat - want_grad).abs().max().item() / want_grad.abs().max().item()
     assert err < 1e-5, err
+
+
+def test_full_size_eval_batch_of_32_scannet_episodes_equals_single_episodes():
+    """configs[3] as bench.py --workload C --mode eval runs it: 32 ScanNet-sized episodes (3-way 5-shot 4096 points, 12 688
+    graph nodes each) through ONE inference launch sequence; four of them against the one-episode forward (logits to
+    rounding, arg-max identical, loss)."""
+    import test_gpu_batched as TB
+    from r3dfsseg_amd.batch import EpisodeBatch
+    from r3dfsseg_amd.batched import EpisodeBatchRunner
+    cfg = S.workload_cfg("C")
+    eps = TB._episodes(cfg, 32, noise=0.4)
+    m = TB._model(cfg, False)
+    run = EpisodeBatchRunner(m)
+    run.begin_step()
+    logits, loss = run.eval_batch(EpisodeBatch.from_episodes(eps), eval=True)
+    assert run.step_status()[:2] == (0, 0)
+    logits, loss = logits.clone(), loss.clone()
+    with torch.no_grad():
+        for e in (0, 11, 22, 31):
+            wl, wloss = m(*eps[e][:4], eval=True, lp_iters=m.lp_max_iter)
+            assert m.lp_converged()
+            np.testing.assert_allclose(logits[e].cpu().numpy(), wl.cpu().numpy(), atol=5e-5, rtol=1e-5)
+            assert torch.equal(logits[e].argmax(1), wl.argmax(1))
+            assert abs(loss[e].item() - wloss.item()) < 2e-5 * max(1.0, abs(wloss.item()))
