@@ -88,6 +88,8 @@ def algorithmic_work(op, cfg, n_nodes, cg_iters, train):
                 len(shapes) * joint)
     if op == "edgeconv_bwd":  # three edge GEMMs (z2 recompute, dh1, dW2) + dy1 round trip
         return 3 * M * K * (3 * 2.0 * 64 * 64), 3 * (M * 128 * 4 * 2 + 2 * M * K * 64 * 4 + M * 64 * 8), "mfma", 3 * passes
+    if op == "edgeconv_bwd_useful":  # what the math needs: dh1 = dz2 W2 and dW2 += dz2^T h1 (the z2 GEMM is a recompute)
+        return 3 * M * K * (2 * 2.0 * 64 * 64), 3 * (M * 128 * 4 * 2 + 2 * M * K * 64 * 4 + M * 64 * 8), "mfma", 3 * passes
     if op == "bn_stats":  # column statistics: every activation / gradient matrix read once
         cols = [512, 256, 128, 64]
         return 4.0 * M * sum(cols) * 3, 3 * M * sum(cols) * 4, "hbm", 3 * len(cols) * passes
@@ -120,10 +122,18 @@ MAIN_KERNEL = {
     "head_prototypes": "r3d_fps_persistent_kernel",
     "label_propagate": "r3d_cg_spmv_lds_kernel + r3d_cg_update_kernel",
     "label_propagate_bwd": "r3d_cg_spmv_lds_kernel + r3d_cg_update_kernel",
-    "gemm_tn": "r3d_gemm_tn_bx3_kernel (bf16 x 3; fp32 arithmetic: r3d_gemm_tn_kernel)", "edgeconv_bwd": "r3d_edgeconv_bwd1_kernel + r3d_edgeconv_bwd2_kernel",
+    "gemm_tn": "r3d_gemm_tn_bx3_kernel (bf16 x 3; fp32 arithmetic: r3d_gemm_tn_kernel)", "edgeconv_bwd": "r3d_edgeconv_bwd1_bx3_kernel + r3d_edgeconv_bwd2_kernel (bf16 x 3; fp32 arithmetic: r3d_edgeconv_bwd1_kernel)",
     "attention_bwd": "r3d_attention_bwd_kv_bx3_kernel + r3d_attention_bwd_q_bx3_kernel (fp32 arithmetic: ..._kv_kernel + ..._q_kernel)",
     "bn_stats": "r3d_colpartial_kernel",
 }
+
+
+BX3_OPS = ("attention", "attention_bwd", "pointwise_conv", "gemm_tn", "edgeconv_bwd")
+
+
+def _lib_arith():
+    from r3dfsseg_amd import _lib
+    return _lib.load().r3d_get_matrix_arith()
 
 
 def committed_profile(workload, mode):
@@ -443,8 +453,11 @@ def main():
         fl, by = fl * E, by * E                       # the step's work of this entry point
         calls = calls_per_step[kern]
         t_launch = per_step_ms[kern] * 1e-3 / calls
+        bx3_now = _lib_arith() == 1 and kern in BX3_OPS
         if bound == "mfma":
-            ach, peak, unit = fl / calls / t_launch / 1e12, F32_MFMA_PEAK_TF, "TFLOP/s"
+            # bf16 x 3 entry points: fp32-EQUIVALENT flops against the fp32-equivalent matrix peak of that arithmetic
+            # (six bf16 MFMA products per fp32 product: dense bf16 peak / 6)
+            ach, peak, unit = fl / calls / t_launch / 1e12, (BF16_MFMA_PEAK_TF / 6.0 if bx3_now else F32_MFMA_PEAK_TF), "TFLOP/s"
         else:
             ach, peak, unit = by / calls / t_launch / 1e9, HBM_PEAK_GBS, "GB/s"
         traffic = rocprof_us = rocprof_ms_step = frac_kernel = None
@@ -461,8 +474,8 @@ def main():
             return bool(base(name)) and base(name) in main
         if pmc is not None:
             hit = [v for k, v in pmc.items() if mine(k)]
-            if hit:
-                traffic = 1024.0 * max(FETCH_SIZE_WIDE_READ_FACTOR * v["fetch_kb_per_launch"] + v["write_kb_per_launch"] for v in hit)
+            if hit:  # the SUM over the named kernels (one launch of each per call of the entry point)
+                traffic = 1024.0 * sum(FETCH_SIZE_WIDE_READ_FACTOR * v["fetch_kb_per_launch"] + v["write_kb_per_launch"] for v in hit)
         if prof is not None:
             hits = [v for k, v in prof.items() if k != "_steps" and mine(k)]
             if hits:
@@ -471,10 +484,16 @@ def main():
                     # the entry point's main kernels in the committed kernel trace of the same workload and schedule: their
                     # time per step, and the roofline fraction from kernel time alone (no helper kernels, no launch gaps)
                     rocprof_ms_step = sum(v[1] for v in hits) / prof["_steps"]
-                    frac_kernel = (fl / (rocprof_ms_step * 1e-3) / 1e12 / F32_MFMA_PEAK_TF) if bound == "mfma" else \
+                    frac_kernel = (fl / (rocprof_ms_step * 1e-3) / 1e12 / peak) if bound == "mfma" else \
                         (by / (rocprof_ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        useful = None
+        if kern + "_useful" in ("edgeconv_bwd_useful",):  # flops the math needs (recompute excluded) over the same time
+            fu = algorithmic_work(kern + "_useful", cfg, n_nodes, cg_mean, train)[0] * E
+            useful = fu / calls / t_launch / 1e12 / peak
         roof = dict(kernel="%s (entry point %s, %d episodes per launch)" % (main, kern, E), bound=bound, achieved=ach, peak=peak,
-                    unit=unit, frac=ach / peak, traffic=traffic, avg_launch_ms=t_launch * 1e3, launches_per_step=calls,
+                    unit=unit, frac=ach / peak, useful_frac=useful if useful is not None else ach / peak,
+                    peak_note=("fp32-equivalent peak of the bf16 x 3 arithmetic: 2500 TFLOP/s dense bf16 / 6 products per fp32 "
+                               "product" if (bound == "mfma" and bx3_now) else None), traffic=traffic, avg_launch_ms=t_launch * 1e3, launches_per_step=calls,
                     algorithmic_gflop_per_launch=fl / calls / 1e9, algorithmic_mb_per_launch=by / calls / 1e6,
                     hbm_gbs=by / calls / t_launch / 1e9, fp32_tflops=fl / calls / t_launch / 1e12,
                     rocprofv3_kernel_us=rocprof_us, rocprofv3_main_kernels_ms_per_step=rocprof_ms_step,
@@ -486,7 +505,6 @@ def main():
     # every entry point against both ceilings (north_star: HBM GB/s for kNN / EdgeConv, MFMA utilisation for attention)
     from r3dfsseg_amd import _lib as _l0
     bx3_attention = _l0.load().r3d_get_matrix_arith() == 1
-    BX3_OPS = ("attention", "attention_bwd", "pointwise_conv", "gemm_tn")
     rooflines = {"_note": "HIP event pairs around every entry-point call of a live step (%d episodes per launch): hbm_gbs is "
                           "algorithmic bytes / device time, not HBM traffic" % E}
     for op, ms in per_step_ms.items():
@@ -503,6 +521,12 @@ def main():
                                  frac_mfma_note="issued bf16 MFMA flops (6 per fp32 product) / 2500 TFLOP/s dense bf16 peak; "
                                                 "fp32_tflops is the useful fp32-equivalent rate")
     breakdown = {k: round(v, 4) for k, v in sorted(per_step_ms.items(), key=lambda kv: -kv[1])}
+    # the whole step: useful fp32-equivalent flops of every matrix-shaped entry point (recomputes excluded) over the step time
+    step_flops = 0.0
+    for op in per_step_ms:
+        f_u = algorithmic_work(op + "_useful" if op == "edgeconv_bwd" else op, cfg, n_nodes, cg_mean, train)
+        if f_u[2] == "mfma":
+            step_flops += f_u[0] * E
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:
@@ -510,13 +534,15 @@ def main():
 
     eps = args.steps * E * world / elapsed
     from r3dfsseg_amd import _lib as _l
-    matrix_arith = ("self-attention, 1x1-convolution GEMMs (forward and input gradient) and weight-gradient GEMMs: fp32 operands "
-                    "as three bf16 pieces on the bf16 MFMA, six products per block, fp32 accumulate (error against float64 as "
-                    "the fp32 kernels: tools/gemm_accuracy.py); index-deciding kernels (kNN scores, the EdgeConv edge GEMM "
-                    "whose max-pool winners route the gradient, FPS) and the 9-channel input layer: fp32 MFMA"
+    matrix_arith = ("self-attention, 1x1-convolution GEMMs (forward and input gradient), weight-gradient GEMMs and the three edge "
+                    "GEMMs of the EdgeConv backward: fp32 operands as three bf16 pieces on the bf16 MFMA, six products per block, "
+                    "fp32 accumulate (error against float64 as the fp32 kernels: tools/gemm_accuracy.py).  kNN on 64 channels: a "
+                    "bf16 bound pass FILTERS the candidates, every emitted score is the exact fp32 fmaf chain (bit-identical "
+                    "to the all-pairs fp32 pass).  Index-deciding kernels (kNN scores, the EdgeConv forward edge GEMM "
+                    "whose max-pool winners route the gradient, FPS) and the 9-channel input layer: fp32"
                     if _l.load().r3d_get_matrix_arith() == 1 else "fp32 MFMA everywhere")
-    dtype_str = ("f32 (index-free GEMMs -- self-attention, 1x1 convolutions, weight gradients -- as bf16x3 split products on the "
-                 "bf16 MFMA with fp32 accumulate; every index-deciding kernel: fp32 MFMA)"
+    dtype_str = ("f32 (index-free GEMMs -- self-attention, 1x1 convolutions, weight gradients, the EdgeConv backward's edge GEMMs "
+                 "-- as bf16x3 split products on the bf16 MFMA with fp32 accumulate; every index-deciding result: fp32)"
                  if _l.load().r3d_get_matrix_arith() == 1 else "f32")
     out = {
         "metric": "episodes/sec %s %d-way %d-shot %d-pt (MPTI+attention, %s)" % (
@@ -533,6 +559,8 @@ def main():
         "valid": int(n_invalid.item()) == 0, "invalid": invalid,
         "roofline": roof, "roofline_cg_iteration": cg_roof, "rooflines": rooflines, "cpu_baseline": cpu,
         "entry_point_ms_per_step": breakdown,
+        "step_fp32_equiv_tflops": step_flops / (elapsed / args.steps) / 1e12,
+        "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
         "lp_cg_iterations": {"mean": cg_mean, "max": cg_max},
         "train_steps_redone": {"count": getattr(trainer, "n_redone", 0) if trainer is not None else 0, "notes": redone_notes},
     }

@@ -691,26 +691,40 @@ void r3d_knn_append_kernel(
     for (int s = 0; s < KCH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bf[s], acc, 0, 0, 0);
   };
   // lower bounds of the scores from the bf16 pass (acc = hi hi + hi lo + lo hi of the inner products)
+  // (the bound terms of this lane's 16 query rows sit in registers for the length of a pass: kb[r]; a score bound is
+  // 2 acc - (kb[row] + k[candidate]) -- one add, one fma and the clamp of the L2 form per element.  The fma's single
+  // rounding against the mul + sub of the exact form is far inside the bounds' (C + 8) 2^-24 slack.)
+  float kb[16];
+  auto load_kb = [&](int which) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) kb[r] = kq_s[32 * which + r3d_acc_row(r, lane)];
+  };
   auto scores_lb = [&](int st, f32x16& sc) {
     const int cand = 32 * st + j;
-    const bool valid = cand < n;
     const float kj = bound_k(min(cand, n - 1));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float d = (kq_s[r3d_acc_row(r, lane)] + kj) - 2.f * acc[r];  // >= the true squared distance
-      const float v = SMODE == R3D_SCORE_DGCNN ? -d : -fmaxf(d, 0.f);
-      sc[r] = valid ? v : -INFINITY;
+      const float v = __builtin_fmaf(2.f, acc[r], -(kb[r] + kj));  // <= the score: -(an upper bound of the squared distance)
+      sc[r] = SMODE == R3D_SCORE_DGCNN ? v : fminf(v, 0.f);
+    }
+    if (32 * st + 32 > n) {  // uniform: only the last sub-tile has candidates beyond n
+      const bool valid = cand < n;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = valid ? sc[r] : -INFINITY;
     }
   };
   auto scores_ub = [&](int st, f32x16& sc) {
     const int cand = 32 * st + j;
-    const bool valid = cand < n;
     const float kj = bound_ku(min(cand, n - 1));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float d = (kq_s[32 + r3d_acc_row(r, lane)] + kj) - 2.f * acc[r];  // <= the squared distance the exact form computes
-      const float v = SMODE == R3D_SCORE_DGCNN ? -d : -fmaxf(d, 0.f);
-      sc[r] = valid ? v : -INFINITY;
+      const float v = __builtin_fmaf(2.f, acc[r], -(kb[r] + kj));  // >= the score the exact form computes
+      sc[r] = SMODE == R3D_SCORE_DGCNN ? v : fminf(v, 0.f);
+    }
+    if (32 * st + 32 > n) {
+      const bool valid = cand < n;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = valid ? sc[r] : -INFINITY;
     }
   };
   auto scores = [&](int st, f32x16& sc) {
@@ -763,15 +777,20 @@ void r3d_knn_append_kernel(
   // issued right in front of them.
   // candidate pieces: 8 consecutive channels of a piece are 16 contiguous bytes of the packed row
   r3d_u32x4 pfA[8], pfB[8];  // [k-step of 16 channels][hi, lo]
+  // (buffer loads: one resource for the set's pieces, the lane's part of the address is its candidate and half alone,
+  // the chunk is a scalar offset -- no 64-bit vector address arithmetic per load)
+  const __amdgpu_buffer_rsrc_t rpk = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(BFA ? xpb : (const unsigned short*)xT), 0, BFA ? (int)((long)N * 2 * Cp * 2) : 0, 0x00020000);
+  const int chunk_b = N * 16;  // bytes of one chunk of all points
   auto pload = [&](int t, r3d_u32x4 (&pf)[8]) {
     const int st = (w + KB_WAVES * stride * (t / nch)) * nsplit + z, ch = (t % nch);
     const int cc = min(32 * st + j, n - 1);
-    const unsigned short* p = xpb + ((long)(8 * ch + h) * N + cc) * 8;  // chunk 8 ch + 2 s4 + h of the hi piece
-    const long cs2 = 2L * N * 8, lo = (long)(Cp / 8) * N * 8;
+    const int voff = (h * N + cc) * 16;                  // chunk 8 ch + 2 s4 + h of the hi piece ...
+    const int soff = 8 * ch * chunk_b, lo = (Cp / 8) * chunk_b;  // ... and of the lo piece, Cp / 8 chunks further on
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
-      pf[2 * s4] = *reinterpret_cast<const r3d_u32x4*>(p + s4 * cs2);
-      pf[2 * s4 + 1] = *reinterpret_cast<const r3d_u32x4*>(p + lo + s4 * cs2);
+      pf[2 * s4] = __builtin_amdgcn_raw_buffer_load_b128(rpk, voff, soff + 2 * s4 * chunk_b, 0);
+      pf[2 * s4 + 1] = __builtin_amdgcn_raw_buffer_load_b128(rpk, voff, soff + lo + 2 * s4 * chunk_b, 0);
     }
   };
   auto pmma = [&](int t, const r3d_u32x4 (&pf)[8]) {
@@ -799,6 +818,7 @@ void r3d_knn_append_kernel(
     }
   };
   if (BFA) {
+    load_kb(0);
     if (TA > 0) pload(0, pfA);
     for (int t = 0; t < TA; ++t) {
       if (t + 1 < TA) pload(t + 1, pfB);
@@ -902,6 +922,7 @@ void r3d_knn_append_kernel(
   // unrolled by hand compiled to chains that waited, through the single in-order vmcnt counter, on the loads
   // issued right in front of them.
   if (BFB) {
+    load_kb(1);
     if (T > 0) pload(0, pfA);
     for (int t = 0; t < T; ++t) {
       if (t + 1 < T) pload(t + 1, pfB);
@@ -1414,9 +1435,14 @@ static int knn_topk_impl(const float* x, long ldx, const float* x_cm, int B, int
       } else {
         if (C % 64 == 0 && bfa && !few) {
           pack_bf();
-          rc = knn_append_launch_bfa<KM_WAVES, KM_CAP, KM_TOP, KM_SAMPLE>(
-              g2, knn_append_lds_bytes(C, KM_WAVES, KM_CAP, KM_TOP, 32, true), st, xT, ldT, N, C, k, mode, n_valid_dev,
-              n_valid_stride, norm_ws, idx_out, score_out, nullptr, tile_flags, (const unsigned short*)bf_ws, bf_cnorm, xpm, ldx);
+          // (with the filter on the bf16 core the threshold pass visits EVERY sub-tile: a tighter threshold means fewer
+          // survivors, and their exact scores cost more than the half pass saved -- 3.30 against 3.63 ms per 384 clouds)
+          rc = xpm ? knn_append_launch_bfa<KM_WAVES, KM_CAP, KM_TOP, 1>(
+                         g2, knn_append_lds_bytes(C, KM_WAVES, KM_CAP, KM_TOP, 32, true), st, xT, ldT, N, C, k, mode, n_valid_dev,
+                         n_valid_stride, norm_ws, idx_out, score_out, nullptr, tile_flags, (const unsigned short*)bf_ws, bf_cnorm, xpm, ldx)
+                   : knn_append_launch_bfa<KM_WAVES, KM_CAP, KM_TOP, KM_SAMPLE>(
+                         g2, knn_append_lds_bytes(C, KM_WAVES, KM_CAP, KM_TOP, 32, true), st, xT, ldT, N, C, k, mode, n_valid_dev,
+                         n_valid_stride, norm_ws, idx_out, score_out, nullptr, tile_flags, (const unsigned short*)bf_ws, bf_cnorm, nullptr, 0);
         } else if (C % 64 == 0) rc = few ? KM_LAUNCH(8, 32, true) : KM_LAUNCH(KM_WAVES, 32, true);
         else rc = few ? KM_LAUNCH(8, 32, false) : KM_LAUNCH(KM_WAVES, 32, false);
         if (rc) return rc;
