@@ -754,11 +754,10 @@ void r3d_knn_append_kernel(
   float g1[16], g2[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { g1[r] = -INFINITY; g2[r] = -INFINITY; }
-  auto finishA = [&](int t) {
-    if ((t % nch) != nch - 1) return;
+  auto finishA_sub = [&](int i) {  // the wave's i-th sub-tile of pass A is complete in acc
     f32x16 sc;
-    if (BFA) scores_lb((w + KB_WAVES * stride * (t / nch)) * nsplit + z, sc);
-    else scores((w + KB_WAVES * stride * (t / nch)) * nsplit + z, sc);
+    if (BFA) scores_lb((w + KB_WAVES * stride * i) * nsplit + z, sc);
+    else scores((w + KB_WAVES * stride * i) * nsplit + z, sc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float x = sc[r];
@@ -768,6 +767,9 @@ void r3d_knn_append_kernel(
       }
       g1[r] = fmaxf(g1[r], x);
     }
+  };
+  auto finishA = [&](int t) {
+    if ((t % nch) == nch - 1) finishA_sub(t / nch);
   };
   KSTAMP(9);
   const int TA = (w < nsub) ? ((my_sub + KB_SAMPLE - 1) / KB_SAMPLE) * nch : 0;  // sampled units of pass A
@@ -782,8 +784,8 @@ void r3d_knn_append_kernel(
   const __amdgpu_buffer_rsrc_t rpk = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(BFA ? xpb : (const unsigned short*)xT), 0, BFA ? (int)((long)N * 2 * Cp * 2) : 0, 0x00020000);
   const int chunk_b = N * 16;  // bytes of one chunk of all points
-  auto pload = [&](int t, r3d_u32x4 (&pf)[8]) {
-    const int st = (w + KB_WAVES * stride * (t / nch)) * nsplit + z, ch = (t % nch);
+  auto pload = [&](int i, int ch, r3d_u32x4 (&pf)[8]) {  // chunk ch of this wave's i-th sub-tile at the running stride
+    const int st = (w + KB_WAVES * stride * i) * nsplit + z;
     const int cc = min(32 * st + j, n - 1);
     const int voff = (h * N + cc) * 16;                  // chunk 8 ch + 2 s4 + h of the hi piece ...
     const int soff = 8 * ch * chunk_b, lo = (Cp / 8) * chunk_b;  // ... and of the lo piece, Cp / 8 chunks further on
@@ -793,9 +795,8 @@ void r3d_knn_append_kernel(
       pf[2 * s4 + 1] = __builtin_amdgcn_raw_buffer_load_b128(rpk, voff, soff + lo + 2 * s4 * chunk_b, 0);
     }
   };
-  auto pmma = [&](int t, const r3d_u32x4 (&pf)[8]) {
-    const int ch = (t % nch);
-    if (ch == 0) {
+  auto pmma = [&](int ch, const r3d_u32x4 (&pf)[8]) {
+    if (ch == 0) {  // (uniform)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     }
@@ -817,17 +818,43 @@ void r3d_knn_append_kernel(
       }
     }
   };
+  // One bf16 pass over n_sub sub-tiles of this wave: (sub-tile, chunk) units walked by two scalar counters (no division
+  // per unit), the two fragment buffers taking turns (no register copies), the next unit's 8 loads issued in front of the
+  // current unit's 12 MFMAs; the last unit requests its own fragments again, so that no load sits behind a branch (the
+  // compiler would wait for ALL loads in flight there).  finish(i): the i-th sub-tile's 32 x 32 bounds are in acc.
+  auto bf_pass = [&](int n_sub, auto&& finish) {
+    const int U = n_sub * nch;
+    if (U <= 0) return;
+    int i_c = 0, ch_c = 0, i_n = 0, ch_n = 0;
+    auto advance = [&](int& i, int& ch) {
+      if (++ch == nch) { ch = 0; ++i; }
+    };
+    pload(0, 0, pfA);
+    advance(i_n, ch_n);
+    int u = 0;
+    for (; u + 1 < U; u += 2) {
+      pload(i_n, ch_n, pfB);  // unit u + 1
+      __builtin_amdgcn_sched_barrier(0);
+      pmma(ch_c, pfA);
+      if (ch_c == nch - 1) finish(i_c);
+      i_c = i_n; ch_c = ch_n;
+      advance(i_n, ch_n);
+      const bool more = u + 2 < U;
+      pload(more ? i_n : i_c, more ? ch_n : ch_c, pfA);  // unit u + 2 (or this one again)
+      __builtin_amdgcn_sched_barrier(0);
+      pmma(ch_c, pfB);
+      if (ch_c == nch - 1) finish(i_c);
+      i_c = i_n; ch_c = ch_n;
+      advance(i_n, ch_n);
+    }
+    if (u < U) {
+      pmma(ch_c, pfA);
+      if (ch_c == nch - 1) finish(i_c);
+    }
+  };
   if (BFA) {
     load_kb(0);
-    if (TA > 0) pload(0, pfA);
-    for (int t = 0; t < TA; ++t) {
-      if (t + 1 < TA) pload(t + 1, pfB);
-      __builtin_amdgcn_sched_barrier(0);
-      pmma(t, pfA);
-      finishA(t);
-#pragma unroll
-      for (int s = 0; s < 8; ++s) pfA[s] = pfB[s];
-    }
+    bf_pass((w < nsub) ? (my_sub + KB_SAMPLE - 1) / KB_SAMPLE : 0, finishA_sub);
   } else {
     if (TA > 0) bload(0, bfA);
     for (int t = 0; t < TA; ++t) {
@@ -902,9 +929,8 @@ void r3d_knn_append_kernel(
     }
   };
   // the bf16 filter (BFB): append the INDEX of every candidate whose score's upper bound reaches tau
-  auto finishBF = [&](int t) {
-    if ((t % nch) != nch - 1) return;
-    const int st = (w + KB_WAVES * (t / nch)) * nsplit + z;
+  auto finishBF = [&](int i) {  // the wave's i-th sub-tile of the filter pass is complete in acc
+    const int st = (w + KB_WAVES * i) * nsplit + z;
     f32x16 sc;
     scores_ub(st, sc);
 #pragma unroll
@@ -923,15 +949,7 @@ void r3d_knn_append_kernel(
   // issued right in front of them.
   if (BFB) {
     load_kb(1);
-    if (T > 0) pload(0, pfA);
-    for (int t = 0; t < T; ++t) {
-      if (t + 1 < T) pload(t + 1, pfB);
-      __builtin_amdgcn_sched_barrier(0);
-      pmma(t, pfA);
-      finishBF(t);
-#pragma unroll
-      for (int s = 0; s < 8; ++s) pfA[s] = pfB[s];
-    }
+    bf_pass((w < nsub) ? my_sub : 0, finishBF);
   } else {
     if (T > 0) bload(0, bfA);
     for (int t = 0; t < T; ++t) {
