@@ -278,7 +278,7 @@ __global__ void r3d_sqnorm_cm_kernel(const float* __restrict__ xT, long ldT, int
 
 #ifdef KNN_STAMPS
 __device__ unsigned long long g_knn_dbg[16];
-#define KSTAMP(i) do { if (blockIdx.x == 7 && blockIdx.y == (gridDim.y > 3 ? 3 : 0) && threadIdx.x == 0) g_knn_dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define KSTAMP(i) do { if (blockIdx.x == 7 && blockIdx.y == (gridDim.y > 3 ? 3 : 0) && blockIdx.z == 0 && threadIdx.x == 0) g_knn_dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define KSTAMP(i)
 #endif
@@ -590,9 +590,13 @@ void r3d_knn_append_kernel(
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int cnt_s[32];
   __shared__ float tau_s[32];
-  const int b = blockIdx.y;
+  // XCD-aware work order (common.h: r3d_xcd_swizzle): the workgroups that share an L2 take the query tiles of the SAME
+  // point sets -- every tile of a set streams that set's whole candidate matrix, so one L2 then holds one or two sets
+  // instead of every set in flight.  (Measured: 2 % on the k <= 32 configuration; the passes are not bound by it.)
+  const int lin = r3d_xcd_swizzle((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+  const int b = lin / (int)gridDim.x, tile_x = lin - b * (int)gridDim.x;
   const int n = n_dev ? min(n_dev[(long)b * n_dev_stride], N) : N;
-  const int q0 = blockIdx.x * 32;
+  const int q0 = tile_x * 32;
   if (q0 >= n) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, j = lane & 31;
@@ -933,6 +937,9 @@ void r3d_knn_append_kernel(
     const int st = (w + KB_WAVES * i) * nsplit + z;
     f32x16 sc;
     scores_ub(st, sc);
+    // (one returning LDS atomic per survivor.  Reserving a half-wave's slots with ONE atomic per register -- all 16 issued
+    // back to back, the survivors ranked by ballot -- was measured and lost: 68.8 k against 59.2 k cycles per tile for this
+    // pass; most registers have no survivor, and the branch around the atomic is cheaper than the ranking arithmetic.)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       if (sc[r] >= tauq[r]) {
@@ -964,14 +971,14 @@ void r3d_knn_append_kernel(
   KSTAMP(12);
   if (__any(overflow) && lane == 0) {
     if (status) atomicOr(status, 1);
-    if (tile_flags) tile_flags[(long)b * gridDim.x + blockIdx.x] = 1;
+    if (tile_flags) tile_flags[(long)b * gridDim.x + tile_x] = 1;
   }
   __syncthreads();
   if (BFA && tid < 32 && q0 + tid < n && cnt_s[tid] < min(k, n)) {
     // fewer than k survivors: the bound was not one (non-finite features).  Same exit as an overflow: flagged (bit 1 tells
     // the two apart for diagnosis; callers test the word against 0), redone exactly.
     if (status) atomicOr(status, 2);
-    if (tile_flags) tile_flags[(long)b * gridDim.x + blockIdx.x] = 1;
+    if (tile_flags) tile_flags[(long)b * gridDim.x + tile_x] = 1;
   }
   KSTAMP(14);
 
