@@ -187,6 +187,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-episode and eval legs (profiling runs)")
+    ap.add_argument("--no-batch-graph", action="store_true",
+                    help="launch the batched training step eagerly instead of replaying its captured hipGraph (A/B; same results)")
     ap.add_argument("--roofline-kernel", default="auto", help="entry point to price (auto = the one taking most time)")
     ap.add_argument("--steady-steps", type=int, default=150,
                     help="train mode: optimiser steps from the initial weights before the headline is timed (0 = headline on fresh weights)")
@@ -243,7 +245,7 @@ def main():
     learner.lr_scheduler = torch.optim.lr_scheduler.StepLR(learner.optimizer, step_size=5000, gamma=0.5)
     train = args.mode == "train"
     model.train(train)
-    trainer = DPTrainer(learner, batch_size=Bsz) if train else None
+    trainer = DPTrainer(learner, batch_size=Bsz, batch_graph=not args.no_batch_graph) if train else None
     runner = trainer.runner if (train and batched) else (EpisodeBatchRunner(model) if batched else None)
     lp_flags = []
     cg_acc = [0, 0, 0]    # CG iterations of the forward solves: sum, systems, max
@@ -375,8 +377,12 @@ def main():
     n_roof = 2
     timer = ops.KernelTimer(OPS, repeat=0)
     ops.set_timer(timer)
+    if trainer is not None:
+        graph_mode, trainer.batch_graph = trainer.batch_graph, False  # the event pairs sit around eager entry-point calls
     for i in range(n_roof):
         step_fn(i)
+    if trainer is not None:
+        trainer.batch_graph = graph_mode
     ops.set_timer(None)
     timer.close()
     ksum_all = timer.summary()
@@ -555,7 +561,9 @@ def main():
             args.workload, cfg["n_way"], cfg["k_shot"], N, B, E,
             "%d per launch sequence (episode-batched kernels)" % Bsz if batched else "eager launches, one at a time", args.mode),
             "episodes_per_step": E * world, "episodes_per_rank": E, "episodes_per_launch_sequence": Bsz,
-            "optimiser_steps_before_timing": (steps_done - args.steps) if train else 0},
+            "optimiser_steps_before_timing": (steps_done - args.steps) if train else 0,
+            "launch": ("one captured hipGraph per step (batched.BatchGraph: the batch's ~450 launches frozen; same kernels, "
+                       "bit-identical results)" if (train and batched and trainer.batch_graph) else "eager launches")},
         "valid": int(n_invalid.item()) == 0, "invalid": invalid,
         "roofline": roof, "roofline_cg_iteration": cg_roof, "rooflines": rooflines, "cpu_baseline": cpu,
         "entry_point_ms_per_step": breakdown,

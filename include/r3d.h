@@ -106,6 +106,11 @@ long r3d_knn_bf_ws_words(int B, int N, int C);
 int r3d_debug_set_knn_bf16_threshold(int on);
 /* the same for the second pass: 0 keeps it the all-pairs fp32 pass (same results) */
 int r3d_debug_set_knn_bf16_filter(int on);
+/* 1: launches captured into a hipGraph may use their stream's packed-weight scratch of the bf16 x 3 point-wise GEMM (it
+ * must exist already: run the sequence eagerly on that stream first).  The caller promises that the captured graph is the
+ * only user of that stream's scratch while it replays.  Default 0: captured launches take the kernel that cuts W itself
+ * (same bits).  Returns the previous setting. */
+int r3d_set_wpack_in_capture(int on);
 
 /* ---- 1x1 convolution + folded BatchNorm/bias + activation ---------------------------
  * models/dgcnn.py:64-80 conv1d, models/mpti.py:18-40 BaseLearner, models/attention.py:39-41.

@@ -95,6 +95,7 @@ _SIGS = {
     "r3d_knn_bf_ws_words": (c_l, [c_i, c_i, c_i]),
     "r3d_debug_set_knn_bf16_threshold": (c_i, [c_i]),
     "r3d_debug_set_knn_bf16_filter": (c_i, [c_i]),
+    "r3d_set_wpack_in_capture": (c_i, [c_i]),
     "r3d_pointwise_conv_stats_seg": (c_i, [c_f, c_l, c_f, c_l, c_i, c_i, c_f, c_l, c_l, c_l, c_f, c_f, c_f]),
     "r3d_colreduce_seg": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_f]),
     "r3d_colstats_seg_ws_words": (c_l, [c_l, c_i, c_l, c_l]),

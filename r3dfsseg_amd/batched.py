@@ -62,6 +62,19 @@ class EpisodeBatchRunner:
         return tuple(int(v) for v in self._pinned)
 
     # ------------------------------------------------------------------ training
+    def train_batch_graph(self, batch, grad_sink, loss_weight=0.1):
+        """train_batch through a captured hipGraph of the batch's shape (captured on first use; BatchGraph).  Same results."""
+        assert self.n_done + batch.E <= self.max_episodes
+        g = self.__dict__.get("_graph")
+        if g is None or not g.matches(batch):
+            g = self.__dict__["_graph"] = BatchGraph(self, batch, grad_sink, loss_weight)
+            self._graph_sink = [t.data_ptr() for t in grad_sink]
+        assert self._graph_sink == [t.data_ptr() for t in grad_sink], "the captured batch writes into the sink it was captured with"
+        self.rec_index.fill_(2 * self.n_done)
+        out = g.replay(batch)
+        self.n_done += batch.E
+        return out
+
     def train_batch(self, batch, grad_sink, loss_weight=0.1):
         """Forward + backward of one EpisodeBatch into grad_sink (accumulating).  BatchNorm batch statistics are RECORDED
         (records 2 (n_done + e) + p); apply_running_stats() folds them into the running statistics once the step is kept.
@@ -93,6 +106,137 @@ class EpisodeBatchRunner:
         self._count(backward=False)
         self.n_done += batch.E
         return out
+
+
+class BatchGraph:
+    """The training launch sequence of ONE batch shape (head_train.explicit_train_batch: ~450 launches for 32 episodes)
+    frozen into a hipGraph and replayed once per step: the same kernels with the same arguments in the same order, so the
+    same results bit for bit (tests/test_gpu_batched.py), without ~450 host launch calls per step and without the queue
+    running dry behind the step's host wait (status words, Adam).  What a frozen sequence needs (as episode_graph.py):
+      * inputs live in static buffers (the step's episodes are copied in: 29 MB at workload S, 32 episodes);
+      * the attention-dropout seed advances in device memory; BatchNorm statistics are recorded (the runner's records);
+      * the CG loops are captured with `lp_budget` iterations, of which only the first 1.5 x (slowly decaying maximum seen)
+        + 8 stay enabled (r3d_graph_set_lp_budget: disabled kernel nodes are empty); a step that needs more reports "not
+        converged" through the runner's counters like any other miss, and the trainer redoes it eagerly;
+      * the folded q | k | v matrix is refreshed in place before a replay (the graph holds its address);
+      * the packed-weight scratch of the point-wise GEMM may be used by the captured launches (r3d_set_wpack_in_capture):
+        this graph is the only user of its stream's scratch while it replays."""
+
+    def __init__(self, runner, example, grad_sink, loss_weight=0.1, lp_budget=None):
+        import ctypes
+        from . import _lib
+        from .mpti import EpisodeSlot
+        self.runner, self.model = runner, runner.model
+        m = self.model
+        self.E = example.E
+        dev = runner.dev
+        clone = lambda t: t.clone() if t is not None else None
+        # static inputs: the same layouts as the example (point-major views stay point-major views)
+        self.batch = EpisodeBatch(self._clone_x(example.support_x), example.support_y.clone(), self._clone_x(example.query_x),
+                                  example.query_y.clone(), clone(example.gt_support_y), clone(example.gt_query_y),
+                                  clone(example.support_flag))
+        self.lp_budget = int(lp_budget if lp_budget is not None else min(m.lp_max_iter, 96))
+        self.active_budget = self.lp_budget
+        self._mx_decay = 0
+        slot = EpisodeSlot(7000 + self.E)
+        slot.fixed_budget = self.lp_budget
+        slot.seed_dev = torch.full((1,), 104729, device=dev, dtype=torch.int32)
+        self.slot = slot
+        self.stream = torch.cuda.Stream()
+        lib = _lib.load()
+        saved_slot, saved_rec = m._slot, T.bn_recorder
+        buffers = {k: v.clone() for k, v in m.named_buffers()}  # warm-up passes must not count in the running statistics
+        sink_backup = [g.clone() for g in grad_sink]
+        counters_backup = runner.counters.clone()
+        old = lib.r3d_set_wpack_in_capture(1)
+        try:
+            m._slot = slot
+            m._lp_force = False
+            T.bn_recorder = runner.bn_records
+            cur = torch.cuda.current_stream()
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                for _ in range(2):  # eager warm-up on the capture stream: allocations, head buffers, the W scratch
+                    self._once(grad_sink, loss_weight)
+            cur.wait_stream(self.stream)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph(keep_graph=True)
+            with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
+                self._once(grad_sink, loss_weight)
+            self.graph.instantiate()
+        finally:
+            lib.r3d_set_wpack_in_capture(old)
+            m._slot, T.bn_recorder = saved_slot, saved_rec
+        with torch.no_grad():
+            for k, v in m.named_buffers():
+                v.copy_(buffers[k])
+            for g, b in zip(grad_sink, sink_backup):
+                g.copy_(b)
+            runner.counters.copy_(counters_backup)
+        n_cg = ctypes.c_int(0)
+        _lib.check(lib.r3d_graph_set_lp_budget(ctypes.c_void_p(self.graph.raw_cuda_graph()),
+                                               ctypes.c_void_p(self.graph.raw_cuda_graph_exec()), self.lp_budget, ctypes.byref(n_cg)))
+        assert n_cg.value > 0, "no CG nodes found in the captured batch"
+        torch.cuda.synchronize()
+
+    @staticmethod
+    def _clone_x(x):
+        if ops.is_point_major_view(x):
+            return x.transpose(-1, -2).contiguous().transpose(-1, -2)
+        return x.clone()
+
+    def _once(self, grad_sink, loss_weight):
+        self.out = explicit_train_batch(self.model, self.batch, grad_sink, loss_weight)
+        self.runner._count(backward=True)
+
+    def matches(self, batch):
+        b = self.batch
+        return (batch.E == b.E and batch.support_x.shape == b.support_x.shape and batch.query_x.shape == b.query_x.shape
+                and (batch.support_flag is None) == (b.support_flag is None)
+                and ops.is_point_major_view(batch.support_x) == ops.is_point_major_view(b.support_x))
+
+    def set_lp_budget(self, budget):
+        import ctypes
+        from . import _lib
+        budget = max(1, min(int(budget), self.lp_budget))
+        if budget == self.active_budget:
+            return
+        torch.cuda.current_stream().synchronize()  # never edit an executable graph that is in flight
+        _lib.check(_lib.load().r3d_graph_set_lp_budget(ctypes.c_void_p(self.graph.raw_cuda_graph()),
+                                                       ctypes.c_void_p(self.graph.raw_cuda_graph_exec()), budget, None))
+        self.active_budget = budget
+
+    def adapt(self, status):
+        """The CG budget of the next replays from a finished step's (bad, overflow, iterations, max)."""
+        bad, _, _, mx = status
+        if bad:
+            self._mx_decay = max(self._mx_decay, mx)
+            self.set_lp_budget(self.lp_budget)
+        elif mx > 0:
+            self._mx_decay = max(mx, self._mx_decay - max(1, self._mx_decay // 16))
+            self.set_lp_budget(max(24, 8 * ((self._mx_decay + self._mx_decay // 2 + 8 + 7) // 8)))
+
+    def replay(self, batch):
+        """One training pass of `batch` (same shapes as the example) on the current stream; returns what
+        explicit_train_batch returns (static tensors: valid until the next replay)."""
+        m, b = self.model, self.batch
+        with torch.no_grad():
+            # (the launch sequence reads the clouds through x_all alone; masks, labels and flags through their own tensors)
+            for dst, src in ((b.x_all, batch.x_all), (b.support_y, batch.support_y), (b.query_y, batch.query_y),
+                             (b.gt_support_y, batch.gt_support_y), (b.gt_query_y, batch.gt_query_y),
+                             (b.support_flag, batch.support_flag)):
+                if dst is not None and dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src)
+            if getattr(m, "use_attention", False):
+                m.att_learner._fold()  # in place: the graph holds the folded matrix's address
+        saved_slot = m._slot
+        m._slot = self.slot  # (lp_converged() and the status counters read the slot's head buffers)
+        try:
+            self.graph.replay()
+        finally:
+            m._slot = saved_slot
+        self.model.__dict__["_last_batch_slot"] = self.slot
+        return self.out
 
 
 def collate(episodes, batch_size):

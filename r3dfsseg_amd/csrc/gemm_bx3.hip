@@ -603,23 +603,37 @@ bool r3d_pointwise_bx3_ok(const float* X, long ldx, const float* W, long M, int 
 // one after the other and replays them concurrently: two slots sharing the buffer computed with each other's weights
 // pieces, caught by tests/test_gpu_parity_full.py) -- captured launch sequences take the kernel that cuts W itself,
 // which gives the same bits.
+// r3d_set_wpack_in_capture(1): the owner of a capture promises that the graph it captures is the ONLY user of its stream's
+// scratch while it replays (one graph per stream, replayed on that stream or never beside another replay of itself:
+// batched.BatchGraph) -- then a captured launch may use the stream's scratch too, provided it exists already (the
+// capture's eager warm-up passes on the same stream allocate it; nothing is allocated while capturing).
+static int g_wpack_in_capture = 0;
+extern "C" int r3d_set_wpack_in_capture(int on) {
+  const int old = g_wpack_in_capture;
+  g_wpack_in_capture = on ? 1 : 0;
+  return old;
+}
 struct WPackBuf { int dev; hipStream_t st; void* p; size_t cap; };
 static unsigned short* wpack_scratch(hipStream_t st, size_t bytes) {
   static std::mutex mu;
   static std::vector<WPackBuf> pool;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) return nullptr;
+  const bool capturing = cs != hipStreamCaptureStatusNone;
+  if (capturing && !g_wpack_in_capture) return nullptr;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lock(mu);
   for (auto& b : pool)
     if (b.dev == dev && b.st == st) {  // (the null stream is one handle on every device: the device is part of the key)
       if (b.cap >= bytes) return (unsigned short*)b.p;
+      if (capturing) return nullptr;
       void* p = nullptr;
       if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
       b.p = p; b.cap = bytes;  // (the old buffer stays allocated: launches already queued on the stream still read it)
       return (unsigned short*)p;
     }
+  if (capturing) return nullptr;
   void* p = nullptr;
   const size_t cap = bytes < (4u << 20) ? (4u << 20) : bytes;  // (512 x 512 pieces = 1.5 MB: one size fits the model)
   if (hipMalloc(&p, cap) != hipSuccess) return nullptr;

@@ -15,10 +15,13 @@ class SolverMiss(RuntimeError):
 
 
 class DPTrainer:
-    def __init__(self, learner, n_slots=0, example=None, lp_budget=None, batch_size=0, guard_every=64):
+    def __init__(self, learner, n_slots=0, example=None, lp_budget=None, batch_size=0, guard_every=64, batch_graph=False):
         """batch_size > 0 (the throughput path, batched.py): the local episodes of a step go through ONE launch sequence
         per batch of up to batch_size episodes -- every kernel works on the whole batch, the weight gradients are summed
         inside the dW GEMMs straight into the bucket.
+        batch_graph (with batch_size > 0): a step whose local episodes are ONE batch of that size replays the batch's
+        launch sequence as a captured hipGraph (batched.BatchGraph; captured at the first such step): same kernels, same
+        results, no per-launch host work.
         n_slots > 0 (round 2's schedule, kept for the single-episode learner): the episodes are replayed as captured
         hipGraphs, n_slots in flight on separate HIP streams (episode_graph.EpisodeGraphs; `example` = one episode fixing
         the shapes); every slot accumulates into its own gradient row and the rows are summed into the bucket.
@@ -35,6 +38,7 @@ class DPTrainer:
         self.graphs = None
         self.runner = None
         self.batch_size = batch_size
+        self.batch_graph = bool(batch_graph) and batch_size > 0
         self.last_outputs = []  # per-episode results of the last step: (loss, lp_loss, contrast_loss, logits (n_q, C, N), metrics (4,))
         self.redone = False   # did the last step fall back to the conservative schedule?
         self.n_redone = 0     # ... and how many steps did so far
@@ -69,12 +73,30 @@ class DPTrainer:
             self.runner.begin_step()
             total = None
             outs = []
+            use_graph = self.batch_graph and len(batches) == 1 and batches[0].E == self.batch_size
+            if use_graph and self.runner.__dict__.get("_graph") is None:
+                try:  # capture on first use; a stack that cannot capture this sequence keeps launching it eagerly
+                    from .batched import BatchGraph
+                    sink = [p.grad for p in self.bucket.params]
+                    self.runner._graph = BatchGraph(self.runner, batches[0], sink)
+                    self.runner._graph_sink = [t.data_ptr() for t in sink]
+                    self.bucket.zero_()
+                    self.runner.begin_step()
+                except Exception as exc:  # noqa: BLE001 -- whatever the capture ran into, the eager path is the same computation
+                    import warnings
+                    warnings.warn("batch graph capture failed (%r): the batched step stays on eager launches" % (exc,))
+                    self.batch_graph = use_graph = False
+                    torch.cuda.synchronize()
+                    self.bucket.zero_()
+                    self.runner.begin_step()
             for b in batches:
-                o = self.runner.train_batch(b, [p.grad for p in self.bucket.params])
+                o = (self.runner.train_batch_graph if use_graph else self.runner.train_batch)(b, [p.grad for p in self.bucket.params])
                 outs += [(o[0][e], o[3][e], o[4][e], o[1][e], o[2][e]) for e in range(b.E)]
                 loss = o[0].sum()
                 total = loss if total is None else total + loss
             self.last_status = self.runner.step_status()
+            if use_graph:
+                self.runner._graph.adapt(self.last_status)
             failed, apply_stats = None, self.runner.apply_running_stats
             if self.last_status[0] or self.last_status[1]:
                 eps = [b.episode(e) for b in batches for e in range(b.E)]

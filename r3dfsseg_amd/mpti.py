@@ -128,8 +128,8 @@ class MPTI_SelfAtten(nn.Module):
             if ev.query():
                 h = host.view(-1, 2)  # one {converged, iterations} pair per system of the batch
                 conv, iters = int(h[:, 0].min()), int(h[:, 1].max())
-                if conv:
-                    self._lp_budget = min(self.lp_max_iter, max(12, iters + iters // 3 + 4))
+                if conv:  # (half as many again + 8: a launch after convergence costs ~2.5 us, a miss redoes the whole step)
+                    self._lp_budget = min(self.lp_max_iter, max(16, iters + iters // 2 + 8))
                 else:
                     self._lp_budget = min(self.lp_max_iter, self._lp_budget * 2)
                 self._lp_probe = None

@@ -146,7 +146,7 @@ class MPTILearner_V3(object):
         from .dp_train import DPTrainer
         E = len(datas)
         if self._batch_trainer is None or self._batch_trainer.batch_size != E:
-            self._batch_trainer = DPTrainer(self, batch_size=E)
+            self._batch_trainer = DPTrainer(self, batch_size=E, batch_graph=True)
         tr = self._batch_trainer
         tr.step(datas, logger=logger)
         outs = tr.last_outputs

@@ -220,6 +220,49 @@ def test_dptrainer_batched_step_equals_eager_step():
         np.testing.assert_allclose(a[3][k].float().cpu().numpy(), b[3][k].float().cpu().numpy(), rtol=1e-3, atol=2e-4)
 
 
+def test_batch_graph_replay_equals_eager_batch():
+    """DPTrainer(batch_size=E, batch_graph=True): the batch's launch sequence as ONE captured hipGraph (batched.BatchGraph)
+    against the same trainer launching eagerly -- the same kernels with the same arguments, so with the dropout off (the
+    two keep different seed counters) every gradient, weight and running statistic agrees bit for bit over several steps,
+    new episodes are copied into the static inputs, and an under-budgeted solve is noticed and redone (fail closed)."""
+    from r3dfsseg_amd.dp_train import DPTrainer
+    cfg = S.make_cfg(n_way=2, k_shot=2, pc_npts=512)
+    sets = [_episodes(cfg, 3), [[t.clone() for t in ep] for ep in _episodes(cfg, 6)[3:]]]
+    res = {}
+    for mode in ("eager", "graph"):
+        m = _model(cfg, True, 0.0)
+        learner = SimpleNamespace(model=m)
+        learner.optimizer = torch.optim.Adam(
+            [{'params': m.encoder.parameters(), 'lr': 0.0001}, {'params': m.base_learner.parameters()},
+             {'params': m.att_learner.parameters()}, {'params': m.proj.parameters()}], lr=1e-3)
+        learner.lr_scheduler = torch.optim.lr_scheduler.StepLR(learner.optimizer, step_size=5000, gamma=0.5)
+        tr = DPTrainer(learner, batch_size=3, batch_graph=(mode == "graph"))
+        losses, grads = [], None
+        for it in range(4):
+            losses.append(float(tr.step(sets[it & 1])))
+            if it == 0:
+                grads = tr.bucket.flat.clone()
+        assert tr.n_redone == 0 and tr.last_status[0] == 0
+        outs = [tuple(t.clone() for t in o) for o in tr.last_outputs]
+        res[mode] = (losses, grads, torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone(),
+                     {k: v.clone() for k, v in m.named_buffers()}, outs)
+        if mode == "graph":
+            g = tr.runner._graph
+            assert g is not None and g.E == 3
+            g.set_lp_budget(2)  # far too few CG iterations enabled: the step must notice and redo its episodes exactly
+            l = float(tr.step(sets[0]))
+            assert tr.redone and tr.n_redone == 1 and np.isfinite(l)
+            assert g.active_budget == g.lp_budget  # a miss returns the budget to everything that was captured
+    a, b = res["eager"], res["graph"]
+    assert a[0] == b[0], (a[0], b[0])
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
+    for oa, ob in zip(a[4], b[4]):
+        for ta, tb in zip(oa, ob):
+            assert torch.equal(ta, tb)
+
+
 def test_lds_resident_spmv_gives_the_same_bits():
     """The CG's SpMV has two forms (one matrix row per wave gathering r from L2; 128-row workgroups with r staged in LDS,
     chosen when a launch holds enough systems): same arithmetic, same <p, q> partials -> bit-identical solves, forward
