@@ -4,7 +4,7 @@
 # (train S with the CPU baseline, eval S, train C).  Everything lands under gpurun_out/ (copy into profiles/ afterwards).
 #   bash tools/final_evidence.sh [TAG] [a|b]      a: profiles + PMC + train bench;  b: eval and workload-C bench lines
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 PART=${2:-a}
 cd "$GRAFT_REPO_ROOT"
 if [ "$PART" = "b" ]; then

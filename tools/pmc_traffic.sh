@@ -6,7 +6,7 @@
 # copies: 4 B and 16 B per lane).  Run on the GPU box from the repository root:  bash tools/pmc_traffic.sh [S|C] [TAG] [modes]
 set -e
 W=${1:-S}
-TAG=${2:-r03}
+TAG=${2:-r04}
 shift 2 || true
 MODES=${@:-train}
 export R3D_WORKLOAD=$W R3D_TAG=$TAG R3D_MODES="$MODES"

@@ -3,7 +3,7 @@
 # times do not overlap) -> gpurun_out/prof/${TAG}_rocprofv3_kernel_stats_${mode}_batched_${W}.txt (copy the ones to be
 # judged into profiles/).  Run on the GPU box from the repository root:  bash tools/profile.sh TAG [S|C] [train|eval ...]
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 W=${2:-S}
 shift 2 || true
 MODES=${@:-train eval}
