@@ -25,6 +25,7 @@
 // EC_CHUNK consecutive points of one cloud: a workgroup takes whole chunks, writes one partial per chunk, and a segment's
 // sums are its chunks added in ascending order in fp64 -- the same numbers whether the episode runs alone or inside a
 // batch, and whatever the grid.  The BatchNorm vectors of segment s sit at (pointer + s * bn_stride).
+#include <stdlib.h>
 #include "edge_tile.h"
 
 #define ET_LD 65
@@ -532,6 +533,88 @@ __global__ __launch_bounds__(1024) void r3d_edge_reverse_kernel(const int* __res
   }
 }
 
+// ---- the same lists without a sort (round 4): one workgroup of 8 waves per cloud ------------------------------------
+// The cloud's E = N K edges are dealt to the waves as 8 CONTIGUOUS ranges, walked in ascending order 64 edges at a time.
+//   count   hist[w][j] = edges of wave w's range that name target j (LDS atomics on the wave's own row);
+//   scan    off[j] = exclusive scan over j of the totals; hist[w][j] becomes the position of wave w's first entry of j;
+//   fill    a wave walks its range again: an edge's position is hist[w][j]++.  The 64 edges of a step belong to at most
+//           64 / K + 2 source points and the K neighbours of ONE point are distinct, so the step is done source point by
+//           source point: the lanes of one point increment DIFFERENT counters (no two of them race for a position), and
+//           the points follow each other in order (LDS operations of a wave execute in order) -- every target's entries
+//           come out in ascending edge order by construction, bit for bit the sorted lists of the kernel above, with no
+//           ranking pass and the cloud's lists read twice instead of 2 x N / 256 times.  (Lists that repeat a neighbour
+//           -- the garbage a non-finite feature cascade can leave, ids clamped to the cloud -- still get one position per
+//           edge from the atomics; only the order among the repeats is then unspecified.)
+// LDS: 8 N counters (64 KB at N = 2048, 128 KB at N = 4096); larger clouds take the kernel above.
+#define RO_WAVES 8
+__global__ __launch_bounds__(64 * RO_WAVES) void r3d_edge_reverse_ordered_kernel(const int* __restrict__ idx, int N, int K,
+                                                                                 int n_clouds, int* __restrict__ rev_ptr,
+                                                                                 int* __restrict__ rev) {
+  extern __shared__ int ro_hist[];  // [RO_WAVES][N]
+  __shared__ int ro_wsum[RO_WAVES];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cloud = blockIdx.x;
+  const int E = N * K;
+  const long gbase = (long)cloud * E;
+  const int* lst = idx + gbase;
+  const int per = ((E + RO_WAVES - 1) / RO_WAVES + 63) & ~63;  // edges per wave, whole steps
+  const int e_beg = min(w * per, E), e_end = min(e_beg + per, E);
+  int* mine = ro_hist + w * N;
+  for (int i = tid; i < RO_WAVES * N; i += 64 * RO_WAVES) ro_hist[i] = 0;
+  __syncthreads();
+  // ---- count (8 list entries in flight per lane)
+  for (int e0 = e_beg + lane; e0 < e_end; e0 += 8 * 64) {
+    int jv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) jv[u] = lst[min(e0 + 64 * u, E - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e0 + 64 * u < e_end) atomicAdd(&mine[min(max(jv[u], 0), N - 1)], 1);
+  }
+  __syncthreads();
+  // ---- scan: thread t owns targets [t * TPT, (t + 1) * TPT)
+  const int TPT = (N + 64 * RO_WAVES - 1) / (64 * RO_WAVES);
+  const int j0 = tid * TPT;
+  int tot = 0;
+  for (int j = j0; j < min(j0 + TPT, N); ++j)
+#pragma unroll
+    for (int q = 0; q < RO_WAVES; ++q) tot += ro_hist[q * N + j];
+  int incl = tot;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(incl, o);
+    if (lane >= o) incl += y;
+  }
+  if (lane == 63) ro_wsum[w] = incl;
+  __syncthreads();
+  int run = incl - tot;  // exclusive over the threads in front of this one
+  for (int q = 0; q < w; ++q) run += ro_wsum[q];
+  for (int j = j0; j < min(j0 + TPT, N); ++j) {
+    rev_ptr[(long)cloud * N + j] = (int)(gbase + run);
+#pragma unroll
+    for (int q = 0; q < RO_WAVES; ++q) {  // counts -> first positions, wave after wave
+      const int c = ro_hist[q * N + j];
+      ro_hist[q * N + j] = run;
+      run += c;
+    }
+  }
+  if (cloud == n_clouds - 1 && tid == 0) rev_ptr[(long)n_clouds * N] = (int)((long)n_clouds * E);
+  __syncthreads();
+  // ---- fill, source point by source point inside every step of 64 edges
+  for (int e0 = e_beg; e0 < e_end; e0 += 64) {
+    const int e = e0 + lane;
+    const bool ok = e < e_end;
+    const int j = min(max(lst[min(e, E - 1)], 0), N - 1);
+    const int src = e / K;
+    const int src0 = __builtin_amdgcn_readfirstlane(e0 / K);
+    const int src1 = __builtin_amdgcn_readfirstlane(min(e0 + 63, e_end - 1) / K);
+    int pos = 0;
+    for (int g = src0; g <= src1; ++g)  // (uniform trip count; a lane takes part in exactly one trip)
+      if (ok && src == g) pos = atomicAdd(&mine[j], 1);
+    if (ok) rev[gbase + pos] = (int)(gbase + e);
+  }
+}
+
 // ---- backward pass B2: dQ from the point sums of B1, dP by a gather over the incoming edges -----------------------
 template <int RT>
 __global__ __launch_bounds__(256) void r3d_edgeconv_bwd2_kernel(
@@ -757,8 +840,21 @@ extern "C" int r3d_edge_reverse(const int32_t* idx, int B, int N, int K, int32_t
               B, N, K);
   R3D_REQUIRE(ws_words >= r3d_edge_reverse_ws_words(B, N, K), "r3d_edge_reverse: workspace of %ld words is shorter than "
               "r3d_edge_reverse_ws_words(%d, %d, %d)", ws_words, B, N, K);
-  hipLaunchKernelGGL(r3d_edge_reverse_kernel, dim3(r3d_cdiv(N, RV_RANGE), B), dim3(1024), 0, (hipStream_t)stream, idx, N, K, B,
-                     rev_ws, rev_ws + (long)B * N + 1);
+  const size_t ro_lds = sizeof(int) * (size_t)RO_WAVES * N;
+  static const bool ro_off = getenv("R3D_EDGE_REVERSE_SORT") != nullptr;  // A/B switch: the sorting kernel
+  if (!ro_off && ro_lds <= 144 * 1024 && (long)N * K >= 64 * RO_WAVES) {
+    static size_t attr = 0;
+    if (ro_lds > attr) {
+      R3D_REQUIRE(hipFuncSetAttribute((const void*)r3d_edge_reverse_ordered_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)ro_lds) == hipSuccess, "r3d_edge_reverse: cannot reserve %zu B of LDS", ro_lds);
+      attr = ro_lds;
+    }
+    hipLaunchKernelGGL(r3d_edge_reverse_ordered_kernel, dim3(B), dim3(64 * RO_WAVES), ro_lds, (hipStream_t)stream, idx, N, K, B,
+                       rev_ws, rev_ws + (long)B * N + 1);
+  } else {
+    hipLaunchKernelGGL(r3d_edge_reverse_kernel, dim3(r3d_cdiv(N, RV_RANGE), B), dim3(1024), 0, (hipStream_t)stream, idx, N, K, B,
+                       rev_ws, rev_ws + (long)B * N + 1);
+  }
   R3D_LAUNCH_CHECK("r3d_edge_reverse");
   return R3D_OK;
 }
