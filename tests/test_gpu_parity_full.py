@@ -263,9 +263,14 @@ def test_config2_full_size_training_episode_gradients():
         print("   %.2e  %.2e  %.2e  %3d of %6d  %s" % r_)
     print("   median max-rel HIP %.2e, torch-fp32 %.2e; parameters with max-rel <= 1e-3: %d of %d" % (
         np.median([r_[0] for r_ in rows]), np.median([r_[1] for r_ in rows]), sum(r_[0] <= 1e-3 for r_ in rows), len(rows)))
+    # (the wider bars belong to the bf16 x 3 arithmetic, whose kink lottery drew 6 flipped parameters on this episode; with
+    # R3D_MATRIX_ARITH=fp32 the bars of the fp32 kernels stand: 1e-3 relative L2, 5e-3 on at most 0.1 % of the entries)
+    from r3dfsseg_amd import _lib as _lb
+    bx3 = _lb.load().r3d_get_matrix_arith() == 1
+    l2_bar, tail_bar, tail_frac = (3e-3, 1e-2, 100) if bx3 else (1e-3, 5e-3, 1000)
     for e_hip, e_t32, l2, n_out, numel, name in rows:
-        assert l2 <= 3e-3, (name, l2)
-        assert e_hip <= 1e-3 or e_hip <= 2.0 * e_t32 or (e_hip <= 1e-2 and n_out <= max(4, numel // 100)), (
+        assert l2 <= l2_bar, (name, l2)
+        assert e_hip <= 1e-3 or e_hip <= 2.0 * e_t32 or (e_hip <= tail_bar and n_out <= max(4, numel // tail_frac)), (
             name, e_hip, e_t32, n_out, numel)
     assert np.median([r_[0] for r_ in rows]) <= 1e-3
 
