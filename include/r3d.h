@@ -38,7 +38,7 @@ extern "C" {
 #endif
 
 const char* r3d_last_error_string(void);
-int r3d_abi_version(void);
+int r3d_abi_version(void); /* 4 (round 4: r3d_edge_stats1 + esum, r3d_edgeconv_bwd + zwin, esum) */
 /* Arithmetic of the GEMM-shaped kernels that decide no index (self-attention forward / backward, r3d_pointwise_conv*,
  * r3d_gemm_tn): 0 = fp32 matrix core (v_mfma_f32_32x32x2_f32), 1 = every fp32 operand cut into three bf16 pieces, six
  * v_mfma_f32_32x32x16_bf16 per product block accumulated in fp32 (fp32-level accuracy at 2.67x the matrix rate;

@@ -135,6 +135,9 @@ def header_symbols():
     return sorted(set(re.findall(r"\b(r3d_[a-z0-9_]+)\s*\(", txt)))
 
 
+ABI_VERSION = 4  # include/r3d.h; 4 (round 4): r3d_edge_stats1(+esum), r3d_edgeconv_bwd(+zwin, esum)
+
+
 def load():
     """Load the shared library and bind every declared symbol; raises if anything is missing."""
     global _lib
@@ -158,6 +161,9 @@ def load():
         fn.restype = res
         fn.argtypes = args
         setattr(lib, name, fn)
+    if lib.r3d_abi_version() != ABI_VERSION:  # a stale build would be CALLED with this round's argument lists
+        raise RuntimeError("r3dfsseg_amd: %s has C ABI version %d, this package binds version %d -- rebuild it "
+                           "(`python -m r3dfsseg_amd.build --force`)" % (LIB_PATH, lib.r3d_abi_version(), ABI_VERSION))
     _lib = lib
     mode = os.environ.get("R3D_MATRIX_ARITH")  # "fp32" | "bf16x3": see r3d_set_matrix_arith in include/r3d.h
     if mode is not None:

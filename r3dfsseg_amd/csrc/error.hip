@@ -13,7 +13,7 @@ void r3d_set_error(const char* fmt, ...) {
 
 extern "C" const char* r3d_last_error_string(void) { return g_err; }
 
-extern "C" int r3d_abi_version(void) { return 3; }
+extern "C" int r3d_abi_version(void) { return 4; }
 
 // Arithmetic of the GEMM-shaped kernels that decide no index (attention; see common.h "bf16 x 3"): 0 = fp32 matrix
 // core, 1 = fp32 values as three bf16 pieces on the bf16 matrix core (default: same accuracy against a float64

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert set(_lib._SIGS) == set(declared), set(_lib._SIGS) ^ set(declared)
     lib.r3d_abi_version.restype = ctypes.c_int
-    assert lib.r3d_abi_version() == 3
+    assert lib.r3d_abi_version() == 4
     lib.r3d_head_desc_words.restype = ctypes.c_int
     assert lib.r3d_head_desc_words() == 32
     lib.r3d_lp_ws_words.restype = ctypes.c_long
