@@ -29,6 +29,19 @@ def test_library_exports_every_declared_symbol():
     assert lib.r3d_lp_ws_words(4396, 201) > 0
 
 
+def test_loading_a_library_of_another_abi_version_is_refused(monkeypatch):
+    """A stale libr3d_hip.so would be called with this package's argument lists (round 4 added arguments to two entry
+    points): load() compares r3d_abi_version() with the version the bindings were written for and says how to rebuild."""
+    from r3dfsseg_amd import build
+    build.build()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(RuntimeError, match="C ABI version 4.*rebuild"):
+        _lib.load()
+    monkeypatch.setattr(_lib, "ABI_VERSION", 4)
+    assert _lib.load().r3d_abi_version() == 4
+
+
 def test_binding_signatures_match_the_header():
     """Every prototype of include/r3d.h against the ctypes signature the binding declares for it: argument count, and per
     argument the class of its type (pointer / int / long / float / double / unsigned).  A binding that has drifted from the
