@@ -58,6 +58,19 @@ static __device__ __forceinline__ float r3d_sum8_dpp(float v) {
   return v;
 }
 
+// Inclusive prefix sum over the 64 lanes in the VALU (DPP row shifts inside the rows of 16, then the row totals carried
+// over by row_bcast:15 and row_bcast:31): 12 instructions, no LDS crossbar round trips (six ds_bpermute of __shfl_up are
+// ~100 cycles each).
+static __device__ __forceinline__ int r3d_wave_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false); // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 static __device__ __forceinline__ float r3d_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

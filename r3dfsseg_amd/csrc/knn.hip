@@ -912,6 +912,14 @@ void r3d_knn_append_kernel(
   static_assert(!BFB || 32 * KB_CAP <= 32 * (KB_TOP * KB_GROUPS + 1), "the index buffer must end in front of the query pieces");
   float* bufv = region + (BFB ? 32 * KB_CAP : 0);          // [32][KB_CAP]
   int* bufi = (int*)(region + (BFB ? 0 : 32 * KB_CAP));    // [32][KB_CAP]
+  // BMP (the filter pass of the k <= 32 configuration): survivors are recorded as ONE BIT each -- the ballot of a score
+  // register's comparison is the 32-candidate mask of two queries -- in a bitmap [sub-tile][query] that sits in the index
+  // buffer's own place (32 KB_CAP words: up to KB_CAP sub-tiles, N <= 32 KB_CAP; the launcher sees to it) and is turned
+  // into the index lists per query once the pass is over.  No LDS atomic: an appending ds_add_rtn costs ~70 cycles per
+  // INSTRUCTION whatever the number of survivors among its lanes, 16 per sub-tile and wave = 18 k of the pass's 59 k
+  // cycles per tile (profiles/r04_experiments.md section 6); and the lists come out in candidate order.
+  constexpr bool BMP = BFB && KB_WAVES == 4;
+  unsigned* bm = reinterpret_cast<unsigned*>(region);  // [sub-tile ls][(q + ls) & 31]: rows written, columns read without bank conflicts
   bool overflow = false;
   auto finishB = [&](int t) {
     if ((t % nch) != nch - 1) return;
@@ -937,6 +945,67 @@ void r3d_knn_append_kernel(
     const int st = (w + KB_WAVES * i) * nsplit + z;
     f32x16 sc;
     scores_ub(st, sc);
+    if (BMP) {
+      // lane q < 32 collects the mask of query q: registers r of the two lane halves are queries row(r, 0), row(r, 1)
+      // (v_writelane_b32 with a constant lane: this clang has no builtin for it.  A v_writelane that reads an SGPR as DATA
+      // right behind the VALU instruction that wrote it gets the old value on gfx950 -- measured: every tile came out with
+      // wrong masks until wait states separated the two; the compiler's hazard recogniser does not look into inline
+      // assembly -- so all 16 comparisons are issued first, then the 32 lane writes: 16+ instructions lie between a
+      // comparison and the first read of its mask.)
+      unsigned long long m[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m[r] = __ballot(sc[r] >= tauq[r]);
+      __builtin_amdgcn_sched_barrier(0);
+      int word = 0;
+#define KB_LO(r) "s"((int)(unsigned)(m[r] & 0xffffffffull))
+#define KB_HI(r) "s"((int)(unsigned)(m[r] >> 32))
+      // (two statements: an asm statement takes at most 30 operands; register r's two masks go to lanes row(r, 0), row(r, 1))
+      asm volatile(
+                   "s_nop 4\n\t"
+                   "v_writelane_b32 %0, %1, 0\n\t"
+                   "v_writelane_b32 %0, %2, 4\n\t"
+                   "v_writelane_b32 %0, %3, 1\n\t"
+                   "v_writelane_b32 %0, %4, 5\n\t"
+                   "v_writelane_b32 %0, %5, 2\n\t"
+                   "v_writelane_b32 %0, %6, 6\n\t"
+                   "v_writelane_b32 %0, %7, 3\n\t"
+                   "v_writelane_b32 %0, %8, 7\n\t"
+                   "v_writelane_b32 %0, %9, 8\n\t"
+                   "v_writelane_b32 %0, %10, 12\n\t"
+                   "v_writelane_b32 %0, %11, 9\n\t"
+                   "v_writelane_b32 %0, %12, 13\n\t"
+                   "v_writelane_b32 %0, %13, 10\n\t"
+                   "v_writelane_b32 %0, %14, 14\n\t"
+                   "v_writelane_b32 %0, %15, 11\n\t"
+                   "v_writelane_b32 %0, %16, 15"
+                   : "+v"(word)
+                   : KB_LO(0), KB_HI(0), KB_LO(1), KB_HI(1), KB_LO(2), KB_HI(2), KB_LO(3), KB_HI(3), KB_LO(4), KB_HI(4), KB_LO(5), KB_HI(5), KB_LO(6), KB_HI(6), KB_LO(7), KB_HI(7));
+      asm volatile(
+                   "v_writelane_b32 %0, %1, 16\n\t"
+                   "v_writelane_b32 %0, %2, 20\n\t"
+                   "v_writelane_b32 %0, %3, 17\n\t"
+                   "v_writelane_b32 %0, %4, 21\n\t"
+                   "v_writelane_b32 %0, %5, 18\n\t"
+                   "v_writelane_b32 %0, %6, 22\n\t"
+                   "v_writelane_b32 %0, %7, 19\n\t"
+                   "v_writelane_b32 %0, %8, 23\n\t"
+                   "v_writelane_b32 %0, %9, 24\n\t"
+                   "v_writelane_b32 %0, %10, 28\n\t"
+                   "v_writelane_b32 %0, %11, 25\n\t"
+                   "v_writelane_b32 %0, %12, 29\n\t"
+                   "v_writelane_b32 %0, %13, 26\n\t"
+                   "v_writelane_b32 %0, %14, 30\n\t"
+                   "v_writelane_b32 %0, %15, 27\n\t"
+                   "v_writelane_b32 %0, %16, 31"
+                   : "+v"(word)
+                   : KB_LO(8), KB_HI(8), KB_LO(9), KB_HI(9), KB_LO(10), KB_HI(10), KB_LO(11), KB_HI(11), KB_LO(12), KB_HI(12), KB_LO(13), KB_HI(13), KB_LO(14), KB_HI(14), KB_LO(15), KB_HI(15));
+#undef KB_LO
+#undef KB_HI
+      __builtin_amdgcn_sched_barrier(0);
+      const int ls = w + KB_WAVES * i;  // (nsplit == 1 in this configuration: st == ls)
+      if (lane < 32) bm[ls * 32 + ((lane + ls) & 31)] = (unsigned)word;
+      return;
+    }
     // (one returning LDS atomic per survivor.  Reserving a half-wave's slots with ONE atomic per register -- all 16 issued
     // back to back, the survivors ranked by ballot -- was measured and lost: 68.8 k against 59.2 k cycles per tile for this
     // pass; most registers have no survivor, and the branch around the atomic is cheaper than the ranking arithmetic.)
@@ -969,6 +1038,42 @@ void r3d_knn_append_kernel(
     }
   }
   KSTAMP(12);
+  if (BMP) {
+    __syncthreads();  // every sub-tile's masks are in the bitmap
+    constexpr int QW = 32 / KB_WAVES, NCH = (KB_CAP + 63) / 64;  // (nsub <= KB_CAP sub-tiles: NCH words per lane and query)
+    unsigned wq[QW][NCH];
+#pragma unroll
+    for (int i = 0; i < QW; ++i)
+#pragma unroll
+      for (int cch = 0; cch < NCH; ++cch) {
+        const int ls = 64 * cch + lane;
+        wq[i][cch] = ls < nsub ? bm[ls * 32 + ((QW * w + i + ls) & 31)] : 0u;
+      }
+    __syncthreads();  // the index lists take the bitmap's place
+#pragma unroll
+    for (int i = 0; i < QW; ++i) {
+      const int q = QW * w + i;
+      int total = 0;
+#pragma unroll
+      for (int cch = 0; cch < NCH; ++cch) {
+        if (64 * cch >= nsub) break;  // (uniform)
+        unsigned word = wq[i][cch];
+        const int c = __popc(word);
+        const int incl = r3d_wave_incl_scan(c);
+        int off = total + incl - c;
+        const int cand0 = 32 * ((64 * cch + lane) * nsplit + z);
+        while (word) {  // candidates in ascending order
+          const int bit = __ffs((int)word) - 1;
+          if (off < KB_CAP) bufi[q * KB_CAP + off] = cand0 + bit;
+          ++off;
+          word &= word - 1;
+        }
+        total += __builtin_amdgcn_readlane(incl, 63);
+      }
+      if (lane == 0) cnt_s[q] = total;
+      overflow = overflow || total > KB_CAP;
+    }
+  }
   if (__any(overflow) && lane == 0) {
     if (status) atomicOr(status, 1);
     if (tile_flags) tile_flags[(long)b * gridDim.x + tile_x] = 1;
@@ -1462,9 +1567,11 @@ static int knn_topk_impl(const float* x, long ldx, const float* x_cm, int B, int
           pack_bf();
           // (with the filter on the bf16 core the threshold pass visits EVERY sub-tile: a tighter threshold means fewer
           // survivors, and their exact scores cost more than the half pass saved -- 3.30 against 3.63 ms per 384 clouds)
-          rc = xpm ? knn_append_launch_bfa<KM_WAVES, KM_CAP, KM_TOP, 1>(
+          // (the filter's survivor bitmap, 32 words per sub-tile, sits in the index buffer's 32 KM_CAP words)
+          const float* xpm_f = (r3d_cdiv(N, 32) <= KM_CAP) ? xpm : nullptr;
+          rc = xpm_f ? knn_append_launch_bfa<KM_WAVES, KM_CAP, KM_TOP, 1>(
                          g2, knn_append_lds_bytes(C, KM_WAVES, KM_CAP, KM_TOP, 32, true), st, xT, ldT, N, C, k, mode, n_valid_dev,
-                         n_valid_stride, norm_ws, idx_out, score_out, nullptr, tile_flags, (const unsigned short*)bf_ws, bf_cnorm, xpm, ldx)
+                         n_valid_stride, norm_ws, idx_out, score_out, nullptr, tile_flags, (const unsigned short*)bf_ws, bf_cnorm, xpm_f, ldx)
                    : knn_append_launch_bfa<KM_WAVES, KM_CAP, KM_TOP, KM_SAMPLE>(
                          g2, knn_append_lds_bytes(C, KM_WAVES, KM_CAP, KM_TOP, 32, true), st, xT, ldT, N, C, k, mode, n_valid_dev,
                          n_valid_stride, norm_ws, idx_out, score_out, nullptr, tile_flags, (const unsigned short*)bf_ws, bf_cnorm, nullptr, 0);
