@@ -601,7 +601,9 @@ void r3d_knn_append_kernel(
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, j = lane & 31;
   const int nch = (C + 2 * KCH - 1) / (2 * KCH);  // channel chunks of 2 KCH
-  const int Cs = nch * 2 * KCH + 1;               // LDS row stride of the query fragments (odd)
+  // LDS row stride of the fp32 query rows: odd for the fp32 passes (lane = row reads a column); a multiple of 4 where only
+  // the exact scores of the bf16 filter's survivors read them (BFB: 16-byte row segments, 8 distinct rows per wave)
+  const int Cs = nch * 2 * KCH + (BFB ? 4 : 1);
   float* Aq = smem;                       // [32][Cs]
   float* region = smem + 32 * Cs;         // pass A: gmax [32][2*KB_GROUPS + 1]; pass B: buffers
   const float* xb = xT + (long)b * C * ldT;
@@ -1134,13 +1136,16 @@ void r3d_knn_append_kernel(
       __builtin_amdgcn_sched_barrier(0);
       const int sg = t % nseg;
       if (sg == 0) a = 0.f;
-      const float* aq = Aq + q_cur * Cs + 32 * sg;
+      const float4* aq = reinterpret_cast<const float4*>(Aq + q_cur * Cs + 32 * sg);  // (Cs % 4 == 0 here)
+      float4 qa[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) qa[u] = aq[u];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        a = __builtin_fmaf(aq[4 * u], xa[u].x, a);
-        a = __builtin_fmaf(aq[4 * u + 1], xa[u].y, a);
-        a = __builtin_fmaf(aq[4 * u + 2], xa[u].z, a);
-        a = __builtin_fmaf(aq[4 * u + 3], xa[u].w, a);
+        a = __builtin_fmaf(qa[u].x, xa[u].x, a);
+        a = __builtin_fmaf(qa[u].y, xa[u].y, a);
+        a = __builtin_fmaf(qa[u].z, xa[u].z, a);
+        a = __builtin_fmaf(qa[u].w, xa[u].w, a);
       }
       if (sg == nseg - 1 && ok_cur) {
         const int cand = min(max(bufi[q_cur * KB_CAP + slot_cur], 0), n - 1);
@@ -1160,6 +1165,7 @@ void r3d_knn_append_kernel(
       q_cur = qn; slot_cur = slotn; ok_cur = okn;
     }
   }
+  KSTAMP(15);
   // ------------------------------------------------------------------ rank the survivors
   for (int qq = 0; qq < 32 / KB_WAVES; ++qq) {
     const int q = (32 / KB_WAVES) * w + qq;
@@ -1273,7 +1279,7 @@ __global__ __launch_bounds__(256) void r3d_knn_merge_kernel(const int* __restric
 
 static size_t knn_append_lds_bytes(int C, int waves, int cap, int top, int kch = 32, bool bfa = false) {
   const int nch = (C + 2 * kch - 1) / (2 * kch);
-  const size_t a = 32 * (size_t)(nch * 2 * kch + 1);
+  const size_t a = 32 * (size_t)(nch * 2 * kch + 4);  // (row stride + 1 for the fp32 passes, + 4 for the filter form)
   size_t g = 32 * (size_t)(top * waves * 32 + 1);
   if (bfa) g = ((g + 3) & ~(size_t)3) + 32 * (size_t)(2 * nch * 64 + 8) / 2 + 64;  // + the query rows' bf16 pieces, bound terms
   const size_t bsz = 2 * 32 * (size_t)cap;
