@@ -953,7 +953,9 @@ void r3d_knn_append_kernel(
       // right behind the VALU instruction that wrote it gets the old value on gfx950 -- measured: every tile came out with
       // wrong masks until wait states separated the two; the compiler's hazard recogniser does not look into inline
       // assembly -- so all 16 comparisons are issued first, then the 32 lane writes: 16+ instructions lie between a
-      // comparison and the first read of its mask.)
+      // comparison and the first read of its mask; five wait states in front of each statement -- the distance that was
+      // measured to be enough -- cover a mask the register allocator might reload right there.  A wrong mask cannot go
+      // unnoticed in the tests: indices and score bits are compared with the oracle's.)
       unsigned long long m[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) m[r] = __ballot(sc[r] >= tauq[r]);
@@ -983,6 +985,7 @@ void r3d_knn_append_kernel(
                    : "+v"(word)
                    : KB_LO(0), KB_HI(0), KB_LO(1), KB_HI(1), KB_LO(2), KB_HI(2), KB_LO(3), KB_HI(3), KB_LO(4), KB_HI(4), KB_LO(5), KB_HI(5), KB_LO(6), KB_HI(6), KB_LO(7), KB_HI(7));
       asm volatile(
+                   "s_nop 4\n\t"  // (as above: should the register allocator ever reload a mask right in front of this statement)
                    "v_writelane_b32 %0, %1, 16\n\t"
                    "v_writelane_b32 %0, %2, 20\n\t"
                    "v_writelane_b32 %0, %3, 17\n\t"

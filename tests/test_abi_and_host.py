@@ -163,3 +163,35 @@ def test_no_packed_fp32_arithmetic_in_the_device_code(tmp_path):
         for op in ("v_pk_fma_f32", "v_pk_add_f32", "v_pk_mul_f32"):
             assert op not in dis, (op, os.path.basename(o))
     assert n_mfma > 100  # it really was the device code
+
+
+def test_lane_writes_keep_their_distance_from_the_mask_they_read(tmp_path):
+    """The kNN filter pass collects ballot masks with blocks of 16 `v_writelane_b32 v, sN, lane` from inline assembly,
+    which the compiler's hazard recogniser does not see; on gfx950 such a write reads a STALE sN when it follows the
+    vector instruction that wrote sN directly (csrc/knn.hip, profiles/r04_experiments.md section 6).  Look at the built
+    code: every such block (8 or more lane writes in a row -- the compiler's own SGPR spills come in ones and twos and
+    carry its own wait states) starts behind `s_nop 4`, the distance that was measured to be enough."""
+    import glob
+    import re
+    import shutil
+    import subprocess
+    from r3dfsseg_amd import _lib
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(objdump) and os.path.exists(_lib.LIB_PATH)):
+        pytest.skip("llvm-objdump or the built library is not here")
+    so = shutil.copy(_lib.LIB_PATH, str(tmp_path / "lib.so"))
+    subprocess.run([objdump, "--offloading", so], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    blocks = 0
+    for o in glob.glob(str(tmp_path / "lib.so.*gfx950")):
+        dis = subprocess.run([objdump, "-d", "--no-show-raw-insn", o], check=True, capture_output=True, text=True).stdout
+        ins = [l.split("//")[0].strip() for l in dis.splitlines() if l.startswith("\t")]
+        i = 0
+        while i < len(ins):
+            j = i
+            while j < len(ins) and re.match(r"v_writelane_b32 v\d+, (?:s\d+|vcc_lo|vcc_hi), \d+$", ins[j]):
+                j += 1
+            if j - i >= 8:
+                blocks += 1
+                assert i > 0 and ins[i - 1] == "s_nop 4", (os.path.basename(o), ins[max(0, i - 3):i + 1])
+            i = max(j, i + 1)
+    assert blocks >= 4  # two blocks per sub-tile in every instantiation of the filter pass
