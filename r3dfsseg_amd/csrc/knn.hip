@@ -522,6 +522,72 @@ __global__ __launch_bounds__(256) void r3d_knn_small_kernel(
   KSTAMP(4);
 }
 
+// Bitonic sort of 64 R keys of 64 bits across one wave, DESCENDING; element e = 64 i + lane sits in register i of lane
+// `lane`.  Stages with a partner distance below 64 exchange across lanes (knn_lane_xor, twice per register), the others
+// between registers of the same lane; every loop is unrolled, the directions are compile-time or lane constants.
+// Used to rank the 201-NN's survivors: sorting 256 keys takes 36 stages of ~6 instructions per register, where counting
+// every key against every other one takes M x (2 v_readlane + 2 R instructions) -- 3.2 k instructions for 230 survivors.
+// v of lane (lane ^ j), j a power of two below 64, inside the VALU: DPP quad permutes (1, 2), row shifts under bank masks
+// (4), a row rotation (8), and gfx950's row / half swaps (16, 32).  No LDS crossbar: a ds_bpermute is a ~200-cycle round
+// trip, and a sorting network is a chain of them (36 dependent stages: 20 k cycles per 256 keys with __shfl_xor, measured).
+static __device__ __forceinline__ unsigned knn_lane_xor(unsigned v, int j, int lane) {
+  const int x = (int)v;
+  switch (j) {
+    case 1: return (unsigned)__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    case 2: return (unsigned)__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    case 4: {
+      const int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);            // row_shl:4 into banks 0, 2 (lane + 4)
+      return (unsigned)__builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);         // row_shr:4 into banks 1, 3 (lane - 4)
+    }
+    case 8: return (unsigned)__builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false);   // row_ror:8
+    case 16: {
+      const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // {rows 0 0 2 2, rows 1 1 3 3}
+      return (lane & 16) ? r[0] : r[1];
+    }
+    default: {
+      const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // {rows 0 1 0 1, rows 2 3 2 3}
+      return (lane & 32) ? r[0] : r[1];
+    }
+  }
+}
+
+template <int R>
+static __device__ __forceinline__ void knn_bitonic_desc(unsigned (&khi)[R], unsigned (&klo)[R], int lane) {
+  static_assert(R == 1 || R == 2 || R == 4 || R == 8, "a power of two");
+#pragma unroll
+  for (int k = 2; k <= 64 * R; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= 64) {
+        const int dj = j >> 6;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          if (i & dj) continue;
+          const bool desc = ((64 * i) & k) == 0;  // (k >= 128 here: the block's direction is a property of the register)
+          const unsigned long long a = ((unsigned long long)khi[i] << 32) | klo[i];
+          const unsigned long long b = ((unsigned long long)khi[i + dj] << 32) | klo[i + dj];
+          const bool swap = desc ? a < b : a > b;
+          const unsigned ah = khi[i], al = klo[i];
+          khi[i] = swap ? khi[i + dj] : ah; klo[i] = swap ? klo[i + dj] : al;
+          khi[i + dj] = swap ? ah : khi[i + dj]; klo[i + dj] = swap ? al : klo[i + dj];
+        }
+      } else {
+        const bool lower = (lane & j) == 0;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          const bool desc = (((64 * i) | lane) & k) == 0;
+          const unsigned oh = knn_lane_xor(khi[i], j, lane), ol = knn_lane_xor(klo[i], j, lane);
+          const unsigned long long a = ((unsigned long long)khi[i] << 32) | klo[i];
+          const unsigned long long b = ((unsigned long long)oh << 32) | ol;
+          const bool take = (lower == desc) ? b > a : b < a;  // this element keeps the larger (smaller) of the pair
+          khi[i] = take ? oh : khi[i];
+          klo[i] = take ? ol : klo[i];
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // 32 < k <= 256 (the head's 201-NN over graph nodes, C = 192): exact two-pass selection,
 // streamed like the small kernel, with the survivors of pass B APPENDED to a per-query LDS
@@ -1191,9 +1257,35 @@ void r3d_knn_append_kernel(
       key[i] = ((unsigned long long)khi[i] << 32) | klo[i];
       rank[i] = 0;
     }
+    // 64 < M <= 256 (the 201-NN: ~230 survivors): SORT the keys (knn_bitonic_desc) with the buffer slot in the low 9 bits
+    // behind a 22-bit index, so that a sorted key still finds its score bits (-0 and +0 share a key) and its index
+    bool sorted = false;
+    if constexpr (KB_CAP >= 256) {
+    if (M > 64 && M <= 256 && N <= (1 << 22)) {  // (uniform)
+      unsigned sh[4], sl[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = 64 * i + lane;
+        sh[i] = e < M ? khi[i] : 0u;
+        sl[i] = e < M ? ((0x3fffffu - (unsigned)mi[i]) << 9) | (unsigned)e : 0u;
+      }
+      knn_bitonic_desc<4>(sh, sl, lane);
+#pragma unroll
+      for (int i = 0; i < KB_CAP / 64; ++i) {
+        const int e = 64 * i + lane;
+        const int slot = i < 4 ? (int)(sl[i < 4 ? i : 0] & 511u) : 0;
+        const bool out = i < 4 && e < M;
+        mi[i] = out ? bufi[q * KB_CAP + slot] : 0x7fffffff;
+        mv[i] = out ? bufv[q * KB_CAP + slot] : -INFINITY;
+        rank[i] = e;  // the sorted position
+      }
+      sorted = true;
+    }
+    }
     // every survivor against every survivor: the opponent's key comes out of the registers the entries sit in
     // (two v_readlane with a uniform lane index), one 64-bit compare and one add per own entry
-    if (M <= 64) {  // uniform; the usual case of the k <= 32 configuration: one register of entries, half the compares
+    if (sorted) {
+    } else if (M <= 64) {  // uniform; the usual case of the k <= 32 configuration: one register of entries, half the compares
 #pragma unroll 4
       for (int t = 0; t < M; ++t) {
         const unsigned long long ok = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)khi[0], t) << 32) |
