@@ -40,6 +40,7 @@ int main(int argc, char** argv) {
   hipDeviceSynchronize();
   hipMemcpyFromSymbol(d, HIP_SYMBOL(g_knn_dbg), sizeof(d));
   printf("  append stamps (ticks): stage %llu  passA %llu  tau %llu  passB %llu  lists %llu  exact %llu  rank %llu\n", d[9]-d[8], d[10]-d[9], d[11]-d[10], d[12]-d[11], d[14]-d[12], d[15]-d[14], d[13]-d[15]);
+  if (getenv("KB_RAW")) { for (int i = 0; i < 16; ++i) printf(" d[%d]=%llu", i, d[i]); printf("\n"); }
   printf("  stamps: passA %llu  tau %llu  passB %llu  merge %llu\n", d[1]-d[0], d[2]-d[1], d[3]-d[2], d[4]-d[3]);
 #endif
   return 0;
