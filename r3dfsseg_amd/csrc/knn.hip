@@ -928,14 +928,14 @@ void r3d_knn_append_kernel(
     load_kb(0);
     bf_pass((w < nsub) ? (my_sub + KB_SAMPLE - 1) / KB_SAMPLE : 0, finishA_sub);
   } else {
-    if (TA > 0) bload(0, bfA);
-    for (int t = 0; t < TA; ++t) {
+    if (TA > 0) bload(0, bfB);
+    for (int t = 0; t < TA; ++t) {  // (copies at the top of the trip: see pass B)
+#pragma unroll
+      for (int s = 0; s < KCH; ++s) bfA[s] = bfB[s];
       if (t + 1 < TA) bload(t + 1, bfB);
       __builtin_amdgcn_sched_barrier(0);
       mma(t, bfA);
       finishA(t);
-#pragma unroll
-      for (int s = 0; s < KCH; ++s) bfA[s] = bfB[s];
     }
   }
   KSTAMP(10);
@@ -1098,14 +1098,18 @@ void r3d_knn_append_kernel(
     load_kb(1);
     bf_pass((w < nsub) ? my_sub : 0, finishBF);
   } else {
-    if (T > 0) bload(0, bfA);
+    // (the hand-over copies stand at the TOP of the trip: with the first fragment loaded straight into bfA in front of
+    // the loop, the compiler's wait-count pass took bfA for load results at the loop header and made every MFMA of a
+    // chain wait for one more of the loads issued right in front of it -- a memory round trip at the start of every
+    // chain, 78 k of pass B's 358 k cycles per tile in the 201-NN)
+    if (T > 0) bload(0, bfB);
     for (int t = 0; t < T; ++t) {
+#pragma unroll
+      for (int s = 0; s < KCH; ++s) bfA[s] = bfB[s];
       if (t + 1 < T) bload(t + 1, bfB);
       __builtin_amdgcn_sched_barrier(0);
       mma(t, bfA);
       finishB(t);
-#pragma unroll
-      for (int s = 0; s < KCH; ++s) bfA[s] = bfB[s];
     }
   }
   KSTAMP(12);
