@@ -1261,24 +1261,34 @@ void r3d_knn_append_kernel(
       key[i] = ((unsigned long long)khi[i] << 32) | klo[i];
       rank[i] = 0;
     }
-    // 64 < M <= 256 (the 201-NN: ~230 survivors): SORT the keys (knn_bitonic_desc) with the buffer slot in the low 9 bits
+    // M > 64 (the 201-NN: ~230 survivors): SORT the keys (knn_bitonic_desc) with the buffer slot in the low 9 bits
     // behind a 22-bit index, so that a sorted key still finds its score bits (-0 and +0 share a key) and its index
     bool sorted = false;
     if constexpr (KB_CAP >= 256) {
-    if (M > 64 && M <= 256 && N <= (1 << 22)) {  // (uniform)
-      unsigned sh[4], sl[4];
+    if (M > 64 && N <= (1 << 22)) {  // (uniform)
+      constexpr int RMAX = KB_CAP > 256 ? 8 : 4;  // registers of the larger network: 64 RMAX >= KB_CAP
+      static_assert(64 * RMAX >= KB_CAP && KB_CAP <= 512, "the slot field of a sort key has 9 bits");
+      unsigned sh[RMAX], sl[RMAX];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < RMAX; ++i) {
         const int e = 64 * i + lane;
-        sh[i] = e < M ? khi[i] : 0u;
-        sl[i] = e < M ? ((0x3fffffu - (unsigned)mi[i]) << 9) | (unsigned)e : 0u;
+        const bool in = i < KB_CAP / 64 && e < M;
+        sh[i] = in ? khi[i < KB_CAP / 64 ? i : 0] : 0u;
+        sl[i] = in ? ((0x3fffffu - (unsigned)mi[i < KB_CAP / 64 ? i : 0]) << 9) | (unsigned)e : 0u;
       }
-      knn_bitonic_desc<4>(sh, sl, lane);
+      if (M <= 256) {  // (uniform) the usual case: four registers, 36 stages
+        unsigned h4[4] = {sh[0], sh[1], sh[2], sh[3]}, l4[4] = {sl[0], sl[1], sl[2], sl[3]};
+        knn_bitonic_desc<4>(h4, l4, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sl[i] = l4[i];
+      } else {
+        knn_bitonic_desc<RMAX>(sh, sl, lane);
+      }
 #pragma unroll
       for (int i = 0; i < KB_CAP / 64; ++i) {
         const int e = 64 * i + lane;
-        const int slot = i < 4 ? (int)(sl[i < 4 ? i : 0] & 511u) : 0;
-        const bool out = i < 4 && e < M;
+        const int slot = (int)(sl[i] & 511u);
+        const bool out = e < M;
         mi[i] = out ? bufi[q * KB_CAP + slot] : 0x7fffffff;
         mv[i] = out ? bufv[q * KB_CAP + slot] : -INFINITY;
         rank[i] = e;  // the sorted position

@@ -194,7 +194,8 @@ def test_knn_full_size_properties(ops):
 
 # ------------------------------------------------------------------ a11 search half (mpti.py:731-736)
 @pytest.mark.parametrize("fast", [True, False])
-@pytest.mark.parametrize("n,n_valid,k", [(1400, 1400, 201), (1500, 1337, 201), (700, 700, 65), (4396, 4396, 201)])
+@pytest.mark.parametrize("n,n_valid,k", [(1400, 1400, 201), (1500, 1337, 201), (700, 700, 65), (4396, 4396, 201),
+                                         (1400, 1400, 250), (3000, 3000, 256)])  # (k >= 250: more than 256 survivors -> the 8-register sorting network)
 def test_knn_l2_bitexact(ops, n, n_valid, k, fast):
     """fast=True: two-pass append-and-rank kernel; fast=False: insertion kernel (the fallback)."""
     X = _rand((n, 192), 31, 0.2)
