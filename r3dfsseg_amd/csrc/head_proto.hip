@@ -347,8 +347,13 @@ extern "C" int r3d_fps_debug_read(unsigned long long* out, int n) {
 // FULL: D == DP.  With a run-time D < DP the unrolled channel loop carries a uniform `c < D` test per channel, which the
 // compiler turns into 192 precomputed lane masks parked in a VGPR: two v_readlane, a wait state and a v_cndmask per
 // channel beside the sub and the fma -- 3.5 times the VALU work of the round (5 of its 8 us with two workgroups per CU).
-template <int DP, bool FULL>
-__global__ __launch_bounds__(HP_BLOCK) void r3d_fps_persistent_kernel(
+// LC: the point's LAST LC channels live in LDS ([channel][thread]: conflict-free), the others in registers.  Measured
+// for DP = 192, LC = 52 (168 registers: three workgroups per CU, 9 episodes of workload S per launch, four launches for
+// a batch of 32 instead of six): 0.83 ms per launch against 0.47 -- a round is not only latency, the CU's waves share
+// the LDS pipe for the seed row's broadcast reads (48 ds_read_b128 per wave and round) -- so LC = 0 is what runs
+// (tools/fps_group_bench.py).  The distance is the same channel-ascending chain either way.
+template <int DP, bool FULL, int LC>
+__global__ __launch_bounds__(HP_BLOCK) __attribute__((amdgpu_waves_per_eu(LC ? 3 : 1))) void r3d_fps_persistent_kernel(
     const float* __restrict__ featC, long pitch, const float* __restrict__ featP, int D, SegGeom g, int* __restrict__ desc,
     int k, int rounds /* k + 1 */, unsigned long long* __restrict__ xch /* [rounds][tb_dense] candidates, then [nseg][HP_MAXK] results */, int tb_dense,
     int* __restrict__ sel, HpEp st, int ep0) {
@@ -356,6 +361,8 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_fps_persistent_kernel(
   __shared__ float red_v[4];
   __shared__ int red_p[4];
   __shared__ int seed_pos_s;
+  __shared__ float xl[LC ? LC : 1][HP_BLOCK];
+  constexpr int DR = DP - LC;  // channels in registers
   {
     const int ep = ep0 + blockIdx.y;  // the launch holds episodes ep0 .. ep0 + gridDim.y - 1 (co-resident together)
     HP_SHIFT(featC, st.ws); HP_SHIFT(featP, st.ws); HP_SHIFT(desc, st.desc); HP_SHIFT(sel, st.ws);
@@ -382,11 +389,13 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_fps_persistent_kernel(
   const unsigned nblk = (unsigned)((count + HP_BLOCK - 1) / HP_BLOCK);
   const int pos = bis * HP_BLOCK + tid;
   const bool have = pos < count;
-  float xv[DP];
+  float xv[DR];
   {
     const float* fp = featC + g.off(seg) + min(pos, count - 1);
 #pragma unroll
-    for (int c = 0; c < DP; ++c) xv[c] = fp[(long)min(c, D - 1) * pitch];
+    for (int c = 0; c < DR; ++c) xv[c] = fp[(long)min(c, D - 1) * pitch];
+#pragma unroll
+    for (int c = 0; c < LC; ++c) xl[c][tid] = fp[(long)min(DR + c, D - 1) * pitch];  // (read back by this thread alone)
   }
   const float* rows = featP + g.off(seg) * HP_DP;
   unsigned long long* res = xch + (long)rounds * tb_dense + (long)seg * HP_MAXK;  // the segment's result word of every round
@@ -400,9 +409,16 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_fps_persistent_kernel(
     __syncthreads();
     float acc = 0.f;
 #pragma unroll
-    for (int c = 0; c < DP; ++c) {
+    for (int c = 0; c < DR; ++c) {
       if (FULL || c < D) {
         const float df = xv[c] - seedf[c];
+        acc = __builtin_fmaf(df, df, acc);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < LC; ++c) {
+      if (FULL || DR + c < D) {
+        const float df = xl[c][tid] - seedf[DR + c];
         acc = __builtin_fmaf(df, df, acc);
       }
     }
@@ -810,6 +826,29 @@ extern "C" long r3d_head_proto_ws_words(int n_way, int k_shot, int N) { return h
 // fps_group: episodes whose farthest-point samplings share ONE persistent launch (flags & R3D_HEAD_FPS_ONE_LAUNCH): all
 // their workgroups that hold points must be co-resident, so the caller sizes it to the chip (~500 workgroup slots at
 // D <= 192, 250 above; an episode needs ceil(S N / 256) + n_way + 1); the batch takes ceil(n_ep / fps_group) such launches.
+// Workgroups of the persistent FPS kernel the chip holds at once (occupancy of the instantiation x CUs; asked once per
+// shape class) -> episodes per launch: what the caller asked for, clamped to that.
+static int fps_slots_clamp(int D, int tb_dense, int fps_group) {
+  static int slots[4] = {0, 0, 0, 0};
+  const int cls = D <= 64 ? 0 : D <= 128 ? 1 : D <= 192 ? 2 : 3;
+  if (!slots[cls]) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    hipError_t e = cls == 0   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, r3d_fps_persistent_kernel<64, true, 0>, HP_BLOCK, 0)
+                   : cls == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, r3d_fps_persistent_kernel<128, true, 0>, HP_BLOCK, 0)
+                   : cls == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, r3d_fps_persistent_kernel<192, true, 0>, HP_BLOCK, 0)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, r3d_fps_persistent_kernel<256, true, 0>, HP_BLOCK, 0);
+    if (e == hipSuccess && per_cu > 0 && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      slots[cls] = per_cu * prop.multiProcessorCount;
+    else {
+      (void)hipGetLastError();
+      slots[cls] = 256;  // one workgroup per CU: always resident
+    }
+  }
+  const int fit = slots[cls] / tb_dense;
+  return fps_group < 1 ? 1 : (fit < 1 ? 1 : (fps_group < fit ? fps_group : fit));
+}
+
 static int head_prototypes_impl(int n_ep, const HpEp& ep, int fps_group, const int32_t* support_y, const int32_t* shot_keep,
                                 const float* feat, long ldf, const float* qfeat, long ldq, int n_way, int k_shot, int N, int D,
                                 int n_query_pts, int k, float* nodes, long ldn, float* node_labels, int32_t* desc,
@@ -859,21 +898,23 @@ static int head_prototypes_impl(int n_ep, const HpEp& ep, int fps_group, const i
   if (flags & 1 /* R3D_HEAD_FPS_ONE_LAUNCH */) {
     const int tb_dense = (int)((g.cap(0) + HP_BLOCK - 1) / HP_BLOCK) + g.nseg();  // the segments' counts add up to cap(0)
     r3d_fill_words_ep(xch, 0u, 2L * kr * tb_dense + 2L * HP_MAXSEG * HP_MAXK, n_ep, e2.ws, st);
-    for (int e0 = 0; e0 < n_ep; e0 += fps_group) {
-      const int ne = n_ep - e0 < fps_group ? n_ep - e0 : fps_group;
-#define FPS_ONE(DPAD)                                                                                                   \
+    // the launch's workgroups wait for each other: never more of them than the chip holds at once, whatever the caller asks
+    const int grp = fps_slots_clamp(D, tb_dense, fps_group);
+    for (int e0 = 0; e0 < n_ep; e0 += grp) {
+      const int ne = n_ep - e0 < grp ? n_ep - e0 : grp;
+#define FPS_ONE(DPAD, LC)                                                                                               \
       do {                                                                                                              \
         if (D == DPAD)                                                                                                  \
-          hipLaunchKernelGGL((r3d_fps_persistent_kernel<DPAD, true>), dim3(tb_dense, ne), dim3(HP_BLOCK), 0, st, featC, pitch, \
+          hipLaunchKernelGGL((r3d_fps_persistent_kernel<DPAD, true, LC>), dim3(tb_dense, ne), dim3(HP_BLOCK), 0, st, featC, pitch, \
                              featP, D, g, desc, k, kr, xch, tb_dense, sel, e2, e0);                                         \
         else                                                                                                            \
-          hipLaunchKernelGGL((r3d_fps_persistent_kernel<DPAD, false>), dim3(tb_dense, ne), dim3(HP_BLOCK), 0, st, featC, pitch, \
+          hipLaunchKernelGGL((r3d_fps_persistent_kernel<DPAD, false, LC>), dim3(tb_dense, ne), dim3(HP_BLOCK), 0, st, featC, pitch, \
                              featP, D, g, desc, k, kr, xch, tb_dense, sel, e2, e0);                                         \
       } while (0)
-      if (D <= 64) FPS_ONE(64);
-      else if (D <= 128) FPS_ONE(128);
-      else if (D <= 192) FPS_ONE(192);
-      else FPS_ONE(256);
+      if (D <= 64) FPS_ONE(64, 0);
+      else if (D <= 128) FPS_ONE(128, 0);
+      else if (D <= 192) FPS_ONE(192, 0);
+      else FPS_ONE(256, 0);
 #undef FPS_ONE
     }
   } else {

@@ -304,6 +304,7 @@ class HeadBuffers:
         self.stats_bwd = one(torch.zeros(E, 2, **i32))
         # all FPS rounds in one persistent launch: its workgroups that hold points must be co-resident (~500 slots of
         # this kernel at D <= 192, 250 above); fps_group episodes share a launch, fps_slots caps what may be resident
+        # (the library clamps the group to the kernel's real occupancy as well: csrc/head_proto.hip::fps_slots_clamp)
         self.fps_one_launch = True
         self.fps_blocks = (n_way * k_shot * N + 255) // 256 + n_way + 1
         self.fps_slots = 500 if D <= 192 else 250

@@ -31,7 +31,7 @@ hb = m._head_buffers(n_q, dev, E)
 sy = b.support_y.reshape(E, Sn, N).contiguous()
 ep_rows = (Sn + n_q) * N
 ref = None
-for slots in (500, 448, 420, 340, 250, 170, 90):
+for slots in (1000, 750, 670, 590, 500, 340, 250, 90):
     hb.fps_slots = slots
     for it in range(3):
         if it == 1:
