@@ -89,6 +89,78 @@ __global__ __launch_bounds__(256) void r3d_colpartial_kernel(
   }
 }
 
+// The same sums for C a multiple of 256 and 16-byte aligned rows: 256 columns per workgroup, a lane owns FOUR consecutive
+// columns (a wave reads 1 KB of a row per instruction instead of 256 bytes).  Which wave adds which rows of a column, in
+// which order, and how the four wave totals meet is unchanged: the same bits.
+__global__ __launch_bounds__(256) void r3d_colpartial_v4_kernel(
+    const float* __restrict__ X, long ldx, const float* __restrict__ DY, long lddy, r3d_segmap sm, int C, int mode,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, long bn_stride, int act, int rows_per_chunk_a, int rows_per_chunk_b, int cmax,
+    float* __restrict__ part /* [seg][cmax][2][C] */) {
+  __shared__ float4 sa[4][64], sb[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + 4 * lane;
+  const int seg = blockIdx.z;
+  const long srows = sm.seg_rows(seg);
+  const int rows_per_chunk = sm.odd(seg) ? rows_per_chunk_b : rows_per_chunk_a;
+  const long s0 = (long)blockIdx.y * rows_per_chunk;
+  if (s0 >= srows) return;  // uniform: this segment has fewer chunks than the longest one
+  const long base = sm.seg_row0(seg);
+  const long r0 = base + s0;
+  const long r1 = base + min(srows, s0 + rows_per_chunk);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f), mu = sh, is = sc;
+  if (mode == 1) {
+    const long o = (long)seg * bn_stride + c;
+    sc = *reinterpret_cast<const float4*>(scale + o); sh = *reinterpret_cast<const float4*>(shift + o);
+    mu = *reinterpret_cast<const float4*>(mean + o); is = *reinterpret_cast<const float4*>(invstd + o);
+  }
+  auto acc = [&](float x, float g0, float sc_, float sh_, float mu_, float is_, float& a_, float& b_) {
+    if (mode == 0) {
+      a_ += x;
+      b_ += x * x;
+    } else {
+      const float uu = sc_ * x + sh_;
+      float g = g0;
+      if (act == 1) g = uu > 0.f ? g : 0.f;
+      else if (act == 2) g = uu > 0.f ? g : 0.2f * g;
+      a_ += g;
+      b_ += g * ((x - mu_) * is_);
+    }
+  };
+  for (long rb = r0 + w; rb < r1; rb += 32) {
+    float4 xv[8], gv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long r = min(rb + 4 * u, r1 - 1);
+      xv[u] = *reinterpret_cast<const float4*>(X + r * ldx + c);
+      gv[u] = mode == 1 ? *reinterpret_cast<const float4*>(DY + r * lddy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (rb + 4 * u < r1) {
+        acc(xv[u].x, gv[u].x, sc.x, sh.x, mu.x, is.x, a.x, b.x);
+        acc(xv[u].y, gv[u].y, sc.y, sh.y, mu.y, is.y, a.y, b.y);
+        acc(xv[u].z, gv[u].z, sc.z, sh.z, mu.z, is.z, a.z, b.z);
+        acc(xv[u].w, gv[u].w, sc.w, sh.w, mu.w, is.w, a.w, b.w);
+      }
+    }
+  }
+  sa[w][lane] = a;
+  sb[w][lane] = b;
+  __syncthreads();
+  if (w == 0) {
+    const long slot = (long)seg * cmax + blockIdx.y;
+    float4 ta, tb;
+    ta.x = ((sa[0][lane].x + sa[1][lane].x) + sa[2][lane].x) + sa[3][lane].x; ta.y = ((sa[0][lane].y + sa[1][lane].y) + sa[2][lane].y) + sa[3][lane].y;
+    ta.z = ((sa[0][lane].z + sa[1][lane].z) + sa[2][lane].z) + sa[3][lane].z; ta.w = ((sa[0][lane].w + sa[1][lane].w) + sa[2][lane].w) + sa[3][lane].w;
+    tb.x = ((sb[0][lane].x + sb[1][lane].x) + sb[2][lane].x) + sb[3][lane].x; tb.y = ((sb[0][lane].y + sb[1][lane].y) + sb[2][lane].y) + sb[3][lane].y;
+    tb.z = ((sb[0][lane].z + sb[1][lane].z) + sb[2][lane].z) + sb[3][lane].z; tb.w = ((sb[0][lane].w + sb[1][lane].w) + sb[2][lane].w) + sb[3][lane].w;
+    *reinterpret_cast<float4*>(part + (slot * 2 + 0) * C + c) = ta;
+    *reinterpret_cast<float4*>(part + (slot * 2 + 1) * C + c) = tb;
+  }
+}
+
 // 64 columns per workgroup; the chunk axis is split over the 4 waves (chunks q, q+4, ...), each adding in
 // ascending order in fp64, and the four wave totals are combined in a fixed order: deterministic for any count.
 // blockIdx.y = segment.  Its chunks are rows [first, first + count) of `part`: cmax > 0: first = seg * cmax (the
@@ -307,6 +379,90 @@ __global__ __launch_bounds__(256) void r3d_bn_bwd_apply_kernel(
   }
 }
 
+// The same for C a power of two (16 .. 1024) and 16-byte aligned rows: a lane owns FOUR consecutive columns (16-byte loads
+// and stores: a wave moves 1 KB per instruction, 64 / (C / 4) rows of it when C < 256), its columns' six constants --
+// scale, shift, mean, 1 / std and the two means, the latter the same fp64 quotients as above -- are formed ONCE per
+// workgroup and segment instead of once per four rows, and the segment is looked up once per workgroup when its rows
+// lie in one (otherwise per row).  Every element goes through the same expression: same bits.  (The kernel above moved
+// 3.6 TB/s at workload S -- 26 loads and two fp64 divisions per lane for four elements --, the other element-wise
+// passes 4.6-5.7.)
+#define BA_ROWS 64
+template <int NK /* column groups of 256 per lane: C / 256, at least 1 */>
+__global__ __launch_bounds__(256) void r3d_bn_bwd_apply_v4_kernel(
+    const float* __restrict__ Z, long ldz, const float* __restrict__ DY, long lddy, int M, int C, r3d_segmap sm,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, long bn_stride, int act, const float* __restrict__ sums, double count_a, double count_b,
+    float* __restrict__ DZ, long lddz) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lpr = NK > 1 ? 64 : C >> 2;   // lanes of a row (C >= 256: the whole wave)
+  const int rpw = 64 / lpr;               // rows per wave and instruction
+  const int col0 = 4 * (lane & (lpr - 1));
+  const int rsub = lane / lpr;            // (lpr is a power of two: a shift)
+  const int rb0 = blockIdx.x * BA_ROWS;
+  const int rb1 = min(rb0 + BA_ROWS, M) - 1;
+  const int seg_first = sm.seg_of_row32(rb0), seg_last = sm.seg_of_row32(rb1);
+  float4 sc[NK], sh[NK], mu[NK], is[NK], m1[NK], m2[NK];
+  int cur = -1;
+  auto load_consts = [&](int seg) {
+    const long bo = (long)seg * bn_stride, so = (long)seg * 2 * C;
+    const double cnt = sm.odd(seg) ? count_b : count_a;
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+      const int c = col0 + 256 * kk;
+      sc[kk] = *reinterpret_cast<const float4*>(scale + bo + c); sh[kk] = *reinterpret_cast<const float4*>(shift + bo + c);
+      mu[kk] = *reinterpret_cast<const float4*>(mean + bo + c); is[kk] = *reinterpret_cast<const float4*>(invstd + bo + c);
+      const float4 s1 = *reinterpret_cast<const float4*>(sums + so + c), s2 = *reinterpret_cast<const float4*>(sums + so + C + c);
+      m1[kk] = make_float4((float)((double)s1.x / cnt), (float)((double)s1.y / cnt), (float)((double)s1.z / cnt), (float)((double)s1.w / cnt));
+      m2[kk] = make_float4((float)((double)s2.x / cnt), (float)((double)s2.y / cnt), (float)((double)s2.z / cnt), (float)((double)s2.w / cnt));
+    }
+    cur = seg;
+  };
+  load_consts(seg_first);
+  const bool one_seg = seg_first == seg_last;  // (uniform over the workgroup)
+  auto elem = [&](float z, float g, float sc_, float sh_, float mu_, float is_, float m1_, float m2_) {
+    const float uu = sc_ * z + sh_;
+    float gg = g;
+    if (act == 1) gg = uu > 0.f ? gg : 0.f;
+    else if (act == 2) gg = uu > 0.f ? gg : 0.2f * gg;
+    const float zh = (z - mu_) * is_;
+    return sc_ * (gg - m1_ - zh * m2_);
+  };
+  constexpr int U = NK > 1 ? 2 : 4;  // row groups in flight per trip
+  const int step = 4 * rpw;          // rows the workgroup's four waves cover per row group
+  for (int it = 0; it < BA_ROWS; it += U * step) {
+    float4 z[U][NK], g[U][NK];
+    int row[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      row[u] = rb0 + it + u * step + rpw * w + rsub;
+      const int r = min(row[u], M - 1);
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+        z[u][kk] = *reinterpret_cast<const float4*>(Z + (long)r * ldz + col0 + 256 * kk);
+        g[u][kk] = *reinterpret_cast<const float4*>(DY + (long)r * lddy + col0 + 256 * kk);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!one_seg) {
+        const int seg = sm.seg_of_row32(min(row[u], M - 1));
+        if (seg != cur) load_consts(seg);
+      }
+      if (row[u] < M && row[u] <= rb1) {
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+          float4 o;
+          o.x = elem(z[u][kk].x, g[u][kk].x, sc[kk].x, sh[kk].x, mu[kk].x, is[kk].x, m1[kk].x, m2[kk].x);
+          o.y = elem(z[u][kk].y, g[u][kk].y, sc[kk].y, sh[kk].y, mu[kk].y, is[kk].y, m1[kk].y, m2[kk].y);
+          o.z = elem(z[u][kk].z, g[u][kk].z, sc[kk].z, sh[kk].z, mu[kk].z, is[kk].z, m1[kk].z, m2[kk].z);
+          o.w = elem(z[u][kk].w, g[u][kk].w, sc[kk].w, sh[kk].w, mu[kk].w, is[kk].w, m1[kk].w, m2[kk].w);
+          *reinterpret_cast<float4*>(DZ + (long)row[u] * lddz + col0 + 256 * kk) = o;
+        }
+      }
+    }
+  }
+}
+
 // ---- C = A^T B over the row axis: out[i][j] = sum_m A[m][i] * B[m][j] ---------------------------
 // (weight gradients: A = dz (M, Ca), B = X (M, Cb) -> dW (Ca, Cb)).  64 x 64 tile per workgroup on the
 // fp32 matrix core, the M axis split in chunks of TN_ROWS with per-chunk partial tiles that a second
@@ -470,6 +626,13 @@ extern "C" int r3d_colstats_seg(const float* X, long ldx, const float* DY, long 
   const int cmax = ca > cb ? ca : cb, n_seg = sm.n_seg(M);
   R3D_REQUIRE(n_seg <= 65535 && cmax <= 65535, "r3d_colstats: too many segments");
   hipStream_t st = (hipStream_t)stream;
+  const bool v4 = C % 256 == 0 && ((ldx | (DY ? lddy : 0) | bn_stride) & 3) == 0 &&
+                  (((uintptr_t)X | (uintptr_t)DY | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)invstd |
+                    (uintptr_t)ws) & 15) == 0;
+  if (v4)
+    hipLaunchKernelGGL(r3d_colpartial_v4_kernel, dim3(C / 256, cmax, n_seg), dim3(256), 0, st, X, ldx, DY, lddy, sm, C, mode,
+                       scale, shift, mean, invstd, bn_stride, act, ra, rb, cmax, ws);
+  else
   hipLaunchKernelGGL(r3d_colpartial_kernel, dim3(r3d_cdiv(C, 64), cmax, n_seg), dim3(256), 0, st, X, ldx, DY, lddy, sm, C, mode,
                      scale, shift, mean, invstd, bn_stride, act, ra, rb, cmax, ws);
   hipLaunchKernelGGL(r3d_colreduce_kernel, dim3(r3d_cdiv(C, 64), n_seg), dim3(256), 0, st, ws, ca, cb, cmax, C, sums_out);
@@ -553,6 +716,19 @@ extern "C" int r3d_bn_bwd_apply_seg(const float* Z, long ldz, const float* DY, l
   const r3d_segmap sm{rows_a, rows_b};
   R3D_REQUIRE(sm.covers(M) && count_a > 0, "r3d_bn_bwd_apply: %ld rows are not whole segments of %ld + %ld rows", M, rows_a,
               rows_b);
+  const bool pow2 = C >= 16 && C <= 1024 && (C & (C - 1)) == 0;
+  const bool al16 = ((ldz | lddy | lddz | bn_stride) & 3) == 0 &&
+                    (((uintptr_t)Z | (uintptr_t)DY | (uintptr_t)DZ | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean |
+                      (uintptr_t)invstd | (uintptr_t)sums) & 15) == 0;
+  if (pow2 && al16) {
+#define BA_GO(NK)                                                                                                             \
+  hipLaunchKernelGGL(r3d_bn_bwd_apply_v4_kernel<NK>, dim3(r3d_cdiv(M, BA_ROWS)), dim3(256), 0, (hipStream_t)stream, Z, ldz, DY, \
+                     lddy, (int)M, C, sm, scale, shift, mean, invstd, bn_stride, act, sums, count_a, count_b, DZ, lddz)
+    if (C <= 256) BA_GO(1);
+    else if (C == 512) BA_GO(2);
+    else BA_GO(4);
+#undef BA_GO
+  } else
   hipLaunchKernelGGL(r3d_bn_bwd_apply_kernel, dim3(r3d_cdiv(M, EW_ROWS)), dim3(256), 0, (hipStream_t)stream, Z, ldz, DY,
                      lddy, (int)M, C, sm, scale, shift, mean, invstd, bn_stride, act, sums, count_a, count_b, DZ, lddz);
   R3D_LAUNCH_CHECK("r3d_bn_bwd_apply");

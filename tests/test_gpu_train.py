@@ -433,3 +433,36 @@ def test_one_launch_sequence_equals_two_getfeatures_calls(N):
     assert abs(a["lp"] - b["lp"]) <= 1e-5 * max(1.0, abs(a["lp"])) and abs(a["cl"] - b["cl"]) <= 1e-5 * max(1.0, abs(a["cl"]))
     for n_ in a["grads"]:
         assert _rel(b["grads"][n_], a["grads"][n_]) <= 2e-3, (n_, _rel(b["grads"][n_], a["grads"][n_]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C", [64, 128, 256, 512])
+@pytest.mark.parametrize("E,S,Q,N", [(3, 3, 1, 100), (2, 2, 1, 96)])  # (N = 100: segments that end inside a workgroup's rows)
+def test_vectorised_batchnorm_passes_give_the_scalar_kernels_bits(C, E, S, Q, N):
+    """r3d_bn_bwd_apply_v4 / r3d_colpartial_v4 (16 bytes per lane, constants formed once per workgroup) against the
+    4-bytes-per-lane kernels they replace -- selected by giving the same matrices rows that are not 16-byte aligned
+    (leading dimension C + 1): every sum and every element bit for bit."""
+    from r3dfsseg_amd import ops, train_ops as T
+    seg = ops.SegLayout(E, S, Q, N)
+    M = seg.M
+    g = torch.Generator().manual_seed(C + N)
+    dev = torch.device("cuda")
+    Z = torch.randn(M, C, generator=g).to(dev)
+    DY = torch.randn(M, C, generator=g).to(dev)
+    bn = T.BNVec(seg.n_seg, C, dev)
+    bn.t.copy_(torch.randn(seg.n_seg, 4, C, generator=g).to(dev))
+    bn.t[:, 3].abs_().add_(0.5)
+
+    def unaligned(t):
+        p = torch.empty(M, C + 1, device=dev)
+        p[:, :C] = t
+        return p[:, :C]
+    for act in (0, 2):
+        s_fast = T.colstats(Z, C, seg, mode=1, DY=DY, bn=bn, act=act)
+        s_slow = T.colstats(unaligned(Z), C, seg, mode=1, DY=unaligned(DY), bn=bn, act=act)
+        assert torch.equal(s_fast.view(torch.int32), s_slow.view(torch.int32)), "backward column sums differ (C %d)" % C
+        f_fast, f_slow = T.colstats(Z, C, seg, mode=0), T.colstats(unaligned(Z), C, seg, mode=0)
+        assert torch.equal(f_fast.view(torch.int32), f_slow.view(torch.int32)), "forward column sums differ (C %d)" % C
+        d_fast = T.bn_bwd_apply(Z, DY, bn, act, s_fast, seg.counts(), seg)
+        d_slow = T.bn_bwd_apply(unaligned(Z), unaligned(DY), bn, act, s_fast, seg.counts(), seg, out=unaligned(torch.zeros(M, C, device=dev)))
+        assert torch.equal(d_fast.view(torch.int32), d_slow.contiguous().view(torch.int32)), "dz differs (C %d, act %d)" % (C, act)
