@@ -467,7 +467,8 @@ __global__ __launch_bounds__(256) void r3d_bn_bwd_apply_v4_kernel(
 // (weight gradients: A = dz (M, Ca), B = X (M, Cb) -> dW (Ca, Cb)).  64 x 64 tile per workgroup on the
 // fp32 matrix core, the M axis split in chunks of TN_ROWS with per-chunk partial tiles that a second
 // kernel adds in ascending chunk order (deterministic, no float atomics).
-#define TN_ROWS_MAX 1024
+#define TN_ROWS_MAX 4096  // (1024 until round 4: 768 partial tiles per weight gradient at 786 432 rows, whose ascending sum --
+                          // r3d_chunk_reduce_kernel, one thread per output walking its chunks -- took 48 us per GEMM; 19 us now)
 // gemm_bx3.hip: the same product on the bf16 matrix core in three-piece arithmetic (128 x 128 / 256 x 64 tiles, 2 per CU)
 bool r3d_gemm_tn_bx3_ok(int Ca, int Cb);
 int r3d_gemm_tn_bx3_tiles(int Ca, int Cb);
