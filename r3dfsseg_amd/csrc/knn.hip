@@ -1452,17 +1452,31 @@ __global__ void r3d_knn_pack_bf_kernel(const float* __restrict__ x, long ldx, lo
 // squared norms of the centred points (one wave per row; fixed order)
 __global__ __launch_bounds__(256) void r3d_knn_cnorm_kernel(const float* __restrict__ x, long ldx, long rows, int N, int C, int Cp,
                                                             const float* __restrict__ mean, float* __restrict__ cnorm) {
-  const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= rows) return;
-  const int lane = threadIdx.x & 63;
-  const float* mu = mean + (m / N) * Cp;
+  // 16 lanes per point, four points per wave: a lane adds the squares of its 16-byte pieces, the 16 partial sums meet in
+  // four DPP steps (ldx % 4 == 0 and 16-byte aligned rows: the filter pass asks the same of them; otherwise one float per
+  // lane and trip).  The sum's order only moves the bound it feeds by roundings that the bound's slack covers.
+  const int lane = threadIdx.x & 63, sub = lane & 15;
+  const long m = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  const long mc = m < rows ? m : rows - 1;
+  const float* mu = mean + (mc / N) * Cp;
   float s = 0.f;
-  for (int c = lane; c < C; c += 64) {
-    const float d = x[m * ldx + c] - mu[c];
-    s = __builtin_fmaf(d, d, s);
+  if ((ldx & 3) == 0 && (C & 3) == 0 && ((uintptr_t)x & 15) == 0) {
+    for (int c = 4 * sub; c < C; c += 64) {
+      const float4 v = *reinterpret_cast<const float4*>(x + mc * ldx + c), u = *reinterpret_cast<const float4*>(mu + c);
+      const float d0 = v.x - u.x, d1 = v.y - u.y, d2 = v.z - u.z, d3 = v.w - u.w;
+      s = __builtin_fmaf(d0, d0, s); s = __builtin_fmaf(d1, d1, s); s = __builtin_fmaf(d2, d2, s); s = __builtin_fmaf(d3, d3, s);
+    }
+  } else {
+    for (int c = sub; c < C; c += 16) {
+      const float d = x[mc * ldx + c] - mu[c];
+      s = __builtin_fmaf(d, d, s);
+    }
   }
-  s = r3d_wave_sum(s);
-  if (lane == 0) cnorm[m] = s;
+  s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0x140, 0xF, 0xF, true));  // row_mirror
+  if (sub == 0 && m < rows) cnorm[m] = s;
 }
 // A/B switch (tests, tools): 0 = the threshold pass stays on the fp32 core even when bf_ws is given.  Same results.
 static int g_knn_bf16_threshold = getenv("R3D_KNN_FP32_THRESHOLD") ? 0 : 1;
@@ -1632,7 +1646,7 @@ static int knn_topk_impl(const float* x, long ldx, const float* x_cm, int B, int
     const long chunks = (long)B * N * (C / 8);
     hipLaunchKernelGGL(r3d_knn_pack_bf_kernel, dim3(r3d_cdiv(chunks, 256)), dim3(256), 0, s_, x, ldx, (long)B * N, N, C, C, bf_mean,
                        (unsigned short*)bf_ws);
-    hipLaunchKernelGGL(r3d_knn_cnorm_kernel, dim3(r3d_cdiv((long)B * N, 4)), dim3(256), 0, s_, x, ldx, (long)B * N, N, C, C, bf_mean,
+    hipLaunchKernelGGL(r3d_knn_cnorm_kernel, dim3(r3d_cdiv((long)B * N, 16)), dim3(256), 0, s_, x, ldx, (long)B * N, N, C, C, bf_mean,
                        bf_cnorm);
   };
   R3D_REQUIRE(B > 0 && N > 0 && C > 0 && (!x || ldx >= C), "r3d_knn_topk: bad shape B=%d N=%d C=%d ldx=%ld", B, N, C, ldx);
