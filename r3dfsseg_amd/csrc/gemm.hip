@@ -297,19 +297,25 @@ extern "C" int r3d_pm_to_cm_pitched(const float* in, long ld, int B, int C, int 
 }
 
 // strided column-block copy: dst[m][0..C) = src[m][0..C)
-__global__ void r3d_copy_cols_kernel(const float* __restrict__ src, long lds_, float* __restrict__ dst,
-                                     long ldd, long M, int C) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= M * C) return;
-  long m = i / C;
-  int c = (int)(i - m * C);
-  dst[m * ldd + c] = src[m * lds_ + c];
+// (a wave takes four rows, its lanes the columns: no 64-bit division per element)
+__global__ __launch_bounds__(256) void r3d_copy_cols_kernel(const float* __restrict__ src, long lds_, float* __restrict__ dst,
+                                                            long ldd, long M, int C) {
+  const int lane = threadIdx.x & 63;
+  const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+  for (int c = lane; c < C; c += 64) {
+    float a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = src[(r0 + u < M ? r0 + u : M - 1) * lds_ + c];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (r0 + u < M) dst[(r0 + u) * ldd + c] = a[u];
+  }
 }
 
 extern "C" int r3d_copy_cols(const float* src, long ld_src, float* dst, long ld_dst, long M, int C,
                              void* stream) {
   R3D_REQUIRE(src && dst && M > 0 && C > 0, "r3d_copy_cols: bad arguments");
-  hipLaunchKernelGGL(r3d_copy_cols_kernel, dim3(r3d_cdiv(M * C, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(r3d_copy_cols_kernel, dim3(r3d_cdiv(M, 16)), dim3(256), 0,
                      (hipStream_t)stream, src, ld_src, dst, ld_dst, M, C);
   R3D_LAUNCH_CHECK("r3d_copy_cols");
   return R3D_OK;

@@ -744,7 +744,7 @@ __global__ void r3d_nodes_append_query_kernel(const float* __restrict__ qfeat, l
   const int n_proto = desc[HD_N_PROTO];
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)nq_pts * D) return;
-  const long r = i / D;
+  const long r = (long)((unsigned)i / (unsigned)D);  // (n_query_pts D < 2^31, checked by the entry point: a 32-bit division)
   const int c = (int)(i - r * D);
   nodes[(n_proto + r) * ldn + c] = qfeat[r * ldq + c];
   if (c < 4) node_labels[(n_proto + r) * 4 + c] = 0.f;
@@ -762,6 +762,13 @@ static int check_geom(const char* fn, int n_way, int k_shot, int N, int D) {
   }
   if ((long)n_way * k_shot * N > 65536L * 4) {
     r3d_set_error("%s: too many support points", fn);
+    return R3D_ERR_ARG;
+  }
+  return 0;
+}
+static int check_query_rows(const char* fn, int n_query_pts, int D) {  // (the query-row kernels index elements in 32 bits)
+  if (n_query_pts < 0 || (long)n_query_pts * D >= 0x7fffffffL) {
+    r3d_set_error("%s: %d query points x %d channels do not fit 31 bits", fn, n_query_pts, D);
     return R3D_ERR_ARG;
   }
   return 0;
@@ -856,6 +863,8 @@ static int head_prototypes_impl(int n_ep, const HpEp& ep, int fps_group, const i
                                 void* stream) {
   R3D_REQUIRE(support_y && feat && qfeat && nodes && node_labels && desc && ws, "r3d_head_prototypes: null pointer");
   int rc = check_geom("r3d_head_prototypes", n_way, k_shot, N, D);
+  if (rc) return rc;
+  rc = check_query_rows("r3d_head_prototypes", n_query_pts, D);
   if (rc) return rc;
   R3D_REQUIRE(ws_words >= r3d_head_proto_ws_words(n_way, k_shot, N),
               "r3d_head_prototypes: workspace of %ld words, r3d_head_proto_ws_words = %ld needed", ws_words,
@@ -1007,7 +1016,7 @@ __global__ void r3d_query_bwd_kernel(const float* __restrict__ dnodes, long ldd,
   const int n_proto = desc[HD_N_PROTO];
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)nq_pts * D) return;
-  const long r = i / D;
+  const long r = (long)((unsigned)i / (unsigned)D);  // (n_query_pts D < 2^31, checked by the entry point: a 32-bit division)
   const int c = (int)(i - r * D);
   dqfeat[r * ldq + c] = dnodes[(n_proto + r) * ldd + c];
 }
@@ -1018,6 +1027,8 @@ static int head_prototypes_bwd_impl(int n_ep, const HpEp& ep, const float* dnode
                                     const int32_t* ws, float* dsfeat, long lds_, float* dqfeat, long ldq, void* stream) {
   R3D_REQUIRE(dnodes && desc && assign && cluster_count && ws && dsfeat && dqfeat, "r3d_head_prototypes_bwd: null pointer");
   int rc = check_geom("r3d_head_prototypes_bwd", n_way, k_shot, N, D);
+  if (rc) return rc;
+  rc = check_query_rows("r3d_head_prototypes_bwd", n_query_pts, D);
   if (rc) return rc;
   R3D_REQUIRE(n_ep >= 1 && n_ep <= 4096, "r3d_head_prototypes_bwd: %d episodes", n_ep);
   SegGeom g{n_way, k_shot, N};

@@ -580,13 +580,22 @@ __global__ void r3d_chunk_reduce_kernel(const float* __restrict__ part, int chun
 }
 
 // ---- out (M, C) (+)= in (M, C) with row strides --------------------------------------------------
-__global__ void r3d_add_cols_kernel(const float* __restrict__ src, long lds_, float* __restrict__ dst, long ldd, long M,
-                                    int C) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= M * C) return;
-  const long r = i / C;
-  const int c = (int)(i - r * C);
-  dst[r * ldd + c] += src[r * lds_ + c];
+// (a wave takes four rows, its lanes the columns: no 64-bit division per element -- ~100 instructions for 8 bytes of traffic)
+__global__ __launch_bounds__(256) void r3d_add_cols_kernel(const float* __restrict__ src, long lds_, float* __restrict__ dst,
+                                                           long ldd, long M, int C) {
+  const int lane = threadIdx.x & 63;
+  const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+  for (int c = lane; c < C; c += 64) {
+    float a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long r = r0 + u < M ? r0 + u : M - 1;
+      a[u] = src[r * lds_ + c]; b[u] = dst[r * ldd + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (r0 + u < M) dst[(r0 + u) * ldd + c] = b[u] + a[u];
+  }
 }
 
 // ===========================================================================
@@ -771,7 +780,7 @@ extern "C" int r3d_gemm_tn(const float* A, long lda, const float* B, long ldb, l
 
 extern "C" int r3d_add_cols(const float* src, long ld_src, float* dst, long ld_dst, long M, int C, void* stream) {
   R3D_REQUIRE(src && dst && M > 0 && C > 0, "r3d_add_cols: bad arguments");
-  hipLaunchKernelGGL(r3d_add_cols_kernel, dim3(r3d_cdiv(M * C, 256)), dim3(256), 0, (hipStream_t)stream, src, ld_src, dst,
+  hipLaunchKernelGGL(r3d_add_cols_kernel, dim3(r3d_cdiv(M, 16)), dim3(256), 0, (hipStream_t)stream, src, ld_src, dst,
                      ld_dst, M, C);
   R3D_LAUNCH_CHECK("r3d_add_cols");
   return R3D_OK;
