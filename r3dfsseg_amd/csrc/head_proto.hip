@@ -319,6 +319,9 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_fps_round_kernel(
 //     instead of a hung GPU.
 // ---------------------------------------------------------------------------
 #define FPS_SPIN_LIMIT (1 << 22)
+#ifndef FPS_SCALAR_SEED
+#define FPS_SCALAR_SEED 0
+#endif
 #ifdef FPS_STAMPS  // residency probe of the persistent kernel (tools/fps_stamps.py; never in the product build)
 __device__ unsigned long long g_fps_dbg[8192 * 4];
 extern "C" int r3d_fps_debug_read(unsigned long long* out, int n) {
@@ -404,6 +407,18 @@ __global__ __launch_bounds__(HP_BLOCK) __attribute__((amdgpu_waves_per_eu(LC ? 3
   for (int round = 0; round < rounds; ++round) {
     if (bis == 0 && tid == 0) sel[seg * HP_MAXK + round] = seed_pos;
     if (round == rounds - 1) break;
+#if FPS_SCALAR_SEED
+    __syncthreads();  // red_* of the previous round are no longer read
+    const float* __restrict__ srow = rows + (long)__builtin_amdgcn_readfirstlane(seed_pos) * HP_DP;  // (uniform: scalar loads)
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < DR; ++c) {
+      if (FULL || c < D) {
+        const float df = xv[c] - srow[c];
+        acc = __builtin_fmaf(df, df, acc);
+      }
+    }
+#else
     __syncthreads();  // seedf / red_* of the previous round are no longer read
     for (int c = tid; c < D; c += HP_BLOCK) seedf[c] = rows[(long)seed_pos * HP_DP + c];
     __syncthreads();
@@ -415,6 +430,7 @@ __global__ __launch_bounds__(HP_BLOCK) __attribute__((amdgpu_waves_per_eu(LC ? 3
         acc = __builtin_fmaf(df, df, acc);
       }
     }
+#endif
 #pragma unroll
     for (int c = 0; c < LC; ++c) {
       if (FULL || DR + c < D) {
