@@ -319,6 +319,9 @@ __global__ __launch_bounds__(HP_BLOCK) void r3d_fps_round_kernel(
 //     instead of a hung GPU.
 // ---------------------------------------------------------------------------
 #define FPS_SPIN_LIMIT (1 << 22)
+// FPS_SCALAR_SEED 1: the seed row read by scalar loads (s_load_dwordx16, SGPR operands) instead of staged in LDS: no
+// staging barrier, but twelve dependent scalar round trips per round -- measured 6.09 against 4.94 ms for the whole
+// r3d_head_prototypes_batched call on 32 episodes (tools/fps_group_bench.py).  Off.
 #ifndef FPS_SCALAR_SEED
 #define FPS_SCALAR_SEED 0
 #endif
